@@ -1,0 +1,353 @@
+"""CPU port of the reference's minimizer step (energy+gradient assembly,
+constraint projection, GD / per-row Polak-Ribiere CG direction, Armijo
+backtracking line search) restricted to the hot-path scope.
+
+TEST INFRASTRUCTURE ONLY (see oracle/ms_oracle.c).  Control flow is a plain
+NumPy restatement of the reference routines cited on each function; the
+per-facet arithmetic is the C oracle.  bench.py times this as the
+``cpu_baseline`` ("port", 1 core).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import ms_oracle as orc
+
+
+@dataclass
+class Problem:
+    """Array view of what the hot path reads from the reference ``Mesh``."""
+
+    positions: np.ndarray  # (nv,3) f64, row order = mesh.vertex_ids
+    tri: np.ndarray  # (nf,3) int32, mesh.triangle_row_cache()
+    gamma: np.ndarray | None = None  # (nf,) get_facet_parameter_array("surface_tension")
+    kappa: np.ndarray | None = None  # (nv,) bending_params._per_vertex_params
+    c0: np.ndarray | None = None
+    is_boundary: np.ndarray | None = None  # (nv,) bool, mesh.boundary_vertex_ids
+    fixed: np.ndarray | None = None  # (nv,) bool, mesh.fixed_mask
+    energy_modules: list = field(default_factory=lambda: ["surface"])
+    constraint_modules: list = field(default_factory=list)
+    body_rows: np.ndarray | None = None  # None = all facets in one body
+    target_volume: float | None = None
+    gp: dict = field(default_factory=dict)
+
+    def __post_init__(self):
+        self.positions = np.ascontiguousarray(self.positions, dtype=np.float64).copy()
+        self.tri = np.ascontiguousarray(self.tri, dtype=np.int32)
+        nv, nf = self.positions.shape[0], self.tri.shape[0]
+        if self.gamma is None:
+            self.gamma = np.full(nf, float(self.gp.get("surface_tension", 1.0)))
+        if self.kappa is None:
+            self.kappa = np.full(nv, float(self.gp.get("bending_modulus", 0.0) or 0.0))
+        if self.c0 is None:
+            val = self.gp.get("spontaneous_curvature")
+            if val is None:
+                val = self.gp.get("intrinsic_curvature", 0.0)
+            self.c0 = np.full(nv, float(val or 0.0))
+        if self.is_boundary is None:
+            self.is_boundary = np.zeros(nv, dtype=bool)
+        if self.fixed is None:
+            self.fixed = np.zeros(nv, dtype=bool)
+        self.is_boundary = np.asarray(self.is_boundary, dtype=bool)
+        self.fixed = np.asarray(self.fixed, dtype=bool)
+
+    # -- parameter helpers (modules/energy/bending_params.py:19-33) ----------
+    @property
+    def model(self) -> str:
+        m = str(self.gp.get("bending_energy_model", "helfrich") or "helfrich").lower().strip()
+        return "helfrich" if m == "helfrich" else "willmore"
+
+    @property
+    def grad_mode(self) -> str:
+        m = str(self.gp.get("bending_gradient_mode", "analytic") or "analytic").lower().strip()
+        return "analytic" if m == "analytic" else "approx"
+
+    @property
+    def volume_mode(self) -> str:
+        return self.gp.get("volume_constraint_mode", "lagrange")
+
+
+# ---------------------------------------------------------------------------
+# runtime/evaluation_manager.py:134-151 + runtime/minimizer.py:941-992
+# ---------------------------------------------------------------------------
+def energy_and_gradient(p: Problem, pos: np.ndarray):
+    grad = np.zeros_like(pos)
+    E = 0.0
+    for name in p.energy_modules:
+        if name == "surface":
+            E += orc.surface_energy_and_gradient(pos, p.tri, p.gamma, grad)
+        elif name == "bending":
+            E += orc.bending_energy_and_gradient(
+                pos, p.tri, p.kappa, p.c0, p.is_boundary,
+                model=p.model, mode=p.grad_mode, grad=grad,
+            )
+        elif name == "volume":
+            # modules/energy/volume.py:94-128 (penalty mode only)
+            if p.volume_mode == "penalty":
+                k = float(p.gp.get("volume_stiffness", 1000.0))
+                V = orc.volume(pos, p.tri, p.body_rows)
+                delta = V - float(p.target_volume)
+                E += 0.5 * k * delta**2
+                orc.volume_gradient(pos, p.tri, grad, factor=k * delta, body_rows=p.body_rows)
+        else:
+            raise ValueError(f"module {name!r} is outside the hot-path scope")
+    # constraint_manager.apply_gradient_modifications_array (k == 1 dense branch :293-301)
+    if "volume" in p.constraint_modules and p.volume_mode == "lagrange" and p.target_volume is not None:
+        gC = np.zeros_like(pos)
+        orc.volume_gradient(pos, p.tri, gC, factor=1.0, body_rows=p.body_rows)
+        norm_sq = float(np.sum(gC * gC))
+        if norm_sq > 1e-18:
+            lam = float(np.sum(grad * gC)) / norm_sq
+            grad -= lam * gC
+    # minimizer.py:988-990
+    grad[p.fixed] = 0.0
+    return float(E), grad
+
+
+# runtime/evaluation_manager.py:184-225 compute_energy_array_total
+def energy_total(p: Problem, pos: np.ndarray) -> float:
+    E = 0.0
+    for name in p.energy_modules:
+        if name == "surface":
+            # no compute_energy_array -> gradient API into a scratch (:201-210)
+            E += orc.surface_energy_and_gradient(pos, p.tri, p.gamma, None)
+        elif name == "bending":
+            E += orc.bending_energy(pos, p.tri, p.kappa, p.c0, p.is_boundary, model=p.model)
+        elif name == "volume":
+            if p.volume_mode == "penalty":
+                k = float(p.gp.get("volume_stiffness", 1000.0))
+                V = orc.volume(pos, p.tri, p.body_rows)
+                E += 0.5 * k * (V - float(p.target_volume)) ** 2
+        else:
+            raise ValueError(name)
+    return float(E)
+
+
+# runtime/topology.py:174-199 (min over mesh edges == min over facet edges)
+def min_edge_length(pos: np.ndarray, tri: np.ndarray) -> float:
+    if tri.shape[0] == 0:
+        return 0.0
+    v0, v1, v2 = pos[tri[:, 0]], pos[tri[:, 1]], pos[tri[:, 2]]
+    m = min(
+        float(np.min(np.linalg.norm(v1 - v0, axis=1))),
+        float(np.min(np.linalg.norm(v2 - v1, axis=1))),
+        float(np.min(np.linalg.norm(v0 - v2, axis=1))),
+    )
+    return m
+
+
+# runtime/topology.py:13-48
+def check_max_normal_change_positions(tri, old, new, limit_radians=0.5) -> bool:
+    if tri.size == 0:
+        return True
+    n_old = np.cross(old[tri[:, 1]] - old[tri[:, 0]], old[tri[:, 2]] - old[tri[:, 0]])
+    norms_old = np.linalg.norm(n_old, axis=1)
+    good = norms_old > 1e-12
+    if not np.any(good):
+        return True
+    n_old = n_old[good] / norms_old[good][:, None]
+    tg = tri[good]
+    n_new = np.cross(new[tg[:, 1]] - new[tg[:, 0]], new[tg[:, 2]] - new[tg[:, 0]])
+    norms_new = np.linalg.norm(n_new, axis=1)
+    if np.any(norms_new < 1e-12):
+        return False
+    n_new = n_new / norms_new[:, None]
+    dots = np.clip(np.sum(n_old * n_new, axis=1), -1.0, 1.0)
+    return bool(np.all(np.arccos(dots) <= limit_radians))
+
+
+# modules/constraints/volume.py:69-149 enforce_constraint (projection loop)
+def project_volume(p: Problem, pos: np.ndarray, tol=1e-12, max_iter=3) -> np.ndarray:
+    for _ in range(max_iter):
+        V = orc.volume(pos, p.tri, p.body_rows)
+        delta = V - float(p.target_volume)
+        if abs(delta) < tol:
+            break
+        g = np.zeros_like(pos)
+        orc.volume_gradient(pos, p.tri, g, factor=1.0, body_rows=p.body_rows)
+        norm_sq = float(np.sum(g * g)) + 1e-12
+        lam = delta / norm_sq
+        pos = pos.copy()
+        pos[~p.fixed] -= lam * g[~p.fixed]
+    return pos
+
+
+@dataclass
+class LineSearchResult:
+    success: bool
+    next_step: float
+    energy: float
+    alpha: float
+    trials: int
+
+
+# runtime/steppers/line_search.py:267-541 backtracking_line_search_array
+def line_search(p: Problem, direction, gradient, step_size, *, max_iter=10, beta=0.7,
+                c=1e-4, gamma=1.5, alpha_max_factor=10.0, enforcer=None) -> LineSearchResult:
+    movable = ~p.fixed
+    baseline = p.positions.copy()
+    energy0 = energy_total(p, baseline)
+    min_edge = min_edge_length(baseline, p.tri)
+    safe_limit = 0.3 * min_edge if min_edge > 0 else float("inf")
+    max_dir = float(np.max(np.linalg.norm(direction[movable], axis=1))) if movable.any() else 0.0
+    g_dot_d = float(np.sum(gradient * direction))
+    if g_dot_d >= 0.0:
+        return LineSearchResult(False, step_size, energy0, 0.0, 0)
+    alpha = step_size
+    edge_fraction = float(p.gp.get("shape_step_edge_fraction", 0.0) or 0.0)
+    if edge_fraction > 0.0 and min_edge > 0.0 and max_dir > 0.0:
+        alpha = min(alpha, edge_fraction * min_edge / max_dir)
+    alpha_max = alpha_max_factor * step_size
+    trials = 0
+    for _ in range(max_iter):
+        safe_small = alpha * max_dir < safe_limit
+        trial = baseline.copy()
+        trial[movable] = baseline[movable] + alpha * direction[movable]
+        if not safe_small:
+            if not check_max_normal_change_positions(p.tri, baseline, trial):
+                alpha *= beta
+                if alpha < 1e-8:
+                    break
+                continue
+        if enforcer is not None:
+            trial = enforcer(trial)
+        E_t = energy_total(p, trial)
+        trials += 1
+        if E_t <= energy0 + c * alpha * g_dot_d:
+            p.positions = trial
+            return LineSearchResult(True, min(alpha * gamma, alpha_max), float(E_t), alpha, trials)
+        alpha *= beta
+        if alpha < 1e-8:
+            break
+    reduced = max(alpha * beta, 0.0)
+    return LineSearchResult(False, max(reduced, step_size * beta), float(energy0), alpha, trials)
+
+
+class GradientDescent:
+    """runtime/steppers/gradient_descent.py:35-84."""
+
+    def __init__(self, max_iter=10, beta=0.7, c=1e-4, gamma=1.5, alpha_max_factor=10.0):
+        self.max_iter, self.beta, self.c, self.gamma, self.alpha_max_factor = (
+            max_iter, beta, c, gamma, alpha_max_factor)
+        self.last_direction = None
+
+    def reset(self):
+        pass
+
+    def step(self, p: Problem, grad, step_size, enforcer=None) -> LineSearchResult:
+        max_iter = int(p.gp.get("shape_line_search_max_iter", self.max_iter) or self.max_iter)
+        direction = -grad
+        self.last_direction = direction
+        return line_search(p, direction, grad, step_size, max_iter=max_iter, beta=self.beta,
+                           c=self.c, gamma=self.gamma, alpha_max_factor=self.alpha_max_factor,
+                           enforcer=enforcer)
+
+
+class ConjugateGradient:
+    """runtime/steppers/conjugate_gradient.py:17-119 (per-row Polak-Ribiere)."""
+
+    def __init__(self, restart_interval=10, max_iter=10, beta=0.7, c=1e-4, gamma=1.5,
+                 alpha_max_factor=10.0):
+        self.restart_interval = restart_interval
+        self.max_iter, self.beta, self.c, self.gamma, self.alpha_max_factor = (
+            max_iter, beta, c, gamma, alpha_max_factor)
+        self.reset()
+
+    def reset(self):
+        self.prev_grad = None
+        self.prev_dir = None
+        self.iter_count = 0
+        self.last_direction = None
+
+    def step(self, p: Problem, grad, step_size, enforcer=None) -> LineSearchResult:
+        g = grad
+        if self.prev_grad is None or self.iter_count % self.restart_interval == 0:
+            direction = -g
+        else:
+            numer = np.einsum("ij,ij->i", g, g - self.prev_grad)
+            denom = np.einsum("ij,ij->i", self.prev_grad, self.prev_grad) + 1e-20
+            beta_pr = numer / denom
+            direction = -g + beta_pr[:, None] * self.prev_dir
+            reset_mask = beta_pr < 0
+            if np.any(reset_mask):
+                direction[reset_mask] = -g[reset_mask]
+        direction[p.fixed] = 0.0
+        self.last_direction = direction
+        res = line_search(p, direction, grad, step_size, max_iter=self.max_iter, beta=self.beta,
+                          c=self.c, gamma=self.gamma, alpha_max_factor=self.alpha_max_factor,
+                          enforcer=enforcer)
+        if res.success:
+            self.prev_grad = grad.copy()
+            self.prev_dir = direction.copy()
+            self.iter_count += 1
+        return res
+
+
+# runtime/minimizer.py:1189-1535 Minimizer.minimize (shape path, tilt_solve_mode "fixed")
+def minimize(p: Problem, stepper, n_steps: int, step_size: float = 1e-3, tol: float = 1e-6):
+    has_enforceable = "volume" in p.constraint_modules
+    proj_flag = bool(p.gp.get("volume_projection_during_minimization", True))
+    vol_tol = float(p.gp.get("volume_tolerance", 1e-3))
+    max_zero_steps = int(p.gp.get("max_zero_steps", 10))
+    step_floor = float(p.gp.get("step_size_floor", 1e-8))
+    step_mode = str(p.gp.get("step_size_mode", "adaptive") or "adaptive").lower()
+    trace = []
+
+    def enforce(pos, context):
+        # constraint_manager.enforce_all :843-905 (volume only)
+        if context == "minimize" and not proj_flag:
+            return pos
+        if p.target_volume is None:
+            return pos
+        return project_volume(p, pos, max_iter=12 if context in ("finalize", "mesh_operation") else 3)
+
+    enforcer = (lambda pos: enforce(pos, "minimize")) if has_enforceable else None
+
+    if has_enforceable:
+        p.positions = enforce(p.positions, "mesh_operation")
+
+    zero_steps = 0
+    step_success = True
+    grad = None
+    for i in range(n_steps):
+        E, grad = energy_and_gradient(p, p.positions)
+        grad_norm = float(np.linalg.norm(grad))
+        if grad_norm < tol:
+            if has_enforceable:
+                p.positions = enforce(p.positions, "finalize")
+            return {"energy": E, "gradient": grad, "step_success": True, "iterations": i + 1,
+                    "terminated_early": True, "trace": trace, "step_size": step_size}
+        fixed_step = float(p.gp.get("step_size", step_size) or step_size)
+        step_in = fixed_step if step_mode == "fixed" else step_size
+        res = stepper.step(p, grad, step_in, enforcer=enforcer)
+        step_success, step_size = res.success, res.next_step
+        trace.append({"E": E, "grad_norm": grad_norm, "success": res.success, "alpha": res.alpha,
+                      "E_accepted": res.energy, "next_step": res.next_step, "trials": res.trials})
+        if step_mode == "fixed":
+            step_size = fixed_step
+        if not step_success:
+            if step_size <= step_floor:
+                zero_steps += 1
+                if zero_steps >= max_zero_steps:
+                    return {"energy": energy_total(p, p.positions), "gradient": grad,
+                            "step_success": False, "iterations": i + 1, "terminated_early": True,
+                            "trace": trace, "step_size": step_size}
+            else:
+                zero_steps = 0
+            stepper.reset()
+        else:
+            zero_steps = 0
+            if p.volume_mode == "lagrange" and not proj_flag and p.target_volume is not None:
+                V = orc.volume(p.positions, p.tri, p.body_rows)
+                rel = abs(V - p.target_volume) / max(abs(p.target_volume), 1.0)
+                if rel > vol_tol:
+                    if has_enforceable:
+                        p.positions = enforce(p.positions, "mesh_operation")
+                    stepper.reset()
+    if has_enforceable:
+        p.positions = enforce(p.positions, "finalize")
+    return {"energy": energy_total(p, p.positions), "gradient": grad, "step_success": step_success,
+            "iterations": n_steps, "terminated_early": False, "trace": trace, "step_size": step_size}

@@ -1,0 +1,244 @@
+"""ctypes front-end for the CPU oracle (oracle/ms_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  Nothing under membrane_solver_amd/ imports it.
+
+Each wrapper takes/returns NumPy arrays in the reference's row order
+((n,3) float64 C-order, int32 triangle rows) and cites the reference routine
+the underlying C function restates.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libms_oracle.so")
+_lib = None
+
+_D = ctypes.POINTER(ctypes.c_double)
+_I = ctypes.POINTER(ctypes.c_int32)
+_B = ctypes.POINTER(ctypes.c_uint8)
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "ms_oracle.c")
+    if (
+        force
+        or not os.path.exists(_LIB_PATH)
+        or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)
+    ):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.orc_volume.restype = ctypes.c_double
+        _lib.orc_bending_energy_and_gradient.restype = ctypes.c_int
+        _lib.orc_bending_energy.restype = ctypes.c_int
+    return _lib
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _pd(a):
+    return None if a is None else a.ctypes.data_as(_D)
+
+
+def _pi(a):
+    return None if a is None else a.ctypes.data_as(_I)
+
+
+def _pb(a):
+    return None if a is None else a.ctypes.data_as(_B)
+
+
+# --- surface ---------------------------------------------------------------
+def surface_energy_and_gradient(pos, tri, gamma, grad=None) -> float:
+    """fortran_kernels/surface_energy.f90:27-99 (grad accumulated in place)."""
+    pos, tri, gamma = _f64(pos), _i32(tri), _f64(gamma)
+    if grad is not None and not (
+        grad.dtype == np.float64 and grad.flags["C_CONTIGUOUS"]
+    ):
+        raise ValueError("grad must be C-contiguous float64 (in-place accumulate)")
+    E = ctypes.c_double(0.0)
+    lib().orc_surface_energy_and_gradient(
+        ctypes.c_int(pos.shape[0]), ctypes.c_int(tri.shape[0]), _pd(pos), _pi(tri),
+        _pd(gamma), _pd(grad), ctypes.byref(E),
+    )
+    return float(E.value)
+
+
+# --- bending kernels -----------------------------------------------------------
+def grad_cotan_batch(u, v):
+    """fortran_kernels/bending_kernels.f90:32-74."""
+    u, v = _f64(u), _f64(v)
+    gu, gv = np.empty_like(u), np.empty_like(v)
+    lib().orc_grad_cotan_batch(ctypes.c_int(u.shape[0]), _pd(u), _pd(v), _pd(gu), _pd(gv))
+    return gu, gv
+
+
+def apply_beltrami_laplacian(weights, tri, field):
+    """fortran_kernels/bending_kernels.f90:87-131."""
+    weights, tri, field = _f64(weights), _i32(tri), _f64(field)
+    out = np.empty_like(field)
+    dim = 1 if field.ndim == 1 else field.shape[1]
+    lib().orc_apply_beltrami_laplacian(
+        ctypes.c_int(dim), ctypes.c_int(field.shape[0]), ctypes.c_int(tri.shape[0]),
+        _pd(weights), _pi(tri), _pd(field), _pd(out),
+    )
+    return out
+
+
+def p1_triangle_divergence(pos, tilts, tri):
+    """fortran_kernels/tilt_kernels.f90:26-86 -> (div, area, g0, g1, g2)."""
+    pos, tilts, tri = _f64(pos), _f64(tilts), _i32(tri)
+    nf = tri.shape[0]
+    div = np.empty(nf)
+    area = np.empty(nf)
+    g0, g1, g2 = np.empty((nf, 3)), np.empty((nf, 3)), np.empty((nf, 3))
+    lib().orc_p1_triangle_divergence(
+        ctypes.c_int(pos.shape[0]), ctypes.c_int(nf), _pd(pos), _pd(tilts), _pi(tri),
+        _pd(div), _pd(area), _pd(g0), _pd(g1), _pd(g2),
+    )
+    return div, area, g0, g1, g2
+
+
+def compute_curvature_data(pos, tri, want_corner_areas: bool = False):
+    """fortran_kernels/tilt_kernels.f90:88-190 -> (k_vecs, vertex_areas, weights[, va0, va1, va2])."""
+    pos, tri = _f64(pos), _i32(tri)
+    nv, nf = pos.shape[0], tri.shape[0]
+    k = np.empty((nv, 3))
+    A = np.empty(nv)
+    w = np.empty((nf, 3))
+    va = [np.empty(nf) for _ in range(3)] if want_corner_areas else [None] * 3
+    lib().orc_compute_curvature_data(
+        ctypes.c_int(nv), ctypes.c_int(nf), _pd(pos), _pi(tri), _pd(k), _pd(A), _pd(w),
+        _pd(va[0]), _pd(va[1]), _pd(va[2]),
+    )
+    if want_corner_areas:
+        return k, A, w, va[0], va[1], va[2]
+    return k, A, w
+
+
+def effective_areas(pos, tri, weights, is_boundary):
+    """modules/energy/bending_utils.py:37-171 -> (vertex_areas_eff, va_eff (nf,3))."""
+    pos, tri, weights = _f64(pos), _i32(tri), _f64(weights)
+    isb = _u8(is_boundary)
+    A = np.empty(pos.shape[0])
+    va = np.empty((tri.shape[0], 3))
+    lib().orc_effective_areas(
+        ctypes.c_int(pos.shape[0]), ctypes.c_int(tri.shape[0]), _pd(pos), _pi(tri),
+        _pd(weights), _pb(isb), _pd(A), _pd(va),
+    )
+    return A, va
+
+
+def vertex_normals(pos, tri):
+    """modules/energy/bending_utils.py:13-34."""
+    pos, tri = _f64(pos), _i32(tri)
+    n = np.empty_like(pos)
+    lib().orc_vertex_normals(ctypes.c_int(pos.shape[0]), ctypes.c_int(tri.shape[0]), _pd(pos), _pi(tri), _pd(n))
+    return n
+
+
+_MODEL = {"helfrich": 0, "willmore": 1}
+_MODE = {"analytic": 0, "approx": 1}
+
+
+def bending_energy_and_gradient(pos, tri, kappa, c0, is_boundary, *, model="helfrich",
+                                mode="analytic", grad=None, want_factors=False):
+    """modules/energy/bending.py:90-181 (+ bending_gradient.py:17-175)."""
+    pos, tri = _f64(pos), _i32(tri)
+    nv = pos.shape[0]
+    kappa, c0 = _f64(kappa, (nv,)), _f64(c0, (nv,))
+    isb = _u8(is_boundary)
+    if grad is not None and not (grad.dtype == np.float64 and grad.flags["C_CONTIGUOUS"]):
+        raise ValueError("grad must be C-contiguous float64")
+    fK = np.empty((nv, 3)) if want_factors else None
+    fAe = np.empty(nv) if want_factors else None
+    fAv = np.empty(nv) if want_factors else None
+    E = ctypes.c_double(0.0)
+    rc = lib().orc_bending_energy_and_gradient(
+        ctypes.c_int(nv), ctypes.c_int(tri.shape[0]), _pd(pos), _pi(tri), _pd(kappa),
+        _pd(c0), _pb(isb), ctypes.c_int(_MODEL[model]), ctypes.c_int(_MODE[mode]),
+        _pd(grad), ctypes.byref(E), _pd(fK), _pd(fAe), _pd(fAv),
+    )
+    if rc != 0:
+        raise MemoryError("oracle allocation failed")
+    if want_factors:
+        return float(E.value), fK, fAe, fAv
+    return float(E.value)
+
+
+def bending_energy(pos, tri, kappa, c0, is_boundary, *, model="helfrich", per_vertex=False):
+    """modules/energy/bending.py:62-87 compute_energy_array."""
+    pos, tri = _f64(pos), _i32(tri)
+    nv = pos.shape[0]
+    kappa, c0 = _f64(kappa, (nv,)), _f64(c0, (nv,))
+    isb = _u8(is_boundary)
+    pv = np.empty(nv) if per_vertex else None
+    E = ctypes.c_double(0.0)
+    rc = lib().orc_bending_energy(
+        ctypes.c_int(nv), ctypes.c_int(tri.shape[0]), _pd(pos), _pi(tri), _pd(kappa),
+        _pd(c0), _pb(isb), ctypes.c_int(_MODEL[model]), ctypes.byref(E), _pd(pv),
+    )
+    if rc != 0:
+        raise MemoryError("oracle allocation failed")
+    return (float(E.value), pv) if per_vertex else float(E.value)
+
+
+# --- volume -------------------------------------------------------------------
+def volume(pos, tri, body_rows=None) -> float:
+    """geometry/body.py:70-148 (vectorised branch)."""
+    pos, tri = _f64(pos), _i32(tri)
+    rows = None if body_rows is None else _i32(body_rows)
+    n = tri.shape[0] if rows is None else rows.shape[0]
+    return float(lib().orc_volume(ctypes.c_int(pos.shape[0]), ctypes.c_int(n), _pd(pos), _pi(tri), _pi(rows)))
+
+
+def volume_gradient(pos, tri, grad, factor=1.0, body_rows=None) -> None:
+    """geometry/body.py:150-190 accumulate_volume_gradient (in place)."""
+    pos, tri = _f64(pos), _i32(tri)
+    rows = None if body_rows is None else _i32(body_rows)
+    n = tri.shape[0] if rows is None else rows.shape[0]
+    if not (grad.dtype == np.float64 and grad.flags["C_CONTIGUOUS"]):
+        raise ValueError("grad must be C-contiguous float64")
+    lib().orc_volume_gradient(
+        ctypes.c_int(pos.shape[0]), ctypes.c_int(n), _pd(pos), _pi(tri), _pi(rows),
+        ctypes.c_double(factor), _pd(grad),
+    )
+
+
+# --- tilt -----------------------------------------------------------------------
+def tilt_energy_and_gradient(pos, tilts, tri, k_tilt, grad=None, tilt_grad=None) -> float:
+    """modules/energy/tilt.py:99-172."""
+    pos, tilts, tri = _f64(pos), _f64(tilts), _i32(tri)
+    E = ctypes.c_double(0.0)
+    lib().orc_tilt_energy_and_gradient(
+        ctypes.c_int(pos.shape[0]), ctypes.c_int(tri.shape[0]), _pd(pos), _pd(tilts),
+        _pi(tri), ctypes.c_double(k_tilt), _pd(grad), _pd(tilt_grad), ctypes.byref(E),
+    )
+    return float(E.value)
