@@ -1,0 +1,234 @@
+/*
+ * membrane_hip.h -- C ABI of libmembrane_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE path of AvishaiBarnoy/membrane_solver: the
+ * per-iteration energy + gradient assembly (surface tension, Helfrich /
+ * Willmore bending, volume penalty + volume-constraint row) and the GD / CG
+ * steppers with Armijo backtracking that consume it.  Reference citations are
+ * relative to the reference checkout.
+ *
+ * Conventions
+ *   - plain C types only; all host arrays are row-major, positions/gradients
+ *     (nv,3) double, triangle rows (nf,3) int32 zero based -- the layouts of
+ *     Mesh.positions_view (geometry/mesh.py:372-389) and
+ *     Mesh.triangle_row_cache (geometry/mesh.py:597-624).  A row-major (n,3)
+ *     array is byte-identical to the (3,n) Fortran-order arrays the
+ *     reference's f2py kernels take, so the same pointers serve both seams.
+ *   - every function returns MS_OK (0) or a negative MS_ERR_*; nothing
+ *     throws; ms_last_error() gives the text.  No global mutable state but
+ *     the last-error string of failed ms_create calls.
+ *   - one context per device/process; a context is not thread-safe (the
+ *     reference is single threaded).
+ *   - all state lives in HBM between calls; host arrays cross PCIe only in
+ *     the ms_set_* / ms_get_* calls and the *_host seam calls.
+ */
+#ifndef MEMBRANE_HIP_H
+#define MEMBRANE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MS_OK 0
+#define MS_ERR_INVALID (-1)       /* bad argument / shape                      */
+#define MS_ERR_HIP (-2)           /* a HIP runtime call failed                 */
+#define MS_ERR_TILE_CAPACITY (-3) /* a vertex patch does not fit LDS / uint16  */
+#define MS_ERR_STATE (-4)         /* call order (e.g. gradient before energy)  */
+#define MS_ERR_NOMEM (-5)
+
+/* energy-module bits (modules/energy/{surface,bending,volume}.py) */
+#define MS_MOD_SURFACE 1u
+#define MS_MOD_BENDING 2u
+#define MS_MOD_VOLUME_PENALTY 4u /* modules/energy/volume.py:94-128            */
+/* constraint row: modules/constraints/volume.py:43-66 + the k==1 dense KKT
+ * branch of runtime/constraint_manager.py:293-301 */
+#define MS_CON_VOLUME 8u
+
+/* bending_params.py:19-33 */
+#define MS_BEND_HELFRICH 0
+#define MS_BEND_WILLMORE 1
+#define MS_GRAD_ANALYTIC 0
+#define MS_GRAD_APPROX 1
+
+#define MS_STEPPER_GD 0 /* runtime/steppers/gradient_descent.py:35-84        */
+#define MS_STEPPER_CG 1 /* runtime/steppers/conjugate_gradient.py:52-119     */
+
+typedef struct ms_ctx ms_ctx;
+
+/* Names of the device-resident per-vertex buffers (internal patch order). */
+enum ms_buffer {
+  MS_BUF_X = 0,     /* positions                      (nvp,3) */
+  MS_BUF_XT = 1,    /* trial positions                (nvp,3) */
+  MS_BUF_G = 2,     /* gradient                       (nvp,3) */
+  MS_BUF_GC = 3,    /* volume-constraint row dV/dx    (nvp,3) */
+  MS_BUF_D = 4,     /* search direction               (nvp,3) */
+  MS_BUF_PG = 5,    /* CG history: previous gradient  (nvp,3) */
+  MS_BUF_PD = 6,    /* CG history: previous direction (nvp,3) */
+  MS_BUF_FK = 7,    /* bending: factor_K_vec          (nvp,3) */
+  MS_BUF_FA = 8,    /* bending: fA_eff, fA_vor        (nvp,2) */
+  MS_BUF_SCAL = 9,  /* reduction scalars              (MS_NSCAL) */
+  MS_BUF_COUNT = 10
+};
+
+/* Reduction scalars produced on the device (ms_fetch_scalars). */
+enum ms_scalar {
+  MS_S_ESURF = 0,   /* sum gamma_f A_f                                  */
+  MS_S_VOL = 1,     /* body volume, geometry/body.py:104-123            */
+  MS_S_EBEND = 2,   /* bending energy, modules/energy/bending.py:117-144 */
+  MS_S_MINEDGE2 = 3, /* min squared edge length, runtime/topology.py:174  */
+  MS_S_GUARD = 4,   /* >0: normal-rotation guard tripped, topology.py:13  */
+  MS_S_GGC = 5,     /* <g, gC>                                          */
+  MS_S_GCGC = 6,    /* <gC, gC>                                         */
+  MS_S_GNORM2 = 7,  /* |g|^2 after projection and fixed-row zeroing     */
+  MS_S_GDOTD = 8,   /* <g, d>                                           */
+  MS_S_MAXD2 = 9,   /* max_i |d_i|^2 over movable rows                  */
+  MS_S_ETILT = 10,  /* tilt magnitude energy, modules/energy/tilt.py    */
+  MS_NSCAL = 16
+};
+
+typedef struct ms_params {
+  uint32_t modules;        /* MS_MOD_* | MS_CON_VOLUME                          */
+  int bending_model;       /* MS_BEND_*                                         */
+  int bending_grad_mode;   /* MS_GRAD_*                                         */
+  double volume_stiffness; /* penalty mode k                                    */
+  double target_volume;    /* V0 (penalty energy and constraint target)         */
+} ms_params;
+
+typedef struct ms_stepper_params {
+  int stepper;             /* MS_STEPPER_*                                      */
+  int max_iter;            /* Armijo trials, default 10                         */
+  double beta;             /* backtrack factor 0.7                              */
+  double c;                /* Armijo slope 1e-4                                 */
+  double gamma;            /* growth 1.5                                        */
+  double alpha_max_factor; /* 10                                                */
+  int restart_interval;    /* CG restart, 10                                    */
+  double edge_fraction;    /* gp["shape_step_edge_fraction"], 0 = off           */
+  int reuse_energy0;       /* 0: re-evaluate energy0 like line_search.py:294;
+                              1: reuse the energy of the gradient evaluation   */
+} ms_stepper_params;
+
+typedef struct ms_step_result {
+  int success;        /* line search accepted a step                            */
+  int converged;      /* |g| < tol before stepping (minimizer.py:1324)          */
+  int trials;         /* energy evaluations spent in the line search            */
+  int guard_rejects;  /* trials rejected by the normal-rotation guard           */
+  double next_step;   /* step size to use next (line_search.py:398-404,425)     */
+  double energy;      /* accepted energy, or energy0 on failure                 */
+  double alpha;       /* accepted alpha (0 on failure)                          */
+  double energy_eval; /* energy of the gradient evaluation                      */
+  double grad_norm;   /* |g|_2                                                  */
+  double g_dot_d;
+  double volume;      /* body volume at the (possibly new) positions            */
+} ms_step_result;
+
+const char *ms_version(void);
+int ms_device_count(void);
+const char *ms_last_error(const ms_ctx *ctx); /* ctx may be NULL */
+
+/*
+ * Build a context: vertices are put in patch (Hilbert) order, cut into tiles
+ * of `tile_vertices` owned vertices (0 = 256), and the tile->facet /
+ * tile->halo-vertex CSR is pushed to HBM once.  Replaces the per-step reads of
+ * Mesh.triangle_row_cache / fixed_mask / boundary_vertex_ids
+ * (geometry/mesh.py:597-624, :210-232, :304-319).  `fixed`, `boundary`,
+ * `body_facets` (1 = facet belongs to the body, geometry/body.py:60-68) may be
+ * NULL (none fixed / closed surface / all facets).  Facets with an index
+ * outside [0,nv) are dropped, as fortran_kernels/surface_energy.f90:57-59 does.
+ * shard_rank/shard_count: this context evaluates tiles of that shard only
+ * (1 process per GPU; per-vertex buffers stay full size, see ms_shard_info).
+ */
+int ms_create(ms_ctx **out, int device, int nv, int nf, const double *positions,
+              const int32_t *tri, const uint8_t *fixed, const uint8_t *boundary,
+              const uint8_t *body_facets, int tile_vertices, int shard_rank,
+              int shard_count);
+void ms_destroy(ms_ctx *ctx);
+
+/* Launch on the caller's HIP stream (hipStream_t as void*); NULL = own stream. */
+int ms_set_stream(ms_ctx *ctx, void *hip_stream);
+
+/* Mesh.get_facet_parameter_array("surface_tension") (geometry/mesh.py:234-265) */
+int ms_set_surface_tension(ms_ctx *ctx, const double *gamma /* nf */);
+/* bending_params._per_vertex_params (modules/energy/bending_params.py:41-115) */
+int ms_set_bending_params(ms_ctx *ctx, const double *kappa /* nv */,
+                          const double *c0 /* nv */);
+int ms_set_params(ms_ctx *ctx, const ms_params *p);
+
+int ms_set_positions(ms_ctx *ctx, const double *positions /* nv*3 */);
+int ms_get_positions(ms_ctx *ctx, double *positions /* nv*3 */);
+int ms_get_gradient(ms_ctx *ctx, double *grad /* nv*3 */);
+int ms_get_vertex_buffer(ms_ctx *ctx, int buffer, double *out /* nv*ncomp */);
+
+/*
+ * Minimizer.compute_energy_and_gradient_array (runtime/minimizer.py:941-992):
+ * module loop, volume-constraint projection, fixed rows zeroed.  energies[3] =
+ * {surface, bending, volume-penalty}.  grad may be NULL (stays on device).
+ */
+int ms_energy_and_gradient(ms_ctx *ctx, double energies[3], double *grad);
+/* EvaluationManager.compute_energy_array_total (evaluation_manager.py:184-225) */
+int ms_energy(ms_ctx *ctx, double energies[3]);
+
+/* One stepper.step at the current positions (the body of minimizer.py:1314-1374
+ * + line_search.py:267-426), fully device resident. */
+int ms_step(ms_ctx *ctx, const ms_stepper_params *sp, double step_size,
+            double tol, ms_step_result *out);
+/* ConjugateGradient.reset (conjugate_gradient.py:44-50) */
+int ms_reset_stepper(ms_ctx *ctx);
+/* modules/constraints/volume.enforce_constraint projection loop (:117-149) */
+int ms_project_volume(ms_ctx *ctx, double target, double tol, int max_iter,
+                      int *iters_out, double *volume_out);
+
+/* ---- phase-level entry points (multi-GPU drivers interleave collectives) -- */
+/* energy pass over this shard's tiles at x (+ alpha*d if use_direction);
+ * writes trial positions to XT when write_trial; guard != 0 also evaluates the
+ * normal-rotation guard.  Asynchronous; partial sums are reduced into SCAL. */
+int ms_phase_energy(ms_ctx *ctx, int use_direction, double alpha, int write_trial,
+                    int guard, int write_bending_factors);
+int ms_phase_gradient(ms_ctx *ctx);   /* gradient pass (needs bending factors) */
+int ms_phase_direction(ms_ctx *ctx, int stepper, int use_history);
+int ms_phase_accept(ms_ctx *ctx, int keep_history); /* x <- xt, CG history     */
+int ms_fetch_scalars(ms_ctx *ctx, double *out /* MS_NSCAL */); /* synchronises */
+int ms_store_scalars(ms_ctx *ctx, const double *in /* MS_NSCAL */);
+
+/* device pointer + geometry of a per-vertex buffer, for RCCL collectives on it */
+int ms_device_buffer(ms_ctx *ctx, int buffer, void **dev_ptr, size_t *bytes);
+/* rows = padded vertex rows (nvp); this shard owns rows [row0,row1) */
+int ms_shard_info(ms_ctx *ctx, int64_t *nvp, int64_t *row0, int64_t *row1,
+                  int64_t *rows_per_shard);
+/* tiling statistics: n_tiles, facet instances (with halo duplicates), max halo */
+int ms_tile_stats(ms_ctx *ctx, int64_t *n_tiles, int64_t *facet_instances,
+                  int64_t *max_halo, int64_t *lds_bytes_energy,
+                  int64_t *lds_bytes_gradient);
+
+/* ---- kernel-provider seam: the five procedures under fortran_kernels/ ----
+ * Host arrays in, host arrays out (H2D/D2H per call: for parity, not speed).
+ * Semantics follow the Fortran: see fortran_kernels/loader.py:15-20 KernelSpec.
+ */
+/* surface_energy.f90:27-99 -- grad (nv*3) is ACCUMULATED into */
+int ms_surface_energy_and_gradient_host(int nv, int nf, const double *pos,
+                                        const int32_t *tri, const double *gamma,
+                                        double *grad, double *energy);
+/* bending_kernels.f90:32-74 */
+int ms_grad_cotan_batch_host(int n, const double *u, const double *v,
+                             double *grad_u, double *grad_v);
+/* bending_kernels.f90:87-131 -- out is overwritten (zeroed first) */
+int ms_apply_beltrami_laplacian_host(int dim, int nv, int nf,
+                                     const double *weights, const int32_t *tri,
+                                     const double *field, double *out);
+/* tilt_kernels.f90:26-86 */
+int ms_p1_triangle_divergence_host(int nv, int nf, const double *pos,
+                                   const double *tilts, const int32_t *tri,
+                                   double *div_tri, double *area, double *g0,
+                                   double *g1, double *g2);
+/* tilt_kernels.f90:88-190 -- va0..va2 may be NULL */
+int ms_compute_curvature_data_host(int nv, int nf, const double *pos,
+                                   const int32_t *tri, double *k_vecs,
+                                   double *vertex_areas, double *weights,
+                                   double *va0, double *va1, double *va2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEMBRANE_HIP_H */

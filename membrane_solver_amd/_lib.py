@@ -1,0 +1,155 @@
+"""ctypes binding of libmembrane_hip.so (include/membrane_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing, or a
+call returns an error, a ``MembraneHipError`` is raised.  ``build()`` compiles
+the library in-tree with hipcc for gfx950.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmembrane_hip.so")
+_CSRC = os.path.join(_PKG, "csrc")
+
+MS_OK = 0
+MS_ERR = {-1: "MS_ERR_INVALID", -2: "MS_ERR_HIP", -3: "MS_ERR_TILE_CAPACITY",
+          -4: "MS_ERR_STATE", -5: "MS_ERR_NOMEM"}
+
+MS_MOD_SURFACE = 1
+MS_MOD_BENDING = 2
+MS_MOD_VOLUME_PENALTY = 4
+MS_CON_VOLUME = 8
+MS_BEND_HELFRICH, MS_BEND_WILLMORE = 0, 1
+MS_GRAD_ANALYTIC, MS_GRAD_APPROX = 0, 1
+MS_STEPPER_GD, MS_STEPPER_CG = 0, 1
+
+(MS_BUF_X, MS_BUF_XT, MS_BUF_G, MS_BUF_GC, MS_BUF_D, MS_BUF_PG, MS_BUF_PD, MS_BUF_FK,
+ MS_BUF_FA, MS_BUF_SCAL) = range(10)
+(MS_S_ESURF, MS_S_VOL, MS_S_EBEND, MS_S_MINEDGE2, MS_S_GUARD, MS_S_GGC, MS_S_GCGC,
+ MS_S_GNORM2, MS_S_GDOTD, MS_S_MAXD2, MS_S_ETILT) = range(11)
+MS_NSCAL = 16
+
+
+class MembraneHipError(RuntimeError):
+    """Raised for every failure of the HIP path (there is no CPU fallback)."""
+
+
+class ms_params(ctypes.Structure):
+    _fields_ = [("modules", ctypes.c_uint32), ("bending_model", ctypes.c_int),
+                ("bending_grad_mode", ctypes.c_int), ("volume_stiffness", ctypes.c_double),
+                ("target_volume", ctypes.c_double)]
+
+
+class ms_stepper_params(ctypes.Structure):
+    _fields_ = [("stepper", ctypes.c_int), ("max_iter", ctypes.c_int), ("beta", ctypes.c_double),
+                ("c", ctypes.c_double), ("gamma", ctypes.c_double),
+                ("alpha_max_factor", ctypes.c_double), ("restart_interval", ctypes.c_int),
+                ("edge_fraction", ctypes.c_double), ("reuse_energy0", ctypes.c_int)]
+
+
+class ms_step_result(ctypes.Structure):
+    _fields_ = [("success", ctypes.c_int), ("converged", ctypes.c_int), ("trials", ctypes.c_int),
+                ("guard_rejects", ctypes.c_int), ("next_step", ctypes.c_double),
+                ("energy", ctypes.c_double), ("alpha", ctypes.c_double),
+                ("energy_eval", ctypes.c_double), ("grad_norm", ctypes.c_double),
+                ("g_dot_d", ctypes.c_double), ("volume", ctypes.c_double)]
+
+
+_P = ctypes.c_void_p
+_D = ctypes.POINTER(ctypes.c_double)
+_I32 = ctypes.POINTER(ctypes.c_int32)
+_U8 = ctypes.POINTER(ctypes.c_uint8)
+_I64 = ctypes.POINTER(ctypes.c_int64)
+
+# name -> (restype, argtypes): every symbol include/membrane_hip.h declares.
+SIGNATURES = {
+    "ms_version": (ctypes.c_char_p, []),
+    "ms_device_count": (ctypes.c_int, []),
+    "ms_last_error": (ctypes.c_char_p, [_P]),
+    "ms_create": (ctypes.c_int, [ctypes.POINTER(_P), ctypes.c_int, ctypes.c_int, ctypes.c_int, _D,
+                                 _I32, _U8, _U8, _U8, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "ms_destroy": (None, [_P]),
+    "ms_set_stream": (ctypes.c_int, [_P, _P]),
+    "ms_set_surface_tension": (ctypes.c_int, [_P, _D]),
+    "ms_set_bending_params": (ctypes.c_int, [_P, _D, _D]),
+    "ms_set_params": (ctypes.c_int, [_P, ctypes.POINTER(ms_params)]),
+    "ms_set_positions": (ctypes.c_int, [_P, _D]),
+    "ms_get_positions": (ctypes.c_int, [_P, _D]),
+    "ms_get_gradient": (ctypes.c_int, [_P, _D]),
+    "ms_get_vertex_buffer": (ctypes.c_int, [_P, ctypes.c_int, _D]),
+    "ms_energy_and_gradient": (ctypes.c_int, [_P, _D, _D]),
+    "ms_energy": (ctypes.c_int, [_P, _D]),
+    "ms_step": (ctypes.c_int, [_P, ctypes.POINTER(ms_stepper_params), ctypes.c_double,
+                               ctypes.c_double, ctypes.POINTER(ms_step_result)]),
+    "ms_reset_stepper": (ctypes.c_int, [_P]),
+    "ms_project_volume": (ctypes.c_int, [_P, ctypes.c_double, ctypes.c_double, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_int), _D]),
+    "ms_phase_energy": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_int]),
+    "ms_phase_gradient": (ctypes.c_int, [_P]),
+    "ms_phase_direction": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
+    "ms_phase_accept": (ctypes.c_int, [_P, ctypes.c_int]),
+    "ms_fetch_scalars": (ctypes.c_int, [_P, _D]),
+    "ms_store_scalars": (ctypes.c_int, [_P, _D]),
+    "ms_device_buffer": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(_P),
+                                        ctypes.POINTER(ctypes.c_size_t)]),
+    "ms_shard_info": (ctypes.c_int, [_P, _I64, _I64, _I64, _I64]),
+    "ms_tile_stats": (ctypes.c_int, [_P, _I64, _I64, _I64, _I64, _I64]),
+    "ms_surface_energy_and_gradient_host": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _D, _I32, _D,
+                                                           _D, _D]),
+    "ms_grad_cotan_batch_host": (ctypes.c_int, [ctypes.c_int, _D, _D, _D, _D]),
+    "ms_apply_beltrami_laplacian_host": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _D,
+                                                        _I32, _D, _D]),
+    "ms_p1_triangle_divergence_host": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _D, _D, _I32, _D,
+                                                      _D, _D, _D, _D]),
+    "ms_compute_curvature_data_host": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _D, _I32, _D, _D,
+                                                      _D, _D, _D, _D]),
+}
+
+_lib = None
+
+
+def build(force: bool = False, fp_contract: str | None = None) -> str:
+    """Compile libmembrane_hip.so for gfx950 with hipcc (csrc/Makefile)."""
+    srcs = [os.path.join(_CSRC, f) for f in ("ms_kernels.hip", "ms_api.cpp", "ms_tiles.cpp",
+                                             "ms_internal.h")]
+    srcs.append(os.path.join(_PKG, "..", "include", "membrane_hip.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        cmd = ["make", "-s", "-C", _CSRC]
+        if force:
+            cmd.append("-B")
+        if fp_contract:
+            cmd.append(f"MS_FP_CONTRACT={fp_contract}")
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """Load the shared library; fail loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MembraneHipError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for this path.")
+        cd = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(cd, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = cd
+    return _lib
+
+
+def check(rc: int, ctx=None, what: str = "") -> None:
+    if rc == MS_OK:
+        return
+    msg = lib().ms_last_error(ctx)
+    text = msg.decode("utf-8", "replace") if msg else ""
+    raise MembraneHipError(f"{what or 'libmembrane_hip'} failed: {MS_ERR.get(rc, rc)}: {text}")

@@ -1,0 +1,811 @@
+// Host side of libmembrane_hip.so: context management, HBM residency, the
+// device-resident minimizer step, and the extern "C" ABI of
+// include/membrane_hip.h.  Arithmetic lives in ms_kernels.hip.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "ms_internal.h"
+
+using namespace ms;
+
+namespace {
+std::string g_last_error;  // for failures that have no context yet
+}
+
+struct ms_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  Tiling til;
+  int shard_rank = 0, shard_count = 1;
+  int tile0 = 0, tile1 = 0;
+  int cap = 0;
+  // connectivity in HBM
+  int32_t* d_perm = nullptr;
+  int32_t* d_tile_facet_off = nullptr;
+  TileFacet* d_tile_facets = nullptr;
+  double* d_tf_gamma = nullptr;
+  int32_t* d_tile_halo_off = nullptr;
+  int32_t* d_halo_ids = nullptr;
+  uint8_t* d_vflags = nullptr;
+  double* d_kappa = nullptr;
+  double* d_c0 = nullptr;
+  // per-vertex state (one allocation), patch order, nvp rows
+  double* state = nullptr;
+  double* buf[MS_BUF_COUNT] = {nullptr};
+  double* d_partials = nullptr;
+  double* d_scal = nullptr;
+  double* h_scal = nullptr;  // pinned mailbox
+  double* d_stage = nullptr;  // nv*3 staging in external row order
+  double* last_g = nullptr;   // buffer holding the most recent finalized gradient
+  ms_params params{};
+  bool cg_have_history = false;
+  int cg_iter_count = 0;
+  bool factors_valid = false;
+  std::string err;
+};
+
+namespace {
+
+int fail(ms_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  g_last_error = msg;
+  return code;
+}
+
+int fail_hip(ms_ctx* c, hipError_t e, const char* what) {
+  return fail(c, MS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIPCHK(c, call)                                   \
+  do {                                                    \
+    hipError_t e_ = (call);                               \
+    if (e_ != hipSuccess) return fail_hip((c), e_, #call); \
+  } while (0)
+
+DeviceMesh device_mesh(const ms_ctx* c) {
+  DeviceMesh m;
+  m.nv = c->til.nv;
+  m.T = c->til.T;
+  m.n_tiles = c->til.n_tiles;
+  m.tile_facet_off = c->d_tile_facet_off;
+  m.tile_facets = c->d_tile_facets;
+  m.tf_gamma = c->d_tf_gamma;
+  m.tile_halo_off = c->d_tile_halo_off;
+  m.halo_ids = c->d_halo_ids;
+  m.vflags = c->d_vflags;
+  m.kappa = c->d_kappa;
+  m.c0 = c->d_c0;
+  return m;
+}
+
+constexpr uint32_t MASK_ENERGY = (1u << MS_S_ESURF) | (1u << MS_S_VOL) | (1u << MS_S_EBEND) |
+                                 (1u << MS_S_MINEDGE2) | (1u << MS_S_GUARD);
+constexpr uint32_t MASK_GRAD = (1u << MS_S_GGC) | (1u << MS_S_GCGC);
+constexpr uint32_t MASK_DIR = (1u << MS_S_GNORM2) | (1u << MS_S_GDOTD) | (1u << MS_S_MAXD2);
+
+int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool write_trial,
+                 bool guard, bool write_factors) {
+  EnergyArgs a;
+  a.m = device_mesh(c);
+  a.tile0 = c->tile0;
+  a.tile1 = c->tile1;
+  a.x = c->buf[MS_BUF_X];
+  a.d = use_dir ? c->buf[MS_BUF_D] : nullptr;
+  a.alpha = alpha;
+  a.xt = write_trial ? c->buf[MS_BUF_XT] : nullptr;
+  const bool bend = (modules & MS_MOD_BENDING) != 0;
+  a.fK = (bend && write_factors) ? c->buf[MS_BUF_FK] : nullptr;
+  a.fA = (bend && write_factors) ? c->buf[MS_BUF_FA] : nullptr;
+  a.partials = c->d_partials;
+  a.bending_model = c->params.bending_model;
+  a.modules = modules;
+  HIPCHK(c, launch_energy(a, guard && use_dir, c->cap, c->stream));
+  HIPCHK(c, launch_reduce(c->d_partials, c->tile0, c->tile1, MASK_ENERGY, c->d_scal, c->stream));
+  if (bend && write_factors) c->factors_valid = !use_dir;
+  return MS_OK;
+}
+
+int phase_gradient(ms_ctx* c, uint32_t modules, double* g_out, bool accumulate) {
+  if ((modules & MS_MOD_BENDING) && !c->factors_valid)
+    return fail(c, MS_ERR_STATE, "gradient pass needs the bending factors of an energy pass at x");
+  GradientArgs a;
+  a.m = device_mesh(c);
+  a.tile0 = c->tile0;
+  a.tile1 = c->tile1;
+  a.x = c->buf[MS_BUF_X];
+  a.fK = c->buf[MS_BUF_FK];
+  a.fA = c->buf[MS_BUF_FA];
+  a.g = g_out;
+  a.gC = (modules & MS_CON_VOLUME) ? c->buf[MS_BUF_GC] : nullptr;
+  a.partials = c->d_partials;
+  a.scal = c->d_scal;
+  a.modules = modules;
+  a.bending_grad_mode = c->params.bending_grad_mode;
+  a.volume_stiffness = c->params.volume_stiffness;
+  a.target_volume = c->params.target_volume;
+  a.accumulate = accumulate ? 1 : 0;
+  HIPCHK(c, launch_gradient(a, c->cap, c->stream));
+  HIPCHK(c, launch_reduce(c->d_partials, c->tile0, c->tile1, MASK_GRAD, c->d_scal, c->stream));
+  return MS_OK;
+}
+
+int phase_direction(ms_ctx* c, int stepper, bool use_history) {
+  const bool use_con = (c->params.modules & MS_CON_VOLUME) != 0;
+  HIPCHK(c, launch_direction(c->tile0, c->tile1, c->til.nv, c->til.T, c->d_vflags, c->buf[MS_BUF_G],
+                             c->buf[MS_BUF_GC], c->buf[MS_BUF_D], c->buf[MS_BUF_PG],
+                             c->buf[MS_BUF_PD], c->d_scal, use_con ? 1 : 0,
+                             (stepper == MS_STEPPER_CG && use_history) ? 1 : 0, c->d_partials,
+                             c->stream));
+  HIPCHK(c, launch_reduce(c->d_partials, c->tile0, c->tile1, MASK_DIR, c->d_scal, c->stream));
+  c->last_g = c->buf[MS_BUF_G];
+  return MS_OK;
+}
+
+int fetch(ms_ctx* c) {
+  HIPCHK(c, hipMemcpyAsync(c->h_scal, c->d_scal, sizeof(double) * MS_NSCAL, hipMemcpyDeviceToHost,
+                           c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MS_OK;
+}
+
+double penalty_energy(const ms_ctx* c, double V) {
+  if (!(c->params.modules & MS_MOD_VOLUME_PENALTY)) return 0.0;
+  const double delta = V - c->params.target_volume;
+  return 0.5 * c->params.volume_stiffness * (delta * delta);
+}
+
+// energies from the pinned mailbox: {surface, bending, penalty}
+void energies_from_mailbox(const ms_ctx* c, double e[3]) {
+  e[0] = (c->params.modules & MS_MOD_SURFACE) ? c->h_scal[MS_S_ESURF] : 0.0;
+  e[1] = (c->params.modules & MS_MOD_BENDING) ? c->h_scal[MS_S_EBEND] : 0.0;
+  e[2] = penalty_energy(c, c->h_scal[MS_S_VOL]);
+}
+
+// gradient assembly at x: energy pass (+factors), gradient pass, finalize via
+// the direction kernel (projection + fixed rows), everything queued async.
+int queue_energy_and_gradient(ms_ctx* c, int stepper, bool use_history) {
+  const uint32_t mods = c->params.modules;
+  int rc = phase_energy(c, mods, false, 0.0, false, false, true);
+  if (rc) return rc;
+  rc = phase_gradient(c, mods, c->buf[MS_BUF_G], false);
+  if (rc) return rc;
+  return phase_direction(c, stepper, use_history);
+}
+
+template <typename Tp>
+int upload(ms_ctx* c, Tp** dst, const std::vector<Tp>& src, size_t min_elems = 1) {
+  size_t n = src.size() > min_elems ? src.size() : min_elems;
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(dst), n * sizeof(Tp)));
+  if (!src.empty())
+    HIPCHK(c, hipMemcpy(*dst, src.data(), src.size() * sizeof(Tp), hipMemcpyHostToDevice));
+  return MS_OK;
+}
+
+int ext_to_patch(ms_ctx* c, const double* host, double* dst, int ncomp) {
+  const size_t bytes = sizeof(double) * (size_t)c->til.nv * ncomp;
+  HIPCHK(c, hipMemcpyAsync(c->d_stage, host, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, launch_permute_in(c->til.nv, c->d_perm, c->d_stage, dst, ncomp, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MS_OK;
+}
+
+int patch_to_ext(ms_ctx* c, const double* src, double* host, int ncomp) {
+  const size_t bytes = sizeof(double) * (size_t)c->til.nv * ncomp;
+  HIPCHK(c, launch_permute_out(c->til.nv, c->d_perm, src, c->d_stage, ncomp, c->stream));
+  HIPCHK(c, hipMemcpyAsync(host, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MS_OK;
+}
+
+}  // namespace
+
+namespace {
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+  template <typename Tp>
+  Tp* as() {
+    return static_cast<Tp*>(p);
+  }
+};
+#define SEAM_HIP(call)                                                         \
+  do {                                                                         \
+    hipError_t e_ = (call);                                                    \
+    if (e_ != hipSuccess) return fail_hip(nullptr, e_, #call);                 \
+  } while (0)
+}  // namespace
+
+extern "C" {
+
+const char* ms_version(void) { return "membrane_hip 0.1 (gfx950)"; }
+
+int ms_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    g_last_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+    return MS_ERR_HIP;
+  }
+  return n;
+}
+
+const char* ms_last_error(const ms_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_last_error.c_str();
+}
+
+int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
+              const int32_t* tri, const uint8_t* fixed, const uint8_t* boundary,
+              const uint8_t* body_facets, int tile_vertices, int shard_rank, int shard_count) {
+  if (!out) return fail(nullptr, MS_ERR_INVALID, "ms_create: out is NULL");
+  *out = nullptr;
+  if (shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count)
+    return fail(nullptr, MS_ERR_INVALID, "ms_create: bad shard_rank/shard_count");
+  ms_ctx* c = new (std::nothrow) ms_ctx();
+  if (!c) return fail(nullptr, MS_ERR_NOMEM, "ms_create: out of host memory");
+  std::string err;
+  int rc = build_tiling(nv, nf, positions, tri, body_facets, tile_vertices, shard_count, c->til, err);
+  if (rc != MS_OK) {
+    delete c;
+    return fail(nullptr, rc, err);
+  }
+  c->device = device;
+  c->shard_rank = shard_rank;
+  c->shard_count = shard_count;
+  const Tiling& t = c->til;
+  c->tile0 = std::min(t.n_tiles, shard_rank * t.tiles_per_shard);
+  c->tile1 = std::min(t.n_tiles, (shard_rank + 1) * t.tiles_per_shard);
+  c->cap = t.T + t.max_halo;
+  {
+    const size_t le = energy_lds_bytes(t.T, c->cap, true, true);
+    const size_t lg = gradient_lds_bytes(t.T, c->cap, true);
+    if (le > 160 * 1024 || lg > 160 * 1024) {
+      delete c;
+      return fail(nullptr, MS_ERR_TILE_CAPACITY,
+                  "ms_create: a vertex patch (tile + halo) exceeds the 160 KiB LDS of a CU; "
+                  "use a smaller tile_vertices");
+    }
+  }
+#define CREATE_CHK(call)                                       \
+  do {                                                         \
+    int rc_ = (call);                                          \
+    if (rc_ != MS_OK) {                                        \
+      std::string m_ = c->err;                                 \
+      ms_destroy(c);                                           \
+      return fail(nullptr, rc_, m_);                           \
+    }                                                          \
+  } while (0)
+#define CREATE_HIP(call)                                                         \
+  do {                                                                           \
+    hipError_t e_ = (call);                                                      \
+    if (e_ != hipSuccess) {                                                      \
+      std::string m_ = std::string(#call) + ": " + hipGetErrorString(e_);        \
+      ms_destroy(c);                                                             \
+      return fail(nullptr, MS_ERR_HIP, m_);                                      \
+    }                                                                            \
+  } while (0)
+  CREATE_HIP(hipSetDevice(device));
+  CREATE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->own_stream = true;
+  CREATE_CHK(upload(c, &c->d_perm, t.perm));
+  CREATE_CHK(upload(c, &c->d_tile_facet_off, t.tile_facet_off));
+  CREATE_CHK(upload(c, &c->d_tile_facets, t.tile_facets));
+  CREATE_CHK(upload(c, &c->d_tile_halo_off, t.tile_halo_off));
+  CREATE_CHK(upload(c, &c->d_halo_ids, t.halo_ids));
+  {
+    std::vector<double> ones(t.tile_facets.size(), 1.0);
+    CREATE_CHK(upload(c, &c->d_tf_gamma, ones));
+  }
+  {
+    std::vector<uint8_t> fl((size_t)t.nvp, VF_FIXED);  // padded rows never move
+    for (int i = 0; i < nv; ++i) {
+      const int e = t.perm[i];
+      uint8_t f = 0;
+      if (fixed && fixed[e]) f |= VF_FIXED;
+      if (boundary && boundary[e]) f |= VF_BOUNDARY;
+      fl[i] = f;
+    }
+    CREATE_CHK(upload(c, &c->d_vflags, fl));
+    std::vector<double> zeros((size_t)t.nvp, 0.0);
+    CREATE_CHK(upload(c, &c->d_kappa, zeros));
+    CREATE_CHK(upload(c, &c->d_c0, zeros));
+  }
+  // state: 8 (nvp,3) vectors + fA (nvp,2)
+  {
+    const size_t n3 = 3 * (size_t)t.nvp;
+    const size_t total = 8 * n3 + 2 * (size_t)t.nvp;
+    CREATE_HIP(hipMalloc(reinterpret_cast<void**>(&c->state), total * sizeof(double)));
+    CREATE_HIP(hipMemset(c->state, 0, total * sizeof(double)));
+    for (int b = 0; b <= MS_BUF_FK; ++b) c->buf[b] = c->state + (size_t)b * n3;
+    c->buf[MS_BUF_FA] = c->state + 8 * n3;
+  }
+  CREATE_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_partials),
+                       sizeof(double) * MS_NSCAL * (size_t)std::max(1, t.n_tiles)));
+  CREATE_HIP(hipMemset(c->d_partials, 0, sizeof(double) * MS_NSCAL * (size_t)std::max(1, t.n_tiles)));
+  CREATE_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_scal), sizeof(double) * MS_NSCAL));
+  CREATE_HIP(hipMemset(c->d_scal, 0, sizeof(double) * MS_NSCAL));
+  c->buf[MS_BUF_SCAL] = c->d_scal;
+  CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scal), sizeof(double) * MS_NSCAL,
+                           hipHostMallocDefault));
+  memset(c->h_scal, 0, sizeof(double) * MS_NSCAL);
+  CREATE_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_stage), sizeof(double) * 3 * (size_t)nv));
+  c->params.modules = MS_MOD_SURFACE;
+  c->params.bending_model = MS_BEND_HELFRICH;
+  c->params.bending_grad_mode = MS_GRAD_ANALYTIC;
+  c->params.volume_stiffness = 1000.0;
+  c->params.target_volume = 0.0;
+  c->last_g = c->buf[MS_BUF_G];
+  CREATE_CHK(ext_to_patch(c, positions, c->buf[MS_BUF_X], 3));
+#undef CREATE_CHK
+#undef CREATE_HIP
+  *out = c;
+  return MS_OK;
+}
+
+void ms_destroy(ms_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  void* ptrs[] = {c->d_perm, c->d_tile_facet_off, c->d_tile_facets, c->d_tf_gamma,
+                  c->d_tile_halo_off, c->d_halo_ids, c->d_vflags, c->d_kappa, c->d_c0,
+                  c->state, c->d_partials, c->d_scal, c->d_stage};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (c->h_scal) (void)hipHostFree(c->h_scal);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int ms_set_stream(ms_ctx* c, void* hip_stream) {
+  if (!c) return MS_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->own_stream && c->stream) {
+    HIPCHK(c, hipStreamDestroy(c->stream));
+    c->own_stream = false;
+  }
+  if (hip_stream) {
+    c->stream = static_cast<hipStream_t>(hip_stream);
+  } else {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  return MS_OK;
+}
+
+int ms_set_surface_tension(ms_ctx* c, const double* gamma) {
+  if (!c || !gamma) return fail(c, MS_ERR_INVALID, "ms_set_surface_tension: NULL argument");
+  const Tiling& t = c->til;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<double> g(t.tile_facets.size());
+  for (size_t p = 0; p < g.size(); ++p) g[p] = gamma[t.tile_facet_ext[p]];
+  if (!g.empty())
+    HIPCHK(c, hipMemcpy(c->d_tf_gamma, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice));
+  return MS_OK;
+}
+
+int ms_set_bending_params(ms_ctx* c, const double* kappa, const double* c0) {
+  if (!c || !kappa || !c0) return fail(c, MS_ERR_INVALID, "ms_set_bending_params: NULL argument");
+  const Tiling& t = c->til;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<double> k((size_t)t.nvp, 0.0), z((size_t)t.nvp, 0.0);
+  for (int i = 0; i < t.nv; ++i) {
+    k[i] = kappa[t.perm[i]];
+    z[i] = c0[t.perm[i]];
+  }
+  HIPCHK(c, hipMemcpy(c->d_kappa, k.data(), k.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_c0, z.data(), z.size() * sizeof(double), hipMemcpyHostToDevice));
+  c->factors_valid = false;
+  return MS_OK;
+}
+
+int ms_set_params(ms_ctx* c, const ms_params* p) {
+  if (!c || !p) return fail(c, MS_ERR_INVALID, "ms_set_params: NULL argument");
+  if (p->bending_model != MS_BEND_HELFRICH && p->bending_model != MS_BEND_WILLMORE)
+    return fail(c, MS_ERR_INVALID, "ms_set_params: bad bending_model");
+  if (p->bending_grad_mode != MS_GRAD_ANALYTIC && p->bending_grad_mode != MS_GRAD_APPROX)
+    return fail(c, MS_ERR_INVALID, "ms_set_params: bad bending_grad_mode");
+  c->params = *p;
+  c->factors_valid = false;
+  return MS_OK;
+}
+
+int ms_set_positions(ms_ctx* c, const double* positions) {
+  if (!c || !positions) return fail(c, MS_ERR_INVALID, "ms_set_positions: NULL argument");
+  c->factors_valid = false;
+  return ext_to_patch(c, positions, c->buf[MS_BUF_X], 3);
+}
+
+int ms_get_positions(ms_ctx* c, double* positions) {
+  if (!c || !positions) return fail(c, MS_ERR_INVALID, "ms_get_positions: NULL argument");
+  return patch_to_ext(c, c->buf[MS_BUF_X], positions, 3);
+}
+
+int ms_get_gradient(ms_ctx* c, double* grad) {
+  if (!c || !grad) return fail(c, MS_ERR_INVALID, "ms_get_gradient: NULL argument");
+  return patch_to_ext(c, c->last_g, grad, 3);
+}
+
+int ms_get_vertex_buffer(ms_ctx* c, int buffer, double* out) {
+  if (!c || !out || buffer < 0 || buffer > MS_BUF_FA)
+    return fail(c, MS_ERR_INVALID, "ms_get_vertex_buffer: bad argument");
+  return patch_to_ext(c, c->buf[buffer], out, buffer == MS_BUF_FA ? 2 : 3);
+}
+
+int ms_energy_and_gradient(ms_ctx* c, double energies[3], double* grad) {
+  if (!c || !energies) return fail(c, MS_ERR_INVALID, "ms_energy_and_gradient: NULL argument");
+  if (c->shard_count != 1)
+    return fail(c, MS_ERR_STATE, "ms_energy_and_gradient: sharded contexts use the phase API");
+  int rc = queue_energy_and_gradient(c, MS_STEPPER_GD, false);
+  if (rc) return rc;
+  rc = fetch(c);
+  if (rc) return rc;
+  energies_from_mailbox(c, energies);
+  if (grad) return patch_to_ext(c, c->buf[MS_BUF_G], grad, 3);
+  return MS_OK;
+}
+
+int ms_energy(ms_ctx* c, double energies[3]) {
+  if (!c || !energies) return fail(c, MS_ERR_INVALID, "ms_energy: NULL argument");
+  if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "ms_energy: sharded contexts use the phase API");
+  int rc = phase_energy(c, c->params.modules, false, 0.0, false, false, false);
+  if (rc) return rc;
+  rc = fetch(c);
+  if (rc) return rc;
+  energies_from_mailbox(c, energies);
+  return MS_OK;
+}
+
+int ms_reset_stepper(ms_ctx* c) {
+  if (!c) return MS_ERR_INVALID;
+  c->cg_have_history = false;
+  c->cg_iter_count = 0;
+  return MS_OK;
+}
+
+int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol,
+            ms_step_result* out) {
+  if (!c || !sp || !out) return fail(c, MS_ERR_INVALID, "ms_step: NULL argument");
+  if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "ms_step: sharded contexts use the phase API");
+  memset(out, 0, sizeof(*out));
+  const bool cg = sp->stepper == MS_STEPPER_CG;
+  const int restart = sp->restart_interval > 0 ? sp->restart_interval : 10;
+  // conjugate_gradient.py:78-82: steepest descent on first call and every restart
+  const bool use_history = cg && c->cg_have_history && (c->cg_iter_count % restart != 0);
+  int rc = queue_energy_and_gradient(c, sp->stepper, use_history);
+  if (rc) return rc;
+  rc = fetch(c);
+  if (rc) return rc;
+  double e[3];
+  energies_from_mailbox(c, e);
+  const double E_eval = e[0] + e[1] + e[2];
+  const double grad_norm = std::sqrt(c->h_scal[MS_S_GNORM2]);
+  const double g_dot_d = c->h_scal[MS_S_GDOTD];
+  const double max_dir = std::sqrt(c->h_scal[MS_S_MAXD2]);
+  out->energy_eval = E_eval;
+  out->grad_norm = grad_norm;
+  out->g_dot_d = g_dot_d;
+  out->volume = c->h_scal[MS_S_VOL];
+  out->next_step = step_size;
+  out->energy = E_eval;
+  if (grad_norm < tol) {  // minimizer.py:1324
+    out->converged = 1;
+    out->success = 1;
+    return MS_OK;
+  }
+  // ---- backtracking_line_search_array (line_search.py:267-426) -------------
+  double energy0 = E_eval;
+  double min_edge = std::sqrt(c->h_scal[MS_S_MINEDGE2]);
+  if (!sp->reuse_energy0) {
+    rc = phase_energy(c, c->params.modules, false, 0.0, false, false, false);
+    if (rc) return rc;
+    rc = fetch(c);
+    if (rc) return rc;
+    energies_from_mailbox(c, e);
+    energy0 = e[0] + e[1] + e[2];
+    min_edge = std::sqrt(c->h_scal[MS_S_MINEDGE2]);
+  }
+  if (c->til.nf == 0) min_edge = 0.0;
+  out->energy = energy0;
+  const double safe_step_limit = min_edge > 0.0 ? 0.3 * min_edge : INFINITY;
+  if (g_dot_d >= 0.0) return MS_OK;  // :325-328 non-descent: (False, step_size, energy0)
+  double alpha = step_size;
+  if (sp->edge_fraction > 0.0 && min_edge > 0.0 && max_dir > 0.0)
+    alpha = std::min(alpha, sp->edge_fraction * min_edge / max_dir);
+  const double alpha_max = sp->alpha_max_factor * step_size;
+  const int max_iter = sp->max_iter > 0 ? sp->max_iter : 10;
+  for (int it = 0; it < max_iter; ++it) {
+    const bool safe_small = alpha * max_dir < safe_step_limit;
+    rc = phase_energy(c, c->params.modules, true, alpha, true, !safe_small, false);
+    if (rc) return rc;
+    rc = fetch(c);
+    if (rc) return rc;
+    if (!safe_small && c->h_scal[MS_S_GUARD] > 0.0) {
+      ++out->guard_rejects;
+      alpha *= sp->beta;
+      if (alpha < 1e-8) break;
+      continue;
+    }
+    ++out->trials;
+    energies_from_mailbox(c, e);
+    const double E_t = e[0] + e[1] + e[2];
+    if (E_t <= energy0 + sp->c * alpha * g_dot_d) {
+      std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
+      c->factors_valid = false;
+      if (cg) {  // conjugate_gradient.py:114-117 history on success only
+        std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
+        std::swap(c->buf[MS_BUF_D], c->buf[MS_BUF_PD]);
+        c->last_g = c->buf[MS_BUF_PG];
+        c->cg_have_history = true;
+        ++c->cg_iter_count;
+      }
+      out->success = 1;
+      out->alpha = alpha;
+      out->energy = E_t;
+      out->volume = c->h_scal[MS_S_VOL];
+      out->next_step = std::min(alpha * sp->gamma, alpha_max);
+      return MS_OK;
+    }
+    alpha *= sp->beta;
+    if (alpha < 1e-8) break;
+  }
+  const double reduced = std::max(alpha * sp->beta, 0.0);  // :425-426
+  out->next_step = std::max(reduced, step_size * sp->beta);
+  return MS_OK;
+}
+
+int ms_project_volume(ms_ctx* c, double target, double tol, int max_iter, int* iters_out,
+                      double* volume_out) {
+  if (!c) return MS_ERR_INVALID;
+  if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "ms_project_volume: single shard only");
+  int it = 0;
+  double V = 0.0;
+  for (; it < max_iter; ++it) {
+    int rc = phase_energy(c, MS_CON_VOLUME, false, 0.0, false, false, false);
+    if (rc) return rc;
+    rc = fetch(c);
+    if (rc) return rc;
+    V = c->h_scal[MS_S_VOL];
+    const double delta = V - target;
+    if (std::fabs(delta) < tol) break;
+    rc = phase_gradient(c, MS_CON_VOLUME, nullptr, false);
+    if (rc) return rc;
+    rc = fetch(c);
+    if (rc) return rc;
+    const double norm_sq = c->h_scal[MS_S_GCGC] + 1e-12;
+    const double lam = delta / norm_sq;
+    HIPCHK(c, launch_axpy_masked(c->til.nv, c->d_vflags, c->buf[MS_BUF_X], c->buf[MS_BUF_GC], -lam,
+                                 c->stream));
+    c->factors_valid = false;
+  }
+  if (iters_out) *iters_out = it;
+  if (volume_out) *volume_out = V;
+  return MS_OK;
+}
+
+// ---- phase-level API -------------------------------------------------------
+int ms_phase_energy(ms_ctx* c, int use_direction, double alpha, int write_trial, int guard,
+                    int write_bending_factors) {
+  if (!c) return MS_ERR_INVALID;
+  return phase_energy(c, c->params.modules, use_direction != 0, alpha, write_trial != 0, guard != 0,
+                      write_bending_factors != 0);
+}
+
+int ms_phase_gradient(ms_ctx* c) {
+  if (!c) return MS_ERR_INVALID;
+  return phase_gradient(c, c->params.modules, c->buf[MS_BUF_G], false);
+}
+
+int ms_phase_direction(ms_ctx* c, int stepper, int use_history) {
+  if (!c) return MS_ERR_INVALID;
+  return phase_direction(c, stepper, use_history != 0);
+}
+
+int ms_phase_accept(ms_ctx* c, int keep_history) {
+  if (!c) return MS_ERR_INVALID;
+  std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
+  c->factors_valid = false;
+  if (keep_history) {
+    std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
+    std::swap(c->buf[MS_BUF_D], c->buf[MS_BUF_PD]);
+    c->last_g = c->buf[MS_BUF_PG];
+    c->cg_have_history = true;
+    ++c->cg_iter_count;
+  }
+  return MS_OK;
+}
+
+int ms_fetch_scalars(ms_ctx* c, double* out) {
+  if (!c || !out) return MS_ERR_INVALID;
+  int rc = fetch(c);
+  if (rc) return rc;
+  memcpy(out, c->h_scal, sizeof(double) * MS_NSCAL);
+  return MS_OK;
+}
+
+int ms_store_scalars(ms_ctx* c, const double* in) {
+  if (!c || !in) return MS_ERR_INVALID;
+  memcpy(c->h_scal, in, sizeof(double) * MS_NSCAL);
+  HIPCHK(c, hipMemcpyAsync(c->d_scal, c->h_scal, sizeof(double) * MS_NSCAL, hipMemcpyHostToDevice,
+                           c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MS_OK;
+}
+
+int ms_device_buffer(ms_ctx* c, int buffer, void** dev_ptr, size_t* bytes) {
+  if (!c || !dev_ptr || buffer < 0 || buffer >= MS_BUF_COUNT) return MS_ERR_INVALID;
+  *dev_ptr = c->buf[buffer];
+  if (bytes) {
+    if (buffer == MS_BUF_SCAL)
+      *bytes = sizeof(double) * MS_NSCAL;
+    else
+      *bytes = sizeof(double) * (size_t)c->til.nvp * (buffer == MS_BUF_FA ? 2 : 3);
+  }
+  return MS_OK;
+}
+
+int ms_shard_info(ms_ctx* c, int64_t* nvp, int64_t* row0, int64_t* row1, int64_t* rows_per_shard) {
+  if (!c) return MS_ERR_INVALID;
+  const Tiling& t = c->til;
+  if (nvp) *nvp = t.nvp;
+  if (rows_per_shard) *rows_per_shard = (int64_t)t.tiles_per_shard * t.T;
+  if (row0) *row0 = (int64_t)c->shard_rank * t.tiles_per_shard * t.T;
+  if (row1) *row1 = (int64_t)(c->shard_rank + 1) * t.tiles_per_shard * t.T;
+  return MS_OK;
+}
+
+int ms_tile_stats(ms_ctx* c, int64_t* n_tiles, int64_t* facet_instances, int64_t* max_halo,
+                  int64_t* lds_bytes_energy, int64_t* lds_bytes_gradient) {
+  if (!c) return MS_ERR_INVALID;
+  const Tiling& t = c->til;
+  const bool bend = (c->params.modules & MS_MOD_BENDING) != 0;
+  if (n_tiles) *n_tiles = t.n_tiles;
+  if (facet_instances) *facet_instances = (int64_t)t.tile_facets.size();
+  if (max_halo) *max_halo = t.max_halo;
+  if (lds_bytes_energy) *lds_bytes_energy = (int64_t)energy_lds_bytes(t.T, c->cap, bend, false);
+  if (lds_bytes_gradient) *lds_bytes_gradient = (int64_t)gradient_lds_bytes(t.T, c->cap, bend);
+  return MS_OK;
+}
+
+// ---- kernel-provider seam ---------------------------------------------------
+
+int ms_surface_energy_and_gradient_host(int nv, int nf, const double* pos, const int32_t* tri,
+                                        const double* gamma, double* grad, double* energy) {
+  if (!pos || !gamma || !energy || (nf > 0 && !tri))
+    return fail(nullptr, MS_ERR_INVALID, "ms_surface_energy_and_gradient_host: NULL argument");
+  ms_ctx* c = nullptr;
+  int rc = ms_create(&c, 0, nv, nf, pos, tri, nullptr, nullptr, nullptr, 0, 0, 1);
+  if (rc) return rc;
+  rc = ms_set_surface_tension(c, gamma);
+  ms_params p = c->params;
+  p.modules = MS_MOD_SURFACE;
+  if (!rc) rc = ms_set_params(c, &p);
+  double e[3] = {0, 0, 0};
+  std::vector<double> g;
+  if (!rc) {
+    g.resize(3 * (size_t)nv);
+    rc = ms_energy_and_gradient(c, e, grad ? g.data() : nullptr);
+  }
+  if (rc) g_last_error = c->err;
+  ms_destroy(c);
+  if (rc) return rc;
+  *energy = e[0];
+  if (grad)
+    for (size_t i = 0; i < g.size(); ++i) grad[i] += g[i];  // intent(inout): accumulate
+  return MS_OK;
+}
+
+int ms_grad_cotan_batch_host(int n, const double* u, const double* v, double* grad_u, double* grad_v) {
+  if (n < 0 || !u || !v || !grad_u || !grad_v)
+    return fail(nullptr, MS_ERR_INVALID, "ms_grad_cotan_batch_host: bad argument");
+  const size_t b = sizeof(double) * 3 * (size_t)n;
+  DevBuf du, dv, dgu, dgv;
+  SEAM_HIP(du.alloc(b));
+  SEAM_HIP(dv.alloc(b));
+  SEAM_HIP(dgu.alloc(b));
+  SEAM_HIP(dgv.alloc(b));
+  SEAM_HIP(hipMemcpy(du.p, u, b, hipMemcpyHostToDevice));
+  SEAM_HIP(hipMemcpy(dv.p, v, b, hipMemcpyHostToDevice));
+  SEAM_HIP(launch_grad_cotan(n, du.as<double>(), dv.as<double>(), dgu.as<double>(), dgv.as<double>(), nullptr));
+  SEAM_HIP(hipMemcpy(grad_u, dgu.p, b, hipMemcpyDeviceToHost));
+  SEAM_HIP(hipMemcpy(grad_v, dgv.p, b, hipMemcpyDeviceToHost));
+  return MS_OK;
+}
+
+int ms_apply_beltrami_laplacian_host(int dim, int nv, int nf, const double* weights,
+                                     const int32_t* tri, const double* field, double* out) {
+  if (dim <= 0 || nv <= 0 || nf < 0 || !weights || !tri || !field || !out)
+    return fail(nullptr, MS_ERR_INVALID, "ms_apply_beltrami_laplacian_host: bad argument");
+  const size_t bw = sizeof(double) * 3 * (size_t)nf, bt = sizeof(int32_t) * 3 * (size_t)nf,
+               bf = sizeof(double) * (size_t)nv * dim;
+  DevBuf dw, dt, df, dout;
+  SEAM_HIP(dw.alloc(bw));
+  SEAM_HIP(dt.alloc(bt));
+  SEAM_HIP(df.alloc(bf));
+  SEAM_HIP(dout.alloc(bf));
+  SEAM_HIP(hipMemcpy(dw.p, weights, bw, hipMemcpyHostToDevice));
+  SEAM_HIP(hipMemcpy(dt.p, tri, bt, hipMemcpyHostToDevice));
+  SEAM_HIP(hipMemcpy(df.p, field, bf, hipMemcpyHostToDevice));
+  SEAM_HIP(hipMemset(dout.p, 0, bf));
+  SEAM_HIP(launch_laplacian_scatter(dim, nv, nf, dw.as<double>(), dt.as<int32_t>(), df.as<double>(),
+                                    dout.as<double>(), nullptr));
+  SEAM_HIP(hipMemcpy(out, dout.p, bf, hipMemcpyDeviceToHost));
+  return MS_OK;
+}
+
+int ms_p1_triangle_divergence_host(int nv, int nf, const double* pos, const double* tilts,
+                                   const int32_t* tri, double* div_tri, double* area, double* g0,
+                                   double* g1, double* g2) {
+  if (nv <= 0 || nf < 0 || !pos || !tilts || !tri || !div_tri || !area || !g0 || !g1 || !g2)
+    return fail(nullptr, MS_ERR_INVALID, "ms_p1_triangle_divergence_host: bad argument");
+  const size_t bp = sizeof(double) * 3 * (size_t)nv, bt = sizeof(int32_t) * 3 * (size_t)nf,
+               b1 = sizeof(double) * (size_t)nf, b3 = 3 * b1;
+  DevBuf dp, dtl, dt, dd, da, d0, d1, d2;
+  SEAM_HIP(dp.alloc(bp));
+  SEAM_HIP(dtl.alloc(bp));
+  SEAM_HIP(dt.alloc(bt));
+  SEAM_HIP(dd.alloc(b1));
+  SEAM_HIP(da.alloc(b1));
+  SEAM_HIP(d0.alloc(b3));
+  SEAM_HIP(d1.alloc(b3));
+  SEAM_HIP(d2.alloc(b3));
+  SEAM_HIP(hipMemcpy(dp.p, pos, bp, hipMemcpyHostToDevice));
+  SEAM_HIP(hipMemcpy(dtl.p, tilts, bp, hipMemcpyHostToDevice));
+  SEAM_HIP(hipMemcpy(dt.p, tri, bt, hipMemcpyHostToDevice));
+  SEAM_HIP(hipMemset(dd.p, 0, b1));
+  SEAM_HIP(hipMemset(da.p, 0, b1));
+  SEAM_HIP(hipMemset(d0.p, 0, b3));
+  SEAM_HIP(hipMemset(d1.p, 0, b3));
+  SEAM_HIP(hipMemset(d2.p, 0, b3));
+  SEAM_HIP(launch_p1_divergence(nv, nf, dp.as<double>(), dtl.as<double>(), dt.as<int32_t>(),
+                                dd.as<double>(), da.as<double>(), d0.as<double>(), d1.as<double>(),
+                                d2.as<double>(), nullptr));
+  SEAM_HIP(hipMemcpy(div_tri, dd.p, b1, hipMemcpyDeviceToHost));
+  SEAM_HIP(hipMemcpy(area, da.p, b1, hipMemcpyDeviceToHost));
+  SEAM_HIP(hipMemcpy(g0, d0.p, b3, hipMemcpyDeviceToHost));
+  SEAM_HIP(hipMemcpy(g1, d1.p, b3, hipMemcpyDeviceToHost));
+  SEAM_HIP(hipMemcpy(g2, d2.p, b3, hipMemcpyDeviceToHost));
+  return MS_OK;
+}
+
+int ms_compute_curvature_data_host(int nv, int nf, const double* pos, const int32_t* tri,
+                                   double* k_vecs, double* vertex_areas, double* weights,
+                                   double* va0, double* va1, double* va2) {
+  if (nv <= 0 || nf < 0 || !pos || !tri || !k_vecs || !vertex_areas || !weights)
+    return fail(nullptr, MS_ERR_INVALID, "ms_compute_curvature_data_host: bad argument");
+  const size_t bp = sizeof(double) * 3 * (size_t)nv, bt = sizeof(int32_t) * 3 * (size_t)nf,
+               b1 = sizeof(double) * (size_t)nf, bv = sizeof(double) * (size_t)nv;
+  DevBuf dp, dt, dk, da, dw, d0, d1, d2;
+  SEAM_HIP(dp.alloc(bp));
+  SEAM_HIP(dt.alloc(bt));
+  SEAM_HIP(dk.alloc(bp));
+  SEAM_HIP(da.alloc(bv));
+  SEAM_HIP(dw.alloc(3 * b1));
+  SEAM_HIP(d0.alloc(b1));
+  SEAM_HIP(d1.alloc(b1));
+  SEAM_HIP(d2.alloc(b1));
+  SEAM_HIP(hipMemcpy(dp.p, pos, bp, hipMemcpyHostToDevice));
+  SEAM_HIP(hipMemcpy(dt.p, tri, bt, hipMemcpyHostToDevice));
+  SEAM_HIP(hipMemset(dk.p, 0, bp));
+  SEAM_HIP(hipMemset(da.p, 0, bv));
+  SEAM_HIP(hipMemset(dw.p, 0, 3 * b1));
+  SEAM_HIP(hipMemset(d0.p, 0, b1));
+  SEAM_HIP(hipMemset(d1.p, 0, b1));
+  SEAM_HIP(hipMemset(d2.p, 0, b1));
+  SEAM_HIP(launch_curvature_raw(nv, nf, dp.as<double>(), dt.as<int32_t>(), dk.as<double>(),
+                                da.as<double>(), dw.as<double>(), d0.as<double>(), d1.as<double>(),
+                                d2.as<double>(), nullptr));
+  SEAM_HIP(hipMemcpy(k_vecs, dk.p, bp, hipMemcpyDeviceToHost));
+  SEAM_HIP(hipMemcpy(vertex_areas, da.p, bv, hipMemcpyDeviceToHost));
+  SEAM_HIP(hipMemcpy(weights, dw.p, 3 * b1, hipMemcpyDeviceToHost));
+  if (va0) SEAM_HIP(hipMemcpy(va0, d0.p, b1, hipMemcpyDeviceToHost));
+  if (va1) SEAM_HIP(hipMemcpy(va1, d1.p, b1, hipMemcpyDeviceToHost));
+  if (va2) SEAM_HIP(hipMemcpy(va2, d2.p, b1, hipMemcpyDeviceToHost));
+  return MS_OK;
+}
+
+}  // extern "C"

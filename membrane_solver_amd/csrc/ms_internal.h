@@ -1,0 +1,126 @@
+// Internal declarations shared by the host API, the tile builder and the
+// gfx950 kernels of libmembrane_hip.so.  Not part of the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "membrane_hip.h"
+
+namespace ms {
+
+// One tile-facet instance: local vertex slots inside the tile's LDS patch
+// ([0,n_owned) owned, then halo) + flags.
+struct TileFacet {
+  uint16_t l0, l1, l2;
+  uint16_t flags;  // bit0: this tile owns the facet's scalar terms (energy, volume,
+                   //       min-edge, guard) ; bit1: facet belongs to the body
+};
+static_assert(sizeof(TileFacet) == 8, "TileFacet must be 8 bytes");
+
+constexpr uint16_t TF_OWNER = 1;
+constexpr uint16_t TF_BODY = 2;
+
+constexpr uint8_t VF_FIXED = 1;
+constexpr uint8_t VF_BOUNDARY = 2;
+
+// Host-side result of the tiling pass.
+struct Tiling {
+  int nv = 0, nf = 0, T = 256;
+  int n_tiles = 0;             // tiles covering real vertices
+  int n_tiles_padded = 0;      // multiple of shard_count
+  int tiles_per_shard = 0;
+  int64_t nvp = 0;             // padded vertex rows = n_tiles_padded * T
+  std::vector<int32_t> perm;   // internal row -> external row   (nv)
+  std::vector<int32_t> iperm;  // external row -> internal row   (nv)
+  std::vector<int32_t> tile_facet_off;  // n_tiles+1
+  std::vector<TileFacet> tile_facets;   // facet instances
+  std::vector<int32_t> tile_facet_ext;  // external facet row of each instance
+  std::vector<int32_t> tile_halo_off;   // n_tiles+1
+  std::vector<int32_t> halo_ids;        // internal vertex ids
+  int max_halo = 0;
+  int max_tile_facets = 0;
+  int64_t dropped_facets = 0;
+};
+
+// Builds the patch ordering + tiles.  Returns MS_OK or MS_ERR_*; `err` gets text.
+int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
+                 const uint8_t* body_facets, int T, int shard_count, Tiling& out,
+                 std::string& err);
+
+// ---- device-side view handed to kernels ---------------------------------
+struct DeviceMesh {
+  int nv, T, n_tiles;
+  const int32_t* tile_facet_off;
+  const TileFacet* tile_facets;
+  const double* tf_gamma;  // surface tension per facet instance
+  const int32_t* tile_halo_off;
+  const int32_t* halo_ids;
+  const uint8_t* vflags;  // nvp
+  const double* kappa;    // nvp
+  const double* c0;       // nvp
+};
+
+struct EnergyArgs {
+  DeviceMesh m;
+  int tile0, tile1;       // this shard's tile range
+  const double* x;        // base positions
+  const double* d;        // direction or nullptr
+  double alpha;
+  double* xt;             // trial positions out or nullptr
+  double* fK;             // (nvp,3) out or nullptr
+  double* fA;             // (nvp,2) out or nullptr
+  double* partials;       // [n_tiles][MS_NSCAL]
+  int bending_model;
+  uint32_t modules;
+};
+
+struct GradientArgs {
+  DeviceMesh m;
+  int tile0, tile1;
+  const double* x;
+  const double* fK;
+  const double* fA;
+  double* g;
+  double* gC;             // or nullptr
+  double* partials;
+  const double* scal;     // device scalars (volume for the penalty factor)
+  uint32_t modules;
+  int bending_grad_mode;
+  double volume_stiffness, target_volume;
+  int accumulate;         // add into existing g instead of overwriting
+};
+
+// kernel launchers (ms_kernels.hip).  cap = T + max halo (LDS patch slots).
+size_t energy_lds_bytes(int T, int cap, bool bend, bool guard);
+size_t gradient_lds_bytes(int T, int cap, bool bend);
+hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, hipStream_t s);
+hipError_t launch_gradient(const GradientArgs& a, int cap, hipStream_t s);
+hipError_t launch_reduce(const double* partials, int tile0, int tile1, uint32_t slot_mask,
+                         double* scal, hipStream_t s);
+hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* g,
+                            const double* gC, double* d, const double* pg, const double* pd,
+                            const double* scal, int use_constraint, int cg_history,
+                            double* partials, hipStream_t s);
+hipError_t launch_axpy_masked(int64_t n_rows, const uint8_t* vflags, double* x, const double* y,
+                              double coef, hipStream_t s);
+hipError_t launch_permute_in(int nv, const int32_t* perm, const double* src_ext, double* dst_int,
+                             int ncomp, hipStream_t s);
+hipError_t launch_permute_out(int nv, const int32_t* perm, const double* src_int, double* dst_ext,
+                              int ncomp, hipStream_t s);
+hipError_t launch_grad_cotan(int n, const double* u, const double* v, double* gu, double* gv,
+                             hipStream_t s);
+hipError_t launch_p1_divergence(int nv, int nf, const double* pos, const double* tilts,
+                                const int32_t* tri, double* div, double* area, double* g0,
+                                double* g1, double* g2, hipStream_t s);
+hipError_t launch_laplacian_scatter(int dim, int nv, int nf, const double* weights,
+                                    const int32_t* tri, const double* field, double* out,
+                                    hipStream_t s);
+hipError_t launch_curvature_raw(int nv, int nf, const double* pos, const int32_t* tri,
+                                double* k_vecs, double* areas, double* weights, double* va0,
+                                double* va1, double* va2, hipStream_t s);
+
+}  // namespace ms

@@ -1,0 +1,216 @@
+// Host-side tiling: patch (Hilbert) ordering of the vertices and the
+// tile -> facet / tile -> halo-vertex CSR that the gfx950 kernels consume.
+//
+// The reference keeps vertices in Mesh.vertex_ids row order and facets in
+// Mesh.triangle_row_cache order (geometry/mesh.py:372-389, :597-624) and walks
+// them with np.add.at scatter-adds.  Here each tile OWNS a contiguous range of
+// T vertices (in patch order) and lists every facet that touches one of them,
+// so a workgroup can accumulate its owned vertices' sums in LDS and write them
+// with plain coalesced stores -- no global atomics, no second pass.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "ms_internal.h"
+
+namespace ms {
+
+namespace {
+
+// Skilling's transpose-based Hilbert index, 3 axes x `bits` bits.
+inline uint64_t hilbert3(uint32_t x, uint32_t y, uint32_t z, int bits) {
+  uint32_t X[3] = {x, y, z};
+  const uint32_t M = 1u << (bits - 1);
+  for (uint32_t Q = M; Q > 1; Q >>= 1) {
+    uint32_t P = Q - 1;
+    for (int i = 0; i < 3; ++i) {
+      if (X[i] & Q) {
+        X[0] ^= P;
+      } else {
+        uint32_t t = (X[0] ^ X[i]) & P;
+        X[0] ^= t;
+        X[i] ^= t;
+      }
+    }
+  }
+  for (int i = 1; i < 3; ++i) X[i] ^= X[i - 1];
+  uint32_t t = 0;
+  for (uint32_t Q = M; Q > 1; Q >>= 1)
+    if (X[2] & Q) t ^= Q - 1;
+  for (int i = 0; i < 3; ++i) X[i] ^= t;
+  uint64_t h = 0;
+  for (int b = bits - 1; b >= 0; --b)
+    for (int i = 0; i < 3; ++i) h = (h << 1) | ((X[i] >> b) & 1u);
+  return h;
+}
+
+}  // namespace
+
+int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
+                 const uint8_t* body_facets, int T, int shard_count, Tiling& out,
+                 std::string& err) {
+  if (nv <= 0 || nf < 0 || !positions || (nf > 0 && !tri)) {
+    err = "ms_create: nv must be > 0 and positions/tri non-null";
+    return MS_ERR_INVALID;
+  }
+  if (T <= 0) T = 256;
+  if (T < 64 || T > 4096 || (T % 64) != 0) {
+    err = "ms_create: tile_vertices must be a multiple of 64 in [64,4096]";
+    return MS_ERR_INVALID;
+  }
+  if (shard_count < 1) shard_count = 1;
+  out = Tiling();
+  out.nv = nv;
+  out.nf = nf;
+  out.T = T;
+
+  // ---- 1. patch order: sort vertices along a 3D Hilbert curve --------------
+  double lo[3] = {positions[0], positions[1], positions[2]};
+  double hi[3] = {lo[0], lo[1], lo[2]};
+  for (int i = 0; i < nv; ++i)
+    for (int d = 0; d < 3; ++d) {
+      double p = positions[3 * (size_t)i + d];
+      if (!(p == p)) {
+        err = "ms_create: NaN in positions";
+        return MS_ERR_INVALID;
+      }
+      lo[d] = std::min(lo[d], p);
+      hi[d] = std::max(hi[d], p);
+    }
+  double span = std::max({hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], 1e-300});
+  const int bits = 21;
+  const double scale = (double)((1u << bits) - 1) / span;
+  std::vector<uint64_t> key(nv);
+  for (int i = 0; i < nv; ++i) {
+    uint32_t q[3];
+    for (int d = 0; d < 3; ++d) {
+      double v = (positions[3 * (size_t)i + d] - lo[d]) * scale;
+      q[d] = (uint32_t)std::min(std::max(v, 0.0), (double)((1u << bits) - 1));
+    }
+    key[i] = hilbert3(q[0], q[1], q[2], bits);
+  }
+  out.perm.resize(nv);
+  std::iota(out.perm.begin(), out.perm.end(), 0);
+  std::stable_sort(out.perm.begin(), out.perm.end(),
+                   [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+  out.iperm.resize(nv);
+  for (int i = 0; i < nv; ++i) out.iperm[out.perm[i]] = i;
+
+  // ---- 2. tiles -----------------------------------------------------------
+  out.n_tiles = (nv + T - 1) / T;
+  out.tiles_per_shard = (out.n_tiles + shard_count - 1) / shard_count;
+  out.n_tiles_padded = out.tiles_per_shard * shard_count;
+  out.nvp = (int64_t)out.n_tiles_padded * T;
+
+  // count facet instances per tile (a facet is listed by every tile owning one
+  // of its corners)
+  std::vector<int32_t> cnt(out.n_tiles + 1, 0);
+  auto tiles_of = [&](int f, int tl[3], int iv[3]) -> int {
+    for (int k = 0; k < 3; ++k) {
+      int e = tri[3 * (size_t)f + k];
+      if (e < 0 || e >= nv) return -1;
+      iv[k] = out.iperm[e];
+    }
+    int n = 0;
+    for (int k = 0; k < 3; ++k) {
+      int t = iv[k] / T;
+      bool dup = false;
+      for (int j = 0; j < n; ++j) dup |= (tl[j] == t);
+      if (!dup) tl[n++] = t;
+    }
+    return n;
+  };
+  for (int f = 0; f < nf; ++f) {
+    int tl[3], iv[3];
+    int n = tiles_of(f, tl, iv);
+    if (n < 0) {
+      ++out.dropped_facets;
+      continue;
+    }
+    for (int j = 0; j < n; ++j) ++cnt[tl[j] + 1];
+  }
+  out.tile_facet_off.assign(out.n_tiles + 1, 0);
+  for (int t = 0; t < out.n_tiles; ++t) out.tile_facet_off[t + 1] = out.tile_facet_off[t] + cnt[t + 1];
+  const size_t n_inst = (size_t)out.tile_facet_off[out.n_tiles];
+  out.tile_facets.resize(n_inst);
+  out.tile_facet_ext.resize(n_inst);
+  std::vector<int32_t> cursor(out.tile_facet_off.begin(), out.tile_facet_off.end() - 1);
+  // temporary: internal vertex ids per instance
+  std::vector<int32_t> inst_v(3 * n_inst);
+  // Walk facets in patch order of their first corner so instances inside a
+  // tile are spatially coherent.
+  std::vector<int32_t> forder(nf);
+  std::iota(forder.begin(), forder.end(), 0);
+  {
+    std::vector<int32_t> fkey(nf);
+    for (int f = 0; f < nf; ++f) {
+      int e = tri[3 * (size_t)f];
+      fkey[f] = (e >= 0 && e < nv) ? out.iperm[e] : 0;
+    }
+    std::stable_sort(forder.begin(), forder.end(),
+                     [&](int32_t a, int32_t b) { return fkey[a] < fkey[b]; });
+  }
+  for (int fi = 0; fi < nf; ++fi) {
+    int f = forder[fi];
+    int tl[3], iv[3];
+    int n = tiles_of(f, tl, iv);
+    if (n < 0) continue;
+    int owner_tile = iv[0] / T;
+    for (int j = 0; j < n; ++j) {
+      size_t p = (size_t)cursor[tl[j]]++;
+      inst_v[3 * p] = iv[0];
+      inst_v[3 * p + 1] = iv[1];
+      inst_v[3 * p + 2] = iv[2];
+      uint16_t fl = 0;
+      if (tl[j] == owner_tile) fl |= TF_OWNER;
+      if (!body_facets || body_facets[f]) fl |= TF_BODY;
+      out.tile_facets[p].flags = fl;
+      out.tile_facet_ext[p] = f;
+    }
+  }
+
+  // ---- 3. halo lists + local slots ----------------------------------------
+  out.tile_halo_off.assign(out.n_tiles + 1, 0);
+  std::vector<int32_t> halo_tmp;
+  for (int t = 0; t < out.n_tiles; ++t) {
+    const int v_lo = t * T;
+    const int v_hi = std::min(nv, v_lo + T);
+    const size_t b = (size_t)out.tile_facet_off[t], e = (size_t)out.tile_facet_off[t + 1];
+    halo_tmp.clear();
+    for (size_t p = b; p < e; ++p)
+      for (int k = 0; k < 3; ++k) {
+        int v = inst_v[3 * p + k];
+        if (v < v_lo || v >= v_hi) halo_tmp.push_back(v);
+      }
+    std::sort(halo_tmp.begin(), halo_tmp.end());
+    halo_tmp.erase(std::unique(halo_tmp.begin(), halo_tmp.end()), halo_tmp.end());
+    const int n_owned = v_hi - v_lo;
+    if ((size_t)n_owned + halo_tmp.size() > 65535u) {
+      err = "ms_create: a vertex patch needs more than 65535 LDS slots (vertex valence too high)";
+      return MS_ERR_TILE_CAPACITY;
+    }
+    for (size_t p = b; p < e; ++p) {
+      uint16_t loc[3];
+      for (int k = 0; k < 3; ++k) {
+        int v = inst_v[3 * p + k];
+        if (v >= v_lo && v < v_hi) {
+          loc[k] = (uint16_t)(v - v_lo);
+        } else {
+          auto it = std::lower_bound(halo_tmp.begin(), halo_tmp.end(), v);
+          loc[k] = (uint16_t)(n_owned + (int)(it - halo_tmp.begin()));
+        }
+      }
+      out.tile_facets[p].l0 = loc[0];
+      out.tile_facets[p].l1 = loc[1];
+      out.tile_facets[p].l2 = loc[2];
+    }
+    out.halo_ids.insert(out.halo_ids.end(), halo_tmp.begin(), halo_tmp.end());
+    out.tile_halo_off[t + 1] = (int32_t)out.halo_ids.size();
+    out.max_halo = std::max(out.max_halo, (int)halo_tmp.size());
+    out.max_tile_facets = std::max(out.max_tile_facets, (int)(e - b));
+  }
+  return MS_OK;
+}
+
+}  // namespace ms

@@ -1,0 +1,217 @@
+"""DeviceMesh: the HBM-resident mirror of what the hot path reads from the
+reference's ``Mesh`` (positions_view, triangle_row_cache, fixed_mask,
+boundary_vertex_ids, per-facet / per-vertex parameter arrays:
+geometry/mesh.py:372-389, :597-624, :210-232, :304-319, :234-265).
+
+Thin object wrapper over the C ABI (include/membrane_hip.h).  All arithmetic
+runs in libmembrane_hip.so on the GPU; every error raises MembraneHipError.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _f64(a, shape=None, name="array"):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"{name} must have shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+def _pd(a):
+    return None if a is None else a.ctypes.data_as(L._D)
+
+
+def _pu8(a):
+    return None if a is None else a.ctypes.data_as(L._U8)
+
+
+@dataclass
+class StepResult:
+    success: bool
+    converged: bool
+    trials: int
+    guard_rejects: int
+    next_step: float
+    energy: float
+    alpha: float
+    energy_eval: float
+    grad_norm: float
+    g_dot_d: float
+    volume: float
+
+
+class DeviceMesh:
+    """One mesh resident on one GPU (or one shard of it)."""
+
+    def __init__(self, positions, tri_rows, *, fixed=None, boundary=None, body_facets=None,
+                 device: int = 0, tile_vertices: int = 0, shard_rank: int = 0, shard_count: int = 1):
+        lib = L.lib()
+        pos = _f64(positions, name="positions")
+        if pos.ndim != 2 or pos.shape[1] != 3:
+            raise ValueError("positions must be (nv,3)")
+        tri = np.ascontiguousarray(tri_rows, dtype=np.int32)
+        if tri.size and (tri.ndim != 2 or tri.shape[1] != 3):
+            raise ValueError("tri_rows must be (nf,3)")
+        self.nv = int(pos.shape[0])
+        self.nf = int(tri.shape[0]) if tri.size else 0
+        fx = None if fixed is None else np.ascontiguousarray(fixed, dtype=np.uint8)
+        bd = None if boundary is None else np.ascontiguousarray(boundary, dtype=np.uint8)
+        bf = None if body_facets is None else np.ascontiguousarray(body_facets, dtype=np.uint8)
+        for arr, n, nm in ((fx, self.nv, "fixed"), (bd, self.nv, "boundary"), (bf, self.nf, "body_facets")):
+            if arr is not None and arr.shape != (n,):
+                raise ValueError(f"{nm} must have shape ({n},)")
+        self._h = ctypes.c_void_p()
+        rc = lib.ms_create(ctypes.byref(self._h), int(device), self.nv, self.nf, _pd(pos),
+                           tri.ctypes.data_as(L._I32) if tri.size else None, _pu8(fx), _pu8(bd),
+                           _pu8(bf), int(tile_vertices), int(shard_rank), int(shard_count))
+        L.check(rc, None, "ms_create")
+        self.device = int(device)
+        self.shard_rank, self.shard_count = int(shard_rank), int(shard_count)
+        self._params = L.ms_params(L.MS_MOD_SURFACE, L.MS_BEND_HELFRICH, L.MS_GRAD_ANALYTIC, 1000.0, 0.0)
+
+    # -- lifetime -------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            L.lib().ms_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        L.check(rc, self._h, what)
+
+    # -- parameters -----------------------------------------------------------
+    def set_stream(self, hip_stream: int | None):
+        self._chk(L.lib().ms_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)), "ms_set_stream")
+
+    def set_surface_tension(self, gamma):
+        g = _f64(gamma, (self.nf,), "gamma")
+        self._chk(L.lib().ms_set_surface_tension(self._h, _pd(g)), "ms_set_surface_tension")
+
+    def set_bending_params(self, kappa, c0):
+        k = _f64(kappa, (self.nv,), "kappa")
+        z = _f64(c0, (self.nv,), "c0")
+        self._chk(L.lib().ms_set_bending_params(self._h, _pd(k), _pd(z)), "ms_set_bending_params")
+
+    def set_params(self, *, modules: int, bending_model: int = L.MS_BEND_HELFRICH,
+                   bending_grad_mode: int = L.MS_GRAD_ANALYTIC, volume_stiffness: float = 1000.0,
+                   target_volume: float = 0.0):
+        self._params = L.ms_params(int(modules), int(bending_model), int(bending_grad_mode),
+                                   float(volume_stiffness), float(target_volume))
+        self._chk(L.lib().ms_set_params(self._h, ctypes.byref(self._params)), "ms_set_params")
+
+    @property
+    def modules(self) -> int:
+        return int(self._params.modules)
+
+    # -- host <-> HBM ---------------------------------------------------------
+    def set_positions(self, positions):
+        p = _f64(positions, (self.nv, 3), "positions")
+        self._chk(L.lib().ms_set_positions(self._h, _pd(p)), "ms_set_positions")
+
+    def get_positions(self) -> np.ndarray:
+        out = np.empty((self.nv, 3), dtype=np.float64)
+        self._chk(L.lib().ms_get_positions(self._h, _pd(out)), "ms_get_positions")
+        return out
+
+    def get_gradient(self) -> np.ndarray:
+        out = np.empty((self.nv, 3), dtype=np.float64)
+        self._chk(L.lib().ms_get_gradient(self._h, _pd(out)), "ms_get_gradient")
+        return out
+
+    def get_vertex_buffer(self, buffer: int) -> np.ndarray:
+        ncomp = 2 if buffer == L.MS_BUF_FA else 3
+        out = np.empty((self.nv, ncomp), dtype=np.float64)
+        self._chk(L.lib().ms_get_vertex_buffer(self._h, int(buffer), _pd(out)), "ms_get_vertex_buffer")
+        return out
+
+    # -- evaluation -----------------------------------------------------------
+    def energy_and_gradient(self, want_grad: bool = True):
+        """-> (energies[surface, bending, volume_penalty], grad (nv,3) | None)."""
+        e = np.zeros(3)
+        g = np.empty((self.nv, 3), dtype=np.float64) if want_grad else None
+        self._chk(L.lib().ms_energy_and_gradient(self._h, _pd(e), _pd(g)), "ms_energy_and_gradient")
+        return e, g
+
+    def energy(self) -> np.ndarray:
+        e = np.zeros(3)
+        self._chk(L.lib().ms_energy(self._h, _pd(e)), "ms_energy")
+        return e
+
+    # -- stepping -------------------------------------------------------------
+    def step(self, *, stepper: int, step_size: float, tol: float = 1e-6, max_iter: int = 10,
+             beta: float = 0.7, c: float = 1e-4, gamma: float = 1.5, alpha_max_factor: float = 10.0,
+             restart_interval: int = 10, edge_fraction: float = 0.0,
+             reuse_energy0: bool = False) -> StepResult:
+        sp = L.ms_stepper_params(int(stepper), int(max_iter), float(beta), float(c), float(gamma),
+                                 float(alpha_max_factor), int(restart_interval), float(edge_fraction),
+                                 1 if reuse_energy0 else 0)
+        r = L.ms_step_result()
+        self._chk(L.lib().ms_step(self._h, ctypes.byref(sp), float(step_size), float(tol),
+                                  ctypes.byref(r)), "ms_step")
+        return StepResult(bool(r.success), bool(r.converged), int(r.trials), int(r.guard_rejects),
+                          float(r.next_step), float(r.energy), float(r.alpha), float(r.energy_eval),
+                          float(r.grad_norm), float(r.g_dot_d), float(r.volume))
+
+    def reset_stepper(self):
+        self._chk(L.lib().ms_reset_stepper(self._h), "ms_reset_stepper")
+
+    def project_volume(self, target: float, tol: float = 1e-12, max_iter: int = 3):
+        it = ctypes.c_int(0)
+        v = ctypes.c_double(0.0)
+        self._chk(L.lib().ms_project_volume(self._h, float(target), float(tol), int(max_iter),
+                                            ctypes.byref(it), ctypes.byref(v)), "ms_project_volume")
+        return int(it.value), float(v.value)
+
+    # -- phase API (multi-GPU drivers) ----------------------------------------
+    def phase_energy(self, *, use_direction=False, alpha=0.0, write_trial=False, guard=False,
+                     write_bending_factors=False):
+        self._chk(L.lib().ms_phase_energy(self._h, int(use_direction), float(alpha), int(write_trial),
+                                          int(guard), int(write_bending_factors)), "ms_phase_energy")
+
+    def phase_gradient(self):
+        self._chk(L.lib().ms_phase_gradient(self._h), "ms_phase_gradient")
+
+    def phase_direction(self, stepper: int, use_history: bool):
+        self._chk(L.lib().ms_phase_direction(self._h, int(stepper), int(use_history)), "ms_phase_direction")
+
+    def phase_accept(self, keep_history: bool):
+        self._chk(L.lib().ms_phase_accept(self._h, int(keep_history)), "ms_phase_accept")
+
+    def fetch_scalars(self) -> np.ndarray:
+        out = np.zeros(L.MS_NSCAL)
+        self._chk(L.lib().ms_fetch_scalars(self._h, _pd(out)), "ms_fetch_scalars")
+        return out
+
+    def store_scalars(self, values):
+        v = _f64(values, (L.MS_NSCAL,), "scalars")
+        self._chk(L.lib().ms_store_scalars(self._h, _pd(v)), "ms_store_scalars")
+
+    def device_buffer(self, buffer: int):
+        p = ctypes.c_void_p()
+        n = ctypes.c_size_t(0)
+        self._chk(L.lib().ms_device_buffer(self._h, int(buffer), ctypes.byref(p), ctypes.byref(n)),
+                  "ms_device_buffer")
+        return int(p.value or 0), int(n.value)
+
+    def shard_info(self):
+        v = [ctypes.c_int64(0) for _ in range(4)]
+        self._chk(L.lib().ms_shard_info(self._h, *[ctypes.byref(x) for x in v]), "ms_shard_info")
+        return {"nvp": v[0].value, "row0": v[1].value, "row1": v[2].value, "rows_per_shard": v[3].value}
+
+    def tile_stats(self):
+        v = [ctypes.c_int64(0) for _ in range(5)]
+        self._chk(L.lib().ms_tile_stats(self._h, *[ctypes.byref(x) for x in v]), "ms_tile_stats")
+        return {"n_tiles": v[0].value, "facet_instances": v[1].value, "max_halo": v[2].value,
+                "lds_bytes_energy": v[3].value, "lds_bytes_gradient": v[4].value}
