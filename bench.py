@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: minimizer steps/sec (energy + gradient + CG) on the
+2 048 000-facet icosphere (BASELINE.json configs[2]; configs[3] when --gpus > 1).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one iteration of Minimizer.minimize (runtime/minimizer.py:1230-1515
+of the reference): energy+gradient of all modules, fixed-row zeroing, per-row
+Polak-Ribiere CG direction, Armijo backtracking line search (energy0 is
+re-evaluated like line_search.py:294, then >= 1 trial energy evaluation) and the
+position commit.  All state is resident in HBM before the timed region starts.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md section "Measurement").
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--freq", type=int, default=320, help="icosphere frequency (320 -> 2 048 000 facets)")
+    ap.add_argument("--tile", type=int, default=0, help="owned vertices per tile (0 = library default)")
+    ap.add_argument("--step-size", type=float, default=1e-4)
+    ap.add_argument("--volume", action="store_true", help="add the volume Lagrange constraint row")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="CPU oracle steps for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(nv, nf):
+    """Compulsory HBM bytes per launch (DESIGN.md 'Kernels'); each array touched once."""
+    return {
+        # tri rows 12 B + gamma 8 B per facet; x 24 + kappa,c0 16 + flags 1 per vertex; fK,fA 40 out
+        "energy_factors": 20 * nf + (24 + 16 + 1) * nv + 40 * nv,
+        # trial energy: x and d in (48), xt out (24), no factor write
+        "energy_trial": 20 * nf + (48 + 16 + 1) * nv + 24 * nv,
+        # gradient: x 24 + fK,fA 40 + flags 1 in, g 24 out
+        "gradient": 20 * nf + (24 + 40 + 1) * nv + 24 * nv,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch --gpus N > 1 through torch.distributed.run (one rank per GPU)")
+    if world > 1:
+        from membrane_solver_amd import parallel
+
+        return parallel.bench_main(args, rank, world, local_rank)
+
+    import torch  # device plumbing: barrier/synchronize bracket of the contract
+
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.geometry.mesh import ArrayBody, ArrayMesh
+    from membrane_solver_amd.runtime.constraint_manager import ConstraintModuleManager
+    from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
+    from membrane_solver_amd.runtime.minimizer import Minimizer
+    from membrane_solver_amd.runtime.steppers import ConjugateGradient
+
+    if L.lib().ms_device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: " + L.lib().ms_last_error(None).decode())
+    torch.cuda.set_device(local_rank)
+
+    P, T = meshgen.icosphere(args.freq)
+    P = meshgen.smooth_displace(P, 0.05)
+    nv, nf = P.shape[0], T.shape[0]
+    gp = {"surface_tension": 1.0, "bending_modulus": 1.0, "bending_energy_model": "helfrich",
+          "spontaneous_curvature": 0.0, "bending_gradient_mode": "analytic",
+          "volume_constraint_mode": "lagrange", "volume_projection_during_minimization": False,
+          "mesh_quality_auto_repair_enabled": False}
+    mods, cons, bodies = ["surface", "bending"], [], []
+    if args.volume:
+        cons = ["volume"]
+        v0, v1, v2 = P[T[:, 0]], P[T[:, 1]], P[T[:, 2]]
+        bodies = [ArrayBody(0, None, float(np.einsum("ij,ij->i", np.cross(v1, v2), v0).sum() / 6.0))]
+    mesh = ArrayMesh(P, T, global_parameters=gp, energy_modules=mods, constraint_modules=cons, bodies=bodies)
+    stepper = ConjugateGradient()
+    mz = Minimizer(mesh, mesh.global_parameters, stepper, EnergyModuleManager(mods),
+                   ConstraintModuleManager(cons), quiet=True, step_size=args.step_size,
+                   device=local_rank, tile_vertices=args.tile)
+    E_start = mz.compute_energy()
+
+    # count what the timed steps actually do
+    stats = {"accepted": 0, "trials": 0, "steps": 0}
+    orig = stepper.device_step
+
+    def counted(dm, m, step_size, tol=0.0):
+        r = orig(dm, m, step_size, tol=tol)
+        stats["steps"] += 1
+        stats["accepted"] += int(r.success)
+        stats["trials"] += r.trials
+        return r
+
+    stepper.device_step = counted
+    mz.minimize(args.warmup, sync_mesh=False)
+    for k in stats:
+        stats[k] = 0
+    step_size_after_warmup = mz.step_size
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = mz.minimize(args.steps, sync_mesh=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timed = dict(stats)
+    ms_per_step = 1e3 * dt / args.steps
+    value = args.steps / dt
+
+    out = {
+        "metric": "minimizer steps/sec (energy+grad+CG) on 2M-facet icosphere",
+        "value": value, "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"class-I icosphere f={args.freq} (nv={nv}, nf={nf}), surface + Helfrich "
+                               "bending (analytic cotan gradient), CG stepper, Armijo line search, "
+                               "energy0 re-evaluated" + (", volume Lagrange row" if args.volume else ""),
+                   "stepper": "conjugate_gradient", "tile_vertices": args.tile or 256,
+                   "initial_step_size": args.step_size, "parallelism": "1 GPU"},
+        "steps_accepted": timed["accepted"], "line_search_trials": timed["trials"],
+        "energy_start": E_start, "energy_end": res["energy"],
+    }
+
+    # -- roofline of the dominant kernel: HIP events inside the library --------
+    mir = mesh._hip_mirror
+    dm = mir.dm
+    if not args.no_roofline:
+        n_prof = min(args.steps, 40)
+        dm.profile_enable(True)
+        dm.profile_read()
+        mz.minimize(n_prof, sync_mesh=False)
+        prof = dm.profile_read()
+        dm.profile_enable(False)
+        ab = algorithmic_bytes(nv, nf)
+        kernels = {}
+        for kind, (ms, n) in prof.items():
+            if n:
+                kernels[kind] = {"avg_us": 1e3 * ms / n, "launches": n, "share_of_profiled_ms": ms}
+        tot = sum(v["share_of_profiled_ms"] for v in kernels.values()) or 1.0
+        for v in kernels.values():
+            v["share_of_profiled_ms"] = v["share_of_profiled_ms"] / tot
+        # per-launch algorithmic bytes: energy launches are a mix (1 with factor write,
+        # 1 energy0, >=1 trials per step) -> use the mix actually launched
+        n_e = prof["energy"][1]
+        n_g = prof["gradient"][1]
+        if n_e:
+            n_fact = n_g  # one factor-writing energy pass per gradient pass
+            n_trial = max(0, n_e - 2 * n_fact)
+            n_e0 = n_e - n_fact - n_trial
+            e_bytes = (n_fact * ab["energy_factors"] + n_e0 * (ab["energy_factors"] - 40 * nv)
+                       + n_trial * ab["energy_trial"]) / n_e
+            kernels["energy"]["algorithmic_bytes"] = e_bytes
+            kernels["energy"]["GBps"] = e_bytes / (kernels["energy"]["avg_us"] * 1e-6) / 1e9
+        if n_g:
+            kernels["gradient"]["algorithmic_bytes"] = ab["gradient"]
+            kernels["gradient"]["GBps"] = ab["gradient"] / (kernels["gradient"]["avg_us"] * 1e-6) / 1e9
+        dom = max((k for k in ("energy", "gradient") if k in kernels),
+                  key=lambda k: kernels[k]["share_of_profiled_ms"])
+        ach = kernels[dom]["GBps"]
+        out["roofline"] = {"bound": "hbm", "kernel": {"energy": "ms::k_energy<true,false>",
+                                                     "gradient": "ms::k_gradient<1>"}[dom],
+                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "avg_launch_us": kernels[dom]["avg_us"],
+                           "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"],
+                           "measured": f"HIP events around every launch over {n_prof} steps after the timed region"}
+        eg = None
+        if "energy" in kernels and "gradient" in kernels:
+            pair_us = kernels["energy"]["avg_us"] + kernels["gradient"]["avg_us"]
+            pair_bytes = ab["energy_factors"] + ab["gradient"]
+            eg = {"us": pair_us, "algorithmic_bytes": pair_bytes,
+                  "GBps": pair_bytes / (pair_us * 1e-6) / 1e9,
+                  "frac": pair_bytes / (pair_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+        out["kernels"] = kernels
+        out["energy_plus_gradient_evaluation"] = eg
+
+    # -- CPU baseline: the oracle port on the host cores, bounded sample ---------
+    if args.cpu_steps > 0:
+        from oracle import minimizer_port as mp
+
+        x_now = dm.get_positions()
+        p = mp.Problem(positions=x_now, tri=T, energy_modules=mods, constraint_modules=cons,
+                       target_volume=bodies[0].target_volume if bodies else None, gp=dict(gp))
+        t0 = time.perf_counter()
+        cres = mp.minimize(p, mp.ConjugateGradient(), args.cpu_steps, step_size=mz.step_size)
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": args.cpu_steps / cdt, "unit": "steps/s", "cores": 1, "kind": "port",
+                               "sample": f"{args.cpu_steps} minimizer steps of the C/NumPy oracle port "
+                                         f"(oracle/minimizer_port.py) on the same {nf}-facet mesh, starting "
+                                         f"from the GPU run's state and step size; "
+                                         f"{sum(t['trials'] for t in cres['trace'])} line-search trials",
+                               "seconds": cdt}
+        out["step_size_after_warmup"] = step_size_after_warmup
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

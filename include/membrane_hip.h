@@ -46,6 +46,10 @@ extern "C" {
 /* constraint row: modules/constraints/volume.py:43-66 + the k==1 dense KKT
  * branch of runtime/constraint_manager.py:293-301 */
 #define MS_CON_VOLUME 8u
+/* also reduce the body volume in energy passes (the Lagrange volume-drift
+ * check of runtime/minimizer.py:1478-1513 needs V even when no volume module
+ * is loaded); no effect on energies or gradients */
+#define MS_TRACK_VOLUME 16u
 
 /* bending_params.py:19-33 */
 #define MS_BEND_HELFRICH 0
@@ -201,6 +205,23 @@ int ms_shard_info(ms_ctx *ctx, int64_t *nvp, int64_t *row0, int64_t *row1,
 int ms_tile_stats(ms_ctx *ctx, int64_t *n_tiles, int64_t *facet_instances,
                   int64_t *max_halo, int64_t *lds_bytes_energy,
                   int64_t *lds_bytes_gradient);
+
+/* Per-kernel device timing with HIP events on the context's stream.  While
+ * enabled every energy / gradient / direction / reduce launch is bracketed by
+ * an event pair; ms_profile_read synchronises, returns the summed milliseconds
+ * and launch counts per kind {0 energy, 1 gradient, 2 direction, 3 reduce} and
+ * resets the counters.  Used by bench.py for the roofline figure. */
+int ms_profile_enable(ms_ctx *ctx, int on);
+int ms_profile_read(ms_ctx *ctx, double total_ms[4], int64_t launches[4]);
+
+/* Host-only planning pass (no GPU needed): runs the same tiling ms_create
+ * uses and reports stats[0..7] = {n_tiles, facet_instances, max_halo,
+ * max_tile_facets, dropped_facets, owner_instances, owned_corner_slots,
+ * lds_bytes_gradient}.  perm_out (nv, patch row -> caller row) may be NULL.
+ * Invariants: owner_instances == nf - dropped, owned_corner_slots == 3*that. */
+int ms_plan_tiling(int nv, int nf, const double *positions, const int32_t *tri,
+                   int tile_vertices, int shard_count, int64_t stats[8],
+                   int32_t *perm_out);
 
 /* ---- kernel-provider seam: the five procedures under fortran_kernels/ ----
  * Host arrays in, host arrays out (H2D/D2H per call: for parity, not speed).

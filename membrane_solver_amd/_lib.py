@@ -23,6 +23,7 @@ MS_MOD_SURFACE = 1
 MS_MOD_BENDING = 2
 MS_MOD_VOLUME_PENALTY = 4
 MS_CON_VOLUME = 8
+MS_TRACK_VOLUME = 16
 MS_BEND_HELFRICH, MS_BEND_WILLMORE = 0, 1
 MS_GRAD_ANALYTIC, MS_GRAD_APPROX = 0, 1
 MS_STEPPER_GD, MS_STEPPER_CG = 0, 1
@@ -99,6 +100,10 @@ SIGNATURES = {
                                         ctypes.POINTER(ctypes.c_size_t)]),
     "ms_shard_info": (ctypes.c_int, [_P, _I64, _I64, _I64, _I64]),
     "ms_tile_stats": (ctypes.c_int, [_P, _I64, _I64, _I64, _I64, _I64]),
+    "ms_profile_enable": (ctypes.c_int, [_P, ctypes.c_int]),
+    "ms_profile_read": (ctypes.c_int, [_P, _D, _I64]),
+    "ms_plan_tiling": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _D, _I32, ctypes.c_int, ctypes.c_int,
+                                      _I64, _I32]),
     "ms_surface_energy_and_gradient_host": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _D, _I32, _D,
                                                            _D, _D]),
     "ms_grad_cotan_batch_host": (ctypes.c_int, [ctypes.c_int, _D, _D, _D, _D]),

@@ -44,6 +44,16 @@ struct ms_ctx {
   bool cg_have_history = false;
   int cg_iter_count = 0;
   bool factors_valid = false;
+  // optional per-kernel timing (ms_profile_*)
+  bool profiling = false;
+  struct ProfRec {
+    hipEvent_t a, b;
+    int kind;
+  };
+  std::vector<ProfRec> prof_pending;
+  std::vector<hipEvent_t> prof_pool;
+  double prof_ms[4] = {0, 0, 0, 0};
+  int64_t prof_n[4] = {0, 0, 0, 0};
   std::string err;
 };
 
@@ -81,6 +91,34 @@ DeviceMesh device_mesh(const ms_ctx* c) {
   return m;
 }
 
+// RAII-free event bracket: begin() before a launch, end() after it.
+struct ProfScope {
+  ms_ctx* c;
+  hipEvent_t a = nullptr, b = nullptr;
+  int kind;
+  ProfScope(ms_ctx* ctx, int k) : c(ctx), kind(k) {
+    if (!c->profiling) return;
+    auto get = [&]() {
+      hipEvent_t e = nullptr;
+      if (!c->prof_pool.empty()) {
+        e = c->prof_pool.back();
+        c->prof_pool.pop_back();
+      } else if (hipEventCreate(&e) != hipSuccess) {
+        e = nullptr;
+      }
+      return e;
+    };
+    a = get();
+    b = get();
+    if (a && b) (void)hipEventRecord(a, c->stream);
+  }
+  ~ProfScope() {
+    if (!c->profiling || !a || !b) return;
+    (void)hipEventRecord(b, c->stream);
+    c->prof_pending.push_back({a, b, kind});
+  }
+};
+
 constexpr uint32_t MASK_ENERGY = (1u << MS_S_ESURF) | (1u << MS_S_VOL) | (1u << MS_S_EBEND) |
                                  (1u << MS_S_MINEDGE2) | (1u << MS_S_GUARD);
 constexpr uint32_t MASK_GRAD = (1u << MS_S_GGC) | (1u << MS_S_GCGC);
@@ -102,8 +140,14 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   a.partials = c->d_partials;
   a.bending_model = c->params.bending_model;
   a.modules = modules;
-  HIPCHK(c, launch_energy(a, guard && use_dir, c->cap, c->stream));
-  HIPCHK(c, launch_reduce(c->d_partials, c->tile0, c->tile1, MASK_ENERGY, c->d_scal, c->stream));
+  {
+    ProfScope ps(c, 0);
+    HIPCHK(c, launch_energy(a, guard && use_dir, c->cap, c->stream));
+  }
+  {
+    ProfScope ps(c, 3);
+    HIPCHK(c, launch_reduce(c->d_partials, c->til.n_tiles, c->tile0, c->tile1, MASK_ENERGY, c->d_scal, c->stream));
+  }
   if (bend && write_factors) c->factors_valid = !use_dir;
   return MS_OK;
 }
@@ -127,19 +171,31 @@ int phase_gradient(ms_ctx* c, uint32_t modules, double* g_out, bool accumulate) 
   a.volume_stiffness = c->params.volume_stiffness;
   a.target_volume = c->params.target_volume;
   a.accumulate = accumulate ? 1 : 0;
-  HIPCHK(c, launch_gradient(a, c->cap, c->stream));
-  HIPCHK(c, launch_reduce(c->d_partials, c->tile0, c->tile1, MASK_GRAD, c->d_scal, c->stream));
+  {
+    ProfScope ps(c, 1);
+    HIPCHK(c, launch_gradient(a, c->cap, c->stream));
+  }
+  {
+    ProfScope ps(c, 3);
+    HIPCHK(c, launch_reduce(c->d_partials, c->til.n_tiles, c->tile0, c->tile1, MASK_GRAD, c->d_scal, c->stream));
+  }
   return MS_OK;
 }
 
 int phase_direction(ms_ctx* c, int stepper, bool use_history) {
   const bool use_con = (c->params.modules & MS_CON_VOLUME) != 0;
+  {
+  ProfScope ps(c, 2);
   HIPCHK(c, launch_direction(c->tile0, c->tile1, c->til.nv, c->til.T, c->d_vflags, c->buf[MS_BUF_G],
                              c->buf[MS_BUF_GC], c->buf[MS_BUF_D], c->buf[MS_BUF_PG],
                              c->buf[MS_BUF_PD], c->d_scal, use_con ? 1 : 0,
                              (stepper == MS_STEPPER_CG && use_history) ? 1 : 0, c->d_partials,
-                             c->stream));
-  HIPCHK(c, launch_reduce(c->d_partials, c->tile0, c->tile1, MASK_DIR, c->d_scal, c->stream));
+                             c->til.n_tiles, c->stream));
+  }
+  {
+    ProfScope ps(c, 3);
+    HIPCHK(c, launch_reduce(c->d_partials, c->til.n_tiles, c->tile0, c->tile1, MASK_DIR, c->d_scal, c->stream));
+  }
   c->last_g = c->buf[MS_BUF_G];
   return MS_OK;
 }
@@ -357,6 +413,11 @@ void ms_destroy(ms_ctx* c) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_scal) (void)hipHostFree(c->h_scal);
+  for (auto& r : c->prof_pending) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  for (auto e : c->prof_pool) (void)hipEventDestroy(e);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -668,6 +729,62 @@ int ms_tile_stats(ms_ctx* c, int64_t* n_tiles, int64_t* facet_instances, int64_t
   if (max_halo) *max_halo = t.max_halo;
   if (lds_bytes_energy) *lds_bytes_energy = (int64_t)energy_lds_bytes(t.T, c->cap, bend, false);
   if (lds_bytes_gradient) *lds_bytes_gradient = (int64_t)gradient_lds_bytes(t.T, c->cap, bend);
+  return MS_OK;
+}
+
+int ms_profile_enable(ms_ctx* c, int on) {
+  if (!c) return MS_ERR_INVALID;
+  c->profiling = on != 0;
+  return MS_OK;
+}
+
+int ms_profile_read(ms_ctx* c, double total_ms[4], int64_t launches[4]) {
+  if (!c || !total_ms || !launches) return MS_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (auto& r : c->prof_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      c->prof_ms[r.kind] += ms;
+      c->prof_n[r.kind] += 1;
+    }
+    c->prof_pool.push_back(r.a);
+    c->prof_pool.push_back(r.b);
+  }
+  c->prof_pending.clear();
+  for (int k = 0; k < 4; ++k) {
+    total_ms[k] = c->prof_ms[k];
+    launches[k] = c->prof_n[k];
+    c->prof_ms[k] = 0.0;
+    c->prof_n[k] = 0;
+  }
+  return MS_OK;
+}
+
+int ms_plan_tiling(int nv, int nf, const double* positions, const int32_t* tri, int tile_vertices,
+                   int shard_count, int64_t stats[8], int32_t* perm_out) {
+  if (!stats) return fail(nullptr, MS_ERR_INVALID, "ms_plan_tiling: stats is NULL");
+  Tiling t;
+  std::string err;
+  int rc = build_tiling(nv, nf, positions, tri, nullptr, tile_vertices, shard_count, t, err);
+  if (rc != MS_OK) return fail(nullptr, rc, err);
+  int64_t owners = 0, owned_corners = 0;
+  for (int tile = 0; tile < t.n_tiles; ++tile) {
+    const int n_owned = std::min(t.T, t.nv - tile * t.T);
+    for (int p = t.tile_facet_off[tile]; p < t.tile_facet_off[tile + 1]; ++p) {
+      const TileFacet& f = t.tile_facets[p];
+      if (f.flags & TF_OWNER) ++owners;
+      owned_corners += (f.l0 < n_owned) + (f.l1 < n_owned) + (f.l2 < n_owned);
+    }
+  }
+  stats[0] = t.n_tiles;
+  stats[1] = (int64_t)t.tile_facets.size();
+  stats[2] = t.max_halo;
+  stats[3] = t.max_tile_facets;
+  stats[4] = t.dropped_facets;
+  stats[5] = owners;
+  stats[6] = owned_corners;
+  stats[7] = (int64_t)gradient_lds_bytes(t.T, t.T + t.max_halo, true);
+  if (perm_out) memcpy(perm_out, t.perm.data(), sizeof(int32_t) * (size_t)nv);
   return MS_OK;
 }
 

@@ -99,12 +99,12 @@ size_t energy_lds_bytes(int T, int cap, bool bend, bool guard);
 size_t gradient_lds_bytes(int T, int cap, bool bend);
 hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, hipStream_t s);
 hipError_t launch_gradient(const GradientArgs& a, int cap, hipStream_t s);
-hipError_t launch_reduce(const double* partials, int tile0, int tile1, uint32_t slot_mask,
-                         double* scal, hipStream_t s);
+hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
+                         uint32_t slot_mask, double* scal, hipStream_t s);
 hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* g,
                             const double* gC, double* d, const double* pg, const double* pd,
                             const double* scal, int use_constraint, int cg_history,
-                            double* partials, hipStream_t s);
+                            double* partials, int n_tiles, hipStream_t s);
 hipError_t launch_axpy_masked(int64_t n_rows, const uint8_t* vflags, double* x, const double* y,
                               double coef, hipStream_t s);
 hipError_t launch_permute_in(int nv, const int32_t* perm, const double* src_ext, double* dst_int,

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(BLOCK) void k_energy(EnergyArgs a, int cap) {
 
   double e_surf = 0.0, vol = 0.0, min_e2 = 1.0e300, guard = 0.0;
   const bool want_surf = a.modules & MS_MOD_SURFACE;
-  const bool want_vol = a.modules & (MS_MOD_VOLUME_PENALTY | MS_CON_VOLUME);
+  const bool want_vol = a.modules & (MS_MOD_VOLUME_PENALTY | MS_CON_VOLUME | MS_TRACK_VOLUME);
   const int f0 = a.m.tile_facet_off[tile], f1 = a.m.tile_facet_off[tile + 1];
   for (int p = f0 + tid; p < f1; p += BLOCK) {
     const TileFacet tf = a.m.tile_facets[p];
@@ -333,18 +333,19 @@ __global__ __launch_bounds__(BLOCK) void k_energy(EnergyArgs a, int cap) {
     if (a.bending_model == MS_BEND_HELFRICH) e_bend *= 0.5;
   }
 
-  double* out = a.partials + (size_t)tile * MS_NSCAL;
+  double* out = a.partials + tile;   // slot-major: partials[slot][n_tiles]
+  const size_t ps = (size_t)a.m.n_tiles;
   double r;
   r = block_reduce(e_surf, 0, red);
-  if (tid == 0) out[MS_S_ESURF] = r;
+  if (tid == 0) out[MS_S_ESURF * ps] = r;
   r = block_reduce(vol, 0, red);
-  if (tid == 0) out[MS_S_VOL] = r;
+  if (tid == 0) out[MS_S_VOL * ps] = r;
   r = block_reduce(e_bend, 0, red);
-  if (tid == 0) out[MS_S_EBEND] = r;
+  if (tid == 0) out[MS_S_EBEND * ps] = r;
   r = block_reduce(min_e2, 1, red);
-  if (tid == 0) out[MS_S_MINEDGE2] = r;
+  if (tid == 0) out[MS_S_MINEDGE2 * ps] = r;
   r = block_reduce(guard, 2, red);
-  if (tid == 0) out[MS_S_GUARD] = r;
+  if (tid == 0) out[MS_S_GUARD * ps] = r;
 }
 
 size_t energy_lds_bytes(int T, int cap, bool bend, bool guard) {
@@ -590,11 +591,12 @@ __global__ __launch_bounds__(BLOCK) void k_gradient(GradientArgs a, int cap) {
       gcgc += gc * gc;
     }
   }
-  double* out = a.partials + (size_t)tile * MS_NSCAL;
+  double* out = a.partials + tile;
+  const size_t ps = (size_t)a.m.n_tiles;
   double r = block_reduce(ggc, 0, red);
-  if (tid == 0) out[MS_S_GGC] = r;
+  if (tid == 0) out[MS_S_GGC * ps] = r;
   r = block_reduce(gcgc, 0, red);
-  if (tid == 0) out[MS_S_GCGC] = r;
+  if (tid == 0) out[MS_S_GCGC * ps] = r;
 }
 
 size_t gradient_lds_bytes(int T, int cap, bool bend) {
@@ -626,25 +628,41 @@ hipError_t launch_gradient(const GradientArgs& a, int cap, hipStream_t s) {
 // requested slots in a fixed order.  Volume gets its 1/6 here
 // (geometry/body.py:121: vol_contrib.sum() / 6.0).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_reduce(const double* partials, int tile0, int tile1,
-                                                  uint32_t slot_mask, double* scal) {
+__global__ __launch_bounds__(BLOCK) void k_reduce(const double* partials, int n_tiles, int tile0,
+                                                  int tile1, uint32_t slot_mask, double* scal) {
   __shared__ double red[4];
-  for (int slot = 0; slot < MS_NSCAL; ++slot) {
-    if (!(slot_mask & (1u << slot))) continue;
-    const int op = (slot == MS_S_MINEDGE2) ? 1 : ((slot == MS_S_GUARD || slot == MS_S_MAXD2) ? 2 : 0);
-    double v = op == 1 ? 1.0e300 : 0.0;
-    for (int t = tile0 + threadIdx.x; t < tile1; t += BLOCK) {
-      const double p = partials[(size_t)t * MS_NSCAL + slot];
-      v = op == 0 ? v + p : (op == 1 ? fmin(v, p) : fmax(v, p));
-    }
-    v = block_reduce(v, op, red);
-    if (threadIdx.x == 0) scal[slot] = (slot == MS_S_VOL) ? v / 6.0 : v;
+  // one workgroup per requested slot; partials are slot-major so lanes read
+  // consecutive doubles.
+  int slot = -1;
+  {
+    int k = blockIdx.x;
+    for (int s = 0; s < MS_NSCAL; ++s)
+      if (slot_mask & (1u << s)) {
+        if (k == 0) {
+          slot = s;
+          break;
+        }
+        --k;
+      }
   }
+  if (slot < 0) return;
+  const int op = (slot == MS_S_MINEDGE2) ? 1 : ((slot == MS_S_GUARD || slot == MS_S_MAXD2) ? 2 : 0);
+  const double* p = partials + (size_t)slot * n_tiles;
+  double v = op == 1 ? 1.0e300 : 0.0;
+  for (int t = tile0 + threadIdx.x; t < tile1; t += BLOCK) {
+    const double q = p[t];
+    v = op == 0 ? v + q : (op == 1 ? fmin(v, q) : fmax(v, q));
+  }
+  v = block_reduce(v, op, red);
+  if (threadIdx.x == 0) scal[slot] = (slot == MS_S_VOL) ? v / 6.0 : v;
 }
 
-hipError_t launch_reduce(const double* partials, int tile0, int tile1, uint32_t slot_mask,
-                         double* scal, hipStream_t s) {
-  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(BLOCK), 0, s, partials, tile0, tile1, slot_mask, scal);
+hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
+                         uint32_t slot_mask, double* scal, hipStream_t s) {
+  const int nslots = __builtin_popcount(slot_mask);
+  if (nslots == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_reduce, dim3(nslots), dim3(BLOCK), 0, s, partials, n_tiles, tile0, tile1,
+                     slot_mask, scal);
   return hipGetLastError();
 }
 
@@ -664,7 +682,8 @@ __global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, c
                                                      double* g, const double* gC, double* d,
                                                      const double* pg, const double* pd,
                                                      const double* scal, int use_constraint,
-                                                     int cg_history, double* partials) {
+                                                     int cg_history, double* partials,
+                                                     int n_tiles) {
   __shared__ double red[4];
   const int tile = tile0 + blockIdx.x;
   double lam = 0.0;
@@ -708,22 +727,23 @@ __global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, c
     gd += dot(gi, di);
     if (!fixed) md2 = fmax(md2, dot(di, di));
   }
-  double* out = partials + (size_t)tile * MS_NSCAL;
+  double* out = partials + tile;
+  const size_t ps = (size_t)n_tiles;
   double r = block_reduce(gn2, 0, red);
-  if (threadIdx.x == 0) out[MS_S_GNORM2] = r;
+  if (threadIdx.x == 0) out[MS_S_GNORM2 * ps] = r;
   r = block_reduce(gd, 0, red);
-  if (threadIdx.x == 0) out[MS_S_GDOTD] = r;
+  if (threadIdx.x == 0) out[MS_S_GDOTD * ps] = r;
   r = block_reduce(md2, 2, red);
-  if (threadIdx.x == 0) out[MS_S_MAXD2] = r;
+  if (threadIdx.x == 0) out[MS_S_MAXD2 * ps] = r;
 }
 
 hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* g,
                             const double* gC, double* d, const double* pg, const double* pd,
                             const double* scal, int use_constraint, int cg_history,
-                            double* partials, hipStream_t s) {
+                            double* partials, int n_tiles, hipStream_t s) {
   if (tile1 <= tile0) return hipSuccess;
   hipLaunchKernelGGL(k_direction, dim3(tile1 - tile0), dim3(BLOCK), 0, s, tile0, nv, T, vflags, g,
-                     gC, d, pg, pd, scal, use_constraint, cg_history, partials);
+                     gC, d, pg, pd, scal, use_constraint, cg_history, partials, n_tiles);
   return hipGetLastError();
 }
 

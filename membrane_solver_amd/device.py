@@ -60,6 +60,7 @@ class DeviceMesh:
         if tri.size and (tri.ndim != 2 or tri.shape[1] != 3):
             raise ValueError("tri_rows must be (nf,3)")
         self.nv = int(pos.shape[0])
+        self._tri_for_tests = tri
         self.nf = int(tri.shape[0]) if tri.size else 0
         fx = None if fixed is None else np.ascontiguousarray(fixed, dtype=np.uint8)
         bd = None if boundary is None else np.ascontiguousarray(boundary, dtype=np.uint8)
@@ -204,6 +205,17 @@ class DeviceMesh:
         self._chk(L.lib().ms_device_buffer(self._h, int(buffer), ctypes.byref(p), ctypes.byref(n)),
                   "ms_device_buffer")
         return int(p.value or 0), int(n.value)
+
+    def profile_enable(self, on: bool = True):
+        self._chk(L.lib().ms_profile_enable(self._h, int(on)), "ms_profile_enable")
+
+    def profile_read(self):
+        """-> {kind: (total_ms, launches)} for energy / gradient / direction / reduce."""
+        ms = np.zeros(4)
+        n = np.zeros(4, dtype=np.int64)
+        self._chk(L.lib().ms_profile_read(self._h, _pd(ms), n.ctypes.data_as(L._I64)), "ms_profile_read")
+        names = ("energy", "gradient", "direction", "reduce")
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
     def shard_info(self):
         v = [ctypes.c_int64(0) for _ in range(4)]

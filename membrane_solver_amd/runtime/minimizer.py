@@ -1,0 +1,355 @@
+"""Device-resident Minimizer with the reference's entry points.
+
+Mirrors ``runtime/minimizer.py`` of the reference for the hot-path scope:
+``Minimizer(mesh, global_params, stepper, energy_manager, constraint_manager,
+energy_modules=None, constraint_modules=None, step_size=1e-3, tol=1e-6,
+quiet=False)`` with ``minimize(n_steps, callback=None) -> dict``,
+``compute_energy()``, ``compute_energy_and_gradient_array()``,
+``compute_energy_breakdown()``, ``refresh_modules()``, ``reset_soa_caches()``
+and the attributes ``step_size``, ``stepper``, ``mesh``.
+
+One iteration (minimizer.py:1230-1515) =
+  energy + gradient over all modules            (:1314, evaluation_manager.py:134-151)
+  volume-constraint KKT projection, fixed rows  (:982-990, constraint_manager.py:293-301)
+  convergence test |g| < tol                    (:1324)
+  stepper.step: direction + Armijo line search  (:1374, line_search.py:267-426)
+  zero-step / reset bookkeeping                 (:1439-1464)
+  Lagrange volume-drift check -> projection     (:1478-1513)
+All array work runs in libmembrane_hip.so with positions, gradient, direction,
+CG history and trial positions resident in HBM; the host sees a handful of
+scalars per step.  ``Vertex.position`` objects / the mesh position array are
+written back once at the end (or before each ``callback``).
+
+Out of scope here (raises MembraneHipError): tilt relaxation modes, energy
+modules other than surface / bending / volume, constraints other than volume,
+the reference's auto mesh-quality repair hook.
+"""
+
+from __future__ import annotations
+
+import logging
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+
+from .. import _lib as L
+from ..core.parameters import ParameterResolver
+from ..geometry.mesh import mirror_for
+from ..modules.energy._common import bending_gradient_mode, bending_model
+from ..modules.energy.volume import body_penalty_params
+from .steppers.base import write_back_positions
+
+logger = logging.getLogger("membrane_solver")
+
+_ENERGY_BITS = {"surface": L.MS_MOD_SURFACE, "bending": L.MS_MOD_BENDING, "volume": L.MS_MOD_VOLUME_PENALTY}
+
+
+class GradientRows:
+    """Lazy stand-in for the reference's ``{vertex_id: grad_row}`` dict of non-zero rows
+    (minimizer.py:1067-1073); materialised on first dict-style access."""
+
+    def __init__(self, mesh, grad_arr: np.ndarray):
+        self.array = grad_arr
+        self._mesh = mesh
+        self._dict = None
+
+    def _materialise(self):
+        if self._dict is None:
+            nz = np.flatnonzero(np.any(self.array != 0.0, axis=1))
+            ids = self._mesh.vertex_ids
+            self._dict = {int(ids[r]): self.array[r].copy() for r in nz}
+        return self._dict
+
+    def __getitem__(self, k):
+        return self._materialise()[k]
+
+    def __iter__(self):
+        return iter(self._materialise())
+
+    def __len__(self):
+        return len(self._materialise())
+
+    def items(self):
+        return self._materialise().items()
+
+    def keys(self):
+        return self._materialise().keys()
+
+    def values(self):
+        return self._materialise().values()
+
+    def __contains__(self, k):
+        return k in self._materialise()
+
+
+class Minimizer:
+    """Coordinate the optimisation loop for a mesh, on the GPU."""
+
+    def __init__(self, mesh, global_params, stepper, energy_manager, constraint_manager,
+                 energy_modules: Optional[List[str]] = None,
+                 constraint_modules: Optional[List[str]] = None, step_size: float = 1e-3,
+                 tol: float = 1e-6, quiet: bool = False, *, device: int = 0, tile_vertices: int = 0):
+        self.mesh = mesh
+        self.global_params = global_params
+        self.energy_manager = energy_manager
+        self.constraint_manager = constraint_manager
+        self.stepper = stepper
+        self.step_size = step_size
+        self.tol = tol
+        self.quiet = quiet
+        self.device = device
+        self.tile_vertices = tile_vertices
+        self.max_zero_steps = int(global_params.get("max_zero_steps", 10))
+        self.step_size_floor = float(global_params.get("step_size_floor", 1e-8))
+        self.param_resolver = ParameterResolver(global_params)
+        module_list = energy_modules if energy_modules is not None else mesh.energy_modules
+        self.energy_module_names = list(module_list)
+        constraint_list = constraint_modules if constraint_modules is not None else mesh.constraint_modules
+        self.constraint_module_names = list(constraint_list)
+        self.refresh_modules()
+
+    # -- module wiring (minimizer.py:100-118, :235-243) -----------------------
+    def refresh_modules(self):
+        self.energy_modules = [self.energy_manager.get_module(m) for m in self.energy_module_names]
+        for name, mod in zip(self.energy_module_names, self.energy_modules):
+            if not hasattr(mod, "compute_energy_and_gradient_array"):
+                raise TypeError(f"energy module {name!r} lacks compute_energy_and_gradient_array")
+            if name not in _ENERGY_BITS:
+                raise L.MembraneHipError(
+                    f"energy module {name!r} is outside the HIP hot path (surface, bending, volume)")
+        self.constraint_modules = [self.constraint_manager.get_constraint(c)
+                                   for c in self.constraint_module_names]
+        for name in self.constraint_module_names:
+            if name != "volume":
+                raise L.MembraneHipError(f"constraint module {name!r} is outside the HIP hot path (volume)")
+        self._has_enforceable_constraints = any(hasattr(m, "enforce_constraint")
+                                                for m in self.constraint_modules)
+        self._configured_key = None
+        self._device_ahead = False
+
+    def sync_mesh_from_device(self):
+        """Write device positions back into the mesh (after minimize(sync_mesh=False))."""
+        mir, dm = self._device_nosync()
+        write_back_positions(self.mesh, dm, mir)
+        self._device_ahead = False
+
+    def _device_nosync(self):
+        mir = mirror_for(self.mesh, device=self.device, tile_vertices=self.tile_vertices)
+        if mir.dm is None:
+            mir.sync()
+        return mir, mir.dm
+
+    def reset_soa_caches(self):
+        """Forget the device mirror (call after topology surgery, minimizer.py:208)."""
+        mir = getattr(self.mesh, "_hip_mirror", None)
+        if mir is not None and mir.dm is not None:
+            mir.dm.close()
+        self.mesh._hip_mirror = None
+        self._configured_key = None
+
+    # -- device configuration --------------------------------------------------
+    def _device(self):
+        gp = self.global_params
+        tilt_mode = gp.get("tilt_solve_mode", "fixed")
+        if tilt_mode not in (None, "fixed"):
+            raise L.MembraneHipError(f"tilt_solve_mode={tilt_mode!r} is outside the HIP hot path")
+        mir = mirror_for(self.mesh, device=self.device, tile_vertices=self.tile_vertices)
+        dm = mir.sync()
+        mods = 0
+        vol_mode = gp.get("volume_constraint_mode", "lagrange")
+        for name in self.energy_module_names:
+            if name == "volume":
+                if vol_mode == "penalty" and getattr(self.mesh, "bodies", None):
+                    mods |= L.MS_MOD_VOLUME_PENALTY
+            else:
+                mods |= _ENERGY_BITS[name]
+        target = 0.0
+        stiffness = float(gp.get("volume_stiffness") or 0.0)
+        body = mir.body
+        if body is not None:
+            t = body.target_volume if body.target_volume is not None else (body.options or {}).get("target_volume")
+            if t is not None:
+                target = float(t)
+        if mods & L.MS_MOD_VOLUME_PENALTY:
+            kv = body_penalty_params(self.mesh, gp, self.param_resolver)
+            stiffness, target = kv
+        if "volume" in self.constraint_module_names and vol_mode == "lagrange" and body is not None \
+                and self._target_volume() is not None:
+            mods |= L.MS_CON_VOLUME
+        if body is not None and self._target_volume() is not None and vol_mode == "lagrange" \
+                and not gp.get("volume_projection_during_minimization", True):
+            mods |= L.MS_TRACK_VOLUME  # drift check of minimizer.py:1478-1513
+        model = bending_model(gp)
+        mode = bending_gradient_mode(gp) if (mods & L.MS_MOD_BENDING) else "analytic"
+        if mode == "approx" and (mods & L.MS_MOD_BENDING):
+            order = self.energy_module_names
+            if order.index("bending") != len(order) - 1 and np.any(_boundary(self.mesh)):
+                raise L.MembraneHipError(
+                    "bending_gradient_mode=approx with energy modules listed AFTER bending on an "
+                    "open mesh is not on the fused device path (bending.py:165-166 zeroes boundary "
+                    "rows of what was accumulated so far); list bending last")
+        if mods & L.MS_MOD_SURFACE:
+            mir.upload_surface_tension()
+        if mods & L.MS_MOD_BENDING:
+            mir.upload_bending_params(gp, model)
+        key = (mods, model, mode, stiffness, target, id(dm))
+        if key != self._configured_key:
+            dm.set_params(modules=mods,
+                          bending_model=L.MS_BEND_HELFRICH if model == "helfrich" else L.MS_BEND_WILLMORE,
+                          bending_grad_mode=L.MS_GRAD_ANALYTIC if mode == "analytic" else L.MS_GRAD_APPROX,
+                          volume_stiffness=stiffness, target_volume=target)
+            self._configured_key = key
+        return mir, dm
+
+    def _target_volume(self):
+        bodies = getattr(self.mesh, "bodies", None) or {}
+        if not bodies:
+            return None
+        body = next(iter(bodies.values()))
+        t = body.target_volume
+        if t is None:
+            t = (body.options or {}).get("target_volume")
+        return None if t is None else float(t)
+
+    # -- evaluation entry points ------------------------------------------------
+    def compute_energy_and_gradient_array(self):
+        """Total energy and dense gradient (minimizer.py:941-992)."""
+        _mir, dm = self._device()
+        e, g = dm.energy_and_gradient(want_grad=True)
+        return float(e.sum()), g
+
+    def compute_energy_and_gradient(self):
+        E, g = self.compute_energy_and_gradient_array()
+        return E, GradientRows(self.mesh, g)
+
+    def compute_energy(self) -> float:
+        """minimizer.py:1051-1054."""
+        _mir, dm = self._device()
+        return float(dm.energy().sum())
+
+    def compute_energy_breakdown(self) -> Dict[str, float]:
+        """Per-module energies (minimizer.py:1056-1065)."""
+        _mir, dm = self._device()
+        e = dm.energy()
+        out = {}
+        for name in self.energy_module_names:
+            out[name] = float({"surface": e[0], "bending": e[1], "volume": e[2]}[name])
+        return out
+
+    # -- constraint enforcement (minimizer.py:1103-1188) ---------------------------
+    def _enforce(self, dm, context: str) -> bool:
+        """Volume projection on the device.  Returns True if positions moved."""
+        if not self._has_enforceable_constraints:
+            return False
+        gp = self.global_params
+        if context == "minimize" and not gp.get("volume_projection_during_minimization", True):
+            return False
+        target = self._target_volume()
+        if target is None:
+            return False
+        max_iter = 12 if context in ("finalize", "mesh_operation") else 3
+        iters, _v = dm.project_volume(target, tol=1e-12, max_iter=max_iter)
+        return iters > 0
+
+    # -- the loop -------------------------------------------------------------------
+    def minimize(self, n_steps: int = 1, callback: Optional[Callable] = None, *, sync_mesh: bool = True):
+        """Run ``n_steps`` iterations (minimizer.py:1189-1535).
+
+        ``sync_mesh=False`` leaves the new positions in HBM only (the mesh object is
+        refreshed by the next call that uses ``sync_mesh=True`` or by
+        ``sync_mesh_from_device()``); benchmarks use it to keep PCIe out of the loop."""
+        mir, dm = self._device()
+        gp = self.global_params
+        if self._has_enforceable_constraints and gp.get("volume_projection_during_minimization", True) \
+                and gp.get("volume_constraint_mode", "lagrange") == "lagrange":
+            raise L.MembraneHipError(
+                "volume_projection_during_minimization=True re-projects the volume inside every "
+                "line-search trial (line_search.py:428-456); that host-side lane is not on the HIP "
+                "path -- set it to False (the reference parser's default for Lagrange decks)")
+        if n_steps <= 0:
+            E, g = self.compute_energy_and_gradient_array()
+            moved = self._enforce(dm, "minimize")
+            if moved:
+                write_back_positions(self.mesh, dm, mir)
+            return {"energy": float(self.compute_energy()), "gradient": GradientRows(self.mesh, g),
+                    "mesh": self.mesh, "step_success": True, "iterations": 0, "terminated_early": True}
+
+        dirty = False
+        if self._has_enforceable_constraints:
+            dirty |= self._enforce(dm, "mesh_operation")
+
+        zero_step_counter = 0
+        step_success = True
+        proj_flag = gp.get("volume_projection_during_minimization", True)
+        vol_tol = float(gp.get("volume_tolerance", 1e-3))
+        vol_mode = gp.get("volume_constraint_mode", "lagrange")
+        target = self._target_volume()
+        have_grad = False
+
+        def finish(result):
+            if dirty_box[0] or self._device_ahead:
+                if sync_mesh:
+                    write_back_positions(self.mesh, dm, mir)
+                    self._device_ahead = False
+                else:
+                    self._device_ahead = True
+            return result
+
+        dirty_box = [dirty]
+        for i in range(n_steps):
+            if callback:
+                if dirty_box[0]:
+                    write_back_positions(self.mesh, dm, mir)
+                    dirty_box[0] = False
+                callback(self.mesh, i)
+                mir, dm = self._device()
+            step_mode = str(gp.get("step_size_mode", "adaptive") or "adaptive").lower()
+            fixed_step = float(gp.get("step_size", self.step_size) or self.step_size)
+            step_size_in = fixed_step if step_mode == "fixed" else self.step_size
+            r = self.stepper.device_step(dm, self.mesh, step_size_in, tol=self.tol)
+            have_grad = True
+            if r.converged:  # minimizer.py:1324-1337
+                logger.info("Converged in %d iterations; |grad E|=%.3e", i, r.grad_norm)
+                dirty_box[0] |= self._enforce(dm, "finalize")
+                return finish({"energy": r.energy_eval, "gradient": GradientRows(self.mesh, dm.get_gradient()),
+                               "mesh": self.mesh, "step_success": True, "iterations": i + 1,
+                               "terminated_early": True})
+            step_success = r.success
+            self.step_size = r.next_step
+            if r.success:
+                dirty_box[0] = True
+            if not self.quiet:
+                print(f"Step {i:4d}: Energy = {r.energy:.5f}, Step Size  = {step_size_in:.2e}")
+            if step_mode == "fixed":
+                self.step_size = fixed_step
+            if not step_success:
+                if self.step_size <= self.step_size_floor:
+                    zero_step_counter += 1
+                    if zero_step_counter >= self.max_zero_steps:
+                        logger.info("Terminating early after %d consecutive zero-steps", zero_step_counter)
+                        return finish({"energy": float(dm.energy().sum()),
+                                       "gradient": GradientRows(self.mesh, dm.get_gradient()),
+                                       "mesh": self.mesh, "step_success": False, "iterations": i + 1,
+                                       "terminated_early": True})
+                else:
+                    zero_step_counter = 0
+                self.stepper.reset()
+            else:
+                zero_step_counter = 0
+                # Lagrange volume drift check (minimizer.py:1478-1513)
+                if vol_mode == "lagrange" and not proj_flag and target is not None:
+                    denom = max(abs(target), 1.0)
+                    if abs(r.volume - target) / denom > vol_tol:
+                        dirty_box[0] |= self._enforce(dm, "mesh_operation")
+                        self.stepper.reset()
+        dirty_box[0] |= self._enforce(dm, "finalize")
+        final_energy = float(dm.energy().sum())
+        grad = GradientRows(self.mesh, dm.get_gradient()) if have_grad else {}
+        return finish({"energy": final_energy, "gradient": grad, "mesh": self.mesh,
+                       "step_success": step_success, "iterations": n_steps, "terminated_early": False})
+
+
+def _boundary(mesh):
+    from ..geometry.mesh import _boundary_mask_of
+
+    return _boundary_mask_of(mesh, len(mesh.vertex_ids))

@@ -1,0 +1,257 @@
+"""GPU parity of the device-resident Minimizer (reference-shaped API) against
+the reference's own trajectories (tests/golden/traj_*.npz) and the CPU oracle.
+
+Trajectory tolerance: accept/reject sequence and step sizes identical; accepted
+energies 1e-10 relative; final positions 1e-8 relative (SURVEY 7.3 item 5:
+trajectories are compared per step, not bitwise)."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(g, mods, cons, gp, with_body):
+    from membrane_solver_amd.geometry.mesh import ArrayBody, ArrayMesh
+
+    bodies = []
+    if with_body:
+        bodies = [ArrayBody(0, None, float(g["target_volume"]))]
+    return ArrayMesh(g["positions0"], g["tri"], fixed=g["fixed"], surface_tension=g["gamma"],
+                     bodies=bodies, global_parameters=gp, energy_modules=mods, constraint_modules=cons)
+
+
+BASE = {"volume_constraint_mode": "lagrange", "volume_projection_during_minimization": False}
+CASES = {
+    "traj_cube_gd.npz": (["surface", "volume"], [], "gd",
+                         {"volume_constraint_mode": "penalty", "volume_projection_during_minimization": True}),
+    "traj_ico8_gd_surface_volume.npz": (["surface"], ["volume"], "gd", dict(BASE)),
+    "traj_ico8_cg_surface_bending.npz": (["surface", "bending"], [], "cg", dict(BASE, bending_modulus=1.0)),
+    "traj_ico8_cg_surface_bending_volume.npz": (["surface", "bending"], ["volume"], "cg",
+                                                dict(BASE, bending_modulus=1.0, spontaneous_curvature=0.3)),
+    "traj_disk5_gd_surface_bending_fixed.npz": (["surface", "bending"], [], "gd",
+                                                dict(BASE, bending_modulus=1.0)),
+}
+
+
+@pytest.mark.parametrize("fname", sorted(CASES))
+def test_minimizer_reproduces_reference_trajectory(fname):
+    from membrane_solver_amd.runtime.constraint_manager import ConstraintModuleManager
+    from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
+    from membrane_solver_amd.runtime.minimizer import Minimizer
+    from membrane_solver_amd.runtime.steppers import ConjugateGradient, GradientDescent
+
+    mods, cons, kind, gp = CASES[fname]
+    g = load_golden(fname)
+    gp = dict(gp)
+    if "gp_volume_stiffness" in g:
+        gp["volume_stiffness"] = float(g["gp_volume_stiffness"])
+        gp["surface_tension"] = float(g["gp_surface_tension"])
+    mesh = _build(g, mods, cons, gp, "target_volume" in g)
+    stepper = GradientDescent() if kind == "gd" else ConjugateGradient()
+    log = []
+    orig = stepper.device_step
+
+    def logged(dm, m, step_size, tol=0.0):
+        r = orig(dm, m, step_size, tol=tol)
+        log.append((float(r.success), r.next_step, r.energy))
+        return r
+
+    stepper.device_step = logged
+    mz = Minimizer(mesh, mesh.global_parameters, stepper, EnergyModuleManager(mods),
+                   ConstraintModuleManager(cons), quiet=True, step_size=float(g["step_size0"]))
+    E0, grad0 = mz.compute_energy_and_gradient_array()
+    assert abs(E0 - g["E0"]) <= 1e-12 * abs(g["E0"])
+    assert relerr(grad0, g["grad0"]) < 1e-10
+    snaps = []
+    res = mz.minimize(int(g["n_steps"]), callback=lambda m, i: snaps.append(m.positions_view().copy()))
+    got, ref = np.array(log), g["step_log"]
+    assert got.shape == ref.shape
+    assert np.array_equal(got[:, 0], ref[:, 0]), "accept/reject sequence differs from the reference"
+    assert np.allclose(got[:, 1], ref[:, 1], rtol=1e-12, atol=0)
+    assert np.allclose(got[:, 2], ref[:, 2], rtol=1e-10, atol=0)
+    assert relerr(np.array(snaps), g["positions_iter"]) < 1e-8
+    assert relerr(mesh.positions_view(), g["positions_final"]) < 1e-8
+    assert abs(res["energy"] - g["E_final"]) <= 1e-10 * abs(g["E_final"])
+    assert abs(mz.step_size - g["step_size_final"]) <= 1e-12 * g["step_size_final"]
+    assert res["iterations"] == int(g["iterations"])
+
+
+def test_config1_cube_g5_energies():
+    """cube.json, g5 -> 5.98402, 5.96632, 5.94183, 5.92462, 5.92118;
+    final 5.9211760891123495."""
+    from membrane_solver_amd.runtime.constraint_manager import ConstraintModuleManager
+    from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
+    from membrane_solver_amd.runtime.minimizer import Minimizer
+    from membrane_solver_amd.runtime.steppers import GradientDescent
+
+    g = load_golden("traj_cube_gd.npz")
+    gp = {"volume_constraint_mode": "penalty", "volume_projection_during_minimization": True,
+          "volume_stiffness": float(g["gp_volume_stiffness"]), "surface_tension": float(g["gp_surface_tension"])}
+    mesh = _build(g, ["surface", "volume"], [], gp, True)
+    mz = Minimizer(mesh, mesh.global_parameters, GradientDescent(), EnergyModuleManager(["surface", "volume"]),
+                   ConstraintModuleManager([]), quiet=True, step_size=1e-3)
+    energies = []
+    for _ in range(5):
+        mz.minimize(1)
+        energies.append(mz.compute_energy())
+    assert np.allclose(energies, [5.98402, 5.96632, 5.94183, 5.92462, 5.92118], atol=5e-6)
+    assert abs(energies[-1] - 5.9211760891123495) < 1e-10
+
+
+def test_guard_and_failure_paths_match_oracle():
+    """Huge initial step: the normal-rotation guard (topology.py:13-48) and the
+    zero-step bookkeeping must follow the oracle's minimizer port step for step."""
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.geometry.mesh import ArrayMesh
+    from membrane_solver_amd.runtime.constraint_manager import ConstraintModuleManager
+    from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
+    from membrane_solver_amd.runtime.minimizer import Minimizer
+    from membrane_solver_amd.runtime.steppers import ConjugateGradient
+    from oracle import minimizer_port as mp
+
+    P, T = meshgen.icosphere(6)
+    P = meshgen.smooth_displace(P, 0.1)
+    gp = {"bending_modulus": 0.5, "surface_tension": 1.0}
+    p = mp.Problem(positions=P, tri=T, energy_modules=["surface", "bending"], gp=dict(gp))
+    ref = mp.minimize(p, mp.ConjugateGradient(), 8, step_size=5.0)
+    mesh = ArrayMesh(P, T, global_parameters=dict(gp), energy_modules=["surface", "bending"])
+    stepper = ConjugateGradient()
+    log = []
+    orig = stepper.device_step
+
+    def logged(dm, m, step_size, tol=0.0):
+        r = orig(dm, m, step_size, tol=tol)
+        log.append((float(r.success), r.next_step, r.energy, r.guard_rejects))
+        return r
+
+    stepper.device_step = logged
+    mz = Minimizer(mesh, mesh.global_parameters, stepper, EnergyModuleManager(["surface", "bending"]),
+                   ConstraintModuleManager([]), quiet=True, step_size=5.0)
+    res = mz.minimize(8)
+    got = np.array(log)
+    want = np.array([[float(t["success"]), t["next_step"], t["E_accepted"]] for t in ref["trace"]])
+    assert got[:, 3].sum() > 0, "the guard was expected to trigger in this case"
+    assert np.array_equal(got[:, 0], want[:, 0])
+    assert np.allclose(got[:, 1], want[:, 1], rtol=1e-12)
+    assert np.allclose(got[:, 2], want[:, 2], rtol=1e-10)
+    assert relerr(mesh.positions_view(), p.positions) < 1e-8
+    assert abs(res["energy"] - ref["energy"]) <= 1e-10 * abs(ref["energy"])
+
+
+def test_plugin_api_host_arrays_match_reference():
+    """modules.energy.* called the way EvaluationManager calls them (accumulate into grad_arr)."""
+    from membrane_solver_amd.core.parameters import ParameterResolver
+    from membrane_solver_amd.geometry.mesh import ArrayBody, ArrayMesh
+    from membrane_solver_amd.modules.constraints import volume as cvolume
+    from membrane_solver_amd.modules.energy import bending, surface
+    from membrane_solver_amd.modules.energy import volume as evolume
+
+    g = load_golden("mesh_disk5.npz")
+    gp = {"bending_modulus": 0.8, "spontaneous_curvature": 0.5, "volume_constraint_mode": "lagrange"}
+    mesh = ArrayMesh(g["positions"], g["tri"], surface_tension=g["gamma"], global_parameters=gp,
+                     bodies=[ArrayBody(0, None, float(g["volpen_target"]))])
+    pr = ParameterResolver(mesh.global_parameters)
+    pos, im = mesh.positions_view(), mesh.vertex_index_to_row
+    grad = np.ones_like(pos)  # accumulate semantics: pre-filled array
+    Es = surface.compute_energy_and_gradient_array(mesh, mesh.global_parameters, pr, positions=pos,
+                                                   index_map=im, grad_arr=grad)
+    Eb = bending.compute_energy_and_gradient_array(mesh, mesh.global_parameters, pr, positions=pos,
+                                                   index_map=im, grad_arr=grad)
+    assert abs(Es - g["E_surface"]) <= 1e-12 * abs(g["E_surface"])
+    assert abs(Eb - g["E_bend_helfrich_c5_analytic"]) <= 1e-12 * abs(g["E_bend_helfrich_c5_analytic"])
+    assert relerr(grad - 1.0, g["grad_surface"] + g["grad_bend_helfrich_c5_analytic"]) < 1e-10
+    assert abs(bending.compute_energy_array(mesh, mesh.global_parameters, pos, im)
+               - float(np.sum(g["Earr_bend_helfrich_c5"]))) <= 1e-12 * abs(Eb)
+    gC = cvolume.constraint_gradients_array(mesh, mesh.global_parameters, positions=pos, index_map=im)
+    assert relerr(gC[0], g["grad_volume"]) < 1e-10
+    mesh.global_parameters.set("volume_constraint_mode", "penalty")
+    mesh.global_parameters.set("volume_stiffness", float(g["volpen_k"]))
+    gv = np.zeros_like(pos)
+    Ev = evolume.compute_energy_and_gradient_array(mesh, mesh.global_parameters, pr, positions=pos,
+                                                   index_map=im, grad_arr=gv)
+    assert abs(Ev - g["E_volpen"]) <= 1e-12 * abs(g["E_volpen"])
+    assert relerr(gv, g["grad_volpen"]) < 1e-10
+    # a foreign positions array (not the mesh's cache) is honoured
+    pos2 = pos * 1.01
+    g2 = np.zeros_like(pos)
+    E2 = surface.compute_energy_and_gradient_array(mesh, mesh.global_parameters, pr, positions=pos2,
+                                                   index_map=im, grad_arr=g2)
+    assert abs(E2 - 1.0201 * g["E_surface"]) <= 1e-11 * abs(g["E_surface"])
+
+
+@pytest.mark.parametrize("freq,kind", [(81, "gd"), (320, "cg")])
+def test_full_size_properties(freq, kind):
+    """BASELINE sizes (configs 2 and 3; nf = 131 220 / 2 048 000): size-independent
+    properties instead of an oracle run.
+    - patch-order round trip of positions is bit exact;
+    - fixed rows of the gradient are exactly zero;
+    - KKT: the volume-projected gradient is orthogonal to dV/dx;
+    - translation invariance of E and grad; closed-surface gradient rows sum to 0;
+    - linearity: doubling gamma doubles E_surface and its gradient;
+    - accepted steps satisfy Armijo decrease and the alpha_max growth cap."""
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+
+    P, T = meshgen.icosphere(freq)
+    P = meshgen.smooth_displace(P, 0.05)
+    nv, nf = P.shape[0], T.shape[0]
+    assert nf == 20 * freq * freq
+    mods = L.MS_MOD_SURFACE | (L.MS_MOD_BENDING if kind == "cg" else 0)
+    dm = DeviceMesh(P, T)
+    assert np.array_equal(dm.get_positions(), P)
+    dm.set_surface_tension(np.ones(nf))
+    dm.set_bending_params(np.ones(nv), np.full(nv, 0.2))
+    # KKT orthogonality
+    dm.set_params(modules=mods | L.MS_CON_VOLUME, target_volume=4.0)
+    e1, g1 = dm.energy_and_gradient()
+    gC = dm.get_vertex_buffer(L.MS_BUF_GC)
+    assert abs(np.sum(g1 * gC)) <= 1e-10 * np.linalg.norm(g1) * np.linalg.norm(gC)
+    # unprojected gradient, translation invariance, zero row-sum of the surface part
+    dm.set_params(modules=mods)
+    e0, g0 = dm.energy_and_gradient()
+    assert abs(e0.sum() - e1.sum()) <= 1e-13 * abs(e0.sum())
+    lam = np.sum(g0 * gC) / np.sum(gC * gC)
+    assert relerr(g1, g0 - lam * gC) < 1e-10
+    dm.set_positions(P + np.array([0.3, -0.2, 0.1]))
+    e2, g2 = dm.energy_and_gradient()
+    assert abs(e2.sum() - e0.sum()) <= 1e-11 * abs(e0.sum())
+    assert relerr(g2, g0) < 1e-7
+    dm.set_positions(P)
+    dm.set_params(modules=L.MS_MOD_SURFACE)
+    es, gs = dm.energy_and_gradient()
+    assert np.max(np.abs(gs.sum(axis=0))) < 1e-12
+    dm.set_surface_tension(np.full(nf, 2.0))
+    es2, gs2 = dm.energy_and_gradient()
+    assert abs(es2[0] - 2.0 * es[0]) <= 1e-14 * es2[0]
+    assert relerr(gs2, 2.0 * gs) < 1e-14
+    dm.close()
+    # fixed rows + a few real steps
+    fixed = np.zeros(nv, dtype=bool)
+    fixed[:: max(1, nv // 97)] = True
+    dm = DeviceMesh(P, T, fixed=fixed)
+    dm.set_surface_tension(np.ones(nf))
+    dm.set_bending_params(np.ones(nv), np.zeros(nv))
+    dm.set_params(modules=mods)
+    _, g = dm.energy_and_gradient()
+    assert np.all(g[fixed] == 0.0) and np.any(g[~fixed] != 0.0)
+    step, e_prev = 1e-6, dm.energy().sum()
+    stepper = L.MS_STEPPER_CG if kind == "cg" else L.MS_STEPPER_GD
+    accepted = 0
+    for _ in range(8):
+        r = dm.step(stepper=stepper, step_size=step)
+        if r.success:
+            accepted += 1
+            assert r.energy <= e_prev + 1e-4 * r.alpha * r.g_dot_d + 1e-15
+            assert r.next_step <= 10.0 * step * (1 + 1e-15)
+            e_prev = r.energy
+        else:
+            dm.reset_stepper()
+        step = r.next_step
+    assert accepted >= 1
+    x = dm.get_positions()
+    assert np.array_equal(x[fixed], P[fixed])
+    dm.close()

@@ -1,0 +1,160 @@
+"""CPU-only checks of the host layer: the C ABI exports what include/ declares,
+the tiling pass keeps its invariants, the reference-shaped managers / steppers /
+mesh accessors behave, and the product path refuses to run without the GPU
+library instead of falling back."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+def test_library_exports_every_declared_symbol():
+    from membrane_solver_amd import _lib
+
+    _lib.build()
+    hdr = open(os.path.join(ROOT, "include", "membrane_hip.h")).read()
+    declared = set(re.findall(r"\b(ms_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"ms_params", "ms_stepper_params", "ms_step_result"}
+    assert declared, "no prototypes found in the header"
+    cd = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in sorted(declared) if not hasattr(cd, n)]
+    assert not missing, f"declared in membrane_hip.h but not exported: {missing}"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert _lib.lib().ms_version().startswith(b"membrane_hip")
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    from membrane_solver_amd import _lib
+
+    lib = _lib.lib()
+    if lib.ms_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from membrane_solver_amd.device import DeviceMesh
+
+    g = load_golden("mesh_ico4.npz")
+    with pytest.raises(_lib.MembraneHipError):
+        DeviceMesh(g["positions"], g["tri"])
+    # and nothing under the package imports the oracle
+    pkg = os.path.join(ROOT, "membrane_solver_amd")
+    for dirpath, _d, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "ms_oracle" not in txt, f
+
+
+@pytest.mark.parametrize("tile", [64, 256, 1024])
+def test_tiling_invariants(tile):
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd import meshgen
+
+    lib = L.lib()
+    for P, T in (meshgen.icosphere(12), meshgen.disk_patch(9, jitter=0.2)[:2]):
+        nv, nf = len(P), len(T)
+        st = (ctypes.c_int64 * 8)()
+        perm = np.empty(nv, np.int32)
+        rc = lib.ms_plan_tiling(nv, nf, P.ctypes.data_as(L._D), T.ctypes.data_as(L._I32), tile, 1, st,
+                                perm.ctypes.data_as(L._I32))
+        assert rc == 0
+        assert st[0] == (nv + tile - 1) // tile
+        assert st[4] == 0 and st[5] == nf and st[6] == 3 * nf  # every facet owned once, every corner once
+        assert st[1] >= nf and sorted(perm.tolist()) == list(range(nv))
+        assert st[7] <= 160 * 1024
+    # out-of-range indices are dropped like surface_energy.f90:57-59
+    P, T = meshgen.icosphere(3)
+    T = T.copy()
+    T[5, 1] = len(P) + 7
+    T[9, 0] = -1
+    st = (ctypes.c_int64 * 8)()
+    assert lib.ms_plan_tiling(len(P), len(T), P.ctypes.data_as(L._D), T.ctypes.data_as(L._I32), 64, 1, st, None) == 0
+    assert st[4] == 2 and st[5] == len(T) - 2
+    # bad arguments come back as error codes with a message, not exceptions
+    assert lib.ms_plan_tiling(len(P), len(T), P.ctypes.data_as(L._D), T.ctypes.data_as(L._I32), 100, 1, st, None) == -1
+    assert b"tile_vertices" in lib.ms_last_error(None)
+
+
+def test_array_mesh_accessors_and_managers():
+    from membrane_solver_amd.core.parameters import GlobalParameters, ParameterResolver
+    from membrane_solver_amd.geometry.mesh import ArrayBody, ArrayMesh, per_vertex_bending_params
+    from membrane_solver_amd.runtime.constraint_manager import ConstraintModuleManager
+    from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
+    from membrane_solver_amd.runtime.steppers import ConjugateGradient, GradientDescent
+
+    g = load_golden("mesh_disk5.npz")
+    mesh = ArrayMesh(g["positions"], g["tri"], surface_tension=1.3,
+                     global_parameters={"bending_modulus": 0.8, "spontaneous_curvature": 0.5},
+                     bodies=[ArrayBody(0, None, 1.0)])
+    assert mesh.positions_view().flags["C_CONTIGUOUS"] and mesh.triangle_row_cache()[0].dtype == np.int32
+    assert np.array_equal(mesh.boundary_mask, g["is_boundary"])
+    assert mesh.boundary_vertex_ids == set(np.flatnonzero(g["is_boundary"]).tolist())
+    assert np.all(mesh.get_facet_parameter_array("surface_tension") == 1.3)
+    v = mesh._version
+    mesh.increment_version()
+    assert mesh._version == v + 1
+    k, c0 = per_vertex_bending_params(mesh, mesh.global_parameters, "helfrich")
+    assert np.all(k == 0.8) and np.all(c0 == 0.5)
+    _, c0w = per_vertex_bending_params(mesh, mesh.global_parameters, "willmore")
+    assert np.all(c0w == 0.0)
+    gp = GlobalParameters({"x": 3})
+    assert gp.get("x") == 3 and gp.get("missing") is None and gp.volume_stiffness == 1000.0
+    assert ParameterResolver(gp).get(ArrayBody(0, None, 1.0, {"volume_stiffness": 7.0}), "volume_stiffness") == 7.0
+    em = EnergyModuleManager(["surface", "bending", "volume"])
+    for name in ("surface", "bending", "volume"):
+        assert hasattr(em.get_module(name), "compute_energy_and_gradient_array")
+    with pytest.raises(KeyError):
+        em.get_module("tilt_smoothness_in")
+    with pytest.raises(ImportError):
+        EnergyModuleManager(["not_a_module"])
+    cm = ConstraintModuleManager(["volume"])
+    assert hasattr(cm.get_constraint("volume"), "enforce_constraint")
+    cg = ConjugateGradient()
+    assert (cg.restart_interval, cg.max_iter, cg.beta, cg.c, cg.gamma, cg.alpha_max_factor) == (10, 10, 0.7, 1e-4, 1.5, 10.0)
+    gd = GradientDescent()
+    mesh.global_parameters.set("shape_line_search_max_iter", 4)
+    assert gd._max_iter_for(mesh) == 4
+    import inspect
+
+    sig = inspect.signature(gd.step)
+    assert list(sig.parameters)[:6] == ["mesh", "grad", "step_size", "energy_fn", "constraint_enforcer", "trial_energy_fn"]
+
+
+def test_minimizer_rejects_out_of_scope_modules():
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd.geometry.mesh import ArrayMesh
+    from membrane_solver_amd.runtime.constraint_manager import ConstraintModuleManager
+    from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
+    from membrane_solver_amd.runtime.minimizer import Minimizer
+    from membrane_solver_amd.runtime.steppers import GradientDescent
+
+    g = load_golden("mesh_ico4.npz")
+    mesh = ArrayMesh(g["positions"], g["tri"])
+
+    class FakeEM:
+        def get_module(self, name):
+            class M:
+                @staticmethod
+                def compute_energy_and_gradient_array(*a, **k):
+                    return 0.0
+            return M
+
+    with pytest.raises(L.MembraneHipError):
+        Minimizer(mesh, mesh.global_parameters, GradientDescent(), FakeEM(), ConstraintModuleManager([]),
+                  energy_modules=["line_tension"], constraint_modules=[])
+    mz = Minimizer(mesh, mesh.global_parameters, GradientDescent(), EnergyModuleManager(["surface"]),
+                   ConstraintModuleManager([]), energy_modules=["surface"], constraint_modules=[], quiet=True)
+    assert mz.step_size == 1e-3 and mz.tol == 1e-6 and mz.stepper.__class__.__name__ == "GradientDescent"
+
+
+def test_meshgen_counts():
+    from membrane_solver_amd import meshgen
+
+    for f in (1, 3, 10):
+        P, T = meshgen.icosphere(f)
+        assert P.shape == (10 * f * f + 2, 3) and T.shape == (20 * f * f, 3)
+        assert np.allclose(np.linalg.norm(P, axis=1), 1.0)
+        assert not meshgen.boundary_mask_from_triangles(len(P), T).any()

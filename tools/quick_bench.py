@@ -51,8 +51,11 @@ for name, fn in (("energy_and_gradient", lambda: dm.energy_and_gradient(want_gra
     print(f"{name}: {(time.time()-t)/n*1e6:.1f} us/call", flush=True)
 stp = L.MS_STEPPER_CG if args.stepper == "cg" else L.MS_STEPPER_GD
 step = 1e-3
-for _ in range(3):
+ap_warm = int(os.environ.get("QB_WARM", "3"))
+for i in range(ap_warm):
     r = dm.step(stepper=stp, step_size=step)
+    if i < 60 or i % 10 == 0:
+        print(f"  warm {i}: ok={r.success} trials={r.trials} guard={r.guard_rejects} alpha={r.alpha:.3e} next={r.next_step:.3e} E={r.energy:.12f} |g|={r.grad_norm:.3e} gd={r.g_dot_d:.3e}", flush=True)
     step = r.next_step
 t = time.time()
 acc = 0
