@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--freq", type=int, default=320, help="icosphere frequency (320 -> 2 048 000 facets)")
     ap.add_argument("--tile", type=int, default=0, help="owned vertices per tile (0 = library default)")
-    ap.add_argument("--step-size", type=float, default=1e-4)
+    ap.add_argument("--step-size", type=float, default=1e-6)
     ap.add_argument("--volume", action="store_true", help="add the volume Lagrange constraint row")
     ap.add_argument("--cpu-steps", type=int, default=3, help="CPU oracle steps for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
