@@ -29,6 +29,9 @@ struct ms_ctx {
   double* d_tf_gamma = nullptr;
   int32_t* d_tile_halo_off = nullptr;
   int32_t* d_halo_ids = nullptr;
+  int32_t* d_tile_ent_off = nullptr;
+  uint16_t* d_tile_voff = nullptr;
+  uint16_t* d_vent = nullptr;
   uint8_t* d_vflags = nullptr;
   double* d_kappa = nullptr;
   double* d_c0 = nullptr;
@@ -85,6 +88,9 @@ DeviceMesh device_mesh(const ms_ctx* c) {
   m.tf_gamma = c->d_tf_gamma;
   m.tile_halo_off = c->d_tile_halo_off;
   m.halo_ids = c->d_halo_ids;
+  m.tile_ent_off = c->d_tile_ent_off;
+  m.tile_voff = c->d_tile_voff;
+  m.vent = c->d_vent;
   m.vflags = c->d_vflags;
   m.kappa = c->d_kappa;
   m.c0 = c->d_c0;
@@ -142,7 +148,7 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   a.modules = modules;
   {
     ProfScope ps(c, 0);
-    HIPCHK(c, launch_energy(a, guard && use_dir, c->cap, c->stream));
+    HIPCHK(c, launch_energy(a, guard && use_dir, c->cap, c->til.max_ent, c->stream));
   }
   {
     ProfScope ps(c, 3);
@@ -173,7 +179,7 @@ int phase_gradient(ms_ctx* c, uint32_t modules, double* g_out, bool accumulate) 
   a.accumulate = accumulate ? 1 : 0;
   {
     ProfScope ps(c, 1);
-    HIPCHK(c, launch_gradient(a, c->cap, c->stream));
+    HIPCHK(c, launch_gradient(a, c->cap, c->til.max_ent, c->stream));
   }
   {
     ProfScope ps(c, 3);
@@ -318,8 +324,8 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
   c->tile1 = std::min(t.n_tiles, (shard_rank + 1) * t.tiles_per_shard);
   c->cap = t.T + t.max_halo;
   {
-    const size_t le = energy_lds_bytes(t.T, c->cap, true, true);
-    const size_t lg = gradient_lds_bytes(t.T, c->cap, true);
+    const size_t le = energy_lds_bytes(t.T, c->cap, t.max_ent, true, true);
+    const size_t lg = gradient_lds_bytes(t.T, c->cap, t.max_ent, true, true);
     if (le > 160 * 1024 || lg > 160 * 1024) {
       delete c;
       return fail(nullptr, MS_ERR_TILE_CAPACITY,
@@ -353,6 +359,9 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
   CREATE_CHK(upload(c, &c->d_tile_facets, t.tile_facets));
   CREATE_CHK(upload(c, &c->d_tile_halo_off, t.tile_halo_off));
   CREATE_CHK(upload(c, &c->d_halo_ids, t.halo_ids));
+  CREATE_CHK(upload(c, &c->d_tile_ent_off, t.tile_ent_off));
+  CREATE_CHK(upload(c, &c->d_tile_voff, t.tile_voff));
+  CREATE_CHK(upload(c, &c->d_vent, t.vent));
   {
     std::vector<double> ones(t.tile_facets.size(), 1.0);
     CREATE_CHK(upload(c, &c->d_tf_gamma, ones));
@@ -408,7 +417,8 @@ void ms_destroy(ms_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->d_perm, c->d_tile_facet_off, c->d_tile_facets, c->d_tf_gamma,
-                  c->d_tile_halo_off, c->d_halo_ids, c->d_vflags, c->d_kappa, c->d_c0,
+                  c->d_tile_halo_off, c->d_halo_ids, c->d_tile_ent_off, c->d_tile_voff, c->d_vent,
+                  c->d_vflags, c->d_kappa, c->d_c0,
                   c->state, c->d_partials, c->d_scal, c->d_stage};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -727,8 +737,10 @@ int ms_tile_stats(ms_ctx* c, int64_t* n_tiles, int64_t* facet_instances, int64_t
   if (n_tiles) *n_tiles = t.n_tiles;
   if (facet_instances) *facet_instances = (int64_t)t.tile_facets.size();
   if (max_halo) *max_halo = t.max_halo;
-  if (lds_bytes_energy) *lds_bytes_energy = (int64_t)energy_lds_bytes(t.T, c->cap, bend, false);
-  if (lds_bytes_gradient) *lds_bytes_gradient = (int64_t)gradient_lds_bytes(t.T, c->cap, bend);
+  if (lds_bytes_energy) *lds_bytes_energy = (int64_t)energy_lds_bytes(t.T, c->cap, t.max_ent, bend, false);
+  if (lds_bytes_gradient)
+    *lds_bytes_gradient = (int64_t)gradient_lds_bytes(t.T, c->cap, t.max_ent, bend,
+                                                      (c->params.modules & MS_CON_VOLUME) != 0);
   return MS_OK;
 }
 
@@ -783,7 +795,7 @@ int ms_plan_tiling(int nv, int nf, const double* positions, const int32_t* tri, 
   stats[4] = t.dropped_facets;
   stats[5] = owners;
   stats[6] = owned_corners;
-  stats[7] = (int64_t)gradient_lds_bytes(t.T, t.T + t.max_halo, true);
+  stats[7] = (int64_t)gradient_lds_bytes(t.T, t.T + t.max_halo, t.max_ent, true, true);
   if (perm_out) memcpy(perm_out, t.perm.data(), sizeof(int32_t) * (size_t)nv);
   return MS_OK;
 }

@@ -41,6 +41,13 @@ struct Tiling {
   std::vector<int32_t> tile_facet_ext;  // external facet row of each instance
   std::vector<int32_t> tile_halo_off;   // n_tiles+1
   std::vector<int32_t> halo_ids;        // internal vertex ids
+  // per-tile vertex -> corner CSR (deterministic gather order): for owned vertex i of
+  // tile t the entries vent[tile_ent_off[t] + voff[t*(T+1)+i] ... +voff[t*(T+1)+i+1])
+  // are (facet_local << 2 | corner), ascending in facet_local.
+  std::vector<int32_t> tile_ent_off;    // n_tiles+1
+  std::vector<uint16_t> tile_voff;      // n_tiles*(T+1)
+  std::vector<uint16_t> vent;
+  int max_ent = 0;
   int max_halo = 0;
   int max_tile_facets = 0;
   int64_t dropped_facets = 0;
@@ -59,6 +66,9 @@ struct DeviceMesh {
   const double* tf_gamma;  // surface tension per facet instance
   const int32_t* tile_halo_off;
   const int32_t* halo_ids;
+  const int32_t* tile_ent_off;
+  const uint16_t* tile_voff;
+  const uint16_t* vent;
   const uint8_t* vflags;  // nvp
   const double* kappa;    // nvp
   const double* c0;       // nvp
@@ -94,11 +104,12 @@ struct GradientArgs {
   int accumulate;         // add into existing g instead of overwriting
 };
 
-// kernel launchers (ms_kernels.hip).  cap = T + max halo (LDS patch slots).
-size_t energy_lds_bytes(int T, int cap, bool bend, bool guard);
-size_t gradient_lds_bytes(int T, int cap, bool bend);
-hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, hipStream_t s);
-hipError_t launch_gradient(const GradientArgs& a, int cap, hipStream_t s);
+// kernel launchers (ms_kernels.hip).  cap = T + max halo (LDS patch slots),
+// max_ent = largest per-tile vertex->corner entry count.
+size_t energy_lds_bytes(int T, int cap, int max_ent, bool bend, bool guard);
+size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow);
+hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, hipStream_t s);
+hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStream_t s);
 hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
                          uint32_t slot_mask, double* scal, hipStream_t s);
 hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* g,

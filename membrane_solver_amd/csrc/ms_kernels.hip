@@ -63,20 +63,54 @@ __device__ __forceinline__ double wave_max(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
   return v;
 }
-// op: 0 sum, 1 min, 2 max.  red = 4 doubles of LDS scratch.  Result valid in thread 0.
+// op: 0 sum, 1 min, 2 max.  red = 16 doubles of LDS scratch.  Result valid in thread 0.
 __device__ __forceinline__ double block_reduce(double v, int op, double* red) {
   v = op == 0 ? wave_sum(v) : (op == 1 ? wave_min(v) : wave_max(v));
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
   __syncthreads();
   if (lane == 0) red[w] = v;
   __syncthreads();
   if (threadIdx.x == 0) {
     double r = red[0];
-    for (int i = 1; i < BLOCK / 64; ++i)
+    for (int i = 1; i < nw; ++i)
       r = op == 0 ? r + red[i] : (op == 1 ? fmin(r, red[i]) : fmax(r, red[i]));
     v = r;
   }
   return v;
+}
+
+// Reduce NV per-thread values with ONE barrier: wave shuffles, lane 0 of each wave
+// parks its partials in red[k*16 + wave], then thread k folds value k across waves
+// and stores it to out[slots[k] * stride].  ops[k]: 0 sum, 1 min, 2 max.
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(const double (&v)[NV], const int (&ops)[NV],
+                                                   const int (&slots)[NV], double* red,
+                                                   double* out, size_t stride) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const double r = ops[k] == 0 ? wave_sum(v[k]) : (ops[k] == 1 ? wave_min(v[k]) : wave_max(v[k]));
+    if (lane == 0) red[k * 16 + w] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    const int k = threadIdx.x;
+    int op = 0, slot = 0;
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+      if (q == k) {
+        op = ops[q];
+        slot = slots[q];
+      }
+    double r = red[k * 16];
+    for (int i = 1; i < nw; ++i) {
+      const double x = red[k * 16 + i];
+      r = op == 0 ? r + x : (op == 1 ? fmin(r, x) : fmax(r, x));
+    }
+    out[(size_t)slot * stride] = r;
+  }
 }
 
 // mixed-Voronoi corner areas with the reference's sequential-overwrite obtuse
@@ -143,214 +177,287 @@ __device__ __forceinline__ void lds_add3(double* base, int stride, int slot, V3 
 }
 
 // ---------------------------------------------------------------------------
+// Tile kernels.  blockDim.x == T: thread i is BOTH "facet lane i of the current
+// chunk" and "owned vertex i".  Per chunk of T facets:
+//   facet phase : each lane computes its facet's per-corner contributions in
+//                 registers and writes them to an LDS staging block with plain,
+//                 conflict-free column stores (stg[component][lane]);
+//   vertex phase: each lane walks its vertex's (facet,corner) list -- a per-tile
+//                 CSR staged in LDS, ascending in facet order -- and adds the
+//                 staged columns it owns into register accumulators.
+// No atomics: the summation order per vertex is fixed by the CSR, so results
+// are bitwise reproducible run to run.
+// ---------------------------------------------------------------------------
+struct TileCtx {
+  int tile, v_lo, n_owned, h0, nh, f0, f1, e0, n_ent;
+};
+__device__ __forceinline__ TileCtx tile_ctx(const DeviceMesh& m, int tile) {
+  TileCtx t;
+  t.tile = tile;
+  t.v_lo = tile * m.T;
+  t.n_owned = min(m.T, m.nv - t.v_lo);
+  t.h0 = m.tile_halo_off[tile];
+  t.nh = m.tile_halo_off[tile + 1] - t.h0;
+  t.f0 = m.tile_facet_off[tile];
+  t.f1 = m.tile_facet_off[tile + 1];
+  t.e0 = m.tile_ent_off[tile];
+  t.n_ent = m.tile_ent_off[tile + 1] - t.e0;
+  return t;
+}
+
+// ---------------------------------------------------------------------------
 // K_A: energy pass.
 //   scalars (owner facets): E_surface (surface_energy.f90:61-78), body volume
 //   (geometry/body.py:104-123), min edge^2 (runtime/topology.py:174-199),
 //   normal-rotation guard (runtime/topology.py:13-48);
 //   BEND: per-vertex K, A_vor (tilt_kernels.f90:88-190), A_eff
 //   (bending_utils.py:37-171), normal sums (bending_utils.py:13-34), then the
-//   per-vertex density / back-prop factors of bending.py:117-161 in the
-//   epilogue (owned rows are complete in LDS there).
-//   Evaluates at x + alpha*d when d != nullptr (trial[movable] = base + alpha d,
-//   line_search.py:362-368) and can write that trial row-block to xt.
-// LDS: px[3][cap] | (GUARD) ox[3][cap] | (BEND) acc[8][T] | red[4] | fl[cap] bytes
+//   per-vertex density / back-prop factors of bending.py:117-161 on the owned
+//   rows.  Evaluates at x + alpha*d when d != nullptr (trial[movable] = base +
+//   alpha d, line_search.py:362-368) and can write that trial block to xt.
+// One normal n = (v1-v0)x(v2-v0) and one sqrt per facet serve the surface term,
+// the cotans (|e1 x e2| is the same vector) and both area clamps.
+// LDS: px[3][cap] | (GUARD) ox[3][cap] | (BEND) stg[18][T] | red[16]
+//      | (BEND) voff[T+1], vent[max_ent] (u16) | fl[cap] (u8)
 // ---------------------------------------------------------------------------
 template <bool BEND, bool GUARD>
-__global__ __launch_bounds__(BLOCK) void k_energy(EnergyArgs a, int cap) {
+__global__ __launch_bounds__(512) void k_energy(EnergyArgs a, int cap, int max_ent) {
   extern __shared__ double lds[];
-  const int T = a.m.T;
+  const int T = a.m.T;  // == blockDim.x
   double* px = lds;
   double* ox = px + 3 * cap;
-  double* acc = ox + (GUARD ? 3 * cap : 0);
-  double* red = acc + (BEND ? 8 * T : 0);
-  uint8_t* lfl = reinterpret_cast<uint8_t*>(red + 4);
+  double* stg = ox + (GUARD ? 3 * cap : 0);
+  double* red = stg + (BEND ? 9 * T : 0);
+  uint16_t* voff = reinterpret_cast<uint16_t*>(red + 5 * 16);
+  uint16_t* vent = voff + (BEND ? (T + 2) : 0);
+  uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + (BEND ? ((max_ent + 3) & ~3) : 0));
 
-  const int tile = a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0);
+  const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
   const int tid = threadIdx.x;
-  const int v_lo = tile * T;
-  const int n_owned = min(T, a.m.nv - v_lo);
-  const int h0 = a.m.tile_halo_off[tile];
-  const int nh = a.m.tile_halo_off[tile + 1] - h0;
   const bool have_d = a.d != nullptr;
 
-  // -- stage owned rows: flat, fully coalesced ------------------------------
-  for (int j = tid; j < 3 * n_owned; j += BLOCK) {
-    const int r = j / 3, c = j - 3 * r;
-    const size_t g = 3 * (size_t)v_lo + j;
-    const double xo = a.x[g];
-    double xv = xo;
-    if (have_d && !(a.m.vflags[v_lo + r] & VF_FIXED)) xv = xo + a.alpha * a.d[g];
-    px[c * cap + r] = xv;
-    if (GUARD) ox[c * cap + r] = xo;
-    if (a.xt) a.xt[g] = xv;
+  // facet records are fetched one chunk ahead so their HBM latency overlaps the
+  // staging / the previous chunk's arithmetic
+  TileFacet tf_nx = {0, 0, 0, 0};
+  double gam_nx = 0.0;
+  if (t.f0 + tid < t.f1) {
+    tf_nx = a.m.tile_facets[t.f0 + tid];
+    gam_nx = a.m.tf_gamma[t.f0 + tid];
   }
-  for (int r = tid; r < n_owned; r += BLOCK) lfl[r] = a.m.vflags[v_lo + r];
-  // -- gather halo rows ------------------------------------------------------
-  for (int h = tid; h < nh; h += BLOCK) {
-    const int v = a.m.halo_ids[h0 + h];
+
+  // -- stage this thread's owned row and the halo rows it covers --------------
+  if (tid < t.n_owned) {
+    const size_t g = 3 * (size_t)(t.v_lo + tid);
+    const uint8_t fl = a.m.vflags[t.v_lo + tid];
+    lfl[tid] = fl;
+    const bool mv = have_d && !(fl & VF_FIXED);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double xo = a.x[g + c];
+      const double xv = mv ? xo + a.alpha * a.d[g + c] : xo;
+      px[c * cap + tid] = xv;
+      if (GUARD) ox[c * cap + tid] = xo;
+      if (a.xt) a.xt[g + c] = xv;
+    }
+  }
+  for (int h = tid; h < t.nh; h += T) {
+    const int v = a.m.halo_ids[t.h0 + h];
     const uint8_t fl = a.m.vflags[v];
-    const int s = n_owned + h;
+    const int s = t.n_owned + h;
     lfl[s] = fl;
+    const bool mv = have_d && !(fl & VF_FIXED);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double xo = a.x[3 * (size_t)v + c];
-      double xv = xo;
-      if (have_d && !(fl & VF_FIXED)) xv = xo + a.alpha * a.d[3 * (size_t)v + c];
-      px[c * cap + s] = xv;
+      px[c * cap + s] = mv ? xo + a.alpha * a.d[3 * (size_t)v + c] : xo;
       if (GUARD) ox[c * cap + s] = xo;
     }
   }
-  if (BEND)
-    for (int j = tid; j < 8 * T; j += BLOCK) acc[j] = 0.0;
+  if (BEND) {
+    const uint16_t* gv = a.m.tile_voff + (size_t)t.tile * (T + 1);
+    voff[tid] = gv[tid];
+    if (tid == 0) voff[T] = gv[T];
+    const uint16_t* ge = a.m.vent + t.e0;
+    for (int j = tid; j < t.n_ent; j += T) vent[j] = ge[j];
+  }
   __syncthreads();
 
   double e_surf = 0.0, vol = 0.0, min_e2 = 1.0e300, guard = 0.0;
   const bool want_surf = a.modules & MS_MOD_SURFACE;
   const bool want_vol = a.modules & (MS_MOD_VOLUME_PENALTY | MS_CON_VOLUME | MS_TRACK_VOLUME);
-  const int f0 = a.m.tile_facet_off[tile], f1 = a.m.tile_facet_off[tile + 1];
-  for (int p = f0 + tid; p < f1; p += BLOCK) {
-    const TileFacet tf = a.m.tile_facets[p];
-    const bool owner = tf.flags & TF_OWNER;
-    if (!BEND && !owner) continue;
-    const V3 v0 = lds_v3(px, cap, tf.l0), v1 = lds_v3(px, cap, tf.l1), v2 = lds_v3(px, cap, tf.l2);
-    const V3 e0 = v2 - v1, e1 = v0 - v2, e2 = v1 - v0;
-    const double l0 = dot(e0, e0), l1 = dot(e1, e1), l2 = dot(e2, e2);
-    // n = (v1-v0) x (v2-v0); (v2-v0) == -(v0-v2) exactly
-    const V3 n = cross(e2, -e1);
-    const double A2 = norm(n);
-    if (owner) {
-      if (want_surf && A2 >= 1.0e-12) e_surf += a.m.tf_gamma[p] * (0.5 * A2);
-      if (want_vol && (tf.flags & TF_BODY)) vol += dot(cross(v1, v2), v0);
-      min_e2 = fmin(min_e2, fmin(l0, fmin(l1, l2)));
-      if (GUARD) {
-        const V3 o0 = lds_v3(ox, cap, tf.l0), o1 = lds_v3(ox, cap, tf.l1), o2 = lds_v3(ox, cap, tf.l2);
-        const V3 no = cross(o1 - o0, o2 - o0);
-        const double nno = norm(no);
-        if (nno > 1.0e-12) {
-          if (A2 < 1.0e-12) {
-            guard = 1.0;
-          } else {
-            double dd = dot(mk(no.x / nno, no.y / nno, no.z / nno), mk(n.x / A2, n.y / A2, n.z / A2));
-            dd = fmin(1.0, fmax(-1.0, dd));
-            if (!(acos(dd) <= 0.5)) guard = 1.0;
+  // vertex accumulators (BEND): K(3), A_vor, A_eff
+  double aKx = 0, aKy = 0, aKz = 0, aAv = 0, aAe = 0;
+  int cur = 0, end = 0;
+  if (BEND && tid < t.n_owned) {
+    cur = voff[tid];
+    end = voff[tid + 1];
+  }
+  const int ent_begin = cur;
+
+  for (int c0 = t.f0; c0 < t.f1; c0 += T) {
+    const int p = c0 + tid;
+    const TileFacet tf = tf_nx;
+    const double gam = gam_nx;
+    if (p + T < t.f1) {
+      tf_nx = a.m.tile_facets[p + T];
+      gam_nx = a.m.tf_gamma[p + T];
+    }
+    double va0 = 0, va1 = 0, va2 = 0, ve0 = 0, ve1 = 0, ve2 = 0;
+    if (p < t.f1) {
+      const bool owner = tf.flags & TF_OWNER;
+      if (BEND || owner) {
+        const V3 v0 = lds_v3(px, cap, tf.l0), v1 = lds_v3(px, cap, tf.l1), v2 = lds_v3(px, cap, tf.l2);
+        const V3 e0 = v2 - v1, e1 = v0 - v2, e2 = v1 - v0;
+        const double l0 = dot(e0, e0), l1 = dot(e1, e1), l2 = dot(e2, e2);
+        const V3 n = cross(e2, -e1);  // (v1-v0) x (v2-v0) == e1 x e2
+        const double A2 = norm(n);
+        if (owner) {
+          if (want_surf && A2 >= 1.0e-12) e_surf += gam * (0.5 * A2);
+          if (want_vol && (tf.flags & TF_BODY)) vol += dot(cross(v1, v2), v0);
+          min_e2 = fmin(min_e2, fmin(l0, fmin(l1, l2)));
+          if (GUARD) {
+            const V3 o0 = lds_v3(ox, cap, tf.l0), o1 = lds_v3(ox, cap, tf.l1), o2 = lds_v3(ox, cap, tf.l2);
+            const V3 no = cross(o1 - o0, o2 - o0);
+            const double nno = norm(no);
+            if (nno > 1.0e-12) {
+              if (A2 < 1.0e-12) {
+                guard = 1.0;
+              } else {
+                double dd = dot(no, n) / (nno * A2);
+                dd = fmin(1.0, fmax(-1.0, dd));
+                if (!(acos(dd) <= 0.5)) guard = 1.0;
+              }
+            }
           }
+        }
+        if (BEND) {
+          // tilt_kernels.f90:133-151 with area_doubled = max(|n|, 1e-12)
+          const double ad = A2 < 1.0e-12 ? 1.0e-12 : A2;
+          const double inv_ad = 1.0 / ad;
+          const double tri_area = 0.5 * ad;
+          const double c0 = dot(-e1, e2) * inv_ad, c1 = dot(-e2, e0) * inv_ad, c2 = dot(-e0, e1) * inv_ad;
+          corner_areas(c0, c1, c2, l0, l1, l2, tri_area, va0, va1, va2);
+          // bending_utils.py:85-119: tri_areas = max(0.5 |n|, 1e-12)
+          ve0 = va0;
+          ve1 = va1;
+          ve2 = va2;
+          const double ta_eff = fmax(0.5 * A2, 1.0e-12);
+          if (ta_eff != tri_area) corner_areas(c0, c1, c2, l0, l1, l2, ta_eff, ve0, ve1, ve2);
+          // bending_utils.py:121-153 boundary -> interior redistribution
+          const int b0 = (lfl[tf.l0] & VF_BOUNDARY) ? 1 : 0, b1 = (lfl[tf.l1] & VF_BOUNDARY) ? 1 : 0,
+                    b2 = (lfl[tf.l2] & VF_BOUNDARY) ? 1 : 0;
+          const int n_int = 3 - (b0 + b1 + b2);
+          if (n_int > 0 && n_int < 3) {
+            const double b_sum = ve0 * b0 + ve1 * b1 + ve2 * b2;
+            const double extra = b_sum / (double)n_int;
+            const double m0 = b0 ? 0.0 : 1.0, m1 = b1 ? 0.0 : 1.0, m2 = b2 ? 0.0 : 1.0;
+            ve0 = ve0 * m0 + m0 * extra;
+            ve1 = ve1 * m1 + m1 * extra;
+            ve2 = ve2 * m2 + m2 * extra;
+          }
+          const V3 K0 = 0.5 * (c1 * (-e1) + c2 * e2);
+          const V3 K1 = 0.5 * (c2 * (-e2) + c0 * e0);
+          const V3 K2 = 0.5 * (c0 * (-e0) + c1 * e1);
+          double* s = stg + tid;
+          s[0 * T] = K0.x; s[1 * T] = K0.y; s[2 * T] = K0.z;
+          s[3 * T] = K1.x; s[4 * T] = K1.y; s[5 * T] = K1.z;
+          s[6 * T] = K2.x; s[7 * T] = K2.y; s[8 * T] = K2.z;
         }
       }
     }
     if (BEND) {
-      const bool in0 = tf.l0 < n_owned, in1 = tf.l1 < n_owned, in2 = tf.l2 < n_owned;
-      // tilt_kernels.f90:133-151
-      const V3 cr = cross(e1, e2);
-      double ad = norm(cr);
-      if (ad < 1.0e-12) ad = 1.0e-12;
-      const double tri_area = 0.5 * ad;
-      const double c0 = dot(-e1, e2) / ad, c1 = dot(-e2, e0) / ad, c2 = dot(-e0, e1) / ad;
-      double va0, va1, va2;
-      corner_areas(c0, c1, c2, l0, l1, l2, tri_area, va0, va1, va2);
-      // bending_utils.py:85-119 (area recomputed from n, clamped at 1e-12)
-      double ta_eff = 0.5 * A2;
-      if (ta_eff < 1.0e-12) ta_eff = 1.0e-12;
-      double ve0, ve1, ve2;
-      corner_areas(c0, c1, c2, l0, l1, l2, ta_eff, ve0, ve1, ve2);
-      // bending_utils.py:121-153 boundary -> interior redistribution
-      const int b0 = (lfl[tf.l0] & VF_BOUNDARY) ? 1 : 0, b1 = (lfl[tf.l1] & VF_BOUNDARY) ? 1 : 0,
-                b2 = (lfl[tf.l2] & VF_BOUNDARY) ? 1 : 0;
-      const int n_int = 3 - (b0 + b1 + b2);
-      if (n_int > 0 && n_int < 3) {
-        const double b_sum = ve0 * b0 + ve1 * b1 + ve2 * b2;
-        const double extra = b_sum / (double)n_int;
-        const double m0 = b0 ? 0.0 : 1.0, m1 = b1 ? 0.0 : 1.0, m2 = b2 ? 0.0 : 1.0;
-        ve0 = ve0 * m0 + m0 * extra;
-        ve1 = ve1 * m1 + m1 * extra;
-        ve2 = ve2 * m2 + m2 * extra;
+      // sub-phase A: curvature vectors; sub-phase B: corner areas (same 9*T buffer)
+      const int lo = c0 - t.f0, hi = min(c0 + T, t.f1) - t.f0;
+      __syncthreads();
+      const int cur0 = cur;
+      while (cur < end) {
+        const int ent = vent[cur];
+        const int fl = ent >> 2;
+        if (fl >= hi) break;
+        const double* s = stg + (fl - lo) + 3 * (ent & 3) * T;
+        aKx += s[0];
+        aKy += s[T];
+        aKz += s[2 * T];
+        ++cur;
       }
-      if (in0) {
-        lds_add3(acc, T, tf.l0, 0.5 * (c1 * (-e1) + c2 * e2));
-        atomicAdd(&acc[3 * T + tf.l0], va0);
-        atomicAdd(&acc[4 * T + tf.l0], ve0);
-        lds_add3(acc + 5 * T, T, tf.l0, n);
+      __syncthreads();
+      if (p < t.f1) {
+        double* s = stg + tid;
+        s[0 * T] = va0; s[1 * T] = va1; s[2 * T] = va2;
+        s[3 * T] = ve0; s[4 * T] = ve1; s[5 * T] = ve2;
       }
-      if (in1) {
-        lds_add3(acc, T, tf.l1, 0.5 * (c2 * (-e2) + c0 * e0));
-        atomicAdd(&acc[3 * T + tf.l1], va1);
-        atomicAdd(&acc[4 * T + tf.l1], ve1);
-        lds_add3(acc + 5 * T, T, tf.l1, n);
+      __syncthreads();
+      for (int q = cur0; q < cur; ++q) {
+        const int ent = vent[q];
+        const double* s = stg + ((ent >> 2) - lo) + (ent & 3) * T;
+        aAv += s[0];
+        aAe += s[3 * T];
       }
-      if (in2) {
-        lds_add3(acc, T, tf.l2, 0.5 * (c0 * (-e0) + c1 * e1));
-        atomicAdd(&acc[3 * T + tf.l2], va2);
-        atomicAdd(&acc[4 * T + tf.l2], ve2);
-        lds_add3(acc + 5 * T, T, tf.l2, n);
-      }
+      __syncthreads();
     }
   }
 
   double e_bend = 0.0;
-  if (BEND) {
-    __syncthreads();
-    // modules/energy/bending.py:111-161 per-vertex pass on the owned rows
-    for (int i = tid; i < n_owned; i += BLOCK) {
-      const int v = v_lo + i;
-      const V3 K = mk(acc[i], acc[T + i], acc[2 * T + i]);
-      const double Avor = acc[3 * T + i], Aeff = acc[4 * T + i];
-      const V3 N = mk(acc[5 * T + i], acc[6 * T + i], acc[7 * T + i]);
-      const double kappa = a.m.kappa[v], c0 = a.m.c0[v];
-      const bool interior = !(lfl[i] & VF_BOUNDARY);
-      const double safe = fmax(Avor, 1.0e-12);
-      const double k_mag = norm(K);
-      const double H = k_mag / (2.0 * safe);
-      const double ratio = safe > 1.0e-15 ? Aeff / safe : 0.0;
-      double scale_K, fe, fv;
-      if (a.bending_model == MS_BEND_HELFRICH) {
-        double term = (2.0 * H) - c0;
-        if (!interior) term = 0.0;
-        e_bend += kappa * (term * term) * Aeff;
-        scale_K = kappa * term * ratio;
-        fe = 0.5 * kappa * (term * term);
-        fv = -2.0 * kappa * term * ratio * H;
-      } else {
-        const double He = interior ? H : 0.0;
-        e_bend += kappa * (He * He) * Aeff;
-        scale_K = kappa * He * ratio;
-        fe = kappa * (He * He);
-        fv = -2.0 * kappa * (He * He) * ratio;
-      }
-      if (a.fK) {
-        V3 Kd;
-        if (k_mag > 1.0e-15) {
-          Kd = mk(K.x / k_mag, K.y / k_mag, K.z / k_mag);
-        } else {
-          const double nn = norm(N);
-          Kd = nn > 1.0e-15 ? mk(N.x / nn, N.y / nn, N.z / nn) : N;
-        }
-        a.fK[3 * (size_t)v] = Kd.x * scale_K;
-        a.fK[3 * (size_t)v + 1] = Kd.y * scale_K;
-        a.fK[3 * (size_t)v + 2] = Kd.z * scale_K;
-        a.fA[2 * (size_t)v] = fe;
-        a.fA[2 * (size_t)v + 1] = fv;
-      }
+  if (BEND && tid < t.n_owned) {
+    // modules/energy/bending.py:111-161 on this thread's owned vertex
+    const int v = t.v_lo + tid;
+    const V3 K = mk(aKx, aKy, aKz);
+    const double kappa = a.m.kappa[v], c0 = a.m.c0[v];
+    const bool interior = !(lfl[tid] & VF_BOUNDARY);
+    const double safe = fmax(aAv, 1.0e-12);
+    const double k_mag = norm(K);
+    const double H = k_mag / (2.0 * safe);
+    const double ratio = safe > 1.0e-15 ? aAe / safe : 0.0;
+    double scale_K, fe, fv;
+    if (a.bending_model == MS_BEND_HELFRICH) {
+      double term = (2.0 * H) - c0;
+      if (!interior) term = 0.0;
+      e_bend = 0.5 * (kappa * (term * term) * aAe);
+      scale_K = kappa * term * ratio;
+      fe = 0.5 * kappa * (term * term);
+      fv = -2.0 * kappa * term * ratio * H;
+    } else {
+      const double He = interior ? H : 0.0;
+      e_bend = kappa * (He * He) * aAe;
+      scale_K = kappa * He * ratio;
+      fe = kappa * (He * He);
+      fv = -2.0 * kappa * (He * He) * ratio;
     }
-    if (a.bending_model == MS_BEND_HELFRICH) e_bend *= 0.5;
+    if (a.fK) {
+      V3 Kd;
+      if (k_mag > 1.0e-15) {
+        Kd = mk(K.x / k_mag, K.y / k_mag, K.z / k_mag);
+      } else {
+        // bending.py:154-158 falls back to the vertex normal (bending_utils.py:13-34)
+        // where K vanishes (flat patches): sum the incident facet normals now.
+        V3 N = mk(0, 0, 0);
+        for (int q = ent_begin; q < end; ++q) {
+          const TileFacet f = a.m.tile_facets[t.f0 + (vent[q] >> 2)];
+          const V3 q0 = lds_v3(px, cap, f.l0), q1 = lds_v3(px, cap, f.l1), q2 = lds_v3(px, cap, f.l2);
+          N = N + cross(q1 - q0, q2 - q0);
+        }
+        const double nn = norm(N);
+        Kd = nn > 1.0e-15 ? mk(N.x / nn, N.y / nn, N.z / nn) : N;
+      }
+      a.fK[3 * (size_t)v] = Kd.x * scale_K;
+      a.fK[3 * (size_t)v + 1] = Kd.y * scale_K;
+      a.fK[3 * (size_t)v + 2] = Kd.z * scale_K;
+      a.fA[2 * (size_t)v] = fe;
+      a.fA[2 * (size_t)v + 1] = fv;
+    }
   }
 
-  double* out = a.partials + tile;   // slot-major: partials[slot][n_tiles]
-  const size_t ps = (size_t)a.m.n_tiles;
-  double r;
-  r = block_reduce(e_surf, 0, red);
-  if (tid == 0) out[MS_S_ESURF * ps] = r;
-  r = block_reduce(vol, 0, red);
-  if (tid == 0) out[MS_S_VOL * ps] = r;
-  r = block_reduce(e_bend, 0, red);
-  if (tid == 0) out[MS_S_EBEND * ps] = r;
-  r = block_reduce(min_e2, 1, red);
-  if (tid == 0) out[MS_S_MINEDGE2 * ps] = r;
-  r = block_reduce(guard, 2, red);
-  if (tid == 0) out[MS_S_GUARD * ps] = r;
+  const double vals[5] = {e_surf, vol, e_bend, min_e2, guard};
+  const int ops[5] = {0, 0, 0, 1, 2};
+  const int slots[5] = {MS_S_ESURF, MS_S_VOL, MS_S_EBEND, MS_S_MINEDGE2, MS_S_GUARD};
+  block_reduce_store<5>(vals, ops, slots, red, a.partials + t.tile, (size_t)a.m.n_tiles);
 }
 
-size_t energy_lds_bytes(int T, int cap, bool bend, bool guard) {
-  size_t d = 3 * (size_t)cap + (guard ? 3 * (size_t)cap : 0) + (bend ? 8 * (size_t)T : 0) + 4;
-  return d * sizeof(double) + (((size_t)cap + 15) / 16) * 16;
+static size_t u16_bytes(int T, int max_ent) { return 2 * ((size_t)T + 2 + ((max_ent + 3) & ~3)); }
+
+size_t energy_lds_bytes(int T, int cap, int max_ent, bool bend, bool guard) {
+  size_t d = 3 * (size_t)cap + (guard ? 3 * (size_t)cap : 0) + (bend ? 9 * (size_t)T : 0) + 5 * 16;
+  return d * sizeof(double) + (bend ? u16_bytes(T, max_ent) : 0) + (((size_t)cap + 15) / 16) * 16;
 }
 
 template <typename K>
@@ -360,17 +467,17 @@ static hipError_t ensure_lds(K kernel, size_t lds) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, hipStream_t s) {
+hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, hipStream_t s) {
   const int nb = a.tile1 - a.tile0;
   if (nb <= 0) return hipSuccess;
   const bool bend = (a.modules & MS_MOD_BENDING) != 0;
-  const size_t lds = energy_lds_bytes(a.m.T, cap, bend, guard);
+  const size_t lds = energy_lds_bytes(a.m.T, cap, max_ent, bend, guard);
   hipError_t e;
-#define MS_LAUNCH_E(B, G)                                                  \
-  do {                                                                     \
-    e = ensure_lds(k_energy<B, G>, lds);                                   \
-    if (e != hipSuccess) return e;                                         \
-    hipLaunchKernelGGL((k_energy<B, G>), dim3(nb), dim3(BLOCK), lds, s, a, cap); \
+#define MS_LAUNCH_E(B, G)                                                                     \
+  do {                                                                                        \
+    e = ensure_lds(k_energy<B, G>, lds);                                                      \
+    if (e != hipSuccess) return e;                                                            \
+    hipLaunchKernelGGL((k_energy<B, G>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);     \
   } while (0)
   if (bend) {
     if (guard) MS_LAUNCH_E(true, true); else MS_LAUNCH_E(true, false);
@@ -388,49 +495,56 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, hipStream_t s
 //             as constraint row gC and/or penalty k (V - V0) dV/dx
 //             (modules/energy/volume.py:94-128)
 //   bending   -L fK + sum_k dE/dc_k grad c_k + area-variation term
-//             (modules/energy/bending_gradient.py:17-175), cotans recomputed as
+//             (modules/energy/bending_gradient.py:17-175); cotans recomputed as
 //             in tilt_kernels.f90:140-151, never stored.
+// The three grad_cotan calls (bending_kernels.f90:32-74) share w = u x v = n and
+// S = |n| (the same vector for all corners of a triangle), so a facet costs one
+// sqrt and two divides.
 // BENDMODE: 0 none, 1 analytic, 2 approx (bending.py:163-167).
-// LDS: px[3][cap] | (BEND) fk[3][cap] fae[cap] fav[cap] | g[3][T] | gc[3][T] | red[4] | fl[cap]
+// LDS: px[3][cap] | (BEND) fk[3][cap] fae[cap] fav[cap] | stg[9 or 18][T] | red[16]
+//      | voff[T+2] vent[max_ent] (u16) | fl[cap] (u8)
 // ---------------------------------------------------------------------------
-template <int BENDMODE>
-__global__ __launch_bounds__(BLOCK) void k_gradient(GradientArgs a, int cap) {
+template <int BENDMODE, bool VOLROW>
+__global__ __launch_bounds__(512) void k_gradient(GradientArgs a, int cap, int max_ent) {
   extern __shared__ double lds[];
   constexpr bool BEND = BENDMODE != 0;
   const int T = a.m.T;
-  const bool volrow = a.gC != nullptr && (a.modules & MS_CON_VOLUME);
   double* px = lds;
   double* fk = px + 3 * cap;
   double* fae = fk + (BEND ? 3 * cap : 0);
   double* fav = fae + (BEND ? cap : 0);
-  double* ag = fav + (BEND ? cap : 0);
-  double* agc = ag + 3 * T;
-  double* red = agc + 3 * T;
-  uint8_t* lfl = reinterpret_cast<uint8_t*>(red + 4);
+  double* stg = fav + (BEND ? cap : 0);
+  double* red = stg + (VOLROW ? 18 : 9) * T;
+  uint16_t* voff = reinterpret_cast<uint16_t*>(red + 2 * 16);
+  uint16_t* vent = voff + (T + 2);
+  uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + ((max_ent + 3) & ~3));
 
-  const int tile = a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0);
+  const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
   const int tid = threadIdx.x;
-  const int v_lo = tile * T;
-  const int n_owned = min(T, a.m.nv - v_lo);
-  const int h0 = a.m.tile_halo_off[tile];
-  const int nh = a.m.tile_halo_off[tile + 1] - h0;
 
-  for (int j = tid; j < 3 * n_owned; j += BLOCK) {
-    const int r = j / 3, c = j - 3 * r;
-    const size_t g = 3 * (size_t)v_lo + j;
-    px[c * cap + r] = a.x[g];
-    if (BEND) fk[c * cap + r] = a.fK[g];
+  TileFacet tf_nx = {0, 0, 0, 0};
+  double gam_nx = 0.0;
+  if (t.f0 + tid < t.f1) {
+    tf_nx = a.m.tile_facets[t.f0 + tid];
+    gam_nx = a.m.tf_gamma[t.f0 + tid];
   }
-  for (int r = tid; r < n_owned; r += BLOCK) {
-    lfl[r] = a.m.vflags[v_lo + r];
+
+  if (tid < t.n_owned) {
+    const size_t g = 3 * (size_t)(t.v_lo + tid);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      px[c * cap + tid] = a.x[g + c];
+      if (BEND) fk[c * cap + tid] = a.fK[g + c];
+    }
+    lfl[tid] = a.m.vflags[t.v_lo + tid];
     if (BEND) {
-      fae[r] = a.fA[2 * (size_t)(v_lo + r)];
-      fav[r] = a.fA[2 * (size_t)(v_lo + r) + 1];
+      fae[tid] = a.fA[2 * (size_t)(t.v_lo + tid)];
+      fav[tid] = a.fA[2 * (size_t)(t.v_lo + tid) + 1];
     }
   }
-  for (int h = tid; h < nh; h += BLOCK) {
-    const int v = a.m.halo_ids[h0 + h];
-    const int s = n_owned + h;
+  for (int h = tid; h < t.nh; h += T) {
+    const int v = a.m.halo_ids[t.h0 + h];
+    const int s = t.n_owned + h;
     lfl[s] = a.m.vflags[v];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -442,7 +556,13 @@ __global__ __launch_bounds__(BLOCK) void k_gradient(GradientArgs a, int cap) {
       fav[s] = a.fA[2 * (size_t)v + 1];
     }
   }
-  for (int j = tid; j < 6 * T; j += BLOCK) ag[j] = 0.0;
+  {
+    const uint16_t* gv = a.m.tile_voff + (size_t)t.tile * (T + 1);
+    voff[tid] = gv[tid];
+    if (tid == 0) voff[T] = gv[T];
+    const uint16_t* ge = a.m.vent + t.e0;
+    for (int j = tid; j < t.n_ent; j += T) vent[j] = ge[j];
+  }
   __syncthreads();
 
   const bool surf = a.modules & MS_MOD_SURFACE;
@@ -450,175 +570,222 @@ __global__ __launch_bounds__(BLOCK) void k_gradient(GradientArgs a, int cap) {
   double pen_factor = 0.0;
   if (volpen) pen_factor = a.volume_stiffness * (a.scal[MS_S_VOL] - a.target_volume) / 6.0;
 
-  const int f0 = a.m.tile_facet_off[tile], f1 = a.m.tile_facet_off[tile + 1];
-  for (int p = f0 + tid; p < f1; p += BLOCK) {
-    const TileFacet tf = a.m.tile_facets[p];
-    const bool in0 = tf.l0 < n_owned, in1 = tf.l1 < n_owned, in2 = tf.l2 < n_owned;
-    const V3 v0 = lds_v3(px, cap, tf.l0), v1 = lds_v3(px, cap, tf.l1), v2 = lds_v3(px, cap, tf.l2);
-    const V3 e0 = v2 - v1, e1 = v0 - v2, e2 = v1 - v0;
-    V3 G0 = mk(0, 0, 0), G1 = mk(0, 0, 0), G2 = mk(0, 0, 0);
-
-    if (surf) {
-      const V3 n = cross(e2, -e1);
-      const double A2 = norm(n);
-      if (A2 >= 1.0e-12) {
-        const V3 nh_ = mk(n.x / A2, n.y / A2, n.z / A2);
-        const double gam = a.m.tf_gamma[p];
-        // g0 = gamma * 0.5 * (v1 - v2) x nhat ; (v1-v2) == -e0 exactly
-        const V3 c0v = cross(-e0, nh_), c1v = cross(-e1, nh_), c2v = cross(-e2, nh_);
-        G0 = G0 + mk(gam * (0.5 * c0v.x), gam * (0.5 * c0v.y), gam * (0.5 * c0v.z));
-        G1 = G1 + mk(gam * (0.5 * c1v.x), gam * (0.5 * c1v.y), gam * (0.5 * c1v.z));
-        G2 = G2 + mk(gam * (0.5 * c2v.x), gam * (0.5 * c2v.y), gam * (0.5 * c2v.z));
-      }
-    }
-    if ((volrow || volpen) && (tf.flags & TF_BODY)) {
-      const V3 w0 = cross(v1, v2), w1 = cross(v2, v0), w2 = cross(v0, v1);
-      if (volpen) {
-        G0 = G0 + pen_factor * w0;
-        G1 = G1 + pen_factor * w1;
-        G2 = G2 + pen_factor * w2;
-      }
-      if (volrow) {
-        const double s6 = 1.0 / 6.0;
-        if (in0) lds_add3(agc, T, tf.l0, s6 * w0);
-        if (in1) lds_add3(agc, T, tf.l1, s6 * w1);
-        if (in2) lds_add3(agc, T, tf.l2, s6 * w2);
-      }
-    }
-    if (BEND) {
-      const V3 k0 = lds_v3(fk, cap, tf.l0), k1 = lds_v3(fk, cap, tf.l1), k2 = lds_v3(fk, cap, tf.l2);
-      // cotans exactly as compute_curvature_data produces `weights`
-      const V3 cr = cross(e1, e2);
-      double ad = norm(cr);
-      if (ad < 1.0e-12) ad = 1.0e-12;
-      const double c0 = dot(-e1, e2) / ad, c1 = dot(-e2, e0) / ad, c2 = dot(-e0, e1) / ad;
-      // term 1: -L fK  (bending_kernels.f90:118-129)
-      {
-        const V3 d02 = k0 - k2, d01 = k0 - k1, d12 = k1 - k2;
-        G0 = G0 - 0.5 * (c1 * d02 + c2 * d01);
-        G1 = G1 - 0.5 * (c2 * (-d01) + c0 * d12);
-        G2 = G2 - 0.5 * (c0 * (-d12) + c1 * (-d02));
-      }
-      if (BENDMODE == 1) {
-        // term 2 (bending_gradient.py:37-78)
-        const double dE0 = -0.5 * dot(k1 - k2, v1 - v2);
-        const double dE1 = -0.5 * dot(k2 - k0, v2 - v0);
-        const double dE2 = -0.5 * dot(k0 - k1, v0 - v1);
-        V3 g0u, g0v, g1u, g1v, g2u, g2v;
-        grad_cotan(e2, -e1, g0u, g0v);   // corner 0: u = v1-v0, v = v2-v0
-        grad_cotan(e0, -e2, g1u, g1v);   // corner 1: u = v2-v1, v = v0-v1
-        grad_cotan(e1, -e0, g2u, g2v);   // corner 2: u = v0-v2, v = v1-v2
-        // term 3 coefficients (bending_gradient.py:80-95)
-        const int t0 = (lfl[tf.l0] & VF_BOUNDARY) ? 0 : 1, t1 = (lfl[tf.l1] & VF_BOUNDARY) ? 0 : 1,
-                  t2 = (lfl[tf.l2] & VF_BOUNDARY) ? 0 : 1;
-        const int cnt = t0 + t1 + t2;
-        const double fe0 = fae[tf.l0], fe1 = fae[tf.l1], fe2 = fae[tf.l2];
-        const double avg = cnt > 0 ? (fe0 * t0 + fe1 * t1 + fe2 * t2) / (double)cnt : 0.0;
-        const double C0 = (t0 ? fe0 : avg) + fav[tf.l0];
-        const double C1 = (t1 ? fe1 : avg) + fav[tf.l1];
-        const double C2 = (t2 ? fe2 : avg) + fav[tf.l2];
-        double w0 = dE0, w1 = dE1, w2 = dE2;   // weights of grad c_k
-        const bool obtuse = (c0 < 0.0) || (c1 < 0.0) || (c2 < 0.0);
-        if (!obtuse) {
-          // six edge terms (:107-124); the second grad_cotan family
-          // (bending_math.py:244-249) has the same arguments as the first, so
-          // its three weights fold into w_k.
-          const double q10 = 0.25 * c1 * C0, q20 = 0.25 * c2 * C0, q21 = 0.25 * c2 * C1,
-                       q01 = 0.25 * c0 * C1, q02 = 0.25 * c0 * C2, q12 = 0.25 * c1 * C2;
-          G0 = G0 + q10 * e1 + (-q20) * e2 + (-q21) * e2 + q12 * e1;
-          G1 = G1 + q20 * e2 + q21 * e2 + (-q01) * e0 + (-q02) * e0;
-          G2 = G2 + (-q10) * e1 + q01 * e0 + q02 * e0 + (-q12) * e1;
-          const double l0 = dot(e0, e0), l1 = dot(e1, e1), l2 = dot(e2, e2);
-          w0 += 0.125 * l0 * (C1 + C2);
-          w1 += 0.125 * l1 * (C0 + C2);
-          w2 += 0.125 * l2 * (C0 + C1);
-        } else {
-          // (:154-173) u = v1-v0, v = v2-v0 for every obtuse corner
-          V3 gTu, gTv;
-          grad_triangle_area(e2, -e1, gTu, gTv);
-          double factor = 0.0;
-          if (c0 < 0.0) factor += 0.5 * C0 + 0.25 * C1 + 0.25 * C2;
-          if (c1 < 0.0) factor += 0.5 * C1 + 0.25 * C0 + 0.25 * C2;
-          if (c2 < 0.0) factor += 0.5 * C2 + 0.25 * C0 + 0.25 * C1;
-          G1 = G1 + factor * gTu;
-          G2 = G2 + factor * gTv;
-          G0 = G0 + factor * (-(gTu + gTv));
-        }
-        // corner 0 -> (+gu to v1, +gv to v2, -(gu+gv) to v0); cyclic for 1, 2
-        G1 = G1 + w0 * g0u;
-        G2 = G2 + w0 * g0v;
-        G0 = G0 + w0 * (-(g0u + g0v));
-        G2 = G2 + w1 * g1u;
-        G0 = G0 + w1 * g1v;
-        G1 = G1 + w1 * (-(g1u + g1v));
-        G0 = G0 + w2 * g2u;
-        G1 = G1 + w2 * g2v;
-        G2 = G2 + w2 * (-(g2u + g2v));
-      }
-    }
-    if (in0) lds_add3(ag, T, tf.l0, G0);
-    if (in1) lds_add3(ag, T, tf.l1, G1);
-    if (in2) lds_add3(ag, T, tf.l2, G2);
+  double gx = 0, gy = 0, gz = 0, cx = 0, cy = 0, cz = 0;
+  int cur = 0, end = 0;
+  if (tid < t.n_owned) {
+    cur = voff[tid];
+    end = voff[tid + 1];
   }
-  __syncthreads();
 
-  // bending.py:165-166: approx mode zeroes the boundary rows of everything
-  // accumulated so far.
-  if (BENDMODE == 2)
-    for (int i = tid; i < n_owned; i += BLOCK)
-      if (lfl[i] & VF_BOUNDARY) ag[i] = ag[T + i] = ag[2 * T + i] = 0.0;
-  if (BENDMODE == 2) __syncthreads();
+  for (int c0f = t.f0; c0f < t.f1; c0f += T) {
+    const int p = c0f + tid;
+    const TileFacet tf = tf_nx;
+    const double gam = gam_nx;
+    if (p + T < t.f1) {
+      tf_nx = a.m.tile_facets[p + T];
+      gam_nx = a.m.tf_gamma[p + T];
+    }
+    if (p < t.f1) {
+      const V3 v0 = lds_v3(px, cap, tf.l0), v1 = lds_v3(px, cap, tf.l1), v2 = lds_v3(px, cap, tf.l2);
+      const V3 e0 = v2 - v1, e1 = v0 - v2, e2 = v1 - v0;
+      V3 G0 = mk(0, 0, 0), G1 = mk(0, 0, 0), G2 = mk(0, 0, 0);
+      const V3 n = cross(e2, -e1);
+      const double S = norm(n);
+
+      if (surf && S >= 1.0e-12) {
+        // g0 = gamma * 0.5 * (v1 - v2) x nhat ; (v1-v2) == -e0 exactly
+        const double hs = 0.5 * gam / S;
+        G0 = G0 + hs * cross(-e0, n);
+        G1 = G1 + hs * cross(-e1, n);
+        G2 = G2 + hs * cross(-e2, n);
+      }
+      if ((VOLROW || volpen) && (tf.flags & TF_BODY)) {
+        const V3 w0 = cross(v1, v2), w1 = cross(v2, v0), w2 = cross(v0, v1);
+        if (volpen) {
+          G0 = G0 + pen_factor * w0;
+          G1 = G1 + pen_factor * w1;
+          G2 = G2 + pen_factor * w2;
+        }
+        if (VOLROW) {
+          const double s6 = 1.0 / 6.0;
+          double* s = stg + 9 * T + tid;
+          s[0 * T] = s6 * w0.x; s[1 * T] = s6 * w0.y; s[2 * T] = s6 * w0.z;
+          s[3 * T] = s6 * w1.x; s[4 * T] = s6 * w1.y; s[5 * T] = s6 * w1.z;
+          s[6 * T] = s6 * w2.x; s[7 * T] = s6 * w2.y; s[8 * T] = s6 * w2.z;
+        }
+      } else if (VOLROW) {
+        double* s = stg + 9 * T + tid;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s[k * T] = 0.0;
+      }
+      if (BEND) {
+        const V3 k0 = lds_v3(fk, cap, tf.l0), k1 = lds_v3(fk, cap, tf.l1), k2 = lds_v3(fk, cap, tf.l2);
+        // cotans exactly as compute_curvature_data produces `weights`
+        const double ad = S < 1.0e-12 ? 1.0e-12 : S;
+        const double inv_ad = 1.0 / ad;
+        const double d12 = dot(e1, e2), d20 = dot(e2, e0), d01 = dot(e0, e1);
+        const double c0 = -d12 * inv_ad, c1 = -d20 * inv_ad, c2 = -d01 * inv_ad;
+        // term 1: -L fK  (bending_kernels.f90:118-129)
+        {
+          const V3 f02 = k0 - k2, f01 = k0 - k1, f12 = k1 - k2;
+          G0 = G0 - 0.5 * (c1 * f02 + c2 * f01);
+          G1 = G1 - 0.5 * (c0 * f12 - c2 * f01);
+          G2 = G2 + 0.5 * (c0 * f12 + c1 * f02);
+        }
+        if (BENDMODE == 1) {
+          // term 2 weights (bending_gradient.py:37-42); (v1-v2) == -e0 etc.
+          double w0 = 0.5 * dot(k1 - k2, e0);
+          double w1 = 0.5 * dot(k2 - k0, e1);
+          double w2 = 0.5 * dot(k0 - k1, e2);
+          // term 3 coefficients (bending_gradient.py:80-95)
+          const int t0 = (lfl[tf.l0] & VF_BOUNDARY) ? 0 : 1, t1 = (lfl[tf.l1] & VF_BOUNDARY) ? 0 : 1,
+                    t2 = (lfl[tf.l2] & VF_BOUNDARY) ? 0 : 1;
+          const int cnt = t0 + t1 + t2;
+          const double fe0 = fae[tf.l0], fe1 = fae[tf.l1], fe2 = fae[tf.l2];
+          const double avg = cnt > 0 ? (fe0 * t0 + fe1 * t1 + fe2 * t2) / (double)cnt : 0.0;
+          const double C0 = (t0 ? fe0 : avg) + fav[tf.l0];
+          const double C1 = (t1 ? fe1 : avg) + fav[tf.l1];
+          const double C2 = (t2 ? fe2 : avg) + fav[tf.l2];
+          const bool obtuse = (c0 < 0.0) || (c1 < 0.0) || (c2 < 0.0);
+          if (!obtuse) {
+            // six edge terms (:107-124); the second grad_cotan family
+            // (bending_math.py:244-249) has the same arguments as the first, so
+            // its weights (:126-152) fold into w_k.
+            const double q0 = 0.25 * c0 * (C1 + C2), q1 = 0.25 * c1 * (C0 + C2), q2 = 0.25 * c2 * (C0 + C1);
+            G0 = G0 + q1 * e1 - q2 * e2;
+            G1 = G1 + q2 * e2 - q0 * e0;
+            G2 = G2 + q0 * e0 - q1 * e1;
+            w0 += 0.125 * dot(e0, e0) * (C1 + C2);
+            w1 += 0.125 * dot(e1, e1) * (C0 + C2);
+            w2 += 0.125 * dot(e2, e2) * (C0 + C1);
+          } else if (S > 1.0e-15) {
+            // (:154-173) grad T with u = v1-v0, v = v2-v0: gT_u = 0.5 (v x n)/S, gT_v = 0.5 (n x u)/S
+            double factor = 0.0;
+            if (c0 < 0.0) factor += 0.5 * C0 + 0.25 * C1 + 0.25 * C2;
+            if (c1 < 0.0) factor += 0.5 * C1 + 0.25 * C0 + 0.25 * C2;
+            if (c2 < 0.0) factor += 0.5 * C2 + 0.25 * C0 + 0.25 * C1;
+            const double fs = 0.5 * factor / S;
+            const V3 gTu = fs * cross(-e1, n), gTv = fs * cross(n, e2);
+            G1 = G1 + gTu;
+            G2 = G2 + gTv;
+            G0 = G0 - (gTu + gTv);
+          }
+          if (S > 1.0e-15) {
+            // grad cot at corner k (u,v) = (e2,-e1), (e0,-e2), (e1,-e0); w = u x v = n:
+            //   gu = v/S - (C/S^3) v x n ,  gv = u/S - (C/S^3) n x u ,  C = u.v
+            const double invS = 1.0 / S;
+            const double invS3 = invS * invS * invS;
+            {  // corner 0: +gu -> v1, +gv -> v2, -(gu+gv) -> v0
+              const double kk = -d12 * invS3;
+              const V3 gu = invS * (-e1) - kk * cross(-e1, n), gv = invS * e2 - kk * cross(n, e2);
+              G1 = G1 + w0 * gu;
+              G2 = G2 + w0 * gv;
+              G0 = G0 - w0 * (gu + gv);
+            }
+            {  // corner 1: +gu -> v2, +gv -> v0, -(gu+gv) -> v1
+              const double kk = -d20 * invS3;
+              const V3 gu = invS * (-e2) - kk * cross(-e2, n), gv = invS * e0 - kk * cross(n, e0);
+              G2 = G2 + w1 * gu;
+              G0 = G0 + w1 * gv;
+              G1 = G1 - w1 * (gu + gv);
+            }
+            {  // corner 2: +gu -> v0, +gv -> v1, -(gu+gv) -> v2
+              const double kk = -d01 * invS3;
+              const V3 gu = invS * (-e0) - kk * cross(-e0, n), gv = invS * e1 - kk * cross(n, e1);
+              G0 = G0 + w2 * gu;
+              G1 = G1 + w2 * gv;
+              G2 = G2 - w2 * (gu + gv);
+            }
+          }
+        }
+      }
+      double* s = stg + tid;
+      s[0 * T] = G0.x; s[1 * T] = G0.y; s[2 * T] = G0.z;
+      s[3 * T] = G1.x; s[4 * T] = G1.y; s[5 * T] = G1.z;
+      s[6 * T] = G2.x; s[7 * T] = G2.y; s[8 * T] = G2.z;
+    }
+    __syncthreads();
+    {
+      const int lo = c0f - t.f0, hi = min(c0f + T, t.f1) - t.f0;
+      while (cur < end) {
+        const int ent = vent[cur];
+        const int fl = ent >> 2;
+        if (fl >= hi) break;
+        const int k = ent & 3;
+        const double* s = stg + (fl - lo);
+        gx += s[(3 * k) * T];
+        gy += s[(3 * k + 1) * T];
+        gz += s[(3 * k + 2) * T];
+        if (VOLROW) {
+          cx += s[(9 + 3 * k) * T];
+          cy += s[(10 + 3 * k) * T];
+          cz += s[(11 + 3 * k) * T];
+        }
+        ++cur;
+      }
+    }
+    __syncthreads();
+  }
 
   double ggc = 0.0, gcgc = 0.0;
-  const bool have_gc = a.gC != nullptr;
-  for (int j = tid; j < 3 * n_owned; j += BLOCK) {
-    const int r = j / 3, c = j - 3 * r;
-    const size_t g = 3 * (size_t)v_lo + j;
-    double gv = ag[c * T + r];
+  if (tid < t.n_owned) {
+    const size_t o = 3 * (size_t)(t.v_lo + tid);
+    // bending.py:165-166: approx mode zeroes the boundary rows of what was accumulated
+    if (BENDMODE == 2 && (lfl[tid] & VF_BOUNDARY)) gx = gy = gz = 0.0;
     if (a.g) {
-      if (a.accumulate) gv += a.g[g];
-      a.g[g] = gv;
-    }
-    if (have_gc) {
-      double gc;
-      if (volrow) {
-        gc = agc[c * T + r];
-        a.gC[g] = gc;
-      } else {
-        gc = a.gC[g];
+      if (a.accumulate) {
+        gx += a.g[o];
+        gy += a.g[o + 1];
+        gz += a.g[o + 2];
       }
-      ggc += gv * gc;
-      gcgc += gc * gc;
+      a.g[o] = gx;
+      a.g[o + 1] = gy;
+      a.g[o + 2] = gz;
+    }
+    if (a.gC) {
+      if (VOLROW) {
+        a.gC[o] = cx;
+        a.gC[o + 1] = cy;
+        a.gC[o + 2] = cz;
+      } else {
+        cx = a.gC[o];
+        cy = a.gC[o + 1];
+        cz = a.gC[o + 2];
+      }
+      ggc = gx * cx + gy * cy + gz * cz;
+      gcgc = cx * cx + cy * cy + cz * cz;
     }
   }
-  double* out = a.partials + tile;
-  const size_t ps = (size_t)a.m.n_tiles;
-  double r = block_reduce(ggc, 0, red);
-  if (tid == 0) out[MS_S_GGC * ps] = r;
-  r = block_reduce(gcgc, 0, red);
-  if (tid == 0) out[MS_S_GCGC * ps] = r;
+  const double vals[2] = {ggc, gcgc};
+  const int ops[2] = {0, 0};
+  const int slots[2] = {MS_S_GGC, MS_S_GCGC};
+  block_reduce_store<2>(vals, ops, slots, red, a.partials + t.tile, (size_t)a.m.n_tiles);
 }
 
-size_t gradient_lds_bytes(int T, int cap, bool bend) {
-  size_t d = 3 * (size_t)cap + (bend ? 5 * (size_t)cap : 0) + 6 * (size_t)T + 4;
-  return d * sizeof(double) + (((size_t)cap + 15) / 16) * 16;
+size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow) {
+  size_t d = 3 * (size_t)cap + (bend ? 5 * (size_t)cap : 0) + (volrow ? 18 : 9) * (size_t)T + 2 * 16;
+  return d * sizeof(double) + u16_bytes(T, max_ent) + (((size_t)cap + 15) / 16) * 16;
 }
 
-hipError_t launch_gradient(const GradientArgs& a, int cap, hipStream_t s) {
+hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStream_t s) {
   const int nb = a.tile1 - a.tile0;
   if (nb <= 0) return hipSuccess;
   const bool bend = (a.modules & MS_MOD_BENDING) != 0;
-  const size_t lds = gradient_lds_bytes(a.m.T, cap, bend);
+  const bool volrow = a.gC != nullptr && (a.modules & MS_CON_VOLUME);
+  const size_t lds = gradient_lds_bytes(a.m.T, cap, max_ent, bend, volrow);
   hipError_t e;
-#define MS_LAUNCH_G(M)                                                              \
-  do {                                                                              \
-    e = ensure_lds(k_gradient<M>, lds);                                             \
-    if (e != hipSuccess) return e;                                                  \
-    hipLaunchKernelGGL((k_gradient<M>), dim3(nb), dim3(BLOCK), lds, s, a, cap);     \
+#define MS_LAUNCH_G(M, V)                                                                       \
+  do {                                                                                          \
+    e = ensure_lds(k_gradient<M, V>, lds);                                                      \
+    if (e != hipSuccess) return e;                                                              \
+    hipLaunchKernelGGL((k_gradient<M, V>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);     \
   } while (0)
-  if (!bend) MS_LAUNCH_G(0);
-  else if (a.bending_grad_mode == MS_GRAD_APPROX) MS_LAUNCH_G(2);
-  else MS_LAUNCH_G(1);
+  const int mode = !bend ? 0 : (a.bending_grad_mode == MS_GRAD_APPROX ? 2 : 1);
+  if (volrow) {
+    if (mode == 0) MS_LAUNCH_G(0, true); else if (mode == 1) MS_LAUNCH_G(1, true); else MS_LAUNCH_G(2, true);
+  } else {
+    if (mode == 0) MS_LAUNCH_G(0, false); else if (mode == 1) MS_LAUNCH_G(1, false); else MS_LAUNCH_G(2, false);
+  }
 #undef MS_LAUNCH_G
   return hipGetLastError();
 }
@@ -630,7 +797,7 @@ hipError_t launch_gradient(const GradientArgs& a, int cap, hipStream_t s) {
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_reduce(const double* partials, int n_tiles, int tile0,
                                                   int tile1, uint32_t slot_mask, double* scal) {
-  __shared__ double red[4];
+  __shared__ double red[16];
   // one workgroup per requested slot; partials are slot-major so lanes read
   // consecutive doubles.
   int slot = -1;
@@ -684,7 +851,7 @@ __global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, c
                                                      const double* scal, int use_constraint,
                                                      int cg_history, double* partials,
                                                      int n_tiles) {
-  __shared__ double red[4];
+  __shared__ double red[16];
   const int tile = tile0 + blockIdx.x;
   double lam = 0.0;
   bool project = false;

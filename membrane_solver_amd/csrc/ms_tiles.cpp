@@ -55,8 +55,8 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
     return MS_ERR_INVALID;
   }
   if (T <= 0) T = 256;
-  if (T < 64 || T > 4096 || (T % 64) != 0) {
-    err = "ms_create: tile_vertices must be a multiple of 64 in [64,4096]";
+  if (!(T == 64 || T == 128 || T == 256 || T == 512)) {
+    err = "ms_create: tile_vertices must be 64, 128, 256 or 512 (one thread per owned vertex)";
     return MS_ERR_INVALID;
   }
   if (shard_count < 1) shard_count = 1;
@@ -172,7 +172,10 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
 
   // ---- 3. halo lists + local slots ----------------------------------------
   out.tile_halo_off.assign(out.n_tiles + 1, 0);
+  out.tile_ent_off.assign(out.n_tiles + 1, 0);
+  out.tile_voff.assign((size_t)out.n_tiles * (T + 1), 0);
   std::vector<int32_t> halo_tmp;
+  std::vector<int32_t> vcnt(T + 1);
   for (int t = 0; t < out.n_tiles; ++t) {
     const int v_lo = t * T;
     const int v_hi = std::min(nv, v_lo + T);
@@ -204,6 +207,40 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
       out.tile_facets[p].l0 = loc[0];
       out.tile_facets[p].l1 = loc[1];
       out.tile_facets[p].l2 = loc[2];
+    }
+    // vertex -> corner CSR of this tile (counting sort keeps facet_local ascending)
+    {
+      if (e - b > 16383u) {
+        err = "ms_create: a tile lists more than 16383 facets (vertex valence too high)";
+        return MS_ERR_TILE_CAPACITY;
+      }
+      std::fill(vcnt.begin(), vcnt.end(), 0);
+      for (size_t p = b; p < e; ++p) {
+        const TileFacet& f = out.tile_facets[p];
+        if (f.l0 < n_owned) ++vcnt[f.l0 + 1];
+        if (f.l1 < n_owned) ++vcnt[f.l1 + 1];
+        if (f.l2 < n_owned) ++vcnt[f.l2 + 1];
+      }
+      for (int i = 0; i < T; ++i) vcnt[i + 1] += vcnt[i];
+      const int n_ent = vcnt[T];
+      if (n_ent > 65535) {
+        err = "ms_create: a tile has more than 65535 owned corners";
+        return MS_ERR_TILE_CAPACITY;
+      }
+      uint16_t* voff = &out.tile_voff[(size_t)t * (T + 1)];
+      for (int i = 0; i <= T; ++i) voff[i] = (uint16_t)vcnt[i];
+      const size_t base = out.vent.size();
+      out.vent.resize(base + n_ent);
+      std::vector<int32_t> fill(vcnt.begin(), vcnt.end() - 1);
+      for (size_t p = b; p < e; ++p) {
+        const TileFacet& f = out.tile_facets[p];
+        const uint16_t fl = (uint16_t)(p - b);
+        if (f.l0 < n_owned) out.vent[base + fill[f.l0]++] = (uint16_t)(fl << 2 | 0);
+        if (f.l1 < n_owned) out.vent[base + fill[f.l1]++] = (uint16_t)(fl << 2 | 1);
+        if (f.l2 < n_owned) out.vent[base + fill[f.l2]++] = (uint16_t)(fl << 2 | 2);
+      }
+      out.tile_ent_off[t + 1] = (int32_t)out.vent.size();
+      out.max_ent = std::max(out.max_ent, n_ent);
     }
     out.halo_ids.insert(out.halo_ids.end(), halo_tmp.begin(), halo_tmp.end());
     out.tile_halo_off[t + 1] = (int32_t)out.halo_ids.size();

@@ -164,3 +164,27 @@ def test_kernel_provider_seam_matches_reference(L):
     grad = np.zeros((3, 3))
     E = loader.get_surface_energy_kernel().func(g["surf_rt_pos"], g["surf_rt_tri"], g["surf_rt_gamma"], grad, 1)
     assert abs(E - 1.0) < 1e-12
+
+
+def test_flat_patch_uses_vertex_normal_fallback(L):
+    """Flat sheet with spontaneous curvature: K vanishes, so factor_K_vec falls back to the
+    vertex normal (bending.py:154-158, bending_utils.py:13-34) -- the lazy path of the kernel."""
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+    from oracle import ms_oracle as orc
+
+    P, T, B = meshgen.disk_patch(7, bulge=0.0, jitter=0.2, seed=2)
+    nv = P.shape[0]
+    kappa, c0 = np.full(nv, 1.2), np.full(nv, 0.7)
+    k, _A, _w = orc.compute_curvature_data(P, T)
+    assert np.sum(np.linalg.norm(k, axis=1) <= 1e-15) > nv // 2  # the fallback really triggers
+    gref = np.zeros_like(P)
+    Eref, fK_ref, _, _ = orc.bending_energy_and_gradient(P, T, kappa, c0, B, grad=gref, want_factors=True)
+    dm = DeviceMesh(P, T, boundary=B)
+    dm.set_bending_params(kappa, c0)
+    dm.set_params(modules=L.MS_MOD_BENDING)
+    e, g = dm.energy_and_gradient()
+    assert abs(e[1] - Eref) <= E_TOL * abs(Eref)
+    assert relerr(dm.get_vertex_buffer(L.MS_BUF_FK), fK_ref) < 1e-12
+    assert relerr(g, gref) < G_TOL
+    dm.close()
