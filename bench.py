@@ -65,7 +65,7 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch --gpus N > 1 through torch.distributed.run (one rank per GPU)")
-    if world > 1:
+    if world > 1 or os.environ.get("MS_BENCH_FORCE_SHARDED"):
         from membrane_solver_amd import parallel
 
         return parallel.bench_main(args, rank, world, local_rank)

@@ -196,6 +196,18 @@ int ms_phase_accept(ms_ctx *ctx, int keep_history); /* x <- xt, CG history     *
 int ms_fetch_scalars(ms_ctx *ctx, double *out /* MS_NSCAL */); /* synchronises */
 int ms_store_scalars(ms_ctx *ctx, const double *in /* MS_NSCAL */);
 
+/* Sharded accept: every rank forms xt = x + alpha*d on ALL rows (x and d are
+ * replicated after the direction all-gather, so no exchange is needed), then
+ * x <-> xt and, if keep_history, the CG history swap of ms_phase_accept. */
+int ms_phase_commit_trial(ms_ctx *ctx, double alpha, int keep_history);
+
+/* Per-vertex state in caller-owned device memory (e.g. a torch tensor, so RCCL
+ * collectives can run on it in place).  ms_state_bytes gives the size;
+ * ms_rebind_state copies the current state there and uses it from then on.
+ * The caller keeps the memory alive until ms_destroy. */
+size_t ms_state_bytes(const ms_ctx *ctx);
+int ms_rebind_state(ms_ctx *ctx, void *device_base, size_t bytes);
+
 /* device pointer + geometry of a per-vertex buffer, for RCCL collectives on it */
 int ms_device_buffer(ms_ctx *ctx, int buffer, void **dev_ptr, size_t *bytes);
 /* rows = padded vertex rows (nvp); this shard owns rows [row0,row1) */

@@ -94,6 +94,9 @@ SIGNATURES = {
     "ms_phase_gradient": (ctypes.c_int, [_P]),
     "ms_phase_direction": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
     "ms_phase_accept": (ctypes.c_int, [_P, ctypes.c_int]),
+    "ms_phase_commit_trial": (ctypes.c_int, [_P, ctypes.c_double, ctypes.c_int]),
+    "ms_state_bytes": (ctypes.c_size_t, [_P]),
+    "ms_rebind_state": (ctypes.c_int, [_P, _P, ctypes.c_size_t]),
     "ms_fetch_scalars": (ctypes.c_int, [_P, _D]),
     "ms_store_scalars": (ctypes.c_int, [_P, _D]),
     "ms_device_buffer": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(_P),

@@ -37,6 +37,7 @@ struct ms_ctx {
   double* d_c0 = nullptr;
   // per-vertex state (one allocation), patch order, nvp rows
   double* state = nullptr;
+  bool own_state = true;
   double* buf[MS_BUF_COUNT] = {nullptr};
   double* d_partials = nullptr;
   double* d_scal = nullptr;
@@ -416,6 +417,7 @@ void ms_destroy(ms_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (!c->own_state) c->state = nullptr;
   void* ptrs[] = {c->d_perm, c->d_tile_facet_off, c->d_tile_facets, c->d_tf_gamma,
                   c->d_tile_halo_off, c->d_halo_ids, c->d_tile_ent_off, c->d_tile_voff, c->d_vent,
                   c->d_vflags, c->d_kappa, c->d_c0,
@@ -687,6 +689,36 @@ int ms_phase_accept(ms_ctx* c, int keep_history) {
     c->cg_have_history = true;
     ++c->cg_iter_count;
   }
+  return MS_OK;
+}
+
+int ms_phase_commit_trial(ms_ctx* c, double alpha, int keep_history) {
+  if (!c) return MS_ERR_INVALID;
+  const size_t n3 = 3 * (size_t)c->til.nvp;
+  HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_XT], c->buf[MS_BUF_X], n3 * sizeof(double),
+                           hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, launch_axpy_masked(c->til.nvp, c->d_vflags, c->buf[MS_BUF_XT], c->buf[MS_BUF_D], alpha,
+                               c->stream));
+  return ms_phase_accept(c, keep_history);
+}
+
+size_t ms_state_bytes(const ms_ctx* c) {
+  if (!c) return 0;
+  return sizeof(double) * (8 * 3 * (size_t)c->til.nvp + 2 * (size_t)c->til.nvp);
+}
+
+int ms_rebind_state(ms_ctx* c, void* device_base, size_t bytes) {
+  if (!c || !device_base) return fail(c, MS_ERR_INVALID, "ms_rebind_state: NULL argument");
+  const size_t need = ms_state_bytes(c);
+  if (bytes < need) return fail(c, MS_ERR_INVALID, "ms_rebind_state: buffer smaller than ms_state_bytes");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(device_base, c->state, need, hipMemcpyDeviceToDevice));
+  double* nb = static_cast<double*>(device_base);
+  for (int b = 0; b <= MS_BUF_FA; ++b) c->buf[b] = nb + (c->buf[b] - c->state);
+  c->last_g = nb + (c->last_g - c->state);
+  if (c->own_state) HIPCHK(c, hipFree(c->state));
+  c->state = nb;
+  c->own_state = false;
   return MS_OK;
 }
 

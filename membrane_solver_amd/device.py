@@ -190,6 +190,17 @@ class DeviceMesh:
     def phase_accept(self, keep_history: bool):
         self._chk(L.lib().ms_phase_accept(self._h, int(keep_history)), "ms_phase_accept")
 
+    def phase_commit_trial(self, alpha: float, keep_history: bool):
+        self._chk(L.lib().ms_phase_commit_trial(self._h, float(alpha), int(keep_history)),
+                  "ms_phase_commit_trial")
+
+    def state_bytes(self) -> int:
+        return int(L.lib().ms_state_bytes(self._h))
+
+    def rebind_state(self, device_ptr: int, nbytes: int):
+        self._chk(L.lib().ms_rebind_state(self._h, ctypes.c_void_p(device_ptr), int(nbytes)),
+                  "ms_rebind_state")
+
     def fetch_scalars(self) -> np.ndarray:
         out = np.zeros(L.MS_NSCAL)
         self._chk(L.lib().ms_fetch_scalars(self._h, _pd(out)), "ms_fetch_scalars")

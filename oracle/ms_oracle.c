@@ -534,6 +534,29 @@ static int backprop_bending(int nv, int nf, const double *pos,
   return 0;
 }
 
+/* bending_gradient.py:17-175 with caller-supplied per-vertex factors (used by the
+ * sharded-driver tests to prove the factors really were exchanged).  weights are
+ * recomputed from pos as compute_curvature_data does. */
+ORC_API int orc_bending_backprop(int nv, int nf, const double *pos, const int32_t *tri,
+                                 const uint8_t *is_boundary, const double *fA_eff,
+                                 const double *fA_vor, const double *fK, double *grad) {
+  double *k_vecs = (double *)malloc(sizeof(double) * 3 * (size_t)nv);
+  double *A_vor = (double *)malloc(sizeof(double) * (size_t)nv);
+  double *weights = (double *)malloc(sizeof(double) * 3 * (size_t)nf);
+  uint8_t *is_int = (uint8_t *)malloc((size_t)nv);
+  int rc = -1;
+  if (k_vecs && A_vor && weights && is_int) {
+    orc_compute_curvature_data(nv, nf, pos, tri, k_vecs, A_vor, weights, NULL, NULL, NULL);
+    for (int i = 0; i < nv; ++i) is_int[i] = is_boundary ? (is_boundary[i] == 0) : 1;
+    rc = backprop_bending(nv, nf, pos, tri, weights, is_int, fA_eff, fA_vor, fK, grad);
+  }
+  free(k_vecs);
+  free(A_vor);
+  free(weights);
+  free(is_int);
+  return rc;
+}
+
 /* ------------------------------------------------------------------------
  * modules/energy/bending.py:90-181  compute_energy_and_gradient_array
  * model: 0 = helfrich, 1 = willmore.  mode: 0 = analytic, 1 = approx.

@@ -45,6 +45,7 @@ def lib() -> ctypes.CDLL:
         _lib.orc_volume.restype = ctypes.c_double
         _lib.orc_bending_energy_and_gradient.restype = ctypes.c_int
         _lib.orc_bending_energy.restype = ctypes.c_int
+        _lib.orc_bending_backprop.restype = ctypes.c_int
     return _lib
 
 
@@ -191,6 +192,17 @@ def bending_energy_and_gradient(pos, tri, kappa, c0, is_boundary, *, model="helf
     if want_factors:
         return float(E.value), fK, fAe, fAv
     return float(E.value)
+
+
+def bending_backprop(pos, tri, is_boundary, fA_eff, fA_vor, fK, grad) -> None:
+    """modules/energy/bending_gradient.py:17-175 with given factors (grad accumulated)."""
+    pos, tri = _f64(pos), _i32(tri)
+    isb = _u8(is_boundary)
+    fae, fav, fk = _f64(fA_eff), _f64(fA_vor), _f64(fK)
+    rc = lib().orc_bending_backprop(ctypes.c_int(pos.shape[0]), ctypes.c_int(tri.shape[0]), _pd(pos),
+                                    _pi(tri), _pb(isb), _pd(fae), _pd(fav), _pd(fk), _pd(grad))
+    if rc != 0:
+        raise MemoryError("oracle allocation failed")
 
 
 def bending_energy(pos, tri, kappa, c0, is_boundary, *, model="helfrich", per_vertex=False):

@@ -1,0 +1,119 @@
+"""Sharded HIP backend on ONE GPU: two shard contexts (rank 0 / rank 1 tile ranges)
+driven by two threads whose collectives are an in-process stand-in for RCCL.  This
+runs the real tile-range kernels, ms_rebind_state, the phase API and
+ms_phase_commit_trial; only the RCCL transport itself is replaced.  The sharded
+run must match the single-context ms_step run."""
+
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+class ThreadGroup:
+    """all_gather_into_tensor for `world` threads of one process (device tensors)."""
+
+    def __init__(self, world):
+        import torch
+
+        self.torch, self.world = torch, world
+        self.slots = [None] * world
+        self.bar = threading.Barrier(world)
+        self.local = threading.local()
+
+    def bind(self, rank):
+        self.local.rank = rank
+
+    def all_gather_into_tensor(self, out, inp):
+        r = self.local.rank
+        self.torch.cuda.synchronize()
+        self.slots[r] = inp
+        self.bar.wait()
+        n = inp.shape[0]
+        for k in range(self.world):
+            out[k * n:(k + 1) * n].copy_(self.slots[k])
+        self.torch.cuda.synchronize()
+        self.bar.wait()
+
+
+@pytest.mark.parametrize("with_volume", [False, True])
+def test_two_shards_match_single_context(with_volume):
+    import torch
+
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+    from membrane_solver_amd.parallel import HipShardBackend, ShardedStepper
+
+    P, T = meshgen.icosphere(16)
+    P = meshgen.smooth_displace(P, 0.06)
+    nv, nf = P.shape[0], T.shape[0]
+    fixed = np.zeros(nv, bool)
+    fixed[::29] = True
+    kappa, c0, gamma = np.full(nv, 0.9), np.full(nv, 0.1), np.full(nf, 1.1)
+    mods = L.MS_MOD_SURFACE | L.MS_MOD_BENDING | (L.MS_CON_VOLUME if with_volume else 0)
+    V0 = 4.0
+    n_steps, step0 = 6, 1e-3
+
+    # single context reference
+    dm = DeviceMesh(P, T, fixed=fixed, tile_vertices=64)
+    dm.set_surface_tension(gamma)
+    dm.set_bending_params(kappa, c0)
+    dm.set_params(modules=mods, target_volume=V0)
+    ref_log, step = [], step0
+    for _ in range(n_steps):
+        r = dm.step(stepper=L.MS_STEPPER_CG, step_size=step, tol=1e-9)
+        ref_log.append((float(r.success), r.next_step, r.energy, r.grad_norm))
+        step = r.next_step
+        if not r.success:
+            dm.reset_stepper()
+    x_ref = dm.get_positions()
+    dm.close()
+
+    world = 2
+    grp = ThreadGroup(world)
+    logs, finals, errors = [None] * world, [None] * world, []
+
+    def run(rank):
+        try:
+            grp.bind(rank)
+            be = HipShardBackend(P, T, rank=rank, world=world, device=0, tile_vertices=64, fixed=fixed, group=grp)
+            be.configure(modules=mods, gamma=gamma, kappa=kappa, c0=c0, target_volume=V0)
+            drv = ShardedStepper(be, stepper=L.MS_STEPPER_CG)
+            log, step = [], step0
+            for _ in range(n_steps):
+                r = drv.step(step, tol=1e-9)
+                log.append((float(r.success), r.next_step, r.energy, r.grad_norm))
+                step = r.next_step
+                if not r.success:
+                    drv.reset()
+            logs[rank] = np.array(log)
+            finals[rank] = be.dm.get_positions()
+            torch.cuda.synchronize()
+        except Exception as e:  # pragma: no cover
+            import traceback
+
+            errors.append(traceback.format_exc())
+            grp.bar.abort()
+            raise e
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors[0]
+    ref = np.array(ref_log)
+    assert ref[:, 0].sum() >= 2
+    for rank in range(world):
+        got = logs[rank]
+        assert np.array_equal(got[:, 0], ref[:, 0]), (got, ref)
+        assert np.allclose(got[:, 1], ref[:, 1], rtol=1e-12)
+        assert np.allclose(got[:, 2], ref[:, 2], rtol=1e-12)
+        assert np.allclose(got[:, 3], ref[:, 3], rtol=1e-9)
+        assert relerr(finals[rank], x_ref) < 1e-11
+    assert np.array_equal(finals[0], finals[1]), "ranks diverged"
