@@ -124,7 +124,7 @@ _lib = None
 def build(force: bool = False, fp_contract: str | None = None) -> str:
     """Compile libmembrane_hip.so for gfx950 with hipcc (csrc/Makefile)."""
     srcs = [os.path.join(_CSRC, f) for f in ("ms_kernels.hip", "ms_api.cpp", "ms_tiles.cpp",
-                                             "ms_internal.h")]
+                                             "ms_internal.h", "Makefile")]
     srcs.append(os.path.join(_PKG, "..", "include", "membrane_hip.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
@@ -138,6 +138,47 @@ def build(force: bool = False, fp_contract: str | None = None) -> str:
     return LIB_PATH
 
 
+HIP_RUNTIME_PATH = None
+
+
+def _preload_hip_runtime() -> str:
+    """Load exactly ONE HIP runtime into the process, globally, before our library.
+
+    libmembrane_hip.so carries no DT_NEEDED on libamdhip64 (csrc/Makefile).  PyTorch
+    wheels bundle their own libamdhip64/libhsa-runtime64; if this process will also use
+    torch (device memory for RCCL, bench.py) both must share one runtime, whichever is
+    imported first, or the second one to start finds no GPU.  So: torch's copy when
+    torch is installed, else the system ROCm one.  MEMBRANE_HIP_RUNTIME overrides.
+    """
+    global HIP_RUNTIME_PATH
+    if HIP_RUNTIME_PATH is not None:
+        return HIP_RUNTIME_PATH
+    candidates = []
+    if os.environ.get("MEMBRANE_HIP_RUNTIME"):
+        candidates.append(os.environ["MEMBRANE_HIP_RUNTIME"])
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.submodule_search_locations:
+            candidates.append(os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so"))
+    except Exception:  # pragma: no cover - torch is optional plumbing
+        pass
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    candidates += [os.path.join(rocm, "lib", "libamdhip64.so"), "libamdhip64.so.7", "libamdhip64.so"]
+    errors = []
+    for c in candidates:
+        if os.path.isabs(c) and not os.path.exists(c):
+            continue
+        try:
+            ctypes.CDLL(c, mode=ctypes.RTLD_GLOBAL)
+            HIP_RUNTIME_PATH = c
+            return c
+        except OSError as e:
+            errors.append(f"{c}: {e}")
+    raise MembraneHipError("no HIP runtime (libamdhip64) could be loaded: " + "; ".join(errors))
+
+
 def lib() -> ctypes.CDLL:
     """Load the shared library; fail loudly if it has not been built."""
     global _lib
@@ -146,6 +187,7 @@ def lib() -> ctypes.CDLL:
             raise MembraneHipError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for this path.")
+        _preload_hip_runtime()
         cd = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(cd, name)  # AttributeError here = header/library mismatch

@@ -220,10 +220,13 @@ __device__ __forceinline__ TileCtx tile_ctx(const DeviceMesh& m, int tile) {
 // LDS: px[3][cap] | (GUARD) ox[3][cap] | (BEND) stg[18][T] | red[16]
 //      | (BEND) voff[T+1], vent[max_ent] (u16) | fl[cap] (u8)
 // ---------------------------------------------------------------------------
-template <bool BEND, bool GUARD>
-__global__ __launch_bounds__(512) void k_energy(EnergyArgs a, int cap, int max_ent) {
+// TT / CAPC: compile-time tile size and LDS patch capacity (0 = take the runtime values);
+// with constants every LDS address becomes base + immediate offset.
+template <bool BEND, bool GUARD, int TT, int CAPC>
+__global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_rt, int max_ent) {
   extern __shared__ double lds[];
-  const int T = a.m.T;  // == blockDim.x
+  const int T = TT ? TT : a.m.T;  // == blockDim.x
+  const int cap = CAPC ? CAPC : cap_rt;
   double* px = lds;
   double* ox = px + 3 * cap;
   double* stg = ox + (GUARD ? 3 * cap : 0);
@@ -467,23 +470,34 @@ static hipError_t ensure_lds(K kernel, size_t lds) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
+constexpr int FAST_T = 256;  // specialised tile size (LDS staging offsets become immediates)
+constexpr int FAST_CAP = 0;  // patch capacity stays a runtime value: a fixed 512 slots would push
+                             // the gradient kernel from 3 to 2 workgroups per CU (LDS)
+
 hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, hipStream_t s) {
   const int nb = a.tile1 - a.tile0;
   if (nb <= 0) return hipSuccess;
   const bool bend = (a.modules & MS_MOD_BENDING) != 0;
+  const bool fast = a.m.T == FAST_T;
   const size_t lds = energy_lds_bytes(a.m.T, cap, max_ent, bend, guard);
   hipError_t e;
-#define MS_LAUNCH_E(B, G)                                                                     \
-  do {                                                                                        \
-    e = ensure_lds(k_energy<B, G>, lds);                                                      \
-    if (e != hipSuccess) return e;                                                            \
-    hipLaunchKernelGGL((k_energy<B, G>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);     \
+#define MS_LAUNCH_E(B, G, TT, CC)                                                                     \
+  do {                                                                                                \
+    e = ensure_lds(k_energy<B, G, TT, CC>, lds);                                                      \
+    if (e != hipSuccess) return e;                                                                    \
+    hipLaunchKernelGGL((k_energy<B, G, TT, CC>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);     \
+  } while (0)
+#define MS_PICK_E(B, G)                                   \
+  do {                                                    \
+    if (fast) MS_LAUNCH_E(B, G, FAST_T, FAST_CAP);        \
+    else MS_LAUNCH_E(B, G, 0, 0);                         \
   } while (0)
   if (bend) {
-    if (guard) MS_LAUNCH_E(true, true); else MS_LAUNCH_E(true, false);
+    if (guard) MS_PICK_E(true, true); else MS_PICK_E(true, false);
   } else {
-    if (guard) MS_LAUNCH_E(false, true); else MS_LAUNCH_E(false, false);
+    if (guard) MS_PICK_E(false, true); else MS_PICK_E(false, false);
   }
+#undef MS_PICK_E
 #undef MS_LAUNCH_E
   return hipGetLastError();
 }
@@ -504,11 +518,12 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
 // LDS: px[3][cap] | (BEND) fk[3][cap] fae[cap] fav[cap] | stg[9 or 18][T] | red[16]
 //      | voff[T+2] vent[max_ent] (u16) | fl[cap] (u8)
 // ---------------------------------------------------------------------------
-template <int BENDMODE, bool VOLROW>
-__global__ __launch_bounds__(512) void k_gradient(GradientArgs a, int cap, int max_ent) {
+template <int BENDMODE, bool VOLROW, int TT, int CAPC>
+__global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
   extern __shared__ double lds[];
   constexpr bool BEND = BENDMODE != 0;
-  const int T = a.m.T;
+  const int T = TT ? TT : a.m.T;
+  const int cap = CAPC ? CAPC : cap_rt;
   double* px = lds;
   double* fk = px + 3 * cap;
   double* fae = fk + (BEND ? 3 * cap : 0);
@@ -772,20 +787,27 @@ hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStrea
   if (nb <= 0) return hipSuccess;
   const bool bend = (a.modules & MS_MOD_BENDING) != 0;
   const bool volrow = a.gC != nullptr && (a.modules & MS_CON_VOLUME);
+  const bool fast = a.m.T == FAST_T;
   const size_t lds = gradient_lds_bytes(a.m.T, cap, max_ent, bend, volrow);
   hipError_t e;
-#define MS_LAUNCH_G(M, V)                                                                       \
-  do {                                                                                          \
-    e = ensure_lds(k_gradient<M, V>, lds);                                                      \
-    if (e != hipSuccess) return e;                                                              \
-    hipLaunchKernelGGL((k_gradient<M, V>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);     \
+#define MS_LAUNCH_G(M, V, TT, CC)                                                                       \
+  do {                                                                                                  \
+    e = ensure_lds(k_gradient<M, V, TT, CC>, lds);                                                      \
+    if (e != hipSuccess) return e;                                                                      \
+    hipLaunchKernelGGL((k_gradient<M, V, TT, CC>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);     \
+  } while (0)
+#define MS_PICK_G(M, V)                                   \
+  do {                                                    \
+    if (fast) MS_LAUNCH_G(M, V, FAST_T, FAST_CAP);        \
+    else MS_LAUNCH_G(M, V, 0, 0);                         \
   } while (0)
   const int mode = !bend ? 0 : (a.bending_grad_mode == MS_GRAD_APPROX ? 2 : 1);
   if (volrow) {
-    if (mode == 0) MS_LAUNCH_G(0, true); else if (mode == 1) MS_LAUNCH_G(1, true); else MS_LAUNCH_G(2, true);
+    if (mode == 0) MS_PICK_G(0, true); else if (mode == 1) MS_PICK_G(1, true); else MS_PICK_G(2, true);
   } else {
-    if (mode == 0) MS_LAUNCH_G(0, false); else if (mode == 1) MS_LAUNCH_G(1, false); else MS_LAUNCH_G(2, false);
+    if (mode == 0) MS_PICK_G(0, false); else if (mode == 1) MS_PICK_G(1, false); else MS_PICK_G(2, false);
   }
+#undef MS_PICK_G
 #undef MS_LAUNCH_G
   return hipGetLastError();
 }

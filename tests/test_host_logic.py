@@ -21,6 +21,7 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(ms_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"ms_params", "ms_stepper_params", "ms_step_result"}
     assert declared, "no prototypes found in the header"
+    _lib.lib()  # preloads the HIP runtime, then the library
     cd = ctypes.CDLL(_lib.LIB_PATH)
     missing = [n for n in sorted(declared) if not hasattr(cd, n)]
     assert not missing, f"declared in membrane_hip.h but not exported: {missing}"
