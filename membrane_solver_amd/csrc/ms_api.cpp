@@ -41,7 +41,8 @@ struct ms_ctx {
   double* buf[MS_BUF_COUNT] = {nullptr};
   double* d_partials = nullptr;
   double* d_scal = nullptr;
-  double* h_scal = nullptr;  // pinned mailbox
+  double* h_scal = nullptr;    // pinned, device-mapped mailbox (k_reduce writes it directly)
+  double* d_h_scal = nullptr;  // device-side address of h_scal
   double* d_stage = nullptr;  // nv*3 staging in external row order
   double* last_g = nullptr;   // buffer holding the most recent finalized gradient
   ms_params params{};
@@ -131,8 +132,15 @@ constexpr uint32_t MASK_ENERGY = (1u << MS_S_ESURF) | (1u << MS_S_VOL) | (1u << 
 constexpr uint32_t MASK_GRAD = (1u << MS_S_GGC) | (1u << MS_S_GCGC);
 constexpr uint32_t MASK_DIR = (1u << MS_S_GNORM2) | (1u << MS_S_GDOTD) | (1u << MS_S_MAXD2);
 
+int reduce_slots(ms_ctx* c, uint32_t mask) {
+  ProfScope ps(c, 3);
+  HIPCHK(c, launch_reduce(c->d_partials, c->til.n_tiles, c->tile0, c->tile1, mask, c->d_scal,
+                          c->d_h_scal, c->stream));
+  return MS_OK;
+}
+
 int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool write_trial,
-                 bool guard, bool write_factors) {
+                 bool guard, bool write_factors, bool reduce_now = true) {
   EnergyArgs a;
   a.m = device_mesh(c);
   a.tile0 = c->tile0;
@@ -151,15 +159,17 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
     ProfScope ps(c, 0);
     HIPCHK(c, launch_energy(a, guard && use_dir, c->cap, c->til.max_ent, c->stream));
   }
-  {
-    ProfScope ps(c, 3);
-    HIPCHK(c, launch_reduce(c->d_partials, c->til.n_tiles, c->tile0, c->tile1, MASK_ENERGY, c->d_scal, c->stream));
+  if (reduce_now) {
+    int rc = reduce_slots(c, MASK_ENERGY);
+    if (rc) return rc;
   }
   if (bend && write_factors) c->factors_valid = !use_dir;
   return MS_OK;
 }
 
-int phase_gradient(ms_ctx* c, uint32_t modules, double* g_out, bool accumulate) {
+// dir_mode: 0 = plain gradient pass (+ <g,gC> partials); 1/2 = fused direction (GD / CG history)
+int phase_gradient(ms_ctx* c, uint32_t modules, double* g_out, bool accumulate, int dir_mode = 0,
+                   bool reduce_now = true) {
   if ((modules & MS_MOD_BENDING) && !c->factors_valid)
     return fail(c, MS_ERR_STATE, "gradient pass needs the bending factors of an energy pass at x");
   GradientArgs a;
@@ -178,14 +188,16 @@ int phase_gradient(ms_ctx* c, uint32_t modules, double* g_out, bool accumulate) 
   a.volume_stiffness = c->params.volume_stiffness;
   a.target_volume = c->params.target_volume;
   a.accumulate = accumulate ? 1 : 0;
+  a.dir_mode = dir_mode;
+  a.d = c->buf[MS_BUF_D];
+  a.pg = c->buf[MS_BUF_PG];
+  a.pd = c->buf[MS_BUF_PD];
   {
     ProfScope ps(c, 1);
     HIPCHK(c, launch_gradient(a, c->cap, c->til.max_ent, c->stream));
   }
-  {
-    ProfScope ps(c, 3);
-    HIPCHK(c, launch_reduce(c->d_partials, c->til.n_tiles, c->tile0, c->tile1, MASK_GRAD, c->d_scal, c->stream));
-  }
+  if (dir_mode) c->last_g = g_out;
+  if (reduce_now) return reduce_slots(c, dir_mode ? MASK_DIR : MASK_GRAD);
   return MS_OK;
 }
 
@@ -199,17 +211,12 @@ int phase_direction(ms_ctx* c, int stepper, bool use_history) {
                              (stepper == MS_STEPPER_CG && use_history) ? 1 : 0, c->d_partials,
                              c->til.n_tiles, c->stream));
   }
-  {
-    ProfScope ps(c, 3);
-    HIPCHK(c, launch_reduce(c->d_partials, c->til.n_tiles, c->tile0, c->tile1, MASK_DIR, c->d_scal, c->stream));
-  }
   c->last_g = c->buf[MS_BUF_G];
-  return MS_OK;
+  return reduce_slots(c, MASK_DIR);
 }
 
+// k_reduce mirrors every slot it folds into the pinned mailbox, so fetching is a stream sync.
 int fetch(ms_ctx* c) {
-  HIPCHK(c, hipMemcpyAsync(c->h_scal, c->d_scal, sizeof(double) * MS_NSCAL, hipMemcpyDeviceToHost,
-                           c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return MS_OK;
 }
@@ -231,9 +238,20 @@ void energies_from_mailbox(const ms_ctx* c, double e[3]) {
 // the direction kernel (projection + fixed rows), everything queued async.
 int queue_energy_and_gradient(ms_ctx* c, int stepper, bool use_history) {
   const uint32_t mods = c->params.modules;
-  int rc = phase_energy(c, mods, false, 0.0, false, false, true);
+  const bool constraint = (mods & MS_CON_VOLUME) != 0;   // lambda needs a global reduction first
+  const bool penalty = (mods & MS_MOD_VOLUME_PENALTY) != 0;  // K_C reads the reduced volume
+  int rc = phase_energy(c, mods, false, 0.0, false, false, true, /*reduce_now=*/penalty);
   if (rc) return rc;
-  rc = phase_gradient(c, mods, c->buf[MS_BUF_G], false);
+  if (!constraint) {
+    // no row to project out: the direction pass rides in K_C's epilogue, one reduce for all
+    const int dir_mode = (stepper == MS_STEPPER_CG && use_history) ? 2 : 1;
+    rc = phase_gradient(c, mods, c->buf[MS_BUF_G], false, dir_mode, /*reduce_now=*/false);
+    if (rc) return rc;
+    return reduce_slots(c, (penalty ? 0u : MASK_ENERGY) | MASK_DIR);
+  }
+  rc = phase_gradient(c, mods, c->buf[MS_BUF_G], false, 0, /*reduce_now=*/false);
+  if (rc) return rc;
+  rc = reduce_slots(c, (penalty ? 0u : MASK_ENERGY) | MASK_GRAD);
   if (rc) return rc;
   return phase_direction(c, stepper, use_history);
 }
@@ -397,8 +415,9 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
   CREATE_HIP(hipMemset(c->d_scal, 0, sizeof(double) * MS_NSCAL));
   c->buf[MS_BUF_SCAL] = c->d_scal;
   CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scal), sizeof(double) * MS_NSCAL,
-                           hipHostMallocDefault));
+                           hipHostMallocMapped));
   memset(c->h_scal, 0, sizeof(double) * MS_NSCAL);
+  CREATE_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_scal), c->h_scal, 0));
   CREATE_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_stage), sizeof(double) * 3 * (size_t)nv));
   c->params.modules = MS_MOD_SURFACE;
   c->params.bending_model = MS_BEND_HELFRICH;

@@ -102,6 +102,11 @@ struct GradientArgs {
   int bending_grad_mode;
   double volume_stiffness, target_volume;
   int accumulate;         // add into existing g instead of overwriting
+  // fused direction pass (only when no constraint row has to be projected out first)
+  int dir_mode;           // 0 off, 1 d = -g (GD / CG restart), 2 per-row Polak-Ribiere with history
+  double* d;
+  const double* pg;
+  const double* pd;
 };
 
 // kernel launchers (ms_kernels.hip).  cap = T + max halo (LDS patch slots),
@@ -111,7 +116,7 @@ size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow);
 hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, hipStream_t s);
 hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStream_t s);
 hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
-                         uint32_t slot_mask, double* scal, hipStream_t s);
+                         uint32_t slot_mask, double* scal, double* host_mirror, hipStream_t s);
 hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* g,
                             const double* gC, double* d, const double* pg, const double* pd,
                             const double* scal, int use_constraint, int cg_history,

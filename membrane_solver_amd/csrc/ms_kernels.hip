@@ -530,7 +530,7 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
   double* fav = fae + (BEND ? cap : 0);
   double* stg = fav + (BEND ? cap : 0);
   double* red = stg + (VOLROW ? 18 : 9) * T;
-  uint16_t* voff = reinterpret_cast<uint16_t*>(red + 2 * 16);
+  uint16_t* voff = reinterpret_cast<uint16_t*>(red + 3 * 16);
   uint16_t* vent = voff + (T + 2);
   uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + ((max_ent + 3) & ~3));
 
@@ -742,12 +742,41 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
     __syncthreads();
   }
 
-  double ggc = 0.0, gcgc = 0.0;
+  double ggc = 0.0, gcgc = 0.0, gn2 = 0.0, gdd = 0.0, md2 = 0.0;
   if (tid < t.n_owned) {
     const size_t o = 3 * (size_t)(t.v_lo + tid);
     // bending.py:165-166: approx mode zeroes the boundary rows of what was accumulated
     if (BENDMODE == 2 && (lfl[tid] & VF_BOUNDARY)) gx = gy = gz = 0.0;
-    if (a.g) {
+    if (a.dir_mode) {
+      // fused direction pass (no constraint row to project against): same arithmetic as
+      // k_direction -- fixed rows zeroed, GD or per-row Polak-Ribiere direction.
+      const bool fixed = lfl[tid] & VF_FIXED;
+      if (a.accumulate) {
+        gx += a.g[o];
+        gy += a.g[o + 1];
+        gz += a.g[o + 2];
+      }
+      V3 gi = fixed ? mk(0, 0, 0) : mk(gx, gy, gz);
+      V3 di = -gi;
+      if (a.dir_mode == 2) {
+        const V3 pgv = mk(a.pg[o], a.pg[o + 1], a.pg[o + 2]);
+        const double beta = dot(gi, gi - pgv) / (dot(pgv, pgv) + 1.0e-20);
+        if (!(beta < 0.0)) {
+          const V3 q = mk(a.pd[o], a.pd[o + 1], a.pd[o + 2]);
+          di = mk(-gi.x + beta * q.x, -gi.y + beta * q.y, -gi.z + beta * q.z);
+        }
+      }
+      if (fixed) di = mk(0, 0, 0);
+      a.g[o] = gi.x;
+      a.g[o + 1] = gi.y;
+      a.g[o + 2] = gi.z;
+      a.d[o] = di.x;
+      a.d[o + 1] = di.y;
+      a.d[o + 2] = di.z;
+      gn2 = dot(gi, gi);
+      gdd = dot(gi, di);
+      md2 = fixed ? 0.0 : dot(di, di);
+    } else if (a.g) {
       if (a.accumulate) {
         gx += a.g[o];
         gy += a.g[o + 1];
@@ -771,14 +800,21 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
       gcgc = cx * cx + cy * cy + cz * cz;
     }
   }
-  const double vals[2] = {ggc, gcgc};
-  const int ops[2] = {0, 0};
-  const int slots[2] = {MS_S_GGC, MS_S_GCGC};
-  block_reduce_store<2>(vals, ops, slots, red, a.partials + t.tile, (size_t)a.m.n_tiles);
+  if (a.dir_mode) {
+    const double vals[3] = {gn2, gdd, md2};
+    const int ops[3] = {0, 0, 2};
+    const int slots[3] = {MS_S_GNORM2, MS_S_GDOTD, MS_S_MAXD2};
+    block_reduce_store<3>(vals, ops, slots, red, a.partials + t.tile, (size_t)a.m.n_tiles);
+  } else {
+    const double vals[2] = {ggc, gcgc};
+    const int ops[2] = {0, 0};
+    const int slots[2] = {MS_S_GGC, MS_S_GCGC};
+    block_reduce_store<2>(vals, ops, slots, red, a.partials + t.tile, (size_t)a.m.n_tiles);
+  }
 }
 
 size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow) {
-  size_t d = 3 * (size_t)cap + (bend ? 5 * (size_t)cap : 0) + (volrow ? 18 : 9) * (size_t)T + 2 * 16;
+  size_t d = 3 * (size_t)cap + (bend ? 5 * (size_t)cap : 0) + (volrow ? 18 : 9) * (size_t)T + 3 * 16;
   return d * sizeof(double) + u16_bytes(T, max_ent) + (((size_t)cap + 15) / 16) * 16;
 }
 
@@ -818,7 +854,8 @@ hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStrea
 // (geometry/body.py:121: vol_contrib.sum() / 6.0).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_reduce(const double* partials, int n_tiles, int tile0,
-                                                  int tile1, uint32_t slot_mask, double* scal) {
+                                                  int tile1, uint32_t slot_mask, double* scal,
+                                                  double* host_mirror) {
   __shared__ double red[16];
   // one workgroup per requested slot; partials are slot-major so lanes read
   // consecutive doubles.
@@ -843,15 +880,19 @@ __global__ __launch_bounds__(BLOCK) void k_reduce(const double* partials, int n_
     v = op == 0 ? v + q : (op == 1 ? fmin(v, q) : fmax(v, q));
   }
   v = block_reduce(v, op, red);
-  if (threadIdx.x == 0) scal[slot] = (slot == MS_S_VOL) ? v / 6.0 : v;
+  if (threadIdx.x == 0) {
+    const double r = (slot == MS_S_VOL) ? v / 6.0 : v;
+    scal[slot] = r;
+    if (host_mirror) host_mirror[slot] = r;  // pinned, device-mapped mailbox: no D2H copy needed
+  }
 }
 
 hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
-                         uint32_t slot_mask, double* scal, hipStream_t s) {
+                         uint32_t slot_mask, double* scal, double* host_mirror, hipStream_t s) {
   const int nslots = __builtin_popcount(slot_mask);
   if (nslots == 0) return hipSuccess;
   hipLaunchKernelGGL(k_reduce, dim3(nslots), dim3(BLOCK), 0, s, partials, n_tiles, tile0, tile1,
-                     slot_mask, scal);
+                     slot_mask, scal, host_mirror);
   return hipGetLastError();
 }
 
