@@ -45,15 +45,17 @@ def parse():
     return ap.parse_args()
 
 
-def algorithmic_bytes(nv, nf):
+def algorithmic_bytes(nv, nf, volume=False):
     """Compulsory HBM bytes per launch (DESIGN.md 'Kernels'); each array touched once."""
     return {
         # tri rows 12 B + gamma 8 B per facet; x 24 + kappa,c0 16 + flags 1 per vertex; fK,fA 40 out
         "energy_factors": 20 * nf + (24 + 16 + 1) * nv + 40 * nv,
         # trial energy: x and d in (48), xt out (24), no factor write
         "energy_trial": 20 * nf + (48 + 16 + 1) * nv + 24 * nv,
-        # gradient: x 24 + fK,fA 40 + flags 1 in, g 24 out
-        "gradient": 20 * nf + (24 + 40 + 1) * nv + 24 * nv,
+        # gradient (+ fused direction pass when no constraint row): x 24 + fK,fA 40 + flags 1 in,
+        # g 24 and d 24 out.  The CG-history reads (pg, pd: 48 B/vertex on non-restart steps) are
+        # NOT counted, so the figure is a lower bound of the compulsory traffic.
+        "gradient": 20 * nf + (24 + 40 + 1) * nv + 24 * nv + (0 if volume else 24 * nv),
     }
 
 
@@ -153,7 +155,7 @@ def main():
         mz.minimize(n_prof, sync_mesh=False)
         prof = dm.profile_read()
         dm.profile_enable(False)
-        ab = algorithmic_bytes(nv, nf)
+        ab = algorithmic_bytes(nv, nf, args.volume)
         kernels = {}
         for kind, (ms, n) in prof.items():
             if n:
@@ -180,7 +182,7 @@ def main():
                   key=lambda k: kernels[k]["share_of_profiled_ms"])
         ach = kernels[dom]["GBps"]
         out["roofline"] = {"bound": "hbm", "kernel": {"energy": "ms::k_energy<true,false>",
-                                                     "gradient": "ms::k_gradient<1>"}[dom],
+                                                     "gradient": "ms::k_gradient<1,false,256,0>"}[dom],
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": None,
                            "avg_launch_us": kernels[dom]["avg_us"],
