@@ -50,6 +50,8 @@ extern "C" {
  * check of runtime/minimizer.py:1478-1513 needs V even when no volume module
  * is loaded); no effect on energies or gradients */
 #define MS_TRACK_VOLUME 16u
+/* vertex-tilt magnitude energy 1/2 k_t sum |t_v|^2 A_v (modules/energy/tilt.py:99-172) */
+#define MS_MOD_TILT 32u
 
 /* bending_params.py:19-33 */
 #define MS_BEND_HELFRICH 0
@@ -159,6 +161,14 @@ int ms_set_surface_tension(ms_ctx *ctx, const double *gamma /* nf */);
 int ms_set_bending_params(ms_ctx *ctx, const double *kappa /* nv */,
                           const double *c0 /* nv */);
 int ms_set_params(ms_ctx *ctx, const ms_params *p);
+/* Mesh.tilts_view() (geometry/mesh.py:391-430) + gp["tilt_rigidity"]; tilts (nv,3) row-major */
+int ms_set_tilts(ms_ctx *ctx, const double *tilts /* nv*3 */, double tilt_rigidity);
+int ms_get_tilts(ms_ctx *ctx, double *tilts /* nv*3 */);
+/* dE/dt = k_t t_v A_v of the last gradient evaluation (tilt.py:160-170) */
+int ms_get_tilt_gradient(ms_ctx *ctx, double *tilt_grad /* nv*3 */);
+/* Mesh.project_tilts_to_tangent (geometry/mesh.py:788-814): t <- t - (t.n) n with the
+ * unit vertex normals of the current positions (triangle_ops.py:55-73) */
+int ms_project_tilts_to_tangent(ms_ctx *ctx);
 
 int ms_set_positions(ms_ctx *ctx, const double *positions /* nv*3 */);
 int ms_get_positions(ms_ctx *ctx, double *positions /* nv*3 */);
@@ -167,12 +177,12 @@ int ms_get_vertex_buffer(ms_ctx *ctx, int buffer, double *out /* nv*ncomp */);
 
 /*
  * Minimizer.compute_energy_and_gradient_array (runtime/minimizer.py:941-992):
- * module loop, volume-constraint projection, fixed rows zeroed.  energies[3] =
- * {surface, bending, volume-penalty}.  grad may be NULL (stays on device).
+ * module loop, volume-constraint projection, fixed rows zeroed.  energies[4] =
+ * {surface, bending, volume-penalty, tilt}.  grad may be NULL (stays on device).
  */
-int ms_energy_and_gradient(ms_ctx *ctx, double energies[3], double *grad);
+int ms_energy_and_gradient(ms_ctx *ctx, double energies[4], double *grad);
 /* EvaluationManager.compute_energy_array_total (evaluation_manager.py:184-225) */
-int ms_energy(ms_ctx *ctx, double energies[3]);
+int ms_energy(ms_ctx *ctx, double energies[4]);
 
 /* One stepper.step at the current positions (the body of minimizer.py:1314-1374
  * + line_search.py:267-426), fully device resident. */

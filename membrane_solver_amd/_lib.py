@@ -24,6 +24,7 @@ MS_MOD_BENDING = 2
 MS_MOD_VOLUME_PENALTY = 4
 MS_CON_VOLUME = 8
 MS_TRACK_VOLUME = 16
+MS_MOD_TILT = 32
 MS_BEND_HELFRICH, MS_BEND_WILLMORE = 0, 1
 MS_GRAD_ANALYTIC, MS_GRAD_APPROX = 0, 1
 MS_STEPPER_GD, MS_STEPPER_CG = 0, 1
@@ -78,6 +79,10 @@ SIGNATURES = {
     "ms_set_surface_tension": (ctypes.c_int, [_P, _D]),
     "ms_set_bending_params": (ctypes.c_int, [_P, _D, _D]),
     "ms_set_params": (ctypes.c_int, [_P, ctypes.POINTER(ms_params)]),
+    "ms_set_tilts": (ctypes.c_int, [_P, _D, ctypes.c_double]),
+    "ms_get_tilts": (ctypes.c_int, [_P, _D]),
+    "ms_get_tilt_gradient": (ctypes.c_int, [_P, _D]),
+    "ms_project_tilts_to_tangent": (ctypes.c_int, [_P]),
     "ms_set_positions": (ctypes.c_int, [_P, _D]),
     "ms_get_positions": (ctypes.c_int, [_P, _D]),
     "ms_get_gradient": (ctypes.c_int, [_P, _D]),

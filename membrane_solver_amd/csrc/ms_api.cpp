@@ -35,6 +35,10 @@ struct ms_ctx {
   uint8_t* d_vflags = nullptr;
   double* d_kappa = nullptr;
   double* d_c0 = nullptr;
+  double* d_tilts = nullptr;      // (nvp,3) vertex tilts, patch order (ms_set_tilts)
+  double* d_tilts_trial = nullptr;  // tilts projected onto a trial surface (line search)
+  double* d_tilt_grad = nullptr;  // (nvp,3) dE/dt of the last gradient evaluation
+  double k_tilt = 0.0;
   // per-vertex state (one allocation), patch order, nvp rows
   double* state = nullptr;
   bool own_state = true;
@@ -128,7 +132,29 @@ struct ProfScope {
 };
 
 constexpr uint32_t MASK_ENERGY = (1u << MS_S_ESURF) | (1u << MS_S_VOL) | (1u << MS_S_EBEND) |
-                                 (1u << MS_S_MINEDGE2) | (1u << MS_S_GUARD);
+                                 (1u << MS_S_MINEDGE2) | (1u << MS_S_GUARD) | (1u << MS_S_ETILT);
+
+// mode 0 energy / 1 energy+gradients read `src`; mode 2 projects `src` onto the tangent
+// planes of x (+ alpha d) and writes `dst`.
+int tilt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* src = nullptr,
+              double* dst = nullptr) {
+  if (!c->d_tilts) return fail(c, MS_ERR_STATE, "tilt module active but ms_set_tilts was never called");
+  TiltArgs a;
+  a.m = device_mesh(c);
+  a.tile0 = c->tile0;
+  a.tile1 = c->tile1;
+  a.x = c->buf[MS_BUF_X];
+  a.d = use_dir ? c->buf[MS_BUF_D] : nullptr;
+  a.alpha = alpha;
+  a.tilts = src ? src : c->d_tilts;
+  a.tilts_out = dst ? dst : c->d_tilts;
+  a.k_tilt = c->k_tilt;
+  a.g = c->buf[MS_BUF_G];
+  a.tilt_grad = c->d_tilt_grad;
+  a.partials = c->d_partials;
+  HIPCHK(c, launch_tilt(a, mode, c->cap, c->til.max_ent, c->stream));
+  return MS_OK;
+}
 constexpr uint32_t MASK_GRAD = (1u << MS_S_GGC) | (1u << MS_S_GCGC);
 constexpr uint32_t MASK_DIR = (1u << MS_S_GNORM2) | (1u << MS_S_GDOTD) | (1u << MS_S_MAXD2);
 
@@ -158,6 +184,20 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   {
     ProfScope ps(c, 0);
     HIPCHK(c, launch_energy(a, guard && use_dir, c->cap, c->til.max_ent, c->stream));
+  }
+  if (modules & MS_MOD_TILT) {
+    int rc;
+    if (use_dir) {
+      // minimizer.py:723-733: the trial energy is taken with the tilts projected onto the
+      // TRIAL surface's vertex tangent planes (kept aside; they become the stored tilts
+      // only if this trial is accepted)
+      rc = tilt_pass(c, 2, true, alpha, c->d_tilts, c->d_tilts_trial);
+      if (rc) return rc;
+      rc = tilt_pass(c, 0, true, alpha, c->d_tilts_trial);
+    } else {
+      rc = tilt_pass(c, 0, false, 0.0);
+    }
+    if (rc) return rc;
   }
   if (reduce_now) {
     int rc = reduce_slots(c, MASK_ENERGY);
@@ -197,6 +237,10 @@ int phase_gradient(ms_ctx* c, uint32_t modules, double* g_out, bool accumulate, 
     HIPCHK(c, launch_gradient(a, c->cap, c->til.max_ent, c->stream));
   }
   if (dir_mode) c->last_g = g_out;
+  if ((modules & MS_MOD_TILT) && g_out) {  // module loop: tilt adds its shape gradient into g
+    int rc = tilt_pass(c, 1, false, 0.0);
+    if (rc) return rc;
+  }
   if (reduce_now) return reduce_slots(c, dir_mode ? MASK_DIR : MASK_GRAD);
   return MS_OK;
 }
@@ -227,18 +271,20 @@ double penalty_energy(const ms_ctx* c, double V) {
   return 0.5 * c->params.volume_stiffness * (delta * delta);
 }
 
-// energies from the pinned mailbox: {surface, bending, penalty}
-void energies_from_mailbox(const ms_ctx* c, double e[3]) {
+// energies from the pinned mailbox: {surface, bending, penalty, tilt}
+void energies_from_mailbox(const ms_ctx* c, double e[4]) {
   e[0] = (c->params.modules & MS_MOD_SURFACE) ? c->h_scal[MS_S_ESURF] : 0.0;
   e[1] = (c->params.modules & MS_MOD_BENDING) ? c->h_scal[MS_S_EBEND] : 0.0;
   e[2] = penalty_energy(c, c->h_scal[MS_S_VOL]);
+  e[3] = (c->params.modules & MS_MOD_TILT) ? c->h_scal[MS_S_ETILT] : 0.0;
 }
 
 // gradient assembly at x: energy pass (+factors), gradient pass, finalize via
 // the direction kernel (projection + fixed rows), everything queued async.
 int queue_energy_and_gradient(ms_ctx* c, int stepper, bool use_history) {
   const uint32_t mods = c->params.modules;
-  const bool constraint = (mods & MS_CON_VOLUME) != 0;   // lambda needs a global reduction first
+  // lambda needs a global reduction first; the tilt module adds into g after K_C
+  const bool constraint = (mods & (MS_CON_VOLUME | MS_MOD_TILT)) != 0;
   const bool penalty = (mods & MS_MOD_VOLUME_PENALTY) != 0;  // K_C reads the reduced volume
   int rc = phase_energy(c, mods, false, 0.0, false, false, true, /*reduce_now=*/penalty);
   if (rc) return rc;
@@ -439,7 +485,7 @@ void ms_destroy(ms_ctx* c) {
   if (!c->own_state) c->state = nullptr;
   void* ptrs[] = {c->d_perm, c->d_tile_facet_off, c->d_tile_facets, c->d_tf_gamma,
                   c->d_tile_halo_off, c->d_halo_ids, c->d_tile_ent_off, c->d_tile_voff, c->d_vent,
-                  c->d_vflags, c->d_kappa, c->d_c0,
+                  c->d_vflags, c->d_kappa, c->d_c0, c->d_tilts, c->d_tilt_grad, c->d_tilts_trial,
                   c->state, c->d_partials, c->d_scal, c->d_stage};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -506,6 +552,39 @@ int ms_set_params(ms_ctx* c, const ms_params* p) {
   return MS_OK;
 }
 
+int ms_set_tilts(ms_ctx* c, const double* tilts, double tilt_rigidity) {
+  if (!c || !tilts) return fail(c, MS_ERR_INVALID, "ms_set_tilts: NULL argument");
+  const size_t bytes = sizeof(double) * 3 * (size_t)c->til.nvp;
+  if (!c->d_tilts) {
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_tilts), bytes));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_tilt_grad), bytes));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_tilts_trial), bytes));
+    HIPCHK(c, hipMemset(c->d_tilts_trial, 0, bytes));
+    HIPCHK(c, hipMemset(c->d_tilts, 0, bytes));
+    HIPCHK(c, hipMemset(c->d_tilt_grad, 0, bytes));
+  }
+  c->k_tilt = tilt_rigidity;
+  return ext_to_patch(c, tilts, c->d_tilts, 3);
+}
+
+int ms_get_tilts(ms_ctx* c, double* tilts) {
+  if (!c || !tilts || !c->d_tilts) return fail(c, MS_ERR_INVALID, "ms_get_tilts: no tilts set");
+  return patch_to_ext(c, c->d_tilts, tilts, 3);
+}
+
+int ms_get_tilt_gradient(ms_ctx* c, double* tilt_grad) {
+  if (!c || !tilt_grad || !c->d_tilt_grad) return fail(c, MS_ERR_INVALID, "ms_get_tilt_gradient: no tilts set");
+  return patch_to_ext(c, c->d_tilt_grad, tilt_grad, 3);
+}
+
+int ms_project_tilts_to_tangent(ms_ctx* c) {
+  if (!c) return MS_ERR_INVALID;
+  if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "tilt passes are single-shard only");
+  int rc = tilt_pass(c, 2, false, 0.0);
+  if (rc) return rc;
+  return fetch(c);
+}
+
 int ms_set_positions(ms_ctx* c, const double* positions) {
   if (!c || !positions) return fail(c, MS_ERR_INVALID, "ms_set_positions: NULL argument");
   c->factors_valid = false;
@@ -528,7 +607,7 @@ int ms_get_vertex_buffer(ms_ctx* c, int buffer, double* out) {
   return patch_to_ext(c, c->buf[buffer], out, buffer == MS_BUF_FA ? 2 : 3);
 }
 
-int ms_energy_and_gradient(ms_ctx* c, double energies[3], double* grad) {
+int ms_energy_and_gradient(ms_ctx* c, double energies[4], double* grad) {
   if (!c || !energies) return fail(c, MS_ERR_INVALID, "ms_energy_and_gradient: NULL argument");
   if (c->shard_count != 1)
     return fail(c, MS_ERR_STATE, "ms_energy_and_gradient: sharded contexts use the phase API");
@@ -541,7 +620,7 @@ int ms_energy_and_gradient(ms_ctx* c, double energies[3], double* grad) {
   return MS_OK;
 }
 
-int ms_energy(ms_ctx* c, double energies[3]) {
+int ms_energy(ms_ctx* c, double energies[4]) {
   if (!c || !energies) return fail(c, MS_ERR_INVALID, "ms_energy: NULL argument");
   if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "ms_energy: sharded contexts use the phase API");
   int rc = phase_energy(c, c->params.modules, false, 0.0, false, false, false);
@@ -572,9 +651,9 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   if (rc) return rc;
   rc = fetch(c);
   if (rc) return rc;
-  double e[3];
+  double e[4];
   energies_from_mailbox(c, e);
-  const double E_eval = e[0] + e[1] + e[2];
+  const double E_eval = e[0] + e[1] + e[2] + e[3];
   const double grad_norm = std::sqrt(c->h_scal[MS_S_GNORM2]);
   const double g_dot_d = c->h_scal[MS_S_GDOTD];
   const double max_dir = std::sqrt(c->h_scal[MS_S_MAXD2]);
@@ -592,13 +671,18 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   // ---- backtracking_line_search_array (line_search.py:267-426) -------------
   double energy0 = E_eval;
   double min_edge = std::sqrt(c->h_scal[MS_S_MINEDGE2]);
-  if (!sp->reuse_energy0) {
+  const bool tilt = (c->params.modules & MS_MOD_TILT) != 0;
+  if (tilt) {  // energy_fn projects the stored tilts first (minimizer.py:581-588)
+    rc = tilt_pass(c, 2, false, 0.0);
+    if (rc) return rc;
+  }
+  if (!sp->reuse_energy0 || tilt) {
     rc = phase_energy(c, c->params.modules, false, 0.0, false, false, false);
     if (rc) return rc;
     rc = fetch(c);
     if (rc) return rc;
     energies_from_mailbox(c, e);
-    energy0 = e[0] + e[1] + e[2];
+    energy0 = e[0] + e[1] + e[2] + e[3];
     min_edge = std::sqrt(c->h_scal[MS_S_MINEDGE2]);
   }
   if (c->til.nf == 0) min_edge = 0.0;
@@ -624,10 +708,13 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     }
     ++out->trials;
     energies_from_mailbox(c, e);
-    const double E_t = e[0] + e[1] + e[2];
+    const double E_t = e[0] + e[1] + e[2] + e[3];
     if (E_t <= energy0 + sp->c * alpha * g_dot_d) {
       std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
       c->factors_valid = false;
+      // minimizer.py:1415 re-projects the stored tilts onto the accepted surface: that is
+      // exactly the trial projection computed above
+      if (tilt) std::swap(c->d_tilts, c->d_tilts_trial);
       if (cg) {  // conjugate_gradient.py:114-117 history on success only
         std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
         std::swap(c->buf[MS_BUF_D], c->buf[MS_BUF_PD]);
@@ -683,6 +770,8 @@ int ms_project_volume(ms_ctx* c, double target, double tol, int max_iter, int* i
 int ms_phase_energy(ms_ctx* c, int use_direction, double alpha, int write_trial, int guard,
                     int write_bending_factors) {
   if (!c) return MS_ERR_INVALID;
+  if ((c->params.modules & MS_MOD_TILT) && c->shard_count != 1)
+    return fail(c, MS_ERR_STATE, "the tilt module is not sharded yet (single GPU only)");
   return phase_energy(c, c->params.modules, use_direction != 0, alpha, write_trial != 0, guard != 0,
                       write_bending_factors != 0);
 }

@@ -109,12 +109,29 @@ struct GradientArgs {
   const double* pd;
 };
 
+struct TiltArgs {
+  DeviceMesh m;
+  int tile0, tile1;
+  const double* x;
+  const double* d;        // direction or nullptr (energy at x + alpha d)
+  double alpha;
+  const double* tilts;    // (nvp,3) tilts read by every mode
+  double* tilts_out;      // mode 2: projected tilts are written here (may alias `tilts`)
+  double k_tilt;
+  double* g;              // mode 1: shape gradient is ADDED into g
+  double* tilt_grad;      // mode 1: k_t t_v A_v (written)
+  double* partials;
+};
+
 // kernel launchers (ms_kernels.hip).  cap = T + max halo (LDS patch slots),
 // max_ent = largest per-tile vertex->corner entry count.
 size_t energy_lds_bytes(int T, int cap, int max_ent, bool bend, bool guard);
 size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow);
 hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, hipStream_t s);
 hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStream_t s);
+// mode 0: energy partial (MS_S_ETILT); 1: energy + gradients; 2: project tilts to tangent
+size_t tilt_lds_bytes(int T, int cap, int max_ent);
+hipError_t launch_tilt(const TiltArgs& a, int mode, int cap, int max_ent, hipStream_t s);
 hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
                          uint32_t slot_mask, double* scal, double* host_mirror, hipStream_t s);
 hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* g,

@@ -248,6 +248,13 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_
     gam_nx = a.m.tf_gamma[t.f0 + tid];
   }
 
+  // per-vertex parameters of the epilogue are requested now, used ~all the way down
+  double kappa_v = 0.0, c0_v = 0.0;
+  if (BEND && tid < t.n_owned) {
+    kappa_v = a.m.kappa[t.v_lo + tid];
+    c0_v = a.m.c0[t.v_lo + tid];
+  }
+
   // -- stage this thread's owned row and the halo rows it covers --------------
   if (tid < t.n_owned) {
     const size_t g = 3 * (size_t)(t.v_lo + tid);
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_
     // modules/energy/bending.py:111-161 on this thread's owned vertex
     const int v = t.v_lo + tid;
     const V3 K = mk(aKx, aKy, aKz);
-    const double kappa = a.m.kappa[v], c0 = a.m.c0[v];
+    const double kappa = kappa_v, c0 = c0_v;
     const bool interior = !(lfl[tid] & VF_BOUNDARY);
     const double safe = fmax(aAv, 1.0e-12);
     const double k_mag = norm(K);
@@ -450,10 +457,24 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_
     }
   }
 
-  const double vals[5] = {e_surf, vol, e_bend, min_e2, guard};
-  const int ops[5] = {0, 0, 0, 1, 2};
-  const int slots[5] = {MS_S_ESURF, MS_S_VOL, MS_S_EBEND, MS_S_MINEDGE2, MS_S_GUARD};
-  block_reduce_store<5>(vals, ops, slots, red, a.partials + t.tile, (size_t)a.m.n_tiles);
+  double* pout = a.partials + t.tile;
+  const size_t pstride = (size_t)a.m.n_tiles;
+  if (GUARD || want_vol) {
+    const double vals[5] = {e_surf, vol, e_bend, min_e2, guard};
+    const int ops[5] = {0, 0, 0, 1, 2};
+    const int slots[5] = {MS_S_ESURF, MS_S_VOL, MS_S_EBEND, MS_S_MINEDGE2, MS_S_GUARD};
+    block_reduce_store<5>(vals, ops, slots, red, pout, pstride);
+  } else {
+    // volume / guard partials are identically zero: store them without reducing
+    const double vals[3] = {e_surf, e_bend, min_e2};
+    const int ops[3] = {0, 0, 1};
+    const int slots[3] = {MS_S_ESURF, MS_S_EBEND, MS_S_MINEDGE2};
+    block_reduce_store<3>(vals, ops, slots, red, pout, pstride);
+    if (tid == 0) {
+      pout[MS_S_VOL * pstride] = 0.0;
+      pout[MS_S_GUARD * pstride] = 0.0;
+    }
+  }
 }
 
 static size_t u16_bytes(int T, int max_ent) { return 2 * ((size_t)T + 2 + ((max_ent + 3) & ~3)); }
@@ -845,6 +866,181 @@ hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStrea
   }
 #undef MS_PICK_G
 #undef MS_LAUNCH_G
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// k_tilt: vertex-tilt magnitude energy (modules/energy/tilt.py:99-172) as a tile
+// kernel of the same shape as K_C.
+//   coeff_f = 1/2 k_t (|t0|^2+|t1|^2+|t2|^2)/3 ;  E = sum_f coeff_f A_f  (|n| >= 1e-12 only)
+//   MODE 1: shape gradient coeff_f dA/dv_k, dA/dv0 = 1/2 nhat x (v2-v1) (cyclic), ADDED
+//           into g; tilt gradient k_t t_v A_v with barycentric A_v = sum A_f/3 (:160-170)
+//   MODE 2: Mesh.project_tilts_to_tangent (geometry/mesh.py:788-814): unit vertex
+//           normals = normalised sum of facet normals (|.| >= 1e-12, triangle_ops.py:55-73),
+//           t <- t - (t.n) n on the owned rows.
+// LDS: px[3][cap] | tq[cap] | stg[10][T] | red[16] | voff, vent (u16)
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) {
+  extern __shared__ double lds[];
+  const int T = a.m.T;
+  double* px = lds;
+  double* tq = px + 3 * cap;
+  double* stg = tq + cap;
+  double* red = stg + 10 * T;
+  uint16_t* voff = reinterpret_cast<uint16_t*>(red + 16);
+  uint16_t* vent = voff + (T + 2);
+
+  const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
+  const int tid = threadIdx.x;
+  const bool have_d = a.d != nullptr;
+
+  V3 tv = mk(0, 0, 0);  // this thread's owned tilt
+  if (tid < t.n_owned) {
+    const int v = t.v_lo + tid;
+    const size_t g = 3 * (size_t)v;
+    const bool mv = have_d && !(a.m.vflags[v] & VF_FIXED);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double xo = a.x[g + c];
+      px[c * cap + tid] = mv ? xo + a.alpha * a.d[g + c] : xo;
+    }
+    tv = mk(a.tilts[g], a.tilts[g + 1], a.tilts[g + 2]);
+    tq[tid] = dot(tv, tv);
+  }
+  for (int h = tid; h < t.nh; h += T) {
+    const int v = a.m.halo_ids[t.h0 + h];
+    const int sl = t.n_owned + h;
+    const size_t g = 3 * (size_t)v;
+    const bool mv = have_d && !(a.m.vflags[v] & VF_FIXED);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double xo = a.x[g + c];
+      px[c * cap + sl] = mv ? xo + a.alpha * a.d[g + c] : xo;
+    }
+    const V3 th = mk(a.tilts[g], a.tilts[g + 1], a.tilts[g + 2]);
+    tq[sl] = dot(th, th);
+  }
+  if (MODE != 0) {
+    const uint16_t* gv = a.m.tile_voff + (size_t)t.tile * (T + 1);
+    voff[tid] = gv[tid];
+    if (tid == 0) voff[T] = gv[T];
+    const uint16_t* ge = a.m.vent + t.e0;
+    for (int j = tid; j < t.n_ent; j += T) vent[j] = ge[j];
+  }
+  __syncthreads();
+
+  double e_tilt = 0.0;
+  double ax = 0, ay = 0, az = 0, aw = 0;  // vertex accumulators: gradient / normal (xyz), area (w)
+  int cur = 0, end = 0;
+  if (MODE != 0 && tid < t.n_owned) {
+    cur = voff[tid];
+    end = voff[tid + 1];
+  }
+  for (int c0 = t.f0; c0 < t.f1; c0 += T) {
+    const int p = c0 + tid;
+    if (p < t.f1) {
+      const TileFacet tf = a.m.tile_facets[p];
+      const V3 v0 = lds_v3(px, cap, tf.l0), v1 = lds_v3(px, cap, tf.l1), v2 = lds_v3(px, cap, tf.l2);
+      const V3 e0 = v2 - v1, e1 = v0 - v2, e2 = v1 - v0;
+      const V3 n = cross(e2, -e1);
+      const double A2 = norm(n);
+      double* s = stg + tid;
+      if (MODE == 2) {
+        s[0 * T] = n.x;
+        s[1 * T] = n.y;
+        s[2 * T] = n.z;
+      } else {
+        V3 G0 = mk(0, 0, 0), G1 = mk(0, 0, 0), G2 = mk(0, 0, 0);
+        double a3 = 0.0;
+        if (A2 >= 1.0e-12) {
+          const double area = 0.5 * A2;
+          const double coeff = 0.5 * a.k_tilt * (((tq[tf.l0] + tq[tf.l1]) + tq[tf.l2]) / 3.0);
+          if (tf.flags & TF_OWNER) e_tilt += coeff * area;
+          if (MODE == 1) {
+            const double hs = 0.5 * coeff / A2;
+            G0 = hs * cross(n, e0);
+            G1 = hs * cross(n, e1);
+            G2 = hs * cross(n, e2);
+            a3 = area / 3.0;
+          }
+        }
+        if (MODE == 1) {
+          s[0 * T] = G0.x; s[1 * T] = G0.y; s[2 * T] = G0.z;
+          s[3 * T] = G1.x; s[4 * T] = G1.y; s[5 * T] = G1.z;
+          s[6 * T] = G2.x; s[7 * T] = G2.y; s[8 * T] = G2.z;
+          s[9 * T] = a3;
+        }
+      }
+    }
+    if (MODE != 0) {
+      __syncthreads();
+      const int lo = c0 - t.f0, hi = min(c0 + T, t.f1) - t.f0;
+      while (cur < end) {
+        const int ent = vent[cur];
+        const int fl = ent >> 2;
+        if (fl >= hi) break;
+        const double* s = stg + (fl - lo);
+        if (MODE == 2) {
+          ax += s[0];
+          ay += s[T];
+          az += s[2 * T];
+        } else {
+          const int k = ent & 3;
+          ax += s[(3 * k) * T];
+          ay += s[(3 * k + 1) * T];
+          az += s[(3 * k + 2) * T];
+          aw += s[9 * T];
+        }
+        ++cur;
+      }
+      __syncthreads();
+    }
+  }
+  if (tid < t.n_owned) {
+    const size_t o = 3 * (size_t)(t.v_lo + tid);
+    if (MODE == 1) {
+      a.g[o] += ax;
+      a.g[o + 1] += ay;
+      a.g[o + 2] += az;
+      a.tilt_grad[o] = a.k_tilt * tv.x * aw;
+      a.tilt_grad[o + 1] = a.k_tilt * tv.y * aw;
+      a.tilt_grad[o + 2] = a.k_tilt * tv.z * aw;
+    } else if (MODE == 2) {
+      V3 nrm = mk(ax, ay, az);
+      const double len = norm(nrm);
+      if (len >= 1.0e-12) nrm = mk(nrm.x / len, nrm.y / len, nrm.z / len);
+      const double dt = dot(tv, nrm);
+      a.tilts_out[o] = tv.x - dt * nrm.x;
+      a.tilts_out[o + 1] = tv.y - dt * nrm.y;
+      a.tilts_out[o + 2] = tv.z - dt * nrm.z;
+    }
+  }
+  if (MODE != 2) {
+    const double vals[1] = {e_tilt};
+    const int ops[1] = {0};
+    const int slots[1] = {MS_S_ETILT};
+    block_reduce_store<1>(vals, ops, slots, red, a.partials + t.tile, (size_t)a.m.n_tiles);
+  }
+}
+
+size_t tilt_lds_bytes(int T, int cap, int max_ent) {
+  return (4 * (size_t)cap + 10 * (size_t)T + 16) * sizeof(double) + 2 * ((size_t)T + 2 + max_ent + 8);
+}
+
+hipError_t launch_tilt(const TiltArgs& a, int mode, int cap, int max_ent, hipStream_t s) {
+  const int nb = a.tile1 - a.tile0;
+  if (nb <= 0) return hipSuccess;
+  const size_t lds = tilt_lds_bytes(a.m.T, cap, max_ent);
+  hipError_t e;
+#define MS_LAUNCH_T(M)                                                                  \
+  do {                                                                                  \
+    e = ensure_lds(k_tilt<M>, lds);                                                     \
+    if (e != hipSuccess) return e;                                                      \
+    hipLaunchKernelGGL((k_tilt<M>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);    \
+  } while (0)
+  if (mode == 0) MS_LAUNCH_T(0); else if (mode == 1) MS_LAUNCH_T(1); else MS_LAUNCH_T(2);
+#undef MS_LAUNCH_T
   return hipGetLastError();
 }
 

@@ -138,15 +138,32 @@ class DeviceMesh:
         return out
 
     # -- evaluation -----------------------------------------------------------
+    def set_tilts(self, tilts, tilt_rigidity: float):
+        t = _f64(tilts, (self.nv, 3), "tilts")
+        self._chk(L.lib().ms_set_tilts(self._h, _pd(t), float(tilt_rigidity)), "ms_set_tilts")
+
+    def get_tilts(self) -> np.ndarray:
+        out = np.empty((self.nv, 3), dtype=np.float64)
+        self._chk(L.lib().ms_get_tilts(self._h, _pd(out)), "ms_get_tilts")
+        return out
+
+    def get_tilt_gradient(self) -> np.ndarray:
+        out = np.empty((self.nv, 3), dtype=np.float64)
+        self._chk(L.lib().ms_get_tilt_gradient(self._h, _pd(out)), "ms_get_tilt_gradient")
+        return out
+
+    def project_tilts_to_tangent(self):
+        self._chk(L.lib().ms_project_tilts_to_tangent(self._h), "ms_project_tilts_to_tangent")
+
     def energy_and_gradient(self, want_grad: bool = True):
-        """-> (energies[surface, bending, volume_penalty], grad (nv,3) | None)."""
-        e = np.zeros(3)
+        """-> (energies[surface, bending, volume_penalty, tilt], grad (nv,3) | None)."""
+        e = np.zeros(4)
         g = np.empty((self.nv, 3), dtype=np.float64) if want_grad else None
         self._chk(L.lib().ms_energy_and_gradient(self._h, _pd(e), _pd(g)), "ms_energy_and_gradient")
         return e, g
 
     def energy(self) -> np.ndarray:
-        e = np.zeros(3)
+        e = np.zeros(4)
         self._chk(L.lib().ms_energy(self._h, _pd(e)), "ms_energy")
         return e
 

@@ -37,7 +37,7 @@ class ArrayBody:
 
 class ArrayMesh:
     def __init__(self, positions, tri_rows, *, fixed=None, surface_tension=None,
-                 bending_modulus=None, spontaneous_curvature=None, bodies=None,
+                 bending_modulus=None, spontaneous_curvature=None, bodies=None, tilts=None,
                  global_parameters=None, energy_modules=None, constraint_modules=None):
         self._positions = np.array(positions, dtype=np.float64, order="C", copy=True)
         self._tri_rows = np.ascontiguousarray(tri_rows, dtype=np.int32)
@@ -70,6 +70,9 @@ class ArrayMesh:
         self.energy_modules = list(energy_modules or [])
         self.constraint_modules = list(constraint_modules or [])
         self._boundary_mask = None
+        self._tilts = (np.zeros_like(self._positions) if tilts is None
+                       else np.array(tilts, dtype=np.float64, order="C", copy=True))
+        self._tilts_version = 0
         self._version = 0
         self._facet_loops_version = 0
         self._vertex_ids_version = 0
@@ -123,6 +126,14 @@ class ArrayMesh:
 
     def increment_version(self):
         self._version += 1
+
+    # vertex tilt field (geometry/mesh.py:391-430, :516-530 of the reference)
+    def tilts_view(self) -> np.ndarray:
+        return self._tilts
+
+    def set_tilts_from_array(self, tilts) -> None:
+        self._tilts[...] = tilts
+        self._tilts_version += 1
 
     def compute_total_surface_area(self) -> float:
         p, t = self._positions, self._tri_rows
@@ -250,6 +261,7 @@ class HipMirror:
             self._pos_version = getattr(m, "_version", None)
             self._gamma_key = None
             self._bend_key = None
+            self._tilt_key = None
         if positions is not None:
             self.dm.set_positions(positions)
             self._pos_version = None  # foreign array: force a re-upload next time
@@ -268,6 +280,20 @@ class HipMirror:
         if key != self._gamma_key:
             self.dm.set_surface_tension(gamma)
             self._gamma_key = key
+
+    def upload_tilts(self, global_params):
+        """Mesh.tilts_view() + gp["tilt_rigidity"] (modules/energy/tilt.py:110, :122-127)."""
+        k_t = float(global_params.get("tilt_rigidity", 0.0) or 0.0)
+        tilts = np.ascontiguousarray(self.mesh.tilts_view(), dtype=np.float64)
+        key = (self._topo_key, getattr(self.mesh, "_tilts_version", None), k_t,
+               None if hasattr(self.mesh, "_tilts_version") else float(np.sum(tilts)))
+        if key != getattr(self, "_tilt_key", None):
+            self.dm.set_tilts(tilts, k_t)
+            self._tilt_key = key
+
+    def mark_device_tilts_current(self):
+        self._tilt_key = (self._topo_key, getattr(self.mesh, "_tilts_version", None),
+                          self._tilt_key[2] if getattr(self, "_tilt_key", None) else 0.0, None)
 
     def upload_bending_params(self, global_params, model: str):
         kappa, c0 = per_vertex_bending_params(self.mesh, global_params, model)

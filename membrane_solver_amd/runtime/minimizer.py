@@ -41,7 +41,9 @@ from .steppers.base import write_back_positions
 
 logger = logging.getLogger("membrane_solver")
 
-_ENERGY_BITS = {"surface": L.MS_MOD_SURFACE, "bending": L.MS_MOD_BENDING, "volume": L.MS_MOD_VOLUME_PENALTY}
+_ENERGY_BITS = {"surface": L.MS_MOD_SURFACE, "bending": L.MS_MOD_BENDING, "volume": L.MS_MOD_VOLUME_PENALTY,
+                "tilt": L.MS_MOD_TILT}
+_ENERGY_SLOT = {"surface": 0, "bending": 1, "volume": 2, "tilt": 3}
 
 
 class GradientRows:
@@ -116,7 +118,7 @@ class Minimizer:
                 raise TypeError(f"energy module {name!r} lacks compute_energy_and_gradient_array")
             if name not in _ENERGY_BITS:
                 raise L.MembraneHipError(
-                    f"energy module {name!r} is outside the HIP hot path (surface, bending, volume)")
+                    f"energy module {name!r} is outside the HIP hot path (surface, bending, volume, tilt)")
         self.constraint_modules = [self.constraint_manager.get_constraint(c)
                                    for c in self.constraint_module_names]
         for name in self.constraint_module_names:
@@ -161,6 +163,9 @@ class Minimizer:
             if name == "volume":
                 if vol_mode == "penalty" and getattr(self.mesh, "bodies", None):
                     mods |= L.MS_MOD_VOLUME_PENALTY
+            elif name == "tilt":
+                if float(gp.get("tilt_rigidity", 0.0) or 0.0) != 0.0:  # tilt.py:110-112
+                    mods |= L.MS_MOD_TILT
             else:
                 mods |= _ENERGY_BITS[name]
         target = 0.0
@@ -192,6 +197,8 @@ class Minimizer:
             mir.upload_surface_tension()
         if mods & L.MS_MOD_BENDING:
             mir.upload_bending_params(gp, model)
+        if mods & L.MS_MOD_TILT:
+            mir.upload_tilts(gp)
         key = (mods, model, mode, stiffness, target, id(dm))
         if key != self._configured_key:
             dm.set_params(modules=mods,
@@ -233,7 +240,7 @@ class Minimizer:
         e = dm.energy()
         out = {}
         for name in self.energy_module_names:
-            out[name] = float({"surface": e[0], "bending": e[1], "volume": e[2]}[name])
+            out[name] = float(e[_ENERGY_SLOT[name]])
         return out
 
     # -- constraint enforcement (minimizer.py:1103-1188) ---------------------------
@@ -290,6 +297,9 @@ class Minimizer:
             if dirty_box[0] or self._device_ahead:
                 if sync_mesh:
                     write_back_positions(self.mesh, dm, mir)
+                    if dm.modules & L.MS_MOD_TILT:  # tilts were re-projected on the device
+                        self.mesh.set_tilts_from_array(dm.get_tilts())
+                        mir.mark_device_tilts_current()
                     self._device_ahead = False
                 else:
                     self._device_ahead = True

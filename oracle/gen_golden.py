@@ -28,6 +28,7 @@ OUT = os.path.join(ROOT, "tests", "golden")
 ap = argparse.ArgumentParser()
 ap.add_argument("--reference", default="/root/reference")
 ap.add_argument("--fortran-dir", default="/tmp/fprobe/f2py_try")
+ap.add_argument("--only-tilt", action="store_true")
 args = ap.parse_args()
 
 sys.dont_write_bytecode = True
@@ -394,8 +395,31 @@ def gen_trajectories():
     print("traj_disk5_gd_surface_bending_fixed.npz E_final=%.16g" % out["E_final"], out["step_log"][:, 0])
 
 
+def gen_tilt_trajectory():
+    """surface + tilt (vertex tilts fixed, re-projected to the tangent plane each step), GD."""
+    rng = np.random.default_rng(21)
+    P, T = meshgen.icosphere(4)
+    P = meshgen.smooth_displace(P, 0.08)
+    tl = 0.3 * rng.normal(size=P.shape)
+    gp = {"surface_tension": 1.0, "tilt_rigidity": 2.5, "volume_constraint_mode": "lagrange",
+          "volume_projection_during_minimization": False, "mesh_quality_auto_repair_enabled": False}
+    mm = build_mesh(P, T, gp, tilts=tl)
+    mm.energy_modules = ["surface", "tilt"]
+    mm.constraint_modules = []
+    out = run_trajectory("ico4_gd_tilt", mm, GradientDescent(), 6, step_size=2e-3)
+    out["tilts0"] = tl
+    out["tilts_final"] = np.ascontiguousarray(mm.tilts_view())
+    out["k_tilt"] = np.array(2.5)
+    np.savez_compressed(os.path.join(OUT, "traj_ico4_gd_surface_tilt.npz"), **out)
+    print("traj_ico4_gd_surface_tilt.npz E_final=%.16g" % out["E_final"], out["step_log"][:, 0])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--only-tilt" in sys.argv:
+        gen_tilt_trajectory()
+        sys.exit(0)
     gen_kernel_cases()
     gen_mesh_cases()
     gen_trajectories()
+    gen_tilt_trajectory()

@@ -28,6 +28,7 @@ class Problem:
     c0: np.ndarray | None = None
     is_boundary: np.ndarray | None = None  # (nv,) bool, mesh.boundary_vertex_ids
     fixed: np.ndarray | None = None  # (nv,) bool, mesh.fixed_mask
+    tilts: np.ndarray | None = None  # (nv,3) mesh.tilts_view() (tilt module)
     energy_modules: list = field(default_factory=lambda: ["surface"])
     constraint_modules: list = field(default_factory=list)
     body_rows: np.ndarray | None = None  # None = all facets in one body
@@ -53,6 +54,8 @@ class Problem:
             self.fixed = np.zeros(nv, dtype=bool)
         self.is_boundary = np.asarray(self.is_boundary, dtype=bool)
         self.fixed = np.asarray(self.fixed, dtype=bool)
+        if self.tilts is not None:
+            self.tilts = np.ascontiguousarray(self.tilts, dtype=np.float64).copy()
 
     # -- parameter helpers (modules/energy/bending_params.py:19-33) ----------
     @property
@@ -92,6 +95,11 @@ def energy_and_gradient(p: Problem, pos: np.ndarray):
                 delta = V - float(p.target_volume)
                 E += 0.5 * k * delta**2
                 orc.volume_gradient(pos, p.tri, grad, factor=k * delta, body_rows=p.body_rows)
+        elif name == "tilt":
+            # modules/energy/tilt.py:99-172
+            k_t = float(p.gp.get("tilt_rigidity", 0.0) or 0.0)
+            if k_t != 0.0:
+                E += orc.tilt_energy_and_gradient(pos, p.tilts, p.tri, k_t, grad, None)
         else:
             raise ValueError(f"module {name!r} is outside the hot-path scope")
     # constraint_manager.apply_gradient_modifications_array (k == 1 dense branch :293-301)
@@ -108,8 +116,10 @@ def energy_and_gradient(p: Problem, pos: np.ndarray):
 
 
 # runtime/evaluation_manager.py:184-225 compute_energy_array_total
-def energy_total(p: Problem, pos: np.ndarray) -> float:
+def energy_total(p: Problem, pos: np.ndarray, tilts=None) -> float:
     E = 0.0
+    if tilts is None:
+        tilts = p.tilts
     for name in p.energy_modules:
         if name == "surface":
             # no compute_energy_array -> gradient API into a scratch (:201-210)
@@ -121,9 +131,36 @@ def energy_total(p: Problem, pos: np.ndarray) -> float:
                 k = float(p.gp.get("volume_stiffness", 1000.0))
                 V = orc.volume(pos, p.tri, p.body_rows)
                 E += 0.5 * k * (V - float(p.target_volume)) ** 2
+        elif name == "tilt":
+            k_t = float(p.gp.get("tilt_rigidity", 0.0) or 0.0)
+            if k_t != 0.0:
+                E += orc.tilt_energy_and_gradient(pos, tilts, p.tri, k_t, None, None)
         else:
             raise ValueError(name)
     return float(E)
+
+
+# geometry/mesh.py:788-814 project_tilts_to_tangent with the unit vertex normals of
+# geometry/triangle_ops.py:55-73 (normalised where the length is >= 1e-12)
+def projected_tilts(p: Problem, pos: np.ndarray):
+    """tilts projected onto the vertex tangent planes of ``pos`` (not stored)."""
+    if p.tilts is None or p.tri.shape[0] == 0:
+        return p.tilts
+    tri = p.tri
+    tn = np.cross(pos[tri[:, 1]] - pos[tri[:, 0]], pos[tri[:, 2]] - pos[tri[:, 0]])
+    normals = np.zeros_like(pos)
+    np.add.at(normals, tri[:, 0], tn)
+    np.add.at(normals, tri[:, 1], tn)
+    np.add.at(normals, tri[:, 2], tn)
+    lens = np.linalg.norm(normals, axis=1)
+    mask = lens >= 1e-12
+    normals[mask] /= lens[mask][:, None]
+    dot = np.einsum("ij,ij->i", p.tilts, normals)
+    return p.tilts - dot[:, None] * normals
+
+
+def project_tilts_to_tangent(p: Problem, pos: np.ndarray) -> None:
+    p.tilts = projected_tilts(p, pos)
 
 
 # runtime/topology.py:174-199 (min over mesh edges == min over facet edges)
@@ -189,6 +226,7 @@ def line_search(p: Problem, direction, gradient, step_size, *, max_iter=10, beta
                 c=1e-4, gamma=1.5, alpha_max_factor=10.0, enforcer=None) -> LineSearchResult:
     movable = ~p.fixed
     baseline = p.positions.copy()
+    project_tilts_to_tangent(p, baseline)  # energy_fn projects first (minimizer.py:581-588)
     energy0 = energy_total(p, baseline)
     min_edge = min_edge_length(baseline, p.tri)
     safe_limit = 0.3 * min_edge if min_edge > 0 else float("inf")
@@ -214,7 +252,9 @@ def line_search(p: Problem, direction, gradient, step_size, *, max_iter=10, beta
                 continue
         if enforcer is not None:
             trial = enforcer(trial)
-        E_t = energy_total(p, trial)
+        # vertex-tilt modules: the trial energy uses the tilts projected onto the TRIAL
+        # surface's tangent planes, without storing them (minimizer.py:723-733)
+        E_t = energy_total(p, trial, tilts=projected_tilts(p, trial) if "tilt" in p.energy_modules else None)
         trials += 1
         if E_t <= energy0 + c * alpha * g_dot_d:
             p.positions = trial
@@ -326,6 +366,7 @@ def minimize(p: Problem, stepper, n_steps: int, step_size: float = 1e-3, tol: fl
         step_success, step_size = res.success, res.next_step
         trace.append({"E": E, "grad_norm": grad_norm, "success": res.success, "alpha": res.alpha,
                       "E_accepted": res.energy, "next_step": res.next_step, "trials": res.trials})
+        project_tilts_to_tangent(p, p.positions)  # minimizer.py:1415
         if step_mode == "fixed":
             step_size = fixed_step
         if not step_success:

@@ -20,6 +20,7 @@ def _build(g, mods, cons, gp, with_body):
     if with_body:
         bodies = [ArrayBody(0, None, float(g["target_volume"]))]
     return ArrayMesh(g["positions0"], g["tri"], fixed=g["fixed"], surface_tension=g["gamma"],
+                     tilts=g["tilts0"] if "tilts0" in g else None,
                      bodies=bodies, global_parameters=gp, energy_modules=mods, constraint_modules=cons)
 
 
@@ -33,6 +34,9 @@ CASES = {
                                                 dict(BASE, bending_modulus=1.0, spontaneous_curvature=0.3)),
     "traj_disk5_gd_surface_bending_fixed.npz": (["surface", "bending"], [], "gd",
                                                 dict(BASE, bending_modulus=1.0)),
+    # vertex tilts: energy + shape gradient each step, tilts re-projected to the tangent
+    # planes (trial energies use tilts projected on the trial surface)
+    "traj_ico4_gd_surface_tilt.npz": (["surface", "tilt"], [], "gd", dict(BASE, tilt_rigidity=2.5)),
 }
 
 
@@ -77,6 +81,8 @@ def test_minimizer_reproduces_reference_trajectory(fname):
     assert abs(res["energy"] - g["E_final"]) <= 1e-10 * abs(g["E_final"])
     assert abs(mz.step_size - g["step_size_final"]) <= 1e-12 * g["step_size_final"]
     assert res["iterations"] == int(g["iterations"])
+    if "tilts_final" in g:
+        assert relerr(mesh.tilts_view(), g["tilts_final"]) < 1e-9
 
 
 def test_config1_cube_g5_energies():
@@ -174,6 +180,19 @@ def test_plugin_api_host_arrays_match_reference():
                                                    index_map=im, grad_arr=gv)
     assert abs(Ev - g["E_volpen"]) <= 1e-12 * abs(g["E_volpen"])
     assert relerr(gv, g["grad_volpen"]) < 1e-10
+    # tilt module (modules/energy/tilt.py): shape gradient accumulated, tilt gradient optional
+    from membrane_solver_amd.modules.energy import tilt as etilt
+
+    mesh.global_parameters.set("tilt_rigidity", float(g["k_tilt"]))
+    mesh.set_tilts_from_array(g["tilts"])
+    gs, gt = np.full_like(pos, 2.0), np.full_like(pos, -1.0)
+    Et = etilt.compute_energy_and_gradient_array(mesh, mesh.global_parameters, pr, positions=pos, index_map=im,
+                                                 grad_arr=gs, tilt_grad_arr=gt)
+    assert abs(Et - g["E_tilt"]) <= 1e-12 * abs(g["E_tilt"])
+    assert relerr(gs - 2.0, g["grad_tilt_shape"]) < 1e-10
+    assert relerr(gt + 1.0, g["grad_tilt_tilt"]) < 1e-10
+    assert abs(etilt.compute_energy_array(mesh, mesh.global_parameters, pr, positions=pos, index_map=im)
+               - g["E_tilt"]) <= 1e-12 * abs(g["E_tilt"])
     # a foreign positions array (not the mesh's cache) is honoured
     pos2 = pos * 1.01
     g2 = np.zeros_like(pos)

@@ -104,8 +104,9 @@ def test_array_mesh_accessors_and_managers():
     gp = GlobalParameters({"x": 3})
     assert gp.get("x") == 3 and gp.get("missing") is None and gp.volume_stiffness == 1000.0
     assert ParameterResolver(gp).get(ArrayBody(0, None, 1.0, {"volume_stiffness": 7.0}), "volume_stiffness") == 7.0
-    em = EnergyModuleManager(["surface", "bending", "volume"])
-    for name in ("surface", "bending", "volume"):
+    em = EnergyModuleManager(["surface", "bending", "volume", "tilt"])
+    assert em.get_module("tilt").USES_TILT is True
+    for name in ("surface", "bending", "volume", "tilt"):
         assert hasattr(em.get_module(name), "compute_energy_and_gradient_array")
     with pytest.raises(KeyError):
         em.get_module("tilt_smoothness_in")

@@ -127,6 +127,7 @@ def test_c_restatement_matches_reference_fortran_objects():
 
 def _problem_from_traj(g, mods, cons, gp):
     return mp.Problem(positions=g["positions0"], tri=g["tri"], gamma=g["gamma"],
+                      tilts=g["tilts0"] if "tilts0" in g else None,
                       is_boundary=g["is_boundary"], fixed=g["fixed"], energy_modules=mods,
                       constraint_modules=cons,
                       target_volume=float(g["target_volume"]) if "target_volume" in g else None, gp=gp)
@@ -147,6 +148,9 @@ TRAJ = {
                                                 {"bending_modulus": 1.0, "spontaneous_curvature": 0.3,
                                                  "volume_constraint_mode": "lagrange",
                                                  "volume_projection_during_minimization": False}),
+    "traj_ico4_gd_surface_tilt.npz": (["surface", "tilt"], [], "gd",
+                                      {"tilt_rigidity": 2.5, "volume_constraint_mode": "lagrange",
+                                       "volume_projection_during_minimization": False}),
     "traj_disk5_gd_surface_bending_fixed.npz": (["surface", "bending"], [], "gd",
                                                 {"bending_modulus": 1.0, "volume_constraint_mode": "lagrange",
                                                  "volume_projection_during_minimization": False}),
@@ -177,3 +181,5 @@ def test_minimizer_port_reproduces_reference_trajectory(fname):
     assert relerr(p.positions, g["positions_final"]) < 1e-9
     assert abs(res["energy"] - g["E_final"]) <= 1e-10 * abs(g["E_final"])
     assert abs(res["step_size"] - g["step_size_final"]) <= 1e-12 * g["step_size_final"]
+    if "tilts_final" in g:
+        assert relerr(p.tilts, g["tilts_final"]) < 1e-9
