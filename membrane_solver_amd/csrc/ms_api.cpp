@@ -47,6 +47,11 @@ struct ms_ctx {
   double* d_scal = nullptr;
   double* h_scal = nullptr;    // pinned, device-mapped mailbox (k_reduce writes it directly)
   double* d_h_scal = nullptr;  // device-side address of h_scal
+  unsigned long long* h_seq = nullptr;    // per-slot sequence words (pinned, mapped)
+  unsigned long long* d_h_seq = nullptr;
+  unsigned long long ticket = 0;          // ticket of the latest reduce launch
+  unsigned long long expected[MS_NSCAL] = {0};  // latest ticket that folds each slot
+  bool has_boundary = false;
   double* d_stage = nullptr;  // nv*3 staging in external row order
   double* last_g = nullptr;   // buffer holding the most recent finalized gradient
   ms_params params{};
@@ -89,6 +94,7 @@ DeviceMesh device_mesh(const ms_ctx* c) {
   m.nv = c->til.nv;
   m.T = c->til.T;
   m.n_tiles = c->til.n_tiles;
+  m.has_boundary = c->has_boundary ? 1 : 0;
   m.tile_facet_off = c->d_tile_facet_off;
   m.tile_facets = c->d_tile_facets;
   m.tf_gamma = c->d_tf_gamma;
@@ -160,8 +166,11 @@ constexpr uint32_t MASK_DIR = (1u << MS_S_GNORM2) | (1u << MS_S_GDOTD) | (1u << 
 
 int reduce_slots(ms_ctx* c, uint32_t mask) {
   ProfScope ps(c, 3);
+  ++c->ticket;
+  for (int sl = 0; sl < MS_NSCAL; ++sl)
+    if (mask & (1u << sl)) c->expected[sl] = c->ticket;
   HIPCHK(c, launch_reduce(c->d_partials, c->til.n_tiles, c->tile0, c->tile1, mask, c->d_scal,
-                          c->d_h_scal, c->stream));
+                          c->d_h_scal, c->d_h_seq, c->ticket, c->stream));
   return MS_OK;
 }
 
@@ -259,8 +268,22 @@ int phase_direction(ms_ctx* c, int stepper, bool use_history) {
   return reduce_slots(c, MASK_DIR);
 }
 
-// k_reduce mirrors every slot it folds into the pinned mailbox, so fetching is a stream sync.
+// k_reduce mirrors every slot it folds into the pinned mailbox and then bumps that slot's
+// sequence word; fetching = spinning on those words (a few microseconds less than waking up
+// from hipStreamSynchronize).  Falls back to a stream sync after ~50 ms of spinning.
 int fetch(ms_ctx* c) {
+  if (c->tile1 > c->tile0) {
+    for (long spin = 0; spin < 20000000L; ++spin) {
+      bool done = true;
+      for (int sl = 0; sl < MS_NSCAL; ++sl)
+        if (__atomic_load_n(&c->h_seq[sl], __ATOMIC_ACQUIRE) < c->expected[sl]) {
+          done = false;
+          break;
+        }
+      if (done) return MS_OK;
+      __builtin_ia32_pause();
+    }
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return MS_OK;
 }
@@ -437,7 +460,10 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
       const int e = t.perm[i];
       uint8_t f = 0;
       if (fixed && fixed[e]) f |= VF_FIXED;
-      if (boundary && boundary[e]) f |= VF_BOUNDARY;
+      if (boundary && boundary[e]) {
+        f |= VF_BOUNDARY;
+        c->has_boundary = true;
+      }
       fl[i] = f;
     }
     CREATE_CHK(upload(c, &c->d_vflags, fl));
@@ -464,6 +490,10 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
                            hipHostMallocMapped));
   memset(c->h_scal, 0, sizeof(double) * MS_NSCAL);
   CREATE_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_scal), c->h_scal, 0));
+  CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_seq), sizeof(unsigned long long) * MS_NSCAL,
+                           hipHostMallocMapped));
+  memset(c->h_seq, 0, sizeof(unsigned long long) * MS_NSCAL);
+  CREATE_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_seq), c->h_seq, 0));
   CREATE_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_stage), sizeof(double) * 3 * (size_t)nv));
   c->params.modules = MS_MOD_SURFACE;
   c->params.bending_model = MS_BEND_HELFRICH;
@@ -490,6 +520,7 @@ void ms_destroy(ms_ctx* c) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_scal) (void)hipHostFree(c->h_scal);
+  if (c->h_seq) (void)hipHostFree(c->h_seq);
   for (auto& r : c->prof_pending) {
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);

@@ -61,6 +61,7 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
 // ---- device-side view handed to kernels ---------------------------------
 struct DeviceMesh {
   int nv, T, n_tiles;
+  int has_boundary;       // any vertex carries VF_BOUNDARY (uniform fast-path switch)
   const int32_t* tile_facet_off;
   const TileFacet* tile_facets;
   const double* tf_gamma;  // surface tension per facet instance
@@ -133,7 +134,8 @@ hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStrea
 size_t tilt_lds_bytes(int T, int cap, int max_ent);
 hipError_t launch_tilt(const TiltArgs& a, int mode, int cap, int max_ent, hipStream_t s);
 hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
-                         uint32_t slot_mask, double* scal, double* host_mirror, hipStream_t s);
+                         uint32_t slot_mask, double* scal, double* host_mirror,
+                         unsigned long long* host_seq, unsigned long long ticket, hipStream_t s);
 hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* g,
                             const double* gC, double* d, const double* pg, const double* pd,
                             const double* scal, int use_constraint, int cg_history,

@@ -354,8 +354,12 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_
           const double ta_eff = fmax(0.5 * A2, 1.0e-12);
           if (ta_eff != tri_area) corner_areas(c0, c1, c2, l0, l1, l2, ta_eff, ve0, ve1, ve2);
           // bending_utils.py:121-153 boundary -> interior redistribution
-          const int b0 = (lfl[tf.l0] & VF_BOUNDARY) ? 1 : 0, b1 = (lfl[tf.l1] & VF_BOUNDARY) ? 1 : 0,
-                    b2 = (lfl[tf.l2] & VF_BOUNDARY) ? 1 : 0;
+          int b0 = 0, b1 = 0, b2 = 0;
+          if (a.m.has_boundary) {  // uniform: closed surfaces skip the flag reads entirely
+            b0 = (lfl[tf.l0] & VF_BOUNDARY) ? 1 : 0;
+            b1 = (lfl[tf.l1] & VF_BOUNDARY) ? 1 : 0;
+            b2 = (lfl[tf.l2] & VF_BOUNDARY) ? 1 : 0;
+          }
           const int n_int = 3 - (b0 + b1 + b2);
           if (n_int > 0 && n_int < 3) {
             const double b_sum = ve0 * b0 + ve1 * b1 + ve2 * b2;
@@ -674,8 +678,12 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
           double w1 = 0.5 * dot(k2 - k0, e1);
           double w2 = 0.5 * dot(k0 - k1, e2);
           // term 3 coefficients (bending_gradient.py:80-95)
-          const int t0 = (lfl[tf.l0] & VF_BOUNDARY) ? 0 : 1, t1 = (lfl[tf.l1] & VF_BOUNDARY) ? 0 : 1,
-                    t2 = (lfl[tf.l2] & VF_BOUNDARY) ? 0 : 1;
+          int t0 = 1, t1 = 1, t2 = 1;
+          if (a.m.has_boundary) {
+            t0 = (lfl[tf.l0] & VF_BOUNDARY) ? 0 : 1;
+            t1 = (lfl[tf.l1] & VF_BOUNDARY) ? 0 : 1;
+            t2 = (lfl[tf.l2] & VF_BOUNDARY) ? 0 : 1;
+          }
           const int cnt = t0 + t1 + t2;
           const double fe0 = fae[tf.l0], fe1 = fae[tf.l1], fe2 = fae[tf.l2];
           const double avg = cnt > 0 ? (fe0 * t0 + fe1 * t1 + fe2 * t2) / (double)cnt : 0.0;
@@ -1051,7 +1059,9 @@ hipError_t launch_tilt(const TiltArgs& a, int mode, int cap, int max_ent, hipStr
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_reduce(const double* partials, int n_tiles, int tile0,
                                                   int tile1, uint32_t slot_mask, double* scal,
-                                                  double* host_mirror) {
+                                                  double* host_mirror,
+                                                  unsigned long long* host_seq,
+                                                  unsigned long long ticket) {
   __shared__ double red[16];
   // one workgroup per requested slot; partials are slot-major so lanes read
   // consecutive doubles.
@@ -1079,16 +1089,23 @@ __global__ __launch_bounds__(BLOCK) void k_reduce(const double* partials, int n_
   if (threadIdx.x == 0) {
     const double r = (slot == MS_S_VOL) ? v / 6.0 : v;
     scal[slot] = r;
-    if (host_mirror) host_mirror[slot] = r;  // pinned, device-mapped mailbox: no D2H copy needed
+    if (host_mirror) {
+      // pinned, device-mapped mailbox: the value, a system-scope fence, then this slot's
+      // sequence word -- the host polls the sequence word instead of synchronising the stream
+      host_mirror[slot] = r;
+      __threadfence_system();
+      *reinterpret_cast<volatile unsigned long long*>(&host_seq[slot]) = ticket;
+    }
   }
 }
 
 hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
-                         uint32_t slot_mask, double* scal, double* host_mirror, hipStream_t s) {
+                         uint32_t slot_mask, double* scal, double* host_mirror,
+                         unsigned long long* host_seq, unsigned long long ticket, hipStream_t s) {
   const int nslots = __builtin_popcount(slot_mask);
   if (nslots == 0) return hipSuccess;
   hipLaunchKernelGGL(k_reduce, dim3(nslots), dim3(BLOCK), 0, s, partials, n_tiles, tile0, tile1,
-                     slot_mask, scal, host_mirror);
+                     slot_mask, scal, host_mirror, host_seq, ticket);
   return hipGetLastError();
 }
 
