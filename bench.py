@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--tile", type=int, default=0, help="owned vertices per tile (0 = library default)")
     ap.add_argument("--step-size", type=float, default=1e-6)
     ap.add_argument("--volume", action="store_true", help="add the volume Lagrange constraint row")
-    ap.add_argument("--cpu-steps", type=int, default=3, help="CPU oracle steps for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=6, help="CPU oracle steps for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
@@ -57,6 +57,31 @@ def algorithmic_bytes(nv, nf, volume=False):
         # NOT counted, so the figure is a lower bound of the compulsory traffic.
         "gradient": 20 * nf + (24 + 40 + 1) * nv + 24 * nv + (0 if volume else 24 * nv),
     }
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of one kernel from the committed rocprofv3 PMC summary
+    (profiles/<tag>_pmc_summary.csv; separate FETCH_SIZE / WRITE_SIZE passes of this same
+    bench command).  gfx950 correction: FETCH_SIZE counts 1/2 of the fetched bytes
+    (MI355X_MICROARCH.md, calibrated here on the direction pass's known byte count)."""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")))
+    if not files:
+        return None, None
+    fetch = write = None
+    with open(files[-1]) as f:
+        for row in csv.reader(line for line in f if not line.startswith("#")):
+            if len(row) < 4 or kernel_prefix not in row[1]:
+                continue
+            if row[0] == "FETCH_SIZE":
+                fetch = float(row[3])
+            elif row[0] == "WRITE_SIZE":
+                write = float(row[3])
+    if fetch is None or write is None:
+        return None, None
+    return (2.0 * fetch + write) * 1024.0, os.path.basename(files[-1])
 
 
 def main():
@@ -184,7 +209,7 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": {"energy": "ms::k_energy<true,false>",
                                                      "gradient": "ms::k_gradient<1,false,256,0>"}[dom],
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                            "avg_launch_us": kernels[dom]["avg_us"],
                            "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"],
                            "measured": f"HIP events around every launch over {n_prof} steps after the timed region"}

@@ -27,10 +27,11 @@ for sub in ("fetch", "write", "sq"):
                 acc[(r["Counter_Name"], k)].append(float(r["Counter_Value"]))
         for (c, k), v in sorted(acc.items()):
             rows.append((c, k, len(v), sum(v) / len(v), min(v), max(v)))
-with open(os.path.join(out, f"{tag}_pmc_summary.csv"), "w") as f:
-    f.write("counter,kernel,dispatches,avg,min,max\n")
+with open(os.path.join(out, f"{tag}_pmc_summary.csv"), "w", newline="") as f:
     f.write("# FETCH_SIZE/WRITE_SIZE in KiB per dispatch; on gfx950 FETCH_SIZE counts 1/2 of the bytes\n")
     f.write("# (calibrated on ms::k_direction / k_gradient's direction epilogue with known bytes) -> double it.\n")
+    w = csv.writer(f)
+    w.writerow(["counter", "kernel", "dispatches", "avg", "min", "max"])
     for r in rows:
-        f.write("%s,%s,%d,%.6g,%.6g,%.6g\n" % r)
+        w.writerow([r[0], r[1], r[2], "%.6g" % r[3], "%.6g" % r[4], "%.6g" % r[5]])
 print(open(os.path.join(out, f"{tag}_pmc_summary.csv")).read())
