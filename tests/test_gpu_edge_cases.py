@@ -1,0 +1,189 @@
+"""Edge cases of the domain, HIP path vs CPU oracle: degenerate and repeated-index
+triangles, out-of-range indices, isolated vertices, empty facet list, everything fixed,
+non-uniform per-facet / per-vertex parameters, a body that covers only some facets,
+oversized valence (error path), and state round trips."""
+
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from membrane_solver_amd import _lib
+
+    _lib.lib()
+    return _lib
+
+
+def _oracle_eg(P, T, gamma, kappa, c0, isb):
+    from oracle import ms_oracle as orc
+
+    g = np.zeros_like(P)
+    Es = orc.surface_energy_and_gradient(P, T, gamma, g)
+    Eb = orc.bending_energy_and_gradient(P, T, kappa, c0, isb, grad=g)
+    return Es, Eb, g
+
+
+def test_degenerate_repeated_and_out_of_range_triangles(L):
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+    from oracle import ms_oracle as orc
+
+    P, T = meshgen.icosphere(3)
+    P = meshgen.smooth_displace(P, 0.1)
+    T = T.copy()
+    nv = len(P)
+    P = np.vstack([P, [[5.0, 5.0, 5.0], [6.0, 5.0, 5.0]]])  # two isolated vertices
+    extra = np.array([[0, 0, 1],          # repeated index (zero area)
+                      [2, 3, 2],          # repeated index
+                      [4, 5, nv + 7],     # out of range -> skipped by the reference kernels
+                      [-1, 2, 3]], dtype=np.int32)
+    T2 = np.vstack([T, extra]).astype(np.int32)
+    # collapse one real triangle to zero area (A2 < 1e-12 branch)
+    P[T[10, 2]] = P[T[10, 1]]
+    gamma = np.linspace(0.5, 1.5, len(T2))
+    gref = np.zeros_like(P)
+    Eref = orc.surface_energy_and_gradient(P, T2, gamma, gref)
+    dm = DeviceMesh(P, T2, tile_vertices=64)
+    dm.set_surface_tension(gamma)
+    dm.set_params(modules=L.MS_MOD_SURFACE)
+    e, g = dm.energy_and_gradient()
+    assert abs(e[0] - Eref) <= 1e-12 * abs(Eref)
+    assert relerr(g, gref) < 1e-10
+    assert np.all(g[-2:] == 0.0)
+    dm.close()
+
+
+def test_empty_facet_list_and_single_triangle(L):
+    from membrane_solver_amd.device import DeviceMesh
+
+    P = np.array([[0.0, 0, 0], [1, 0, 0], [0, 1, 0]])
+    dm = DeviceMesh(P, np.zeros((0, 3), np.int32))
+    dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING)
+    e, g = dm.energy_and_gradient()
+    assert np.all(e == 0.0) and np.all(g == 0.0)
+    r = dm.step(stepper=L.MS_STEPPER_GD, step_size=1e-3)
+    assert r.converged and r.success and r.grad_norm == 0.0
+    dm.close()
+    # tests/test_surface.py:61-93 of the reference: right triangle, gamma = 2 -> E = 1
+    dm = DeviceMesh(P, np.array([[0, 1, 2]], np.int32))
+    dm.set_surface_tension(np.array([2.0]))
+    dm.set_params(modules=L.MS_MOD_SURFACE)
+    e, g = dm.energy_and_gradient()
+    assert abs(e[0] - 1.0) < 1e-15 and np.all(np.isfinite(g))
+    assert np.allclose(g.sum(axis=0), 0.0, atol=1e-15)
+    dm.close()
+
+
+def test_all_fixed_and_partially_fixed(L):
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+
+    P, T = meshgen.icosphere(4)
+    dm = DeviceMesh(P, T, fixed=np.ones(len(P), bool))
+    dm.set_params(modules=L.MS_MOD_SURFACE)
+    e, g = dm.energy_and_gradient()
+    assert e[0] > 0 and np.all(g == 0.0)
+    r = dm.step(stepper=L.MS_STEPPER_CG, step_size=1e-2)
+    assert r.converged
+    assert np.array_equal(dm.get_positions(), P)
+    dm.close()
+
+
+def test_nonuniform_parameters_boundary_and_body_subset(L):
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+    from oracle import ms_oracle as orc
+
+    P, T, B = meshgen.disk_patch(8, jitter=0.25, seed=9)
+    rng = np.random.default_rng(4)
+    nv, nf = len(P), len(T)
+    gamma = 0.5 + rng.random(nf)
+    kappa = 0.2 + rng.random(nv)
+    c0 = rng.normal(scale=0.4, size=nv)
+    Es, Eb, gref = _oracle_eg(P, T, gamma, kappa, c0, B)
+    body = (rng.random(nf) < 0.6)
+    rows = np.flatnonzero(body).astype(np.int32)
+    Vref = orc.volume(P, T, rows)
+    gCref = np.zeros_like(P)
+    orc.volume_gradient(P, T, gCref, body_rows=rows)
+    for tile in (64, 256):
+        dm = DeviceMesh(P, T, boundary=B, body_facets=body, tile_vertices=tile)
+        dm.set_surface_tension(gamma)
+        dm.set_bending_params(kappa, c0)
+        dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING)
+        e, g = dm.energy_and_gradient()
+        assert abs(e[0] - Es) <= 1e-12 * abs(Es) and abs(e[1] - Eb) <= 1e-12 * abs(Eb)
+        assert relerr(g, gref) < 1e-10
+        dm.set_params(modules=L.MS_CON_VOLUME)
+        dm.energy_and_gradient(want_grad=False)
+        assert abs(dm.fetch_scalars()[L.MS_S_VOL] - Vref) <= 1e-12 * abs(Vref)
+        assert relerr(dm.get_vertex_buffer(L.MS_BUF_GC), gCref) < 1e-12
+        dm.close()
+
+
+def test_willmore_and_approx_on_open_noisy_mesh(L):
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+    from oracle import ms_oracle as orc
+
+    P, T, B = meshgen.disk_patch(6, jitter=0.3, seed=1)
+    nv = len(P)
+    kappa, c0 = np.full(nv, 1.3), np.zeros(nv)
+    dm = DeviceMesh(P, T, boundary=B)
+    dm.set_bending_params(kappa, c0)
+    for model, mid in (("willmore", L.MS_BEND_WILLMORE), ("helfrich", L.MS_BEND_HELFRICH)):
+        for mode, gid in (("analytic", L.MS_GRAD_ANALYTIC), ("approx", L.MS_GRAD_APPROX)):
+            gref = np.zeros_like(P)
+            Eref = orc.bending_energy_and_gradient(P, T, kappa, c0, B, model=model, mode=mode, grad=gref)
+            dm.set_params(modules=L.MS_MOD_BENDING, bending_model=mid, bending_grad_mode=gid)
+            e, g = dm.energy_and_gradient()
+            assert abs(e[1] - Eref) <= 1e-12 * abs(Eref), (model, mode)
+            assert relerr(g, gref) < 1e-10, (model, mode)
+    dm.close()
+
+
+def test_oversized_valence_and_bad_arguments_are_errors_not_crashes(L):
+    from membrane_solver_amd.device import DeviceMesh
+
+    # a fan with 70 000 triangles around vertex 0: its patch cannot fit uint16 LDS slots
+    n = 70000
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    P = np.vstack([[0.0, 0, 0], np.column_stack([np.cos(ang), np.sin(ang), np.zeros(n)])])
+    T = np.column_stack([np.zeros(n, int), 1 + np.arange(n), 1 + (np.arange(n) + 1) % n]).astype(np.int32)
+    with pytest.raises(L.MembraneHipError, match="TILE_CAPACITY"):
+        DeviceMesh(P, T, tile_vertices=64)
+    with pytest.raises(L.MembraneHipError, match="NaN"):
+        DeviceMesh(np.array([[0.0, np.nan, 0], [1, 0, 0], [0, 1, 0]]), np.array([[0, 1, 2]], np.int32))
+    with pytest.raises(L.MembraneHipError, match="tile_vertices"):
+        DeviceMesh(P[:10], T[:3] % 10, tile_vertices=100)
+    dm = DeviceMesh(P[:10], (T[:3] % 10).astype(np.int32))
+    with pytest.raises(ValueError):
+        dm.set_surface_tension(np.ones(7))
+    dm.set_params(modules=L.MS_MOD_BENDING)
+    with pytest.raises(L.MembraneHipError, match="bad bending_model"):
+        dm.set_params(modules=L.MS_MOD_BENDING, bending_model=7)
+    dm.close()
+
+
+def test_set_positions_and_reevaluate_is_consistent(L):
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+
+    P, T = meshgen.icosphere(6)
+    dm = DeviceMesh(P, T)
+    dm.set_bending_params(np.ones(len(P)), np.zeros(len(P)))
+    dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING)
+    e1, g1 = dm.energy_and_gradient()
+    P2 = meshgen.smooth_displace(P, 0.2)
+    dm.set_positions(P2)
+    e2, _ = dm.energy_and_gradient()
+    dm.set_positions(P)
+    e3, g3 = dm.energy_and_gradient()
+    assert e2.sum() != e1.sum()
+    assert np.array_equal(e1, e3) and np.array_equal(g1, g3)  # bitwise reproducible
+    dm.close()
