@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--volume", action="store_true", help="add the volume Lagrange constraint row")
     ap.add_argument("--cpu-steps", type=int, default=6, help="CPU oracle steps for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--reuse-level", type=int, default=2, choices=(0, 1, 2),
+                    help="ms_stepper_params.reuse_energy0: 0 repeats every pass the reference repeats, "
+                         "2 (library default) never repeats a pass whose result is already on the device")
     return ap.parse_args()
 
 
@@ -52,6 +55,9 @@ def algorithmic_bytes(nv, nf, volume=False):
         "energy_factors": 20 * nf + (24 + 16 + 1) * nv + 40 * nv,
         # trial energy: x and d in (48), xt out (24), no factor write
         "energy_trial": 20 * nf + (48 + 16 + 1) * nv + 24 * nv,
+        # trial energy that also writes the factors (reuse level 2: an accepted trial is the
+        # next step's energy pass)
+        "energy_trial_factors": 20 * nf + (48 + 16 + 1) * nv + 24 * nv + 40 * nv,
         # gradient (+ fused direction pass when no constraint row): x 24 + fK,fA 40 + flags 1 in,
         # g 24 and d 24 out.  The CG-history reads (pg, pd: 48 B/vertex on non-restart steps) are
         # NOT counted, so the figure is a lower bound of the compulsory traffic.
@@ -70,17 +76,19 @@ def pmc_traffic(kernel_prefix):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")))
     if not files:
         return None, None
-    fetch = write = None
+    # dispatch-weighted mean over every instantiation of the kernel family in the summary
+    acc = {"FETCH_SIZE": [0.0, 0.0], "WRITE_SIZE": [0.0, 0.0]}
     with open(files[-1]) as f:
         for row in csv.reader(line for line in f if not line.startswith("#")):
-            if len(row) < 4 or kernel_prefix not in row[1]:
+            if len(row) < 4 or kernel_prefix not in row[1] or row[0] not in acc:
                 continue
-            if row[0] == "FETCH_SIZE":
-                fetch = float(row[3])
-            elif row[0] == "WRITE_SIZE":
-                write = float(row[3])
-    if fetch is None or write is None:
+            n = float(row[2])
+            acc[row[0]][0] += n * float(row[3])
+            acc[row[0]][1] += n
+    if not acc["FETCH_SIZE"][1] or not acc["WRITE_SIZE"][1]:
         return None, None
+    fetch = acc["FETCH_SIZE"][0] / acc["FETCH_SIZE"][1]
+    write = acc["WRITE_SIZE"][0] / acc["WRITE_SIZE"][1]
     return (2.0 * fetch + write) * 1024.0, os.path.basename(files[-1])
 
 
@@ -125,13 +133,14 @@ def main():
         bodies = [ArrayBody(0, None, float(np.einsum("ij,ij->i", np.cross(v1, v2), v0).sum() / 6.0))]
     mesh = ArrayMesh(P, T, global_parameters=gp, energy_modules=mods, constraint_modules=cons, bodies=bodies)
     stepper = ConjugateGradient()
+    stepper.reuse_energy0 = args.reuse_level
     mz = Minimizer(mesh, mesh.global_parameters, stepper, EnergyModuleManager(mods),
                    ConstraintModuleManager(cons), quiet=True, step_size=args.step_size,
                    device=local_rank, tile_vertices=args.tile)
     E_start = mz.compute_energy()
 
     # count what the timed steps actually do
-    stats = {"accepted": 0, "trials": 0, "steps": 0}
+    stats = {"accepted": 0, "trials": 0, "steps": 0, "trial_passes": 0}
     orig = stepper.device_step
 
     def counted(dm, m, step_size, tol=0.0):
@@ -139,6 +148,7 @@ def main():
         stats["steps"] += 1
         stats["accepted"] += int(r.success)
         stats["trials"] += r.trials
+        stats["trial_passes"] += r.trials + r.guard_rejects
         return r
 
     stepper.device_step = counted
@@ -163,7 +173,10 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"class-I icosphere f={args.freq} (nv={nv}, nf={nf}), surface + Helfrich "
                                "bending (analytic cotan gradient), CG stepper, Armijo line search, "
-                               "energy0 re-evaluated" + (", volume Lagrange row" if args.volume else ""),
+                               f"evaluation reuse level {stepper.reuse_energy0} (0 = every pass the "
+                               "reference re-runs, 2 = passes already on the device are not repeated; "
+                               "bitwise identical trajectories)"
+                               + (", volume Lagrange row" if args.volume else ""),
                    "stepper": "conjugate_gradient", "tile_vertices": args.tile or 256,
                    "initial_step_size": args.step_size, "parallelism": "1 GPU"},
         "steps_accepted": timed["accepted"], "line_search_trials": timed["trials"],
@@ -177,6 +190,7 @@ def main():
         n_prof = min(args.steps, 40)
         dm.profile_enable(True)
         dm.profile_read()
+        stats["trial_passes"] = 0
         mz.minimize(n_prof, sync_mesh=False)
         prof = dm.profile_read()
         dm.profile_enable(False)
@@ -188,16 +202,19 @@ def main():
         tot = sum(v["share_of_profiled_ms"] for v in kernels.values()) or 1.0
         for v in kernels.values():
             v["share_of_profiled_ms"] = v["share_of_profiled_ms"] / tot
-        # per-launch algorithmic bytes: energy launches are a mix (1 with factor write,
-        # 1 energy0, >=1 trials per step) -> use the mix actually launched
+        # per-launch algorithmic bytes: energy launches are a mix of plain passes at x (with or
+        # without the factor write) and trial passes -> weight by what was actually launched
         n_e = prof["energy"][1]
         n_g = prof["gradient"][1]
         if n_e:
-            n_fact = n_g  # one factor-writing energy pass per gradient pass
-            n_trial = max(0, n_e - 2 * n_fact)
-            n_e0 = n_e - n_fact - n_trial
+            n_trial = min(n_e, stats["trial_passes"])
+            n_plain = n_e - n_trial
+            level = int(stepper.reuse_energy0)
+            n_fact = min(n_plain, n_g)          # factor-writing passes at x
+            n_e0 = n_plain - n_fact             # energy0 re-evaluations (level 0)
+            trial_key = "energy_trial_factors" if level >= 2 else "energy_trial"
             e_bytes = (n_fact * ab["energy_factors"] + n_e0 * (ab["energy_factors"] - 40 * nv)
-                       + n_trial * ab["energy_trial"]) / n_e
+                       + n_trial * ab[trial_key]) / n_e
             kernels["energy"]["algorithmic_bytes"] = e_bytes
             kernels["energy"]["GBps"] = e_bytes / (kernels["energy"]["avg_us"] * 1e-6) / 1e9
         if n_g:
@@ -206,7 +223,8 @@ def main():
         dom = max((k for k in ("energy", "gradient") if k in kernels),
                   key=lambda k: kernels[k]["share_of_profiled_ms"])
         ach = kernels[dom]["GBps"]
-        out["roofline"] = {"bound": "hbm", "kernel": {"energy": "ms::k_energy<true,false>",
+        traffic, traffic_src = pmc_traffic({"energy": "ms::k_energy", "gradient": "ms::k_gradient"}[dom])
+        out["roofline"] = {"bound": "hbm", "kernel": {"energy": "ms::k_energy* (energy pass)",
                                                      "gradient": "ms::k_gradient<1,false,256,0>"}[dom],
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

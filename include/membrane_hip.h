@@ -113,7 +113,11 @@ typedef struct ms_stepper_params {
   int restart_interval;    /* CG restart, 10                                    */
   double edge_fraction;    /* gp["shape_step_edge_fraction"], 0 = off           */
   int reuse_energy0;       /* 0: re-evaluate energy0 like line_search.py:294;
-                              1: reuse the energy of the gradient evaluation   */
+                              1: reuse the energy of the gradient evaluation;
+                              2: 1 + an accepted trial pass (which also writes the
+                                 bending factors) serves as the next step's energy
+                                 pass.  Same kernel on the same doubles: all three
+                                 modes give bitwise identical trajectories.       */
 } ms_stepper_params;
 
 typedef struct ms_step_result {

@@ -58,6 +58,13 @@ struct ms_ctx {
   bool cg_have_history = false;
   int cg_iter_count = 0;
   bool factors_valid = false;
+  // true while the mailbox energies / min edge / volume AND the factor buffers describe the
+  // current x: set when ms_step accepts a trial that also wrote the factors, cleared by
+  // every other energy pass and by every mutator
+  bool carry_valid = false;
+  // true while buffer G holds the finalized gradient of the current x (set by ms_step's fused
+  // gradient pass, survives a failed line search, cleared together with carry_valid)
+  bool grad_valid = false;
   // optional per-kernel timing (ms_profile_*)
   bool profiling = false;
   struct ProfRec {
@@ -176,6 +183,7 @@ int reduce_slots(ms_ctx* c, uint32_t mask) {
 
 int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool write_trial,
                  bool guard, bool write_factors, bool reduce_now = true) {
+  c->carry_valid = c->grad_valid = false;
   EnergyArgs a;
   a.m = device_mesh(c);
   a.tile0 = c->tile0;
@@ -304,12 +312,16 @@ void energies_from_mailbox(const ms_ctx* c, double e[4]) {
 
 // gradient assembly at x: energy pass (+factors), gradient pass, finalize via
 // the direction kernel (projection + fixed rows), everything queued async.
-int queue_energy_and_gradient(ms_ctx* c, int stepper, bool use_history) {
+// skip_energy: the accepted trial of the previous step already was this energy pass (same
+// kernel, same x: its factors are in fK/fA, its scalars in d_scal and in the mailbox).
+int queue_energy_and_gradient(ms_ctx* c, int stepper, bool use_history, bool skip_energy = false) {
   const uint32_t mods = c->params.modules;
   // lambda needs a global reduction first; the tilt module adds into g after K_C
   const bool constraint = (mods & (MS_CON_VOLUME | MS_MOD_TILT)) != 0;
-  const bool penalty = (mods & MS_MOD_VOLUME_PENALTY) != 0;  // K_C reads the reduced volume
-  int rc = phase_energy(c, mods, false, 0.0, false, false, true, /*reduce_now=*/penalty);
+  // K_C reads the reduced volume (already reduced when the energy pass is skipped)
+  const bool penalty = skip_energy || (mods & MS_MOD_VOLUME_PENALTY) != 0;
+  int rc = MS_OK;
+  if (!skip_energy) rc = phase_energy(c, mods, false, 0.0, false, false, true, /*reduce_now=*/penalty);
   if (rc) return rc;
   if (!constraint) {
     // no row to project out: the direction pass rides in K_C's epilogue, one reduce for all
@@ -554,6 +566,7 @@ int ms_set_surface_tension(ms_ctx* c, const double* gamma) {
   for (size_t p = 0; p < g.size(); ++p) g[p] = gamma[t.tile_facet_ext[p]];
   if (!g.empty())
     HIPCHK(c, hipMemcpy(c->d_tf_gamma, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice));
+  c->carry_valid = c->grad_valid = false;
   return MS_OK;
 }
 
@@ -569,6 +582,7 @@ int ms_set_bending_params(ms_ctx* c, const double* kappa, const double* c0) {
   HIPCHK(c, hipMemcpy(c->d_kappa, k.data(), k.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_c0, z.data(), z.size() * sizeof(double), hipMemcpyHostToDevice));
   c->factors_valid = false;
+  c->carry_valid = c->grad_valid = false;
   return MS_OK;
 }
 
@@ -580,6 +594,7 @@ int ms_set_params(ms_ctx* c, const ms_params* p) {
     return fail(c, MS_ERR_INVALID, "ms_set_params: bad bending_grad_mode");
   c->params = *p;
   c->factors_valid = false;
+  c->carry_valid = c->grad_valid = false;
   return MS_OK;
 }
 
@@ -595,6 +610,7 @@ int ms_set_tilts(ms_ctx* c, const double* tilts, double tilt_rigidity) {
     HIPCHK(c, hipMemset(c->d_tilt_grad, 0, bytes));
   }
   c->k_tilt = tilt_rigidity;
+  c->carry_valid = c->grad_valid = false;
   return ext_to_patch(c, tilts, c->d_tilts, 3);
 }
 
@@ -619,6 +635,7 @@ int ms_project_tilts_to_tangent(ms_ctx* c) {
 int ms_set_positions(ms_ctx* c, const double* positions) {
   if (!c || !positions) return fail(c, MS_ERR_INVALID, "ms_set_positions: NULL argument");
   c->factors_valid = false;
+  c->carry_valid = c->grad_valid = false;
   return ext_to_patch(c, positions, c->buf[MS_BUF_X], 3);
 }
 
@@ -678,10 +695,27 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   const int restart = sp->restart_interval > 0 ? sp->restart_interval : 10;
   // conjugate_gradient.py:78-82: steepest descent on first call and every restart
   const bool use_history = cg && c->cg_have_history && (c->cg_iter_count % restart != 0);
-  int rc = queue_energy_and_gradient(c, sp->stepper, use_history);
+  const bool tilt = (c->params.modules & MS_MOD_TILT) != 0;
+  // reuse_energy0 == 2: an accepted trial doubles as the next step's energy/factor pass
+  const bool carry_mode = sp->reuse_energy0 >= 2 && !tilt;
+  const bool carried = carry_mode && c->carry_valid &&
+                       (c->factors_valid || !(c->params.modules & MS_MOD_BENDING));
+  const bool constraint = (c->params.modules & (MS_CON_VOLUME | MS_MOD_TILT)) != 0;
+  int rc;
+  if (carried && c->grad_valid && !constraint && c->til.T <= 256) {
+    // x has not moved since the last gradient pass (failed search, stepper reset): only the
+    // direction changes.  k_direction on the finalized g repeats the fused epilogue's
+    // arithmetic and reduction order exactly.
+    rc = phase_direction(c, sp->stepper, use_history);
+  } else {
+    rc = queue_energy_and_gradient(c, sp->stepper, use_history, carried);
+  }
   if (rc) return rc;
   rc = fetch(c);
   if (rc) return rc;
+  // factors, mailbox energies and G now describe x (until a trial pass overwrites them)
+  c->carry_valid = carry_mode;
+  c->grad_valid = carry_mode && !constraint;
   double e[4];
   energies_from_mailbox(c, e);
   const double E_eval = e[0] + e[1] + e[2] + e[3];
@@ -702,7 +736,6 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   // ---- backtracking_line_search_array (line_search.py:267-426) -------------
   double energy0 = E_eval;
   double min_edge = std::sqrt(c->h_scal[MS_S_MINEDGE2]);
-  const bool tilt = (c->params.modules & MS_MOD_TILT) != 0;
   if (tilt) {  // energy_fn projects the stored tilts first (minimizer.py:581-588)
     rc = tilt_pass(c, 2, false, 0.0);
     if (rc) return rc;
@@ -727,7 +760,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   const int max_iter = sp->max_iter > 0 ? sp->max_iter : 10;
   for (int it = 0; it < max_iter; ++it) {
     const bool safe_small = alpha * max_dir < safe_step_limit;
-    rc = phase_energy(c, c->params.modules, true, alpha, true, !safe_small, false);
+    rc = phase_energy(c, c->params.modules, true, alpha, true, !safe_small, carry_mode);
     if (rc) return rc;
     rc = fetch(c);
     if (rc) return rc;
@@ -742,7 +775,11 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     const double E_t = e[0] + e[1] + e[2] + e[3];
     if (E_t <= energy0 + sp->c * alpha * g_dot_d) {
       std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
-      c->factors_valid = false;
+      // carry mode: the trial pass evaluated exactly the accepted x (it wrote those very
+      // doubles to xt) with the factor outputs on -> it IS the next step's energy pass
+      c->factors_valid = carry_mode;
+      c->carry_valid = carry_mode;
+      c->grad_valid = false;
       // minimizer.py:1415 re-projects the stored tilts onto the accepted surface: that is
       // exactly the trial projection computed above
       if (tilt) std::swap(c->d_tilts, c->d_tilts_trial);
@@ -809,6 +846,7 @@ int ms_phase_energy(ms_ctx* c, int use_direction, double alpha, int write_trial,
 
 int ms_phase_gradient(ms_ctx* c) {
   if (!c) return MS_ERR_INVALID;
+  c->grad_valid = false;  // G receives the raw (unfinalized) gradient
   return phase_gradient(c, c->params.modules, c->buf[MS_BUF_G], false);
 }
 
@@ -821,6 +859,7 @@ int ms_phase_accept(ms_ctx* c, int keep_history) {
   if (!c) return MS_ERR_INVALID;
   std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
   c->factors_valid = false;
+  c->carry_valid = c->grad_valid = false;
   if (keep_history) {
     std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
     std::swap(c->buf[MS_BUF_D], c->buf[MS_BUF_PD]);
@@ -872,6 +911,7 @@ int ms_fetch_scalars(ms_ctx* c, double* out) {
 int ms_store_scalars(ms_ctx* c, const double* in) {
   if (!c || !in) return MS_ERR_INVALID;
   memcpy(c->h_scal, in, sizeof(double) * MS_NSCAL);
+  c->carry_valid = c->grad_valid = false;
   HIPCHK(c, hipMemcpyAsync(c->d_scal, c->h_scal, sizeof(double) * MS_NSCAL, hipMemcpyHostToDevice,
                            c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -167,6 +167,13 @@ __device__ __forceinline__ void grad_triangle_area(V3 u, V3 v, V3& gu, V3& gv) {
   gv = mk(0.5 * wxu.x * invS, 0.5 * wxu.y * invS, 0.5 * wxu.z * invS);
 }
 
+// dot product with the contraction spelled out: the direction scalars (|g|^2, <g,d>,
+// max|d_i|^2) are produced at two code sites (k_gradient's fused epilogue, k_direction) that
+// must agree to the last bit.
+__device__ __forceinline__ double dot_pinned(V3 a, V3 b) {
+  return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
+}
+
 __device__ __forceinline__ V3 lds_v3(const double* base, int cap, int slot) {
   return mk(base[slot], base[cap + slot], base[2 * cap + slot]);
 }
@@ -789,10 +796,10 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
       V3 di = -gi;
       if (a.dir_mode == 2) {
         const V3 pgv = mk(a.pg[o], a.pg[o + 1], a.pg[o + 2]);
-        const double beta = dot(gi, gi - pgv) / (dot(pgv, pgv) + 1.0e-20);
+        const double beta = dot_pinned(gi, gi - pgv) / (dot_pinned(pgv, pgv) + 1.0e-20);
         if (!(beta < 0.0)) {
           const V3 q = mk(a.pd[o], a.pd[o + 1], a.pd[o + 2]);
-          di = mk(-gi.x + beta * q.x, -gi.y + beta * q.y, -gi.z + beta * q.z);
+          di = mk(fma(beta, q.x, -gi.x), fma(beta, q.y, -gi.y), fma(beta, q.z, -gi.z));
         }
       }
       if (fixed) di = mk(0, 0, 0);
@@ -802,9 +809,9 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
       a.d[o] = di.x;
       a.d[o + 1] = di.y;
       a.d[o + 2] = di.z;
-      gn2 = dot(gi, gi);
-      gdd = dot(gi, di);
-      md2 = fixed ? 0.0 : dot(di, di);
+      gn2 = dot_pinned(gi, gi);
+      gdd = dot_pinned(gi, di);
+      md2 = fixed ? 0.0 : dot_pinned(di, di);
     } else if (a.g) {
       if (a.accumulate) {
         gx += a.g[o];
@@ -1153,10 +1160,10 @@ __global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, c
     V3 di = -gi;
     if (cg_history) {
       const V3 p = mk(pg[o], pg[o + 1], pg[o + 2]);
-      const double beta = dot(gi, gi - p) / (dot(p, p) + 1.0e-20);
+      const double beta = dot_pinned(gi, gi - p) / (dot_pinned(p, p) + 1.0e-20);
       if (!(beta < 0.0)) {
         const V3 q = mk(pd[o], pd[o + 1], pd[o + 2]);
-        di = mk(-gi.x + beta * q.x, -gi.y + beta * q.y, -gi.z + beta * q.z);
+        di = mk(fma(beta, q.x, -gi.x), fma(beta, q.y, -gi.y), fma(beta, q.z, -gi.z));
       }
     }
     if (fixed) di = mk(0, 0, 0);
@@ -1166,9 +1173,9 @@ __global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, c
     d[o] = di.x;
     d[o + 1] = di.y;
     d[o + 2] = di.z;
-    gn2 += dot(gi, gi);
-    gd += dot(gi, di);
-    if (!fixed) md2 = fmax(md2, dot(di, di));
+    gn2 += dot_pinned(gi, gi);
+    gd += dot_pinned(gi, di);
+    if (!fixed) md2 = fmax(md2, dot_pinned(di, di));
   }
   double* out = partials + tile;
   const size_t ps = (size_t)n_tiles;

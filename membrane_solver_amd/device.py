@@ -171,10 +171,10 @@ class DeviceMesh:
     def step(self, *, stepper: int, step_size: float, tol: float = 1e-6, max_iter: int = 10,
              beta: float = 0.7, c: float = 1e-4, gamma: float = 1.5, alpha_max_factor: float = 10.0,
              restart_interval: int = 10, edge_fraction: float = 0.0,
-             reuse_energy0: bool = False) -> StepResult:
+             reuse_energy0: int = 0) -> StepResult:
         sp = L.ms_stepper_params(int(stepper), int(max_iter), float(beta), float(c), float(gamma),
                                  float(alpha_max_factor), int(restart_interval), float(edge_fraction),
-                                 1 if reuse_energy0 else 0)
+                                 int(reuse_energy0))
         r = L.ms_step_result()
         self._chk(L.lib().ms_step(self._h, ctypes.byref(sp), float(step_size), float(tol),
                                   ctypes.byref(r)), "ms_step")

@@ -278,3 +278,76 @@ def test_full_size_properties(freq, kind):
     x = dm.get_positions()
     assert np.array_equal(x[fixed], P[fixed])
     dm.close()
+
+
+@pytest.mark.parametrize("fname", sorted(CASES))
+def test_evaluation_reuse_levels_are_bitwise_identical(fname):
+    """ms_stepper_params.reuse_energy0 = 0 (re-evaluate everything the reference re-evaluates),
+    1 (reuse energy0) and 2 (an accepted trial is the next step's energy/factor pass) must give
+    the SAME doubles: the skipped passes are the same kernel on the same inputs."""
+    from membrane_solver_amd.runtime.constraint_manager import ConstraintModuleManager
+    from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
+    from membrane_solver_amd.runtime.minimizer import Minimizer
+    from membrane_solver_amd.runtime.steppers import ConjugateGradient, GradientDescent
+
+    mods, cons, kind, gp = CASES[fname]
+    g = load_golden(fname)
+    gp = dict(gp)
+    if "gp_volume_stiffness" in g:
+        gp["volume_stiffness"] = float(g["gp_volume_stiffness"])
+        gp["surface_tension"] = float(g["gp_surface_tension"])
+    runs = []
+    for level in (0, 1, 2):
+        mesh = _build(g, mods, cons, gp, "target_volume" in g)
+        stepper = GradientDescent() if kind == "gd" else ConjugateGradient()
+        stepper.reuse_energy0 = level
+        log = []
+        orig = stepper.device_step
+
+        def logged(dm, m, step_size, tol=0.0, _orig=orig, _log=log):
+            r = _orig(dm, m, step_size, tol=tol)
+            _log.append((float(r.success), r.next_step, r.energy, r.energy_eval, r.grad_norm,
+                         r.g_dot_d, r.alpha, r.volume))
+            return r
+
+        stepper.device_step = logged
+        mz = Minimizer(mesh, mesh.global_parameters, stepper, EnergyModuleManager(mods),
+                       ConstraintModuleManager(cons), quiet=True, step_size=float(g["step_size0"]))
+        mz.minimize(int(g["n_steps"]) + 7)
+        runs.append((np.array(log), mesh.positions_view().copy()))
+    for log, pos in runs[1:]:
+        assert np.array_equal(log, runs[0][0])
+        assert np.array_equal(pos, runs[0][1])
+
+
+def test_reuse_levels_bitwise_identical_multitile_with_rejections():
+    """Same, straight on DeviceMesh.step for a multi-tile noisy sphere with an over-long first
+    step (forces backtracking / failed searches, i.e. the carried state must be invalidated)."""
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+
+    pos, tri = meshgen.icosphere(24)
+    pos = meshgen.smooth_displace(pos, 0.05)
+    pos = pos + 2.0e-3 * np.random.default_rng(3).standard_normal(pos.shape)
+    nv = pos.shape[0]
+    outs = []
+    for level in (0, 1, 2):
+        dm = DeviceMesh(pos, tri)
+        dm.set_surface_tension(np.full(tri.shape[0], 1.0))
+        dm.set_bending_params(np.full(nv, 1.0), np.full(nv, 0.2))
+        dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING)
+        step, rows = 5.0e-2, []
+        for _ in range(25):
+            r = dm.step(stepper=L.MS_STEPPER_CG, step_size=step, reuse_energy0=level)
+            rows.append((r.success, r.trials, r.energy, r.energy_eval, r.grad_norm, r.g_dot_d, r.alpha))
+            step = r.next_step
+            if not r.success:
+                dm.reset_stepper()
+        outs.append((np.array(rows, dtype=np.float64), dm.get_positions()))
+        dm.close()
+    assert outs[0][0][:, 1].max() > 1, "the case is meant to exercise backtracking"
+    assert (outs[0][0][:, 0] == 0).any(), "the case is meant to exercise failed searches"
+    for rows, x in outs[1:]:
+        assert np.array_equal(outs[0][0], rows)
+        assert np.array_equal(outs[0][1], x)
