@@ -183,6 +183,21 @@ def main():
         "energy_start": E_start, "energy_end": res["energy"],
     }
 
+    # -- the same K steps with every pass the reference repeats (reuse level 0): energy0
+    #    re-evaluated, a fresh energy/factor pass after every accepted step, a full gradient
+    #    pass after a failed search.  Same doubles out (tests/test_gpu_minimizer.py), more launches.
+    if args.reuse_level != 0:
+        stepper.reuse_energy0 = 0
+        mz.minimize(5, sync_mesh=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mz.minimize(args.steps, sync_mesh=False)
+        torch.cuda.synchronize()
+        dt0 = time.perf_counter() - t0
+        out["all_reference_passes_repeated"] = {"value": args.steps / dt0, "unit": "steps/s",
+                                                "ms_per_step": 1e3 * dt0 / args.steps, "reuse_level": 0}
+        stepper.reuse_energy0 = args.reuse_level
+
     # -- roofline of the dominant kernel: HIP events inside the library --------
     mir = mesh._hip_mirror
     dm = mir.dm

@@ -215,6 +215,32 @@ int ms_store_scalars(ms_ctx *ctx, const double *in /* MS_NSCAL */);
  * x <-> xt and, if keep_history, the CG history swap of ms_phase_accept. */
 int ms_phase_commit_trial(ms_ctx *ctx, double alpha, int keep_history);
 
+/* Fused K_C + direction pass (no constraint row, no tilt module): the sharded
+ * counterpart of what ms_step queues (runtime/minimizer.py:941-992 followed by
+ * conjugate_gradient.py:60-100 / gradient_descent.py:35-84); reduces the
+ * direction scalars of this rank's rows. */
+int ms_phase_gradient_direction(ms_ctx *ctx, int stepper, int use_history);
+/* After a boundary exchange of fK/fA written by an accepted trial pass: the
+ * factor buffers describe the committed x. */
+int ms_phase_set_factors_valid(ms_ctx *ctx, int valid);
+
+/* ---- shard boundary exchange (multi-GPU; the reference is single-process) ----
+ * A rank's boundary rows are the rows it owns that other ranks' tiles read as
+ * halo.  One exchange = ms_pack_boundary -> all-gather of the fixed-size
+ * messages (RCCL, done by the caller on the context's stream) ->
+ * ms_unpack_boundary.  Message = [MS_NSCAL reduction scalars | boundary rows of
+ * the listed per-vertex buffers]; unpack scatters every peer's rows into the
+ * local buffers and returns all ranks' scalar headers (shard_count x MS_NSCAL)
+ * for the rank-ordered host fold.
+ * info = {max boundary rows over ranks, this rank's, this rank's halo rows, shard_count}. */
+int ms_boundary_info(ms_ctx *ctx, int64_t info[4]);
+size_t ms_exchange_bytes(ms_ctx *ctx, int n_buffers, const int *buffer_ids);
+int ms_pack_boundary(ms_ctx *ctx, int n_buffers, const int *buffer_ids,
+                     void *send_dev, size_t send_bytes);
+int ms_unpack_boundary(ms_ctx *ctx, int n_buffers, const int *buffer_ids,
+                       const void *recv_dev, size_t stride_bytes,
+                       double *scal_all_host);
+
 /* Per-vertex state in caller-owned device memory (e.g. a torch tensor, so RCCL
  * collectives can run on it in place).  ms_state_bytes gives the size;
  * ms_rebind_state copies the current state there and uses it from then on.

@@ -100,6 +100,14 @@ SIGNATURES = {
     "ms_phase_direction": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
     "ms_phase_accept": (ctypes.c_int, [_P, ctypes.c_int]),
     "ms_phase_commit_trial": (ctypes.c_int, [_P, ctypes.c_double, ctypes.c_int]),
+    "ms_phase_gradient_direction": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
+    "ms_phase_set_factors_valid": (ctypes.c_int, [_P, ctypes.c_int]),
+    "ms_boundary_info": (ctypes.c_int, [_P, _I64]),
+    "ms_exchange_bytes": (ctypes.c_size_t, [_P, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    "ms_pack_boundary": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _P,
+                                        ctypes.c_size_t]),
+    "ms_unpack_boundary": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _P,
+                                          ctypes.c_size_t, _D]),
     "ms_state_bytes": (ctypes.c_size_t, [_P]),
     "ms_rebind_state": (ctypes.c_int, [_P, _P, ctypes.c_size_t]),
     "ms_fetch_scalars": (ctypes.c_int, [_P, _D]),

@@ -3,6 +3,8 @@
 // include/membrane_hip.h.  Arithmetic lives in ms_kernels.hip.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
 
@@ -61,6 +63,14 @@ struct ms_ctx {
   // true while the mailbox energies / min edge / volume AND the factor buffers describe the
   // current x: set when ms_step accepts a trial that also wrote the factors, cleared by
   // every other energy pass and by every mutator
+  // shard boundary exchange: rows each rank owns that other ranks' tiles read as halo
+  std::vector<int32_t> bnd_off;  // shard_count + 1
+  int32_t* d_bnd_rows = nullptr;
+  int32_t* d_bnd_off = nullptr;
+  int bnd_max = 0;               // longest per-rank list (message stride)
+  int32_t* d_halo_rows = nullptr;  // rows of other ranks that THIS rank's tiles read
+  int n_halo_rows = 0;
+  double* d_scal_all = nullptr;    // shard_count x MS_NSCAL, filled by unpack
   bool carry_valid = false;
   // true while buffer G holds the finalized gradient of the current x (set by ms_step's fused
   // gradient pass, survives a failed line search, cleared together with carry_valid)
@@ -507,6 +517,41 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
   memset(c->h_seq, 0, sizeof(unsigned long long) * MS_NSCAL);
   CREATE_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_seq), c->h_seq, 0));
   CREATE_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_stage), sizeof(double) * 3 * (size_t)nv));
+  {
+    // boundary lists of every rank (each rank derives all of them from the shared tiling)
+    const int W = shard_count;
+    const int rows_per = t.tiles_per_shard * t.T;
+    std::vector<std::vector<int32_t>> lists((size_t)W);
+    std::vector<int32_t> my_halo;
+    for (int tile = 0; tile < t.n_tiles; ++tile) {
+      const int tr = tile / t.tiles_per_shard;
+      for (int h = t.tile_halo_off[tile]; h < t.tile_halo_off[tile + 1]; ++h) {
+        const int32_t v = t.halo_ids[h];
+        const int owner = v / rows_per;
+        if (owner == tr) continue;
+        lists[(size_t)owner].push_back(v);
+        if (tr == shard_rank) my_halo.push_back(v);
+      }
+    }
+    std::vector<int32_t> flat;
+    c->bnd_off.assign((size_t)W + 1, 0);
+    for (int r = 0; r < W; ++r) {
+      auto& l = lists[(size_t)r];
+      std::sort(l.begin(), l.end());
+      l.erase(std::unique(l.begin(), l.end()), l.end());
+      c->bnd_off[(size_t)r + 1] = c->bnd_off[(size_t)r] + (int32_t)l.size();
+      c->bnd_max = std::max(c->bnd_max, (int)l.size());
+      flat.insert(flat.end(), l.begin(), l.end());
+    }
+    std::sort(my_halo.begin(), my_halo.end());
+    my_halo.erase(std::unique(my_halo.begin(), my_halo.end()), my_halo.end());
+    c->n_halo_rows = (int)my_halo.size();
+    CREATE_CHK(upload(c, &c->d_bnd_rows, flat));
+    CREATE_CHK(upload(c, &c->d_bnd_off, c->bnd_off));
+    CREATE_CHK(upload(c, &c->d_halo_rows, my_halo));
+    CREATE_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_scal_all), sizeof(double) * MS_NSCAL * (size_t)W));
+    CREATE_HIP(hipMemset(c->d_scal_all, 0, sizeof(double) * MS_NSCAL * (size_t)W));
+  }
   c->params.modules = MS_MOD_SURFACE;
   c->params.bending_model = MS_BEND_HELFRICH;
   c->params.bending_grad_mode = MS_GRAD_ANALYTIC;
@@ -528,7 +573,8 @@ void ms_destroy(ms_ctx* c) {
   void* ptrs[] = {c->d_perm, c->d_tile_facet_off, c->d_tile_facets, c->d_tf_gamma,
                   c->d_tile_halo_off, c->d_halo_ids, c->d_tile_ent_off, c->d_tile_voff, c->d_vent,
                   c->d_vflags, c->d_kappa, c->d_c0, c->d_tilts, c->d_tilt_grad, c->d_tilts_trial,
-                  c->state, c->d_partials, c->d_scal, c->d_stage};
+                  c->state, c->d_partials, c->d_scal, c->d_stage, c->d_bnd_rows, c->d_bnd_off,
+                  c->d_halo_rows, c->d_scal_all};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_scal) (void)hipHostFree(c->h_scal);
@@ -872,12 +918,102 @@ int ms_phase_accept(ms_ctx* c, int keep_history) {
 
 int ms_phase_commit_trial(ms_ctx* c, double alpha, int keep_history) {
   if (!c) return MS_ERR_INVALID;
+  if (c->shard_count > 1) {
+    // x <- x + alpha d in place on the rows this rank reads: its own rows and the halo rows
+    // of its tiles (d is valid there after the boundary exchange); same expression as the
+    // trial pass, so the committed doubles are the evaluated ones
+    const Tiling& t = c->til;
+    const int64_t rows_per = (int64_t)t.tiles_per_shard * t.T;
+    HIPCHK(c, launch_axpy_rows(c->shard_rank * rows_per, (c->shard_rank + 1) * rows_per, c->d_halo_rows,
+                               c->n_halo_rows, c->d_vflags, c->buf[MS_BUF_X], c->buf[MS_BUF_D], alpha,
+                               c->stream));
+    std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);  // undone by ms_phase_accept's swap
+    return ms_phase_accept(c, keep_history);
+  }
   const size_t n3 = 3 * (size_t)c->til.nvp;
   HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_XT], c->buf[MS_BUF_X], n3 * sizeof(double),
                            hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, launch_axpy_masked(c->til.nvp, c->d_vflags, c->buf[MS_BUF_XT], c->buf[MS_BUF_D], alpha,
                                c->stream));
   return ms_phase_accept(c, keep_history);
+}
+
+int ms_phase_gradient_direction(ms_ctx* c, int stepper, int use_history) {
+  if (!c) return MS_ERR_INVALID;
+  if (c->params.modules & (MS_CON_VOLUME | MS_MOD_TILT))
+    return fail(c, MS_ERR_STATE, "fused gradient+direction needs no constraint row and no tilt module");
+  c->grad_valid = false;
+  const int dir_mode = (stepper == MS_STEPPER_CG && use_history) ? 2 : 1;
+  return phase_gradient(c, c->params.modules, c->buf[MS_BUF_G], false, dir_mode);
+}
+
+int ms_phase_set_factors_valid(ms_ctx* c, int valid) {
+  if (!c) return MS_ERR_INVALID;
+  c->factors_valid = valid != 0;
+  return MS_OK;
+}
+
+namespace {
+int row_buffers(ms_ctx* c, int n, const int* ids, double* p[4], int ncomp[4], int* comps) {
+  if (n < 0 || n > 4 || (n > 0 && !ids)) return fail(c, MS_ERR_INVALID, "boundary exchange: 0..4 buffers");
+  *comps = 0;
+  for (int k = 0; k < n; ++k) {
+    if (ids[k] < 0 || ids[k] > MS_BUF_FA) return fail(c, MS_ERR_INVALID, "boundary exchange: bad buffer id");
+    p[k] = c->buf[ids[k]];
+    ncomp[k] = ids[k] == MS_BUF_FA ? 2 : 3;
+    *comps += ncomp[k];
+  }
+  return MS_OK;
+}
+}  // namespace
+
+int ms_boundary_info(ms_ctx* c, int64_t info[4]) {
+  if (!c || !info) return MS_ERR_INVALID;
+  info[0] = c->bnd_max;
+  info[1] = c->bnd_off[(size_t)c->shard_rank + 1] - c->bnd_off[(size_t)c->shard_rank];
+  info[2] = c->n_halo_rows;
+  info[3] = c->shard_count;
+  return MS_OK;
+}
+
+size_t ms_exchange_bytes(ms_ctx* c, int n_buffers, const int* buffer_ids) {
+  double* p[4];
+  int nc[4], comps = 0;
+  if (!c || row_buffers(c, n_buffers, buffer_ids, p, nc, &comps)) return 0;
+  return sizeof(double) * ((size_t)MS_NSCAL + (size_t)c->bnd_max * comps);
+}
+
+int ms_pack_boundary(ms_ctx* c, int n_buffers, const int* buffer_ids, void* send_dev, size_t send_bytes) {
+  if (!c || !send_dev) return MS_ERR_INVALID;
+  double* p[4];
+  int nc[4], comps = 0;
+  int rc = row_buffers(c, n_buffers, buffer_ids, p, nc, &comps);
+  if (rc) return rc;
+  if (send_bytes < ms_exchange_bytes(c, n_buffers, buffer_ids))
+    return fail(c, MS_ERR_INVALID, "ms_pack_boundary: send buffer smaller than ms_exchange_bytes");
+  const int me = c->shard_rank;
+  HIPCHK(c, launch_pack_boundary(c->d_bnd_rows + c->bnd_off[(size_t)me],
+                                 c->bnd_off[(size_t)me + 1] - c->bnd_off[(size_t)me], p, nc, n_buffers,
+                                 c->d_scal, static_cast<double*>(send_dev), c->stream));
+  return MS_OK;
+}
+
+int ms_unpack_boundary(ms_ctx* c, int n_buffers, const int* buffer_ids, const void* recv_dev,
+                       size_t stride_bytes, double* scal_all_host) {
+  if (!c || !recv_dev || !scal_all_host) return MS_ERR_INVALID;
+  double* p[4];
+  int nc[4], comps = 0;
+  int rc = row_buffers(c, n_buffers, buffer_ids, p, nc, &comps);
+  if (rc) return rc;
+  if (stride_bytes < ms_exchange_bytes(c, n_buffers, buffer_ids) || stride_bytes % sizeof(double))
+    return fail(c, MS_ERR_INVALID, "ms_unpack_boundary: bad stride");
+  HIPCHK(c, launch_unpack_boundary(c->d_bnd_rows, c->d_bnd_off, c->shard_rank, c->shard_count, c->bnd_max,
+                                   p, nc, n_buffers, static_cast<const double*>(recv_dev),
+                                   stride_bytes / sizeof(double), c->d_scal_all, c->stream));
+  HIPCHK(c, hipMemcpyAsync(scal_all_host, c->d_scal_all, sizeof(double) * MS_NSCAL * (size_t)c->shard_count,
+                           hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MS_OK;
 }
 
 size_t ms_state_bytes(const ms_ctx* c) {

@@ -136,6 +136,15 @@ hipError_t launch_tilt(const TiltArgs& a, int mode, int cap, int max_ent, hipStr
 hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
                          uint32_t slot_mask, double* scal, double* host_mirror,
                          unsigned long long* host_seq, unsigned long long ticket, hipStream_t s);
+hipError_t launch_pack_boundary(const int32_t* rows, int n_rows, const double* const* bufs,
+                                const int* ncomp, int n_bufs, const double* scal, double* send,
+                                hipStream_t s);
+hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_off, int me, int world,
+                                  int max_rows, double* const* bufs, const int* ncomp, int n_bufs,
+                                  const double* recv, size_t stride, double* scal_all, hipStream_t s);
+hipError_t launch_axpy_rows(int64_t row0, int64_t row1, const int32_t* extra, int n_extra,
+                            const uint8_t* vflags, double* x, const double* y, double coef,
+                            hipStream_t s);
 hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* g,
                             const double* gC, double* d, const double* pg, const double* pd,
                             const double* scal, int use_constraint, int cg_history,

@@ -1197,6 +1197,102 @@ hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* 
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Shard boundary exchange (multi-GPU): a rank's BOUNDARY rows are the rows it owns that some
+// other rank's tiles list as halo.  pack: send = [16 reduction scalars | boundary rows of up
+// to 4 per-vertex buffers, interleaved per row]; after the all-gather, unpack scatters every
+// peer's rows into the local buffers and lifts the per-rank scalar headers into one array.
+// ---------------------------------------------------------------------------
+struct RowBufs {
+  double* p[4];
+  int ncomp[4];
+  int n, comps;  // buffers, sum of ncomp
+};
+
+__global__ void k_pack_boundary(const int32_t* rows, int n_rows, RowBufs b, const double* scal,
+                                double* send) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < MS_NSCAL) send[j] = scal[j];
+  if (j >= n_rows) return;
+  const size_t v = (size_t)rows[j];
+  double* o = send + MS_NSCAL + (size_t)j * b.comps;
+  for (int k = 0; k < b.n; ++k)
+    for (int c = 0; c < b.ncomp[k]; ++c) *o++ = b.p[k][v * b.ncomp[k] + c];
+}
+
+// grid (ceil(max_rows/256), world); recv = world x stride doubles
+__global__ void k_unpack_boundary(const int32_t* rows_all, const int32_t* row_off, int me,
+                                  RowBufs b, const double* recv, size_t stride, double* scal_all) {
+  const int r = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const double* src = recv + (size_t)r * stride;
+  if (j < MS_NSCAL) scal_all[r * MS_NSCAL + j] = src[j];
+  if (r == me) return;
+  const int n_rows = row_off[r + 1] - row_off[r];
+  if (j >= n_rows) return;
+  const size_t v = (size_t)rows_all[row_off[r] + j];
+  const double* i = src + MS_NSCAL + (size_t)j * b.comps;
+  for (int k = 0; k < b.n; ++k)
+    for (int c = 0; c < b.ncomp[k]; ++c) b.p[k][v * b.ncomp[k] + c] = *i++;
+}
+
+hipError_t launch_pack_boundary(const int32_t* rows, int n_rows, const double* const* bufs,
+                                const int* ncomp, int n_bufs, const double* scal, double* send,
+                                hipStream_t s) {
+  RowBufs b{};
+  b.n = n_bufs;
+  for (int k = 0; k < n_bufs; ++k) {
+    b.p[k] = const_cast<double*>(bufs[k]);
+    b.ncomp[k] = ncomp[k];
+    b.comps += ncomp[k];
+  }
+  const int n = n_rows > MS_NSCAL ? n_rows : MS_NSCAL;
+  hipLaunchKernelGGL(k_pack_boundary, dim3((n + 255) / 256), dim3(256), 0, s, rows, n_rows, b, scal, send);
+  return hipGetLastError();
+}
+
+hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_off, int me, int world,
+                                  int max_rows, double* const* bufs, const int* ncomp, int n_bufs,
+                                  const double* recv, size_t stride, double* scal_all, hipStream_t s) {
+  RowBufs b{};
+  b.n = n_bufs;
+  for (int k = 0; k < n_bufs; ++k) {
+    b.p[k] = bufs[k];
+    b.ncomp[k] = ncomp[k];
+    b.comps += ncomp[k];
+  }
+  const int n = max_rows > MS_NSCAL ? max_rows : MS_NSCAL;
+  hipLaunchKernelGGL(k_unpack_boundary, dim3((n + 255) / 256, world), dim3(256), 0, s, rows_all, row_off,
+                     me, b, recv, stride, scal_all);
+  return hipGetLastError();
+}
+
+// x[i] += coef * y[i] on movable rows of [row0, row1) and of an explicit row list (shard commit)
+__global__ void k_axpy_rows(int64_t row0, int64_t row1, const int32_t* extra, int n_extra,
+                            const uint8_t* vflags, double* x, const double* y, double coef) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n_own = row1 - row0;
+  int64_t v;
+  if (j < n_own)
+    v = row0 + j;
+  else if (j < n_own + n_extra)
+    v = extra[j - n_own];
+  else
+    return;
+  if (vflags[v] & VF_FIXED) return;
+  for (int c = 0; c < 3; ++c) x[3 * v + c] += coef * y[3 * v + c];
+}
+
+hipError_t launch_axpy_rows(int64_t row0, int64_t row1, const int32_t* extra, int n_extra,
+                            const uint8_t* vflags, double* x, const double* y, double coef,
+                            hipStream_t s) {
+  const int64_t n = (row1 - row0) + n_extra;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_axpy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, row0, row1, extra,
+                     n_extra, vflags, x, y, coef);
+  return hipGetLastError();
+}
+
 // x[i] += coef * y[i] on movable rows (volume projection, constraints/volume.py:137-141)
 __global__ void k_axpy_masked(int64_t n_rows, const uint8_t* vflags, double* x, const double* y,
                               double coef) {

@@ -211,6 +211,37 @@ class DeviceMesh:
         self._chk(L.lib().ms_phase_commit_trial(self._h, float(alpha), int(keep_history)),
                   "ms_phase_commit_trial")
 
+    def phase_gradient_direction(self, stepper: int, use_history: bool):
+        self._chk(L.lib().ms_phase_gradient_direction(self._h, int(stepper), int(use_history)),
+                  "ms_phase_gradient_direction")
+
+    def phase_set_factors_valid(self, valid: bool):
+        self._chk(L.lib().ms_phase_set_factors_valid(self._h, int(valid)), "ms_phase_set_factors_valid")
+
+    # -- shard boundary exchange ------------------------------------------------
+    def boundary_info(self):
+        v = np.zeros(4, dtype=np.int64)
+        self._chk(L.lib().ms_boundary_info(self._h, v.ctypes.data_as(L._I64)), "ms_boundary_info")
+        return {"max_rows": int(v[0]), "my_rows": int(v[1]), "halo_rows": int(v[2]), "world": int(v[3])}
+
+    @staticmethod
+    def _ids(buffers):
+        return (ctypes.c_int * max(1, len(buffers)))(*[int(b) for b in buffers])
+
+    def exchange_bytes(self, buffers) -> int:
+        return int(L.lib().ms_exchange_bytes(self._h, len(buffers), self._ids(buffers)))
+
+    def pack_boundary(self, buffers, send_ptr: int, send_bytes: int):
+        self._chk(L.lib().ms_pack_boundary(self._h, len(buffers), self._ids(buffers),
+                                           ctypes.c_void_p(send_ptr), int(send_bytes)), "ms_pack_boundary")
+
+    def unpack_boundary(self, buffers, recv_ptr: int, stride_bytes: int, world: int) -> np.ndarray:
+        out = np.zeros((world, L.MS_NSCAL))
+        self._chk(L.lib().ms_unpack_boundary(self._h, len(buffers), self._ids(buffers),
+                                             ctypes.c_void_p(recv_ptr), int(stride_bytes), _pd(out)),
+                  "ms_unpack_boundary")
+        return out
+
     def state_bytes(self) -> int:
         return int(L.lib().ms_state_bytes(self._h))
 

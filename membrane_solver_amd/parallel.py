@@ -5,21 +5,23 @@ The reference has no parallelism at all; this is the
 facet-block partition BASELINE.json asks for.  Tiles (blocks of 256 vertices in
 patch order, each listing every facet that touches it) are dealt to ranks in
 contiguous ranges, so every rank OWNS a contiguous row range of each per-vertex
-vector and evaluates only its own facet blocks.  Positions are replicated.
+vector and evaluates only its own facet blocks.  A rank reads its own rows plus
+the HALO rows of its tiles (a thin band along the patch border: the patch order
+is a Hilbert curve, so a rank's rows form a compact surface patch).
 
-Exchanges per gradient evaluation ("simple mode" of SURVEY 8e):
-  * all-gather of the bending back-prop factors fK (nv,3) + fA (nv,2) between
-    the energy pass and the gradient pass (owner rows -> every rank);
-  * all-gather of the direction d (nv,3) after the direction pass;
-  * small all-gathers of the 16 reduction scalars (energies, <g,gC>, |g|^2,
-    <g,d>, max|d|, min edge, guard flag), folded on the host in rank order, so
-    every rank takes identical Armijo decisions.
-The per-vertex gradient itself never travels: the volume-row projection, the
-fixed-row zeroing and the per-row Polak-Ribiere beta are all row-local, so the
-dense gradient all-reduce of the north-star text reduces to these all-gathers
-of owner rows (half the bytes of an all-reduce of zero-padded partial vectors).
-Accepting a trial needs no exchange either: x and d are replicated, every rank
-forms x + alpha*d on all rows itself.
+One exchange = one fixed-size all-gather per rank of
+    [16 reduction scalars | this rank's BOUNDARY rows of the listed buffers]
+(boundary rows = rows it owns that other ranks read as halo; a few thousand rows
+of a million).  Every rank scatters the peers' rows into its buffers and folds the
+scalar headers on the host in rank order, so all ranks take identical Armijo
+decisions.  Per accepted step (no constraint row, reuse level 2):
+  * gradient pass with fused direction  ->  exchange [|g|^2, <g,d>, max|d| | d]
+  * trial energy pass (writes the bending factors at the trial point)
+                                        ->  exchange [energies, min edge | fK, fA]
+and nothing else: the per-vertex gradient itself never travels (fixed-row zeroing,
+volume-row projection and the per-row Polak-Ribiere beta are row-local), accepting
+a trial is x += alpha*d on the rows a rank reads, and the accepted trial's factors
+and energies are the next step's (same reuse as ms_step, include/membrane_hip.h).
 
 ``ShardedStepper`` holds the control flow (a restatement of ms_step, i.e. of
 runtime/minimizer.py:1314-1374 + line_search.py:267-426 of the reference) on
@@ -83,36 +85,47 @@ class ShardedStepper:
     modules (int), volume_stiffness, target_volume, nf,
     phase_energy(use_direction, alpha, write_trial, guard, write_bending_factors),
     phase_gradient(), phase_direction(stepper, use_history),
-    phase_commit_trial(alpha, keep_history), fetch_scalars() -> (16,), store_scalars((16,)),
-    allgather_rows(buffer_id)   # owner rows -> all ranks, in place
-    allgather_scalars((16,)) -> (world, 16)
+    phase_gradient_direction(stepper, use_history)      # fused, no constraint row
+    phase_commit_trial(alpha, keep_history), set_factors_valid(bool),
+    store_scalars((16,))                                # folded values -> device
+    exchange(buffer_ids) -> (world, 16)                 # see module docstring
     """
 
     def __init__(self, backend, *, stepper: int = L.MS_STEPPER_CG, max_iter: int = 10, beta: float = 0.7,
                  c: float = 1e-4, gamma: float = 1.5, alpha_max_factor: float = 10.0,
-                 restart_interval: int = 10, edge_fraction: float = 0.0, reuse_energy0: bool = False):
+                 restart_interval: int = 10, edge_fraction: float = 0.0, reuse_energy0: int = 2):
         self.b = backend
         self.stepper = stepper
         self.max_iter, self.beta, self.c, self.gamma = max_iter, beta, c, gamma
         self.alpha_max_factor, self.restart_interval = alpha_max_factor, restart_interval
-        self.edge_fraction, self.reuse_energy0 = edge_fraction, reuse_energy0
+        self.edge_fraction, self.reuse_energy0 = edge_fraction, int(reuse_energy0)
         self.have_history = False
         self.iter_count = 0
         self.scal = np.zeros(L.MS_NSCAL)
+        self.carry_valid = False   # factors + energy scalars describe the current x
+        self.grad_valid = False    # buffer G holds the finalized gradient of the current x
+        self.exchanges = 0
 
     def reset(self):
         """ConjugateGradient.reset (conjugate_gradient.py:44-50)."""
         self.have_history = False
         self.iter_count = 0
 
+    def invalidate(self):
+        """Call after changing positions / parameters behind the stepper's back."""
+        self.carry_valid = self.grad_valid = False
+
     # -- helpers ---------------------------------------------------------------
-    def _exchange(self, slots):
-        """Fold the given slots over ranks, keep the rest, push the result to the device."""
-        local = self.b.fetch_scalars()
-        folded = fold_scalars(self.b.allgather_scalars(local))
+    def _exchange(self, buffers, slots, push=False):
+        """Make `buffers` valid on every row this rank reads, fold `slots` over ranks (rank
+        order), keep the other slots; push=True also writes the folded values to the device
+        (the gradient pass reads the global volume, the direction pass <g,gC> and <gC,gC>)."""
+        folded = fold_scalars(self.b.exchange(tuple(buffers)))
         for s in slots:
             self.scal[s] = folded[s]
-        self.b.store_scalars(self.scal)
+        if push:
+            self.b.store_scalars(self.scal)
+        self.exchanges += 1
 
     def _energy(self):
         m = self.b.modules
@@ -132,17 +145,27 @@ class ShardedStepper:
         cg = self.stepper == L.MS_STEPPER_CG
         use_history = cg and self.have_history and (self.iter_count % self.restart_interval != 0)
         bend = bool(b.modules & L.MS_MOD_BENDING)
-        b.phase_energy(False, 0.0, False, False, True)
-        if bend:
-            b.allgather_rows(L.MS_BUF_FK)
-            b.allgather_rows(L.MS_BUF_FA)
-        if b.modules & L.MS_MOD_VOLUME_PENALTY:
-            self._exchange(ENERGY_SLOTS)  # the penalty factor k (V - V0) needs the global V
-        b.phase_gradient()
-        self._exchange(ENERGY_SLOTS + GRAD_SLOTS)
-        b.phase_direction(self.stepper, use_history)
-        b.allgather_rows(L.MS_BUF_D)
-        self._exchange(DIR_SLOTS)
+        constraint = bool(b.modules & L.MS_CON_VOLUME)
+        penalty = bool(b.modules & L.MS_MOD_VOLUME_PENALTY)
+        carry_mode = self.reuse_energy0 >= 2
+        factor_bufs = (L.MS_BUF_FK, L.MS_BUF_FA) if bend else ()
+        carried = carry_mode and self.carry_valid
+        if not carried:
+            b.phase_energy(False, 0.0, False, False, True)
+            # the gradient pass reads the factors on halo rows and (penalty) the global volume
+            self._exchange(factor_bufs, ENERGY_SLOTS, push=penalty)
+            self.grad_valid = False
+        if carried and self.grad_valid and not constraint:
+            b.phase_direction(self.stepper, use_history)  # x has not moved: direction only
+        elif constraint:
+            b.phase_gradient()
+            self._exchange((), GRAD_SLOTS, push=True)
+            b.phase_direction(self.stepper, use_history)
+        else:
+            b.phase_gradient_direction(self.stepper, use_history)
+        self._exchange((L.MS_BUF_D,), DIR_SLOTS)
+        self.carry_valid = carry_mode
+        self.grad_valid = carry_mode and not constraint
         E_eval = self._energy()
         grad_norm = math.sqrt(self.scal[L.MS_S_GNORM2])
         g_dot_d = self.scal[L.MS_S_GDOTD]
@@ -153,9 +176,9 @@ class ShardedStepper:
             res.converged = res.success = True
             return res
         energy0 = E_eval
-        if not self.reuse_energy0:
+        if self.reuse_energy0 == 0:
             b.phase_energy(False, 0.0, False, False, False)
-            self._exchange(ENERGY_SLOTS)
+            self._exchange((), ENERGY_SLOTS)
             energy0 = self._energy()
         min_edge = math.sqrt(self.scal[L.MS_S_MINEDGE2]) if b.nf > 0 else 0.0
         res.energy = energy0
@@ -168,8 +191,10 @@ class ShardedStepper:
         alpha_max = self.alpha_max_factor * step_size
         for _ in range(self.max_iter):
             safe_small = alpha * max_dir < safe_limit
-            b.phase_energy(True, alpha, False, not safe_small, False)
-            self._exchange(ENERGY_SLOTS)
+            b.phase_energy(True, alpha, False, not safe_small, carry_mode)
+            if carry_mode:
+                self.carry_valid = False  # the factor buffers now belong to the trial point
+            self._exchange(factor_bufs if carry_mode else (), ENERGY_SLOTS)
             if (not safe_small) and self.scal[L.MS_S_GUARD] > 0.0:
                 res.guard_rejects += 1
                 alpha *= self.beta
@@ -180,6 +205,12 @@ class ShardedStepper:
             E_t = self._energy()
             if E_t <= energy0 + self.c * alpha * g_dot_d:
                 b.phase_commit_trial(alpha, cg)
+                self.grad_valid = False
+                if carry_mode:
+                    b.set_factors_valid(True)
+                    if penalty:
+                        b.store_scalars(self.scal)  # the next gradient pass reads the new volume
+                    self.carry_valid = True
                 if cg:
                     self.have_history = True
                     self.iter_count += 1
@@ -200,7 +231,7 @@ class HipShardBackend:
     """HIP kernels on this rank's tile range; collectives through torch.distributed."""
 
     def __init__(self, positions, tri_rows, *, rank: int, world: int, device: int, tile_vertices: int = 0,
-                 fixed=None, boundary=None, body_facets=None, group=None):
+                 fixed=None, boundary=None, body_facets=None, group=None, debug_poison=False):
         import torch
 
         from .device import DeviceMesh
@@ -225,8 +256,12 @@ class HipShardBackend:
         self.modules = L.MS_MOD_SURFACE
         self.volume_stiffness = 0.0
         self.target_volume = 0.0
-        self._scal_all = torch.empty(world * L.MS_NSCAL, dtype=torch.float64, device=self.device)
-        self._scal_mine = torch.empty(L.MS_NSCAL, dtype=torch.float64, device=self.device)
+        self.debug_poison = bool(debug_poison)  # tests: NaN every non-owned row before an exchange
+        self.boundary = self.dm.boundary_info()
+        # message buffers for the widest exchange (fK 3 + fA 2 + d 3 components per boundary row)
+        n_max = L.MS_NSCAL + 8 * self.boundary["max_rows"]
+        self._send = torch.zeros(n_max, dtype=torch.float64, device=self.device)
+        self._recv = torch.zeros(world * n_max, dtype=torch.float64, device=self.device)
 
     def configure(self, *, modules, gamma=None, kappa=None, c0=None, **params):
         if gamma is not None:
@@ -264,15 +299,33 @@ class HipShardBackend:
     def store_scalars(self, values):
         self.dm.store_scalars(values)
 
-    def allgather_rows(self, buffer_id):
-        full = self._view(buffer_id)
-        mine = full[self.rank * self.rows: (self.rank + 1) * self.rows].clone()
-        self.dist.all_gather_into_tensor(full, mine)
+    def phase_gradient_direction(self, stepper, use_history):
+        self.dm.phase_gradient_direction(stepper, use_history)
 
-    def allgather_scalars(self, local):
-        self._scal_mine.copy_(self.torch.from_numpy(np.ascontiguousarray(local)))
-        self.dist.all_gather_into_tensor(self._scal_all, self._scal_mine)
-        return self._scal_all.cpu().numpy().reshape(self.world, L.MS_NSCAL)
+    def set_factors_valid(self, valid):
+        self.dm.phase_set_factors_valid(valid)
+
+    def gather_positions(self) -> np.ndarray:
+        """Assemble the full position array (owner rows of x from every rank) -- between steps a
+        rank only keeps the rows it reads (own + halo) current."""
+        full = self._view(L.MS_BUF_X)
+        mine = full[self.rank * self.rows: (self.rank + 1) * self.rows].reshape(-1).clone()
+        self.dist.all_gather_into_tensor(full.view(-1), mine)
+        return self.dm.get_positions()
+
+    def exchange(self, buffers):
+        """pack -> RCCL all-gather of the fixed-size messages -> unpack (see module docstring)."""
+        if self.debug_poison:
+            r0, r1 = self.rank * self.rows, (self.rank + 1) * self.rows
+            for bid in buffers:
+                v = self._view(bid)
+                v[:r0] = float("nan")
+                v[r1:] = float("nan")
+        n = self.dm.exchange_bytes(buffers) // 8
+        send, recv = self._send[:n], self._recv[: self.world * n]
+        self.dm.pack_boundary(buffers, send.data_ptr(), n * 8)
+        self.dist.all_gather_into_tensor(recv, send)
+        return self.dm.unpack_boundary(buffers, recv.data_ptr(), n * 8, self.world)
 
 
 def bench_main(args, rank: int, world: int, local_rank: int):
@@ -308,6 +361,7 @@ def bench_main(args, rank: int, world: int, local_rank: int):
         return acc, trials, r
 
     run(args.warmup)
+    drv.exchanges = 0
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -326,9 +380,10 @@ def bench_main(args, rank: int, world: int, local_rank: int):
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"class-I icosphere f={args.freq} (nv={nv}, nf={nf}), surface + Helfrich "
                                    "bending (analytic cotan gradient), CG stepper, Armijo line search, "
-                                   "energy0 re-evaluated",
-                       "parallelism": f"tiles (facet blocks) sharded over {world} GPUs; RCCL all-gather of "
-                                      "owner rows of fK/fA and d; replicated positions",
+                                   f"evaluation reuse level {drv.reuse_energy0}",
+                       "parallelism": f"tiles (facet blocks) sharded over {world} GPUs; per exchange one RCCL "
+                                      f"all-gather of [16 scalars | <= {be.boundary['max_rows']} boundary rows] "
+                                      f"per rank ({drv.exchanges} exchanges in the timed steps)",
                        "tile_vertices": args.tile or 256, "initial_step_size": args.step_size},
             "steps_accepted": acc, "line_search_trials": trials, "energy_end": r.energy,
         }))

@@ -1,8 +1,9 @@
-"""Sharded HIP backend on ONE GPU: two shard contexts (rank 0 / rank 1 tile ranges)
-driven by two threads whose collectives are an in-process stand-in for RCCL.  This
-runs the real tile-range kernels, ms_rebind_state, the phase API and
-ms_phase_commit_trial; only the RCCL transport itself is replaced.  The sharded
-run must match the single-context ms_step run."""
+"""Sharded HIP backend on ONE GPU: 2-3 shard contexts (tile ranges) driven by threads whose
+collectives are an in-process stand-in for RCCL.  This runs the real tile-range kernels,
+ms_rebind_state, the phase API, the boundary pack/unpack kernels and the in-place shard commit;
+only the RCCL transport itself is replaced.  Before every exchange each rank NaN-poisons all the
+rows it does not own, so a halo row missing from the boundary lists cannot go unnoticed.  The
+sharded run must match the single-context ms_step run."""
 
 import threading
 
@@ -40,8 +41,9 @@ class ThreadGroup:
         self.bar.wait()
 
 
-@pytest.mark.parametrize("with_volume", [False, True])
-def test_two_shards_match_single_context(with_volume):
+@pytest.mark.parametrize("with_volume,world,level", [(False, 2, 2), (True, 2, 2), (False, 3, 2), (False, 2, 0),
+                                                     (True, 3, 0)])
+def test_shards_match_single_context(with_volume, world, level):
     import torch
 
     from membrane_solver_amd import _lib as L
@@ -57,7 +59,7 @@ def test_two_shards_match_single_context(with_volume):
     kappa, c0, gamma = np.full(nv, 0.9), np.full(nv, 0.1), np.full(nf, 1.1)
     mods = L.MS_MOD_SURFACE | L.MS_MOD_BENDING | (L.MS_CON_VOLUME if with_volume else 0)
     V0 = 4.0
-    n_steps, step0 = 6, 1e-3
+    n_steps, step0 = 9, 1e-3
 
     # single context reference
     dm = DeviceMesh(P, T, fixed=fixed, tile_vertices=64)
@@ -74,16 +76,16 @@ def test_two_shards_match_single_context(with_volume):
     x_ref = dm.get_positions()
     dm.close()
 
-    world = 2
     grp = ThreadGroup(world)
     logs, finals, errors = [None] * world, [None] * world, []
 
     def run(rank):
         try:
             grp.bind(rank)
-            be = HipShardBackend(P, T, rank=rank, world=world, device=0, tile_vertices=64, fixed=fixed, group=grp)
+            be = HipShardBackend(P, T, rank=rank, world=world, device=0, tile_vertices=64, fixed=fixed, group=grp,
+                                 debug_poison=True)
             be.configure(modules=mods, gamma=gamma, kappa=kappa, c0=c0, target_volume=V0)
-            drv = ShardedStepper(be, stepper=L.MS_STEPPER_CG)
+            drv = ShardedStepper(be, stepper=L.MS_STEPPER_CG, reuse_energy0=level)
             log, step = [], step0
             for _ in range(n_steps):
                 r = drv.step(step, tol=1e-9)
@@ -92,7 +94,7 @@ def test_two_shards_match_single_context(with_volume):
                 if not r.success:
                     drv.reset()
             logs[rank] = np.array(log)
-            finals[rank] = be.dm.get_positions()
+            finals[rank] = be.gather_positions()
             torch.cuda.synchronize()
         except Exception as e:  # pragma: no cover
             import traceback
@@ -116,4 +118,5 @@ def test_two_shards_match_single_context(with_volume):
         assert np.allclose(got[:, 2], ref[:, 2], rtol=1e-12)
         assert np.allclose(got[:, 3], ref[:, 3], rtol=1e-9)
         assert relerr(finals[rank], x_ref) < 1e-11
-    assert np.array_equal(finals[0], finals[1]), "ranks diverged"
+    for rank in range(1, world):
+        assert np.array_equal(finals[0], finals[rank]), "ranks diverged"

@@ -147,20 +147,25 @@ class OracleShardBackend:
             b[L.MS_BUF_G], b[L.MS_BUF_PG] = b[L.MS_BUF_PG], b[L.MS_BUF_G]
             b[L.MS_BUF_D], b[L.MS_BUF_PD] = b[L.MS_BUF_PD], b[L.MS_BUF_D]
 
-    def fetch_scalars(self):
-        return self.scal.copy()
-
     def store_scalars(self, values):
         self.scal[...] = values
 
-    def allgather_rows(self, buffer_id):
-        full = self.buf[buffer_id]
-        mine = full[self.rank * self.rows:(self.rank + 1) * self.rows].clone()
-        self.dist.all_gather_into_tensor(full, mine)
+    def phase_gradient_direction(self, stepper, use_history):
+        self.phase_gradient()
+        self.phase_direction(stepper, use_history)
 
-    def allgather_scalars(self, local):
+    def set_factors_valid(self, valid):
+        pass
+
+    def exchange(self, buffers):
+        """Stand-in for the boundary exchange: owner rows of each buffer -> all ranks (a
+        superset of the boundary rows), scalar headers -> (world, 16)."""
+        for buffer_id in buffers:
+            full = self.buf[buffer_id]
+            mine = full[self.rank * self.rows:(self.rank + 1) * self.rows].clone()
+            self.dist.all_gather_into_tensor(full.view(-1), mine.view(-1))
         out = self.torch.empty(self.world * self.L.MS_NSCAL, dtype=self.torch.float64)
-        self.dist.all_gather_into_tensor(out, self.torch.from_numpy(np.ascontiguousarray(local)))
+        self.dist.all_gather_into_tensor(out, self.torch.from_numpy(np.ascontiguousarray(self.scal)))
         return out.numpy().reshape(self.world, self.L.MS_NSCAL)
 
 
@@ -176,6 +181,7 @@ def _worker(rank, world, port, case, q):
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        case, level = case.split(":")
         P, T = meshgen.icosphere(5)
         P = meshgen.smooth_displace(P, 0.08)
         nv, nf = P.shape[0], T.shape[0]
@@ -183,7 +189,12 @@ def _worker(rank, world, port, case, q):
         fixed = np.zeros(nv, bool)
         fixed[::17] = True
         V0 = 0.97 * float(np.einsum("ij,ij->i", np.cross(P[T[:, 1]], P[T[:, 2]]), P[T[:, 0]]).sum() / 6.0)
-        if case == "cg_bending_volume":
+        if case == "cg_bending":  # no constraint row: fused gradient+direction, direction-only restarts
+            modules = L.MS_MOD_SURFACE | L.MS_MOD_BENDING
+            mods, cons, gp = ["surface", "bending"], [], {"volume_constraint_mode": "lagrange",
+                                                          "volume_projection_during_minimization": False}
+            stepper_id, ref_stepper = L.MS_STEPPER_CG, mp.ConjugateGradient()
+        elif case == "cg_bending_volume":
             modules = L.MS_MOD_SURFACE | L.MS_MOD_BENDING | L.MS_CON_VOLUME
             mods, cons, gp = ["surface", "bending"], ["volume"], {"volume_constraint_mode": "lagrange",
                                                                   "volume_projection_during_minimization": False}
@@ -194,7 +205,7 @@ def _worker(rank, world, port, case, q):
             stepper_id, ref_stepper = L.MS_STEPPER_GD, mp.GradientDescent()
         be = OracleShardBackend(P, T, rank=rank, world=world, dist=dist, modules=modules, kappa=kappa, c0=c0,
                                 gamma=gamma, target_volume=V0, volume_stiffness=30.0, fixed=fixed)
-        drv = ShardedStepper(be, stepper=stepper_id)
+        drv = ShardedStepper(be, stepper=stepper_id, reuse_energy0=int(level))
         step, log = 2e-3, []
         for _ in range(7):
             r = drv.step(step, tol=1e-9)
@@ -232,7 +243,8 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("case", ["cg_bending_volume", "gd_surface_penalty"])
+@pytest.mark.parametrize("case", ["cg_bending_volume:0", "cg_bending_volume:2", "gd_surface_penalty:0",
+                                  "gd_surface_penalty:2", "cg_bending:2"])
 def test_sharded_driver_world2_matches_single_process(case):
     import torch.multiprocessing as tmp
 
