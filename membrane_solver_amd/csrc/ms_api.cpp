@@ -434,7 +434,7 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
   c->tile1 = std::min(t.n_tiles, (shard_rank + 1) * t.tiles_per_shard);
   c->cap = t.T + t.max_halo;
   {
-    const size_t le = energy_lds_bytes(t.T, c->cap, t.max_ent, true, true);
+    const size_t le = energy_lds_bytes(t.T, c->cap, t.max_ent, true, true, true);
     const size_t lg = gradient_lds_bytes(t.T, c->cap, t.max_ent, true, true);
     if (le > 160 * 1024 || lg > 160 * 1024) {
       delete c;
@@ -1084,7 +1084,7 @@ int ms_tile_stats(ms_ctx* c, int64_t* n_tiles, int64_t* facet_instances, int64_t
   if (n_tiles) *n_tiles = t.n_tiles;
   if (facet_instances) *facet_instances = (int64_t)t.tile_facets.size();
   if (max_halo) *max_halo = t.max_halo;
-  if (lds_bytes_energy) *lds_bytes_energy = (int64_t)energy_lds_bytes(t.T, c->cap, t.max_ent, bend, false);
+  if (lds_bytes_energy) *lds_bytes_energy = (int64_t)energy_lds_bytes(t.T, c->cap, t.max_ent, bend, false, c->has_boundary);
   if (lds_bytes_gradient)
     *lds_bytes_gradient = (int64_t)gradient_lds_bytes(t.T, c->cap, t.max_ent, bend,
                                                       (c->params.modules & MS_CON_VOLUME) != 0);

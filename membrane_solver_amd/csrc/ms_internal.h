@@ -126,7 +126,7 @@ struct TiltArgs {
 
 // kernel launchers (ms_kernels.hip).  cap = T + max halo (LDS patch slots),
 // max_ent = largest per-tile vertex->corner entry count.
-size_t energy_lds_bytes(int T, int cap, int max_ent, bool bend, bool guard);
+size_t energy_lds_bytes(int T, int cap, int max_ent, bool bend, bool guard, bool flags);
 size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow);
 hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, hipStream_t s);
 hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStream_t s);

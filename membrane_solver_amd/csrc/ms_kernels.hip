@@ -17,6 +17,8 @@
 // Each device routine cites the reference code it restates (paths relative to
 // the reference checkout).
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 
 #include "ms_internal.h"
 
@@ -212,6 +214,37 @@ __device__ __forceinline__ TileCtx tile_ctx(const DeviceMesh& m, int tile) {
   return t;
 }
 
+// Per-tile CSR words held in registers between "issue" and "commit": every global load of a
+// tile's stage-in is issued before the first LDS write, so the whole prologue costs two HBM
+// round trips (ids/rows/CSR, then the halo rows the ids name) instead of one per array.
+constexpr int CSR_REGS = 12;  // entries per thread held in registers (T=256: 3072 entries)
+struct CsrStage {
+  uint16_t vo0, vo1;  // this vertex's entry range [vo0, vo1) (offset row of the tile)
+  uint16_t e[CSR_REGS];
+};
+__device__ __forceinline__ void csr_issue(CsrStage& r, const DeviceMesh& m, const TileCtx& t, int T,
+                                          int tid) {
+  const uint16_t* gv = m.tile_voff + (size_t)t.tile * (T + 1);
+  r.vo0 = gv[tid];
+  r.vo1 = gv[tid + 1];
+  const uint16_t* ge = m.vent + t.e0;
+#pragma unroll
+  for (int k = 0; k < CSR_REGS; ++k) {
+    const int j = tid + k * T;
+    r.e[k] = j < t.n_ent ? ge[j] : (uint16_t)0;
+  }
+}
+__device__ __forceinline__ void csr_commit(const CsrStage& r, const DeviceMesh& m, const TileCtx& t,
+                                           int T, int tid, uint16_t* vent) {
+#pragma unroll
+  for (int k = 0; k < CSR_REGS; ++k) {
+    const int j = tid + k * T;
+    if (j < t.n_ent) vent[j] = r.e[k];
+  }
+  const uint16_t* ge = m.vent + t.e0;
+  for (int j = tid + CSR_REGS * T; j < t.n_ent; j += T) vent[j] = ge[j];
+}
+
 // ---------------------------------------------------------------------------
 // K_A: energy pass.
 //   scalars (owner facets): E_surface (surface_energy.f90:61-78), body volume
@@ -237,10 +270,13 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_
   double* px = lds;
   double* ox = px + 3 * cap;
   double* stg = ox + (GUARD ? 3 * cap : 0);
-  double* red = stg + (BEND ? 9 * T : 0);
-  uint16_t* voff = reinterpret_cast<uint16_t*>(red + 5 * 16);
-  uint16_t* vent = voff + (BEND ? (T + 2) : 0);
+  // the reduction scratch aliases the staging block (free after the chunk loop's last
+  // barrier); the vertex offsets stay in registers; the flag bytes are staged only when
+  // some vertex carries VF_BOUNDARY
+  double* red = stg;
+  uint16_t* vent = reinterpret_cast<uint16_t*>(stg + (BEND ? 9 * T : 5 * 16));
   uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + (BEND ? ((max_ent + 3) & ~3) : 0));
+  const bool stage_flags = a.m.has_boundary || GUARD;
 
   const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
   const int tid = threadIdx.x;
@@ -262,40 +298,111 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_
     c0_v = a.m.c0[t.v_lo + tid];
   }
 
-  // -- stage this thread's owned row and the halo rows it covers --------------
-  if (tid < t.n_owned) {
-    const size_t g = 3 * (size_t)(t.v_lo + tid);
-    const uint8_t fl = a.m.vflags[t.v_lo + tid];
-    lfl[tid] = fl;
-    const bool mv = have_d && !(fl & VF_FIXED);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const double xo = a.x[g + c];
-      const double xv = mv ? xo + a.alpha * a.d[g + c] : xo;
-      px[c * cap + tid] = xv;
-      if (GUARD) ox[c * cap + tid] = xo;
-      if (a.xt) a.xt[g + c] = xv;
+  uint8_t own_fl = 0;  // this thread's own vertex flags (epilogue)
+  int cur = 0, end = 0;  // this vertex's CSR range, straight from the tile's offset row
+  // -- stage-in: issue every independent load, then the halo rows, then write LDS ------
+  // (the xt store may alias x/d as far as the compiler knows; a store or an LDS write in the
+  // middle would serialise the prologue into one HBM round trip per array)
+  {
+    const bool own = tid < t.n_owned;
+    const int v_own = t.v_lo + tid;
+    const bool has_h = tid < t.nh;
+    int hv = 0;
+    if (has_h) hv = a.m.halo_ids[t.h0 + tid];
+    double xo0 = 0, xo1 = 0, xo2 = 0, dd0 = 0, dd1 = 0, dd2 = 0;
+    uint8_t fl = 0;
+    if (own) {
+      const size_t g = 3 * (size_t)v_own;
+      fl = a.m.vflags[v_own];
+      xo0 = a.x[g];
+      xo1 = a.x[g + 1];
+      xo2 = a.x[g + 2];
+      if (have_d) {
+        dd0 = a.d[g];
+        dd1 = a.d[g + 1];
+        dd2 = a.d[g + 2];
+      }
     }
-  }
-  for (int h = tid; h < t.nh; h += T) {
-    const int v = a.m.halo_ids[t.h0 + h];
-    const uint8_t fl = a.m.vflags[v];
-    const int s = t.n_owned + h;
-    lfl[s] = fl;
-    const bool mv = have_d && !(fl & VF_FIXED);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const double xo = a.x[3 * (size_t)v + c];
-      px[c * cap + s] = mv ? xo + a.alpha * a.d[3 * (size_t)v + c] : xo;
-      if (GUARD) ox[c * cap + s] = xo;
+    CsrStage cs;
+    if (BEND) csr_issue(cs, a.m, t, T, tid);
+    own_fl = fl;
+    // second round trip: the halo row this thread covers
+    double h0 = 0, h1 = 0, h2 = 0, e0 = 0, e1 = 0, e2 = 0;
+    uint8_t hfl = 0;
+    if (has_h) {
+      const size_t g = 3 * (size_t)hv;
+      hfl = a.m.vflags[hv];
+      h0 = a.x[g];
+      h1 = a.x[g + 1];
+      h2 = a.x[g + 2];
+      if (have_d) {
+        e0 = a.d[g];
+        e1 = a.d[g + 1];
+        e2 = a.d[g + 2];
+      }
     }
-  }
-  if (BEND) {
-    const uint16_t* gv = a.m.tile_voff + (size_t)t.tile * (T + 1);
-    voff[tid] = gv[tid];
-    if (tid == 0) voff[T] = gv[T];
-    const uint16_t* ge = a.m.vent + t.e0;
-    for (int j = tid; j < t.n_ent; j += T) vent[j] = ge[j];
+    if (own) {
+      const size_t g = 3 * (size_t)v_own;
+      const bool mv = have_d && !(fl & VF_FIXED);
+      const double x0 = mv ? xo0 + a.alpha * dd0 : xo0;
+      const double x1 = mv ? xo1 + a.alpha * dd1 : xo1;
+      const double x2 = mv ? xo2 + a.alpha * dd2 : xo2;
+      if (stage_flags) lfl[tid] = fl;
+      px[tid] = x0;
+      px[cap + tid] = x1;
+      px[2 * cap + tid] = x2;
+      if (GUARD) {
+        ox[tid] = xo0;
+        ox[cap + tid] = xo1;
+        ox[2 * cap + tid] = xo2;
+      }
+      if (a.xt) {
+        a.xt[g] = x0;
+        a.xt[g + 1] = x1;
+        a.xt[g + 2] = x2;
+      }
+    }
+    if (BEND) {
+      csr_commit(cs, a.m, t, T, tid, vent);
+      cur = cs.vo0;
+      end = cs.vo1;
+    }
+    if (has_h) {
+      const int s = t.n_owned + tid;
+      const bool mv = have_d && !(hfl & VF_FIXED);
+      if (stage_flags) lfl[s] = hfl;
+      px[s] = mv ? h0 + a.alpha * e0 : h0;
+      px[cap + s] = mv ? h1 + a.alpha * e1 : h1;
+      px[2 * cap + s] = mv ? h2 + a.alpha * e2 : h2;
+      if (GUARD) {
+        ox[s] = h0;
+        ox[cap + s] = h1;
+        ox[2 * cap + s] = h2;
+      }
+    }
+    for (int h = tid + T; h < t.nh; h += T) {  // halo longer than the workgroup (small tiles)
+      const int v = a.m.halo_ids[t.h0 + h];
+      const size_t g = 3 * (size_t)v;
+      const uint8_t f2 = a.m.vflags[v];
+      const double q0 = a.x[g], q1 = a.x[g + 1], q2 = a.x[g + 2];
+      double r0 = 0, r1 = 0, r2 = 0;
+      if (have_d) {
+        r0 = a.d[g];
+        r1 = a.d[g + 1];
+        r2 = a.d[g + 2];
+      }
+      const int s = t.n_owned + h;
+      const bool mv = have_d && !(f2 & VF_FIXED);
+      if (stage_flags) lfl[s] = f2;
+      px[s] = mv ? q0 + a.alpha * r0 : q0;
+      px[cap + s] = mv ? q1 + a.alpha * r1 : q1;
+      px[2 * cap + s] = mv ? q2 + a.alpha * r2 : q2;
+      if (GUARD) {
+        ox[s] = q0;
+        ox[cap + s] = q1;
+        ox[2 * cap + s] = q2;
+      }
+    }
   }
   __syncthreads();
 
@@ -304,11 +411,7 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_
   const bool want_vol = a.modules & (MS_MOD_VOLUME_PENALTY | MS_CON_VOLUME | MS_TRACK_VOLUME);
   // vertex accumulators (BEND): K(3), A_vor, A_eff
   double aKx = 0, aKy = 0, aKz = 0, aAv = 0, aAe = 0;
-  int cur = 0, end = 0;
-  if (BEND && tid < t.n_owned) {
-    cur = voff[tid];
-    end = voff[tid + 1];
-  }
+  if (!(BEND && tid < t.n_owned)) cur = end = 0;
   const int ent_begin = cur;
 
   for (int c0 = t.f0; c0 < t.f1; c0 += T) {
@@ -424,7 +527,7 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_
     const int v = t.v_lo + tid;
     const V3 K = mk(aKx, aKy, aKz);
     const double kappa = kappa_v, c0 = c0_v;
-    const bool interior = !(lfl[tid] & VF_BOUNDARY);
+    const bool interior = !(own_fl & VF_BOUNDARY);
     const double safe = fmax(aAv, 1.0e-12);
     const double k_mag = norm(K);
     const double H = k_mag / (2.0 * safe);
@@ -488,11 +591,12 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_
   }
 }
 
-static size_t u16_bytes(int T, int max_ent) { return 2 * ((size_t)T + 2 + ((max_ent + 3) & ~3)); }
+static size_t u16_bytes(int T, int max_ent) { return 2 * ((size_t)((max_ent + 3) & ~3)); }
 
-size_t energy_lds_bytes(int T, int cap, int max_ent, bool bend, bool guard) {
-  size_t d = 3 * (size_t)cap + (guard ? 3 * (size_t)cap : 0) + (bend ? 9 * (size_t)T : 0) + 5 * 16;
-  return d * sizeof(double) + (bend ? u16_bytes(T, max_ent) : 0) + (((size_t)cap + 15) / 16) * 16;
+size_t energy_lds_bytes(int T, int cap, int max_ent, bool bend, bool guard, bool flags) {
+  size_t d = 3 * (size_t)cap + (guard ? 3 * (size_t)cap : 0) + (bend ? 9 * (size_t)T : 5 * 16);
+  return d * sizeof(double) + (bend ? u16_bytes(T, max_ent) : 0) +
+         ((flags || guard) ? (((size_t)cap + 15) / 16) * 16 : 0);
 }
 
 template <typename K>
@@ -511,7 +615,7 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
   if (nb <= 0) return hipSuccess;
   const bool bend = (a.modules & MS_MOD_BENDING) != 0;
   const bool fast = a.m.T == FAST_T;
-  const size_t lds = energy_lds_bytes(a.m.T, cap, max_ent, bend, guard);
+  const size_t lds = energy_lds_bytes(a.m.T, cap, max_ent, bend, guard, a.m.has_boundary != 0);
   hipError_t e;
 #define MS_LAUNCH_E(B, G, TT, CC)                                                                     \
   do {                                                                                                \
@@ -562,8 +666,7 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
   double* fav = fae + (BEND ? cap : 0);
   double* stg = fav + (BEND ? cap : 0);
   double* red = stg + (VOLROW ? 18 : 9) * T;
-  uint16_t* voff = reinterpret_cast<uint16_t*>(red + 3 * 16);
-  uint16_t* vent = voff + (T + 2);
+  uint16_t* vent = reinterpret_cast<uint16_t*>(red + 3 * 16);
   uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + ((max_ent + 3) & ~3));
 
   const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
@@ -576,39 +679,92 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
     gam_nx = a.m.tf_gamma[t.f0 + tid];
   }
 
-  if (tid < t.n_owned) {
-    const size_t g = 3 * (size_t)(t.v_lo + tid);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      px[c * cap + tid] = a.x[g + c];
-      if (BEND) fk[c * cap + tid] = a.fK[g + c];
-    }
-    lfl[tid] = a.m.vflags[t.v_lo + tid];
-    if (BEND) {
-      fae[tid] = a.fA[2 * (size_t)(t.v_lo + tid)];
-      fav[tid] = a.fA[2 * (size_t)(t.v_lo + tid) + 1];
-    }
-  }
-  for (int h = tid; h < t.nh; h += T) {
-    const int v = a.m.halo_ids[t.h0 + h];
-    const int s = t.n_owned + h;
-    lfl[s] = a.m.vflags[v];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      px[c * cap + s] = a.x[3 * (size_t)v + c];
-      if (BEND) fk[c * cap + s] = a.fK[3 * (size_t)v + c];
-    }
-    if (BEND) {
-      fae[s] = a.fA[2 * (size_t)v];
-      fav[s] = a.fA[2 * (size_t)v + 1];
-    }
-  }
+  int cur = 0, end = 0;  // this vertex's CSR range
+  // -- stage-in: all independent loads first, then the halo rows, then the LDS writes --
   {
-    const uint16_t* gv = a.m.tile_voff + (size_t)t.tile * (T + 1);
-    voff[tid] = gv[tid];
-    if (tid == 0) voff[T] = gv[T];
-    const uint16_t* ge = a.m.vent + t.e0;
-    for (int j = tid; j < t.n_ent; j += T) vent[j] = ge[j];
+    const bool own = tid < t.n_owned;
+    const int v_own = t.v_lo + tid;
+    const bool has_h = tid < t.nh;
+    int hv = 0;
+    if (has_h) hv = a.m.halo_ids[t.h0 + tid];
+    double x0 = 0, x1 = 0, x2 = 0, k0 = 0, k1 = 0, k2 = 0, ae = 0, av = 0;
+    uint8_t fl = 0;
+    if (own) {
+      const size_t g = 3 * (size_t)v_own;
+      fl = a.m.vflags[v_own];
+      x0 = a.x[g];
+      x1 = a.x[g + 1];
+      x2 = a.x[g + 2];
+      if (BEND) {
+        k0 = a.fK[g];
+        k1 = a.fK[g + 1];
+        k2 = a.fK[g + 2];
+        ae = a.fA[2 * (size_t)v_own];
+        av = a.fA[2 * (size_t)v_own + 1];
+      }
+    }
+    CsrStage cs;
+    csr_issue(cs, a.m, t, T, tid);
+    double hx0 = 0, hx1 = 0, hx2 = 0, hk0 = 0, hk1 = 0, hk2 = 0, hae = 0, hav = 0;
+    uint8_t hfl = 0;
+    if (has_h) {
+      const size_t g = 3 * (size_t)hv;
+      hfl = a.m.vflags[hv];
+      hx0 = a.x[g];
+      hx1 = a.x[g + 1];
+      hx2 = a.x[g + 2];
+      if (BEND) {
+        hk0 = a.fK[g];
+        hk1 = a.fK[g + 1];
+        hk2 = a.fK[g + 2];
+        hae = a.fA[2 * (size_t)hv];
+        hav = a.fA[2 * (size_t)hv + 1];
+      }
+    }
+    if (own) {
+      lfl[tid] = fl;
+      px[tid] = x0;
+      px[cap + tid] = x1;
+      px[2 * cap + tid] = x2;
+      if (BEND) {
+        fk[tid] = k0;
+        fk[cap + tid] = k1;
+        fk[2 * cap + tid] = k2;
+        fae[tid] = ae;
+        fav[tid] = av;
+      }
+    }
+    csr_commit(cs, a.m, t, T, tid, vent);
+    cur = cs.vo0;
+    end = cs.vo1;
+    if (has_h) {
+      const int s = t.n_owned + tid;
+      lfl[s] = hfl;
+      px[s] = hx0;
+      px[cap + s] = hx1;
+      px[2 * cap + s] = hx2;
+      if (BEND) {
+        fk[s] = hk0;
+        fk[cap + s] = hk1;
+        fk[2 * cap + s] = hk2;
+        fae[s] = hae;
+        fav[s] = hav;
+      }
+    }
+    for (int h = tid + T; h < t.nh; h += T) {  // halo longer than the workgroup (small tiles)
+      const int v = a.m.halo_ids[t.h0 + h];
+      const int s = t.n_owned + h;
+      lfl[s] = a.m.vflags[v];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        px[c * cap + s] = a.x[3 * (size_t)v + c];
+        if (BEND) fk[c * cap + s] = a.fK[3 * (size_t)v + c];
+      }
+      if (BEND) {
+        fae[s] = a.fA[2 * (size_t)v];
+        fav[s] = a.fA[2 * (size_t)v + 1];
+      }
+    }
   }
   __syncthreads();
 
@@ -618,11 +774,7 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
   if (volpen) pen_factor = a.volume_stiffness * (a.scal[MS_S_VOL] - a.target_volume) / 6.0;
 
   double gx = 0, gy = 0, gz = 0, cx = 0, cy = 0, cz = 0;
-  int cur = 0, end = 0;
-  if (tid < t.n_owned) {
-    cur = voff[tid];
-    end = voff[tid + 1];
-  }
+  if (tid >= t.n_owned) cur = end = 0;
 
   for (int c0f = t.f0; c0f < t.f1; c0f += T) {
     const int p = c0f + tid;
