@@ -29,6 +29,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reference", default="/root/reference")
 ap.add_argument("--fortran-dir", default="/tmp/fprobe/f2py_try")
 ap.add_argument("--only-tilt", action="store_true")
+ap.add_argument("--only-bt", action="store_true", help="bending_tilt + tilt relaxation vectors only")
 args = ap.parse_args()
 
 sys.dont_write_bytecode = True
@@ -414,12 +415,172 @@ def gen_tilt_trajectory():
     print("traj_ico4_gd_surface_tilt.npz E_final=%.16g" % out["E_final"], out["step_log"][:, 0])
 
 
+# ---------------------------------------------------------------------------
+# (d) bending_tilt (modules/energy/bending_tilt.py) and nested tilt relaxation
+#     (runtime/steppers/tilt_relaxation.py:237-424), single tilt field
+# ---------------------------------------------------------------------------
+def _tangent_tilts(m, rng, scale):
+    pos = m.positions_view()
+    tl = scale * rng.normal(size=pos.shape)
+    nrm = m.vertex_normals(pos)
+    return tl - np.einsum("ij,ij->i", tl, nrm)[:, None] * nrm
+
+
+def gen_bending_tilt_cases():
+    from modules.energy import bending_tilt
+    from runtime.preconditioners import build_tilt_cg_preconditioner
+
+    out = {"meta_fortran": META}
+    rng = np.random.default_rng(33)
+    meshes = {}
+    P, T = meshgen.icosphere(5)
+    P = meshgen.smooth_displace(P, 0.08) + 4e-3 * rng.normal(size=P.shape)
+    meshes["ico5"] = (P, T)
+    Pd, Td, _isb = meshgen.disk_patch(5, bulge=0.35, jitter=0.03, seed=5)
+    meshes["disk5"] = (Pd, Td)
+    for name, (P, T) in meshes.items():
+        for mode in ("analytic", "approx"):
+            gp = {"surface_tension": 1.0, "bending_modulus": 1.3, "spontaneous_curvature": 0.2,
+                  "bending_energy_model": "helfrich", "bending_gradient_mode": mode, "tilt_rigidity": 2.0}
+            m = build_mesh(P, T, gp)
+            pos, tri, isb, fixed = mesh_arrays(m)
+            tl = _tangent_tilts(m, np.random.default_rng(7), 0.25)
+            res = ParameterResolver(m.global_parameters)
+            g = np.zeros_like(pos)
+            tg = np.zeros_like(pos)
+            E = bending_tilt.compute_energy_and_gradient_array(
+                m, m.global_parameters, res, positions=pos, index_map=m.vertex_index_to_row,
+                grad_arr=g, tilts=tl, tilt_grad_arr=tg)
+            tg2 = np.zeros_like(pos)
+            E2 = bending_tilt.compute_energy_and_gradient_array(
+                m, m.global_parameters, res, positions=pos, index_map=m.vertex_index_to_row,
+                grad_arr=None, tilts=tl, tilt_grad_arr=tg2)
+            k = f"{name}_{mode}"
+            out[k + "_E"] = np.array(E)
+            out[k + "_E_tiltonly"] = np.array(E2)
+            out[k + "_grad"] = g
+            out[k + "_tilt_grad"] = tg
+            out[k + "_tilt_grad_tiltonly"] = tg2
+            if mode == "analytic":
+                out[name + "_positions"] = pos
+                out[name + "_tri"] = tri
+                out[name + "_is_boundary"] = isb
+                out[name + "_tilts"] = tl
+                em = EnergyModuleManager(["tilt", "bending_tilt"])
+                mz = Minimizer(m, m.global_parameters, GradientDescent(), em, ConstraintModuleManager([]),
+                               quiet=True)
+                M_inv = build_tilt_cg_preconditioner(
+                    m, mz.param_resolver, mz.energy_context(), positions=pos,
+                    index_map=m.vertex_index_to_row, fixed_mask=np.zeros(len(pos), bool))
+                out[name + "_jacobi_Minv"] = M_inv
+            print(k, "E=%.16g" % E)
+    np.savez_compressed(os.path.join(OUT, "bending_tilt_cases.npz"), **out)
+
+
+def run_tilt_trajectory(fname, P, T, gp, mods, stepper, n_steps, step_size, tilt_scale=0.3, seed=21,
+                        tilt_fixed_every=0):
+    mm = build_mesh(P, T, gp)
+    rng = np.random.default_rng(seed)
+    tl = _tangent_tilts(mm, rng, tilt_scale)
+    mm.set_tilts_from_array(tl)
+    tfix = np.zeros(len(P), bool)
+    if tilt_fixed_every:
+        tfix[::tilt_fixed_every] = True
+        for i in np.flatnonzero(tfix):
+            mm.vertices[int(i)].tilt_fixed = True
+    mm.energy_modules = list(mods)
+    mm.constraint_modules = []
+    tilt_snaps = []
+    em = EnergyModuleManager(mm.energy_modules)
+    cm = ConstraintModuleManager(mm.constraint_modules)
+    mz = Minimizer(mm, mm.global_parameters, stepper, em, cm, quiet=True, step_size=step_size)
+    pos0, tri, isb, fixed = mesh_arrays(mm)
+    log = []
+    orig_step = stepper.step
+
+    def logged_step(*a, **kw):
+        r = orig_step(*a, **kw)
+        log.append((float(bool(r[0])), float(r[1]), float(r[2])))
+        return r
+
+    stepper.step = logged_step
+    snaps = []
+
+    def cb(mesh, i):
+        snaps.append(mesh.positions_view().copy())
+        tilt_snaps.append(np.ascontiguousarray(mesh.tilts_view()).copy())
+
+    E0, g0 = mz.compute_energy_and_gradient_array()
+    res = mz.minimize(n_steps, callback=cb)
+    out = {"meta_fortran": META, "positions0": pos0, "tri": tri, "is_boundary": isb, "fixed": fixed,
+           "tilt_fixed": tfix, "gamma": mm.get_facet_parameter_array("surface_tension").copy(),
+           "E0": np.array(E0), "grad0": np.array(g0), "tilts0": tl,
+           "positions_iter": np.array(snaps), "tilts_iter": np.array(tilt_snaps),
+           "positions_final": mm.positions_view().copy(),
+           "tilts_final": np.ascontiguousarray(mm.tilts_view()).copy(),
+           "step_log": np.array(log), "E_final": np.array(res["energy"]),
+           "n_steps": np.array(n_steps), "step_size0": np.array(step_size)}
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, "E_final=%.16g" % out["E_final"], out["step_log"][:, 0])
+
+
+def gen_bending_tilt_trajectories():
+    base = {"surface_tension": 1.0, "bending_modulus": 1.0, "spontaneous_curvature": 0.1,
+            "bending_energy_model": "helfrich", "bending_gradient_mode": "analytic",
+            "tilt_rigidity": 2.5, "volume_constraint_mode": "lagrange",
+            "volume_projection_during_minimization": False, "mesh_quality_auto_repair_enabled": False}
+    P, T = meshgen.icosphere(4)
+    P = meshgen.smooth_displace(P, 0.08)
+    # tilts fixed (only re-projected), shape steps feel the tilt-splay coupling
+    run_tilt_trajectory("traj_ico4_gd_bt_fixed.npz", P, T, dict(base, tilt_solve_mode="fixed"),
+                        ["surface", "tilt", "bending_tilt"], GradientDescent(), 5, 1e-3)
+    # nested tilt relaxation, preconditioned CG inner solve
+    run_tilt_trajectory("traj_ico4_gd_bt_nested_cg.npz", P, T,
+                        dict(base, tilt_solve_mode="nested", tilt_solver="cg", tilt_step_size=0.1,
+                             tilt_inner_steps=6, tilt_tol=1e-10),
+                        ["surface", "tilt", "bending_tilt"], GradientDescent(), 5, 1e-3)
+    # nested, gradient-descent inner solve, CG shape stepper, some tilts pinned
+    run_tilt_trajectory("traj_ico4_cg_bt_nested_gd.npz", P, T,
+                        dict(base, tilt_solve_mode="nested", tilt_solver="gd", tilt_step_size=0.08,
+                             tilt_inner_steps=4),
+                        ["surface", "tilt", "bending_tilt"], ConjugateGradient(), 6, 1e-3, tilt_fixed_every=9)
+    # open patch with boundary: coupled mode, CG inner solve without preconditioner
+    Pd, Td, isb = meshgen.disk_patch(5, bulge=0.35, jitter=0.02, seed=5)
+    gpd = dict(base, tilt_solve_mode="coupled", tilt_solver="cg", tilt_cg_preconditioner="none",
+               tilt_step_size=0.1, tilt_coupled_steps=3, bending_modulus=0.8)
+    # boundary vertices are held (fixed positions), like the reference's open-patch decks
+    run_tilt_trajectory_disk("traj_disk5_gd_bt_coupled.npz", Pd, Td, gpd, np.asarray(isb, bool).copy())
+
+
+def run_tilt_trajectory_disk(fname, P, T, gp, fixed):
+    """Same as run_tilt_trajectory with fixed boundary positions."""
+    global build_mesh
+    orig = build_mesh
+
+    def bm(P_, T_, gp_, fixed=None, tilts=None):
+        return orig(P_, T_, gp_, fixed=fixed_mask, tilts=tilts)
+
+    fixed_mask = fixed
+    build_mesh = bm
+    try:
+        run_tilt_trajectory(fname, P, T, gp, ["surface", "tilt", "bending_tilt"], GradientDescent(), 5, 1e-3,
+                            tilt_scale=0.2, seed=4)
+    finally:
+        build_mesh = orig
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if "--only-tilt" in sys.argv:
         gen_tilt_trajectory()
         sys.exit(0)
+    if "--only-bt" in sys.argv:
+        gen_bending_tilt_cases()
+        gen_bending_tilt_trajectories()
+        sys.exit(0)
     gen_kernel_cases()
     gen_mesh_cases()
     gen_trajectories()
     gen_tilt_trajectory()
+    gen_bending_tilt_cases()
+    gen_bending_tilt_trajectories()

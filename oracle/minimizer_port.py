@@ -28,7 +28,8 @@ class Problem:
     c0: np.ndarray | None = None
     is_boundary: np.ndarray | None = None  # (nv,) bool, mesh.boundary_vertex_ids
     fixed: np.ndarray | None = None  # (nv,) bool, mesh.fixed_mask
-    tilts: np.ndarray | None = None  # (nv,3) mesh.tilts_view() (tilt module)
+    tilts: np.ndarray | None = None  # (nv,3) mesh.tilts_view() (tilt / bending_tilt modules)
+    tilt_fixed: np.ndarray | None = None  # (nv,) bool, vertex.tilt_fixed (minimizer_helpers.py:49-75)
     energy_modules: list = field(default_factory=lambda: ["surface"])
     constraint_modules: list = field(default_factory=list)
     body_rows: np.ndarray | None = None  # None = all facets in one body
@@ -56,6 +57,9 @@ class Problem:
         self.fixed = np.asarray(self.fixed, dtype=bool)
         if self.tilts is not None:
             self.tilts = np.ascontiguousarray(self.tilts, dtype=np.float64).copy()
+        if self.tilt_fixed is None:
+            self.tilt_fixed = np.zeros(nv, dtype=bool)
+        self.tilt_fixed = np.asarray(self.tilt_fixed, dtype=bool)
 
     # -- parameter helpers (modules/energy/bending_params.py:19-33) ----------
     @property
@@ -100,6 +104,10 @@ def energy_and_gradient(p: Problem, pos: np.ndarray):
             k_t = float(p.gp.get("tilt_rigidity", 0.0) or 0.0)
             if k_t != 0.0:
                 E += orc.tilt_energy_and_gradient(pos, p.tilts, p.tri, k_t, grad, None)
+        elif name == "bending_tilt":
+            # modules/energy/bending_tilt.py:151-482 (always the Helfrich form, :212-215)
+            E += orc.bending_tilt_energy_and_gradient(pos, p.tilts, p.tri, p.kappa, p.c0, p.is_boundary,
+                                                      mode=p.grad_mode, grad=grad)
         else:
             raise ValueError(f"module {name!r} is outside the hot-path scope")
     # constraint_manager.apply_gradient_modifications_array (k == 1 dense branch :293-301)
@@ -135,9 +143,187 @@ def energy_total(p: Problem, pos: np.ndarray, tilts=None) -> float:
             k_t = float(p.gp.get("tilt_rigidity", 0.0) or 0.0)
             if k_t != 0.0:
                 E += orc.tilt_energy_and_gradient(pos, tilts, p.tri, k_t, None, None)
+        elif name == "bending_tilt":
+            E += orc.bending_tilt_energy_and_gradient(pos, tilts, p.tri, p.kappa, p.c0, p.is_boundary)
         else:
             raise ValueError(name)
     return float(E)
+
+
+TILT_MODULES = ("tilt", "bending_tilt")  # modules with USES_TILT = True in scope
+
+
+# runtime/evaluation_manager.py:386-462 (energy of the USES_TILT modules + dense tilt gradient)
+def energy_and_tilt_gradient(p: Problem, pos: np.ndarray, tilts: np.ndarray):
+    tg = np.zeros_like(pos)
+    E = 0.0
+    for name in p.energy_modules:
+        if name == "tilt":
+            k_t = float(p.gp.get("tilt_rigidity", 0.0) or 0.0)
+            if k_t != 0.0:
+                E += orc.tilt_energy_and_gradient(pos, tilts, p.tri, k_t, None, tg)
+        elif name == "bending_tilt":
+            E += orc.bending_tilt_energy_and_gradient(pos, tilts, p.tri, p.kappa, p.c0, p.is_boundary,
+                                                      tilt_grad=tg)
+    return float(E), tg
+
+
+# runtime/evaluation_manager.py:303-384 compute_energy_array_with_tilts
+def tilt_dependent_energy(p: Problem, pos: np.ndarray, tilts: np.ndarray) -> float:
+    E = 0.0
+    for name in p.energy_modules:
+        if name == "tilt":
+            k_t = float(p.gp.get("tilt_rigidity", 0.0) or 0.0)
+            if k_t != 0.0:
+                E += orc.tilt_energy_and_gradient(pos, tilts, p.tri, k_t, None, None)
+        elif name == "bending_tilt":
+            E += orc.bending_tilt_energy_and_gradient(pos, tilts, p.tri, p.kappa, p.c0, p.is_boundary)
+    return float(E)
+
+
+def unit_vertex_normals(pos: np.ndarray, tri: np.ndarray) -> np.ndarray:
+    """geometry/triangle_ops.py:55-73 (normalised where the length is >= 1e-12)."""
+    tn = np.cross(pos[tri[:, 1]] - pos[tri[:, 0]], pos[tri[:, 2]] - pos[tri[:, 0]])
+    normals = np.zeros_like(pos)
+    np.add.at(normals, tri[:, 0], tn)
+    np.add.at(normals, tri[:, 1], tn)
+    np.add.at(normals, tri[:, 2], tn)
+    lens = np.linalg.norm(normals, axis=1)
+    mask = lens >= 1e-12
+    normals[mask] /= lens[mask][:, None]
+    return normals
+
+
+# runtime/preconditioners.py:15-59 (tilt_rigidity term only; tilt_smoothness is out of scope)
+def tilt_cg_preconditioner(p: Problem, pos: np.ndarray, fixed_mask: np.ndarray) -> np.ndarray:
+    nv = pos.shape[0]
+    diag = np.zeros(nv)
+    k_t = float(p.gp.get("tilt_rigidity", 0.0) or 0.0)
+    if k_t != 0.0 and p.tri.shape[0]:
+        tri = p.tri
+        n = np.cross(pos[tri[:, 1]] - pos[tri[:, 0]], pos[tri[:, 2]] - pos[tri[:, 0]])
+        thirds = 0.5 * np.linalg.norm(n, axis=1) / 3.0
+        va = np.zeros(nv)
+        for kcol in range(3):
+            np.add.at(va, tri[:, kcol], thirds)
+        diag += k_t * va
+    if float(p.gp.get("tilt_smoothness_rigidity", 0.0) or 0.0) != 0.0:
+        raise ValueError("tilt_smoothness is outside the hot-path scope")
+    diag = np.where(diag > 1e-12, diag, 1.0)
+    diag[fixed_mask] = 1.0
+    return 1.0 / diag
+
+
+# runtime/steppers/tilt_relaxation.py:237-424 relax_tilts (positions frozen)
+def relax_tilts(p: Problem, pos: np.ndarray) -> dict:
+    stats = {"iters": 0, "evals": 0}
+    mode = str(p.gp.get("tilt_solve_mode", "fixed") or "").strip().lower()
+    if mode in ("", "none", "off", "false", "fixed") or mode not in ("nested", "coupled"):
+        return stats
+    step_size = float(p.gp.get("tilt_step_size", 0.0) or 0.0)
+    if step_size <= 0.0:
+        return stats
+    tol = float(p.gp.get("tilt_tol", 0.0) or 0.0)
+    if tol <= 0.0:
+        tol = 0.0
+    if mode == "nested":
+        n_inner = int(p.gp.get("tilt_inner_steps", 0) or 0)
+    else:
+        n_inner = int(p.gp.get("tilt_coupled_steps", p.gp.get("tilt_inner_steps", 0)) or 0)
+    if n_inner <= 0:
+        return stats
+    solver = str(p.gp.get("tilt_solver", "cg") or "cg").strip().lower()
+    if solver not in ("gd", "cg"):
+        solver = "gd"
+    if solver == "cg":
+        max_iters = int(p.gp.get("tilt_cg_max_iters", n_inner) or 0)
+        if max_iters <= 0:
+            return stats
+    else:
+        max_iters = n_inner
+    fixed = p.tilt_fixed
+    if not np.any(~fixed):
+        return stats
+    normals = unit_vertex_normals(pos, p.tri)
+
+    def project(t):
+        return t - np.einsum("ij,ij->i", t, normals)[:, None] * normals
+
+    tilts = project(p.tilts.copy())
+    fixed_vals = tilts[fixed].copy() if np.any(fixed) else None
+
+    def trial_of(base, step, direction):
+        t = project(base + step * direction)
+        if fixed_vals is not None:
+            t[fixed] = fixed_vals
+        return t
+
+    def grad_at(t):
+        E, tg = energy_and_tilt_gradient(p, pos, t)
+        stats["evals"] += 1
+        tg[fixed] = 0.0
+        return E, tg, float(np.linalg.norm(tg[~fixed]))
+
+    if solver == "gd":
+        for _ in range(max_iters):
+            E0, tg, gnorm = grad_at(tilts)
+            if gnorm == 0.0 or (tol > 0.0 and gnorm < tol):
+                break
+            step, accepted = step_size, False
+            for _bt in range(12):
+                trial = trial_of(tilts, -step, tg)
+                E1 = tilt_dependent_energy(p, pos, trial)
+                stats["evals"] += 1
+                if E1 <= E0:
+                    tilts, accepted = trial, True
+                    break
+                step *= 0.5
+                if step < 1e-16:
+                    break
+            stats["iters"] += 1
+            if not accepted:
+                break
+    else:
+        pre = str(p.gp.get("tilt_cg_preconditioner", "jacobi") or "jacobi").strip().lower()
+        M_inv = tilt_cg_preconditioner(p, pos, fixed) if pre == "jacobi" else None
+        E0, tg, gnorm = grad_at(tilts)
+        if gnorm == 0.0 or (tol > 0.0 and gnorm < tol):
+            p.tilts = tilts
+            return stats
+        residual = -tg
+        z = residual * M_inv[:, None] if M_inv is not None else residual
+        direction = z.copy()
+        rz_old = float(np.sum(residual * z))
+        for _ in range(max_iters):
+            if gnorm == 0.0 or (tol > 0.0 and gnorm < tol):
+                break
+            step, accepted = step_size, False
+            for _bt in range(12):
+                trial = trial_of(tilts, step, direction)
+                E1 = tilt_dependent_energy(p, pos, trial)
+                stats["evals"] += 1
+                if E1 <= E0:
+                    tilts, E0, accepted = trial, E1, True
+                    break
+                step *= 0.5
+                if step < 1e-16:
+                    break
+            stats["iters"] += 1
+            if not accepted:
+                break
+            E0, tg, gnorm = grad_at(tilts)
+            if gnorm == 0.0 or (tol > 0.0 and gnorm < tol):
+                break
+            residual = -tg
+            z = residual * M_inv[:, None] if M_inv is not None else residual
+            rz_new = float(np.sum(residual * z))
+            if rz_old == 0.0:
+                break
+            beta = rz_new / rz_old
+            direction = z + beta * direction
+            rz_old = rz_new
+    p.tilts = tilts
+    return stats
 
 
 # geometry/mesh.py:788-814 project_tilts_to_tangent with the unit vertex normals of
@@ -254,7 +440,8 @@ def line_search(p: Problem, direction, gradient, step_size, *, max_iter=10, beta
             trial = enforcer(trial)
         # vertex-tilt modules: the trial energy uses the tilts projected onto the TRIAL
         # surface's tangent planes, without storing them (minimizer.py:723-733)
-        E_t = energy_total(p, trial, tilts=projected_tilts(p, trial) if "tilt" in p.energy_modules else None)
+        E_t = energy_total(p, trial, tilts=projected_tilts(p, trial)
+                           if any(m in p.energy_modules for m in TILT_MODULES) else None)
         trials += 1
         if E_t <= energy0 + c * alpha * g_dot_d:
             p.positions = trial
@@ -353,6 +540,8 @@ def minimize(p: Problem, stepper, n_steps: int, step_size: float = 1e-3, tol: fl
     step_success = True
     grad = None
     for i in range(n_steps):
+        if p.tilts is not None:
+            relax_tilts(p, p.positions)  # minimizer.py:1237-1307 (single tilt field)
         E, grad = energy_and_gradient(p, p.positions)
         grad_norm = float(np.linalg.norm(grad))
         if grad_norm < tol:

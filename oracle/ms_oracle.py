@@ -254,3 +254,61 @@ def tilt_energy_and_gradient(pos, tilts, tri, k_tilt, grad=None, tilt_grad=None)
         _pi(tri), ctypes.c_double(k_tilt), _pd(grad), _pd(tilt_grad), ctypes.byref(E),
     )
     return float(E.value)
+
+
+# --- bending + tilt-splay coupling ------------------------------------------------
+def bending_tilt_energy_and_gradient(pos, tilts, tri, kappa, c0, is_boundary, *, mode="analytic",
+                                     grad=None, tilt_grad=None) -> float:
+    """modules/energy/bending_tilt.py:151-482: E = 1/2 sum_f sum_k kappa_k (2H_k - c0_k + div_f t)^2
+    va_eff[f,k] on the bending module's discretisation; shape gradient = bending back-propagation
+    with term -> base + div_eff (div treated as constant in x, :24-28), tilt gradient exact.
+    Composition of the C oracle's kernels; the per-vertex / per-corner arithmetic is NumPy."""
+    pos, tilts, tri = _f64(pos), _f64(tilts), _i32(tri)
+    nv = pos.shape[0]
+    kappa, c0 = _f64(kappa, (nv,)), _f64(c0, (nv,))
+    isb = np.asarray(is_boundary, dtype=bool)
+    if tri.shape[0] == 0:
+        return 0.0
+    k_vecs, A_vor, weights = compute_curvature_data(pos, tri)          # :170-172
+    div_tri, _area, g0, g1, g2 = p1_triangle_divergence(pos, tilts, tri)  # :194-205
+    A_eff, va_eff = effective_areas(pos, tri, weights, isb)              # :208-210
+    safe = np.maximum(A_vor, 1e-12)
+    k_mag = np.linalg.norm(k_vecs, axis=1)
+    H = k_mag / (2.0 * safe)
+    ratio = np.zeros_like(A_eff)
+    m = safe > 1e-15
+    ratio[m] = A_eff[m] / safe[m]
+    base = (2.0 * H) - c0
+    base[isb] = 0.0
+    term_tri = base[tri] + div_tri[:, None]
+    kappa_tri = kappa[tri]
+    E = float(0.5 * np.sum(kappa_tri * term_tri**2 * va_eff))           # :236-239
+    if tilt_grad is not None:                                           # :438-448 / :258-268
+        f = np.sum(kappa_tri * term_tri * va_eff, axis=1)[:, None]
+        np.add.at(tilt_grad, tri[:, 0], f * g0)
+        np.add.at(tilt_grad, tri[:, 1], f * g1)
+        np.add.at(tilt_grad, tri[:, 2], f * g2)
+    if grad is None:
+        return E
+    num = np.zeros(nv)                                                   # :243-253
+    for kcol in range(3):
+        np.add.at(num, tri[:, kcol], va_eff[:, kcol] * div_tri)
+    div_eff = np.zeros(nv)
+    me = A_eff > 1e-20
+    div_eff[me] = num[me] / A_eff[me]
+    term = base + div_eff
+    term[isb] = 0.0
+    normals = vertex_normals(pos, tri)                                   # :271-276
+    K_dir = np.zeros_like(k_vecs)
+    mk = k_mag > 1e-15
+    K_dir[mk] = k_vecs[mk] / k_mag[mk][:, None]
+    K_dir[~mk] = normals[~mk]
+    fK = np.ascontiguousarray(K_dir * (kappa * term * ratio)[:, None])
+    fA_eff = 0.5 * kappa * term**2
+    fA_vor = -2.0 * kappa * term * ratio * H
+    if mode == "approx":                                                 # :296-299
+        grad -= apply_beltrami_laplacian(weights, tri, fK)
+        grad[isb] = 0.0
+    else:
+        bending_backprop(pos, tri, isb, fA_eff, fA_vor, fK, grad)        # :300-436
+    return E

@@ -183,3 +183,67 @@ def test_minimizer_port_reproduces_reference_trajectory(fname):
     assert abs(res["step_size"] - g["step_size_final"]) <= 1e-12 * g["step_size_final"]
     if "tilts_final" in g:
         assert relerr(p.tilts, g["tilts_final"]) < 1e-9
+
+
+# ---- bending_tilt + nested tilt relaxation (single tilt field) ----------------------
+@pytest.mark.parametrize("name", ["ico5", "disk5"])
+@pytest.mark.parametrize("mode", ["analytic", "approx"])
+def test_bending_tilt_matches_reference(name, mode):
+    """modules/energy/bending_tilt.py on a closed and an open (boundary, obtuse) mesh."""
+    g = load_golden("bending_tilt_cases.npz")
+    pos, tri, isb, tl = g[name + "_positions"], g[name + "_tri"], g[name + "_is_boundary"], g[name + "_tilts"]
+    nv = pos.shape[0]
+    grad, tg = np.zeros_like(pos), np.zeros_like(pos)
+    E = orc.bending_tilt_energy_and_gradient(pos, tl, tri, np.full(nv, 1.3), np.full(nv, 0.2), isb,
+                                             mode=mode, grad=grad, tilt_grad=tg)
+    k = f"{name}_{mode}"
+    assert abs(E - g[k + "_E"]) <= 1e-12 * abs(g[k + "_E"])
+    assert relerr(grad, g[k + "_grad"]) < 1e-11
+    assert relerr(tg, g[k + "_tilt_grad"]) < 1e-11
+    tg2 = np.zeros_like(pos)
+    E2 = orc.bending_tilt_energy_and_gradient(pos, tl, tri, np.full(nv, 1.3), np.full(nv, 0.2), isb,
+                                              tilt_grad=tg2)
+    assert abs(E2 - g[k + "_E_tiltonly"]) <= 1e-12 * abs(E2)
+    assert relerr(tg2, g[k + "_tilt_grad_tiltonly"]) < 1e-11
+    p = mp.Problem(positions=pos, tri=tri, is_boundary=isb, tilts=tl, gp={"tilt_rigidity": 2.0})
+    assert relerr(mp.tilt_cg_preconditioner(p, pos, np.zeros(nv, bool)), g[name + "_jacobi_Minv"]) < 1e-12
+
+
+BT_BASE = {"surface_tension": 1.0, "bending_modulus": 1.0, "spontaneous_curvature": 0.1,
+           "bending_energy_model": "helfrich", "bending_gradient_mode": "analytic", "tilt_rigidity": 2.5,
+           "volume_constraint_mode": "lagrange", "volume_projection_during_minimization": False}
+BT_TRAJ = {
+    "traj_ico4_gd_bt_fixed.npz": ("gd", dict(BT_BASE, tilt_solve_mode="fixed")),
+    "traj_ico4_gd_bt_nested_cg.npz": ("gd", dict(BT_BASE, tilt_solve_mode="nested", tilt_solver="cg",
+                                                 tilt_step_size=0.1, tilt_inner_steps=6, tilt_tol=1e-10)),
+    "traj_ico4_cg_bt_nested_gd.npz": ("cg", dict(BT_BASE, tilt_solve_mode="nested", tilt_solver="gd",
+                                                 tilt_step_size=0.08, tilt_inner_steps=4)),
+    "traj_disk5_gd_bt_coupled.npz": ("gd", dict(BT_BASE, tilt_solve_mode="coupled", tilt_solver="cg",
+                                                tilt_cg_preconditioner="none", tilt_step_size=0.1,
+                                                tilt_coupled_steps=3, bending_modulus=0.8)),
+}
+
+
+@pytest.mark.parametrize("fname", sorted(BT_TRAJ))
+def test_port_reproduces_bending_tilt_trajectory(fname):
+    """surface + tilt + bending_tilt with the tilt field fixed / relaxed by the nested GD or
+    (Jacobi-preconditioned) CG inner solve of runtime/steppers/tilt_relaxation.py:237-424."""
+    kind, gp = BT_TRAJ[fname]
+    g = load_golden(fname)
+    p = mp.Problem(positions=g["positions0"], tri=g["tri"], gamma=g["gamma"], is_boundary=g["is_boundary"],
+                   fixed=g["fixed"], tilts=g["tilts0"], tilt_fixed=g["tilt_fixed"],
+                   energy_modules=["surface", "tilt", "bending_tilt"], constraint_modules=[], gp=dict(gp))
+    E0, grad0 = mp.energy_and_gradient(p, p.positions)
+    assert abs(E0 - g["E0"]) <= 1e-12 * abs(g["E0"])
+    assert relerr(grad0, g["grad0"]) < 1e-11
+    stepper = mp.GradientDescent() if kind == "gd" else mp.ConjugateGradient()
+    res = mp.minimize(p, stepper, int(g["n_steps"]), step_size=float(g["step_size0"]))
+    log = g["step_log"]
+    got = np.array([[float(t["success"]), t["next_step"], t["E_accepted"]] for t in res["trace"]])
+    assert got.shape == log.shape
+    assert np.array_equal(got[:, 0], log[:, 0])
+    assert np.allclose(got[:, 1], log[:, 1], rtol=1e-12, atol=0)
+    assert np.allclose(got[:, 2], log[:, 2], rtol=1e-9, atol=0)
+    assert relerr(p.positions, g["positions_final"]) < 1e-8
+    assert relerr(p.tilts, g["tilts_final"]) < 1e-8
+    assert abs(res["energy"] - g["E_final"]) <= 1e-9 * abs(g["E_final"])
