@@ -52,6 +52,7 @@ extern "C" {
 #define MS_TRACK_VOLUME 16u
 /* vertex-tilt magnitude energy 1/2 k_t sum |t_v|^2 A_v (modules/energy/tilt.py:99-172) */
 #define MS_MOD_TILT 32u
+#define MS_MOD_BENDING_TILT 64u /* modules/energy/bending_tilt.py (replaces MS_MOD_BENDING) */
 
 /* bending_params.py:19-33 */
 #define MS_BEND_HELFRICH 0
@@ -92,6 +93,9 @@ enum ms_scalar {
   MS_S_GDOTD = 8,   /* <g, d>                                           */
   MS_S_MAXD2 = 9,   /* max_i |d_i|^2 over movable rows                  */
   MS_S_ETILT = 10,  /* tilt magnitude energy, modules/energy/tilt.py    */
+  MS_S_EBT = 11,    /* bending + tilt-splay energy, modules/energy/bending_tilt.py */
+  MS_S_TGNORM2 = 12, /* |tilt gradient|^2 over free rows (tilt_relaxation.py:318) */
+  MS_S_TRZ = 13,    /* <r, M^-1 r> of the tilt CG (tilt_relaxation.py:369,416) */
   MS_NSCAL = 16
 };
 
@@ -170,6 +174,30 @@ int ms_set_tilts(ms_ctx *ctx, const double *tilts /* nv*3 */, double tilt_rigidi
 int ms_get_tilts(ms_ctx *ctx, double *tilts /* nv*3 */);
 /* dE/dt = k_t t_v A_v of the last gradient evaluation (tilt.py:160-170) */
 int ms_get_tilt_gradient(ms_ctx *ctx, double *tilt_grad /* nv*3 */);
+/* ---- tilt field (single vertex-tilt field): relaxation at frozen positions ----
+ * ms_set_tilt_fixed: vertex.tilt_fixed flags (runtime/minimizer_helpers.py:49-75),
+ *   NULL clears them.
+ * ms_tilt_energy_and_gradient: energy of the tilt-reading modules (tilt,
+ *   bending_tilt) and the dense tilt gradient dE/dt at the stored tilts
+ *   (runtime/evaluation_manager.py:386-462); tilt_grad (nv*3, host) may be NULL
+ *   (then read it back with ms_get_tilt_gradient).
+ * ms_relax_tilts: TiltRelaxationManager.relax_tilts
+ *   (runtime/steppers/tilt_relaxation.py:237-424) on the device: tilts projected
+ *   to the tangent planes, then gradient descent or (Jacobi-preconditioned)
+ *   Fletcher-Reeves CG with halving back-tracking (<= 12 halvings, accept on
+ *   E1 <= E0); tilt-fixed rows keep their projected value. */
+typedef struct ms_tilt_relax_params {
+  int solver;        /* 0 gradient descent, 1 conjugate gradient ("tilt_solver") */
+  int max_iters;     /* tilt_inner_steps / tilt_coupled_steps / tilt_cg_max_iters */
+  double step_size;  /* "tilt_step_size" */
+  double tol;        /* "tilt_tol" on |dE/dt| over free rows, <= 0: off */
+  int jacobi;        /* CG: "tilt_cg_preconditioner" == jacobi */
+} ms_tilt_relax_params;
+int ms_set_tilt_fixed(ms_ctx *ctx, const uint8_t *tilt_fixed /* nv or NULL */);
+int ms_tilt_energy_and_gradient(ms_ctx *ctx, double *energy, double *tilt_grad);
+int ms_relax_tilts(ms_ctx *ctx, const ms_tilt_relax_params *params,
+                   int *iters_out, int *evals_out);
+
 /* Mesh.project_tilts_to_tangent (geometry/mesh.py:788-814): t <- t - (t.n) n with the
  * unit vertex normals of the current positions (triangle_ops.py:55-73) */
 int ms_project_tilts_to_tangent(ms_ctx *ctx);

@@ -40,6 +40,13 @@ struct ms_ctx {
   double* d_tilts = nullptr;      // (nvp,3) vertex tilts, patch order (ms_set_tilts)
   double* d_tilts_trial = nullptr;  // tilts projected onto a trial surface (line search)
   double* d_tilt_grad = nullptr;  // (nvp,3) dE/dt of the last gradient evaluation
+  double* d_bt_vert = nullptr;    // (nvp,4) bending_tilt per-vertex record of the last energy pass
+  bool bt_valid = false;          // d_bt_vert describes the current x
+  // tilt relaxation work space (positions frozen): unit vertex normals, CG direction, Jacobi M^-1
+  double* d_tn = nullptr;
+  double* d_tdir = nullptr;
+  double* d_minv = nullptr;
+  std::vector<uint8_t> h_vflags;  // host copy of the vertex flag bytes (patch order)
   double k_tilt = 0.0;
   // per-vertex state (one allocation), patch order, nvp rows
   double* state = nullptr;
@@ -155,12 +162,14 @@ struct ProfScope {
 };
 
 constexpr uint32_t MASK_ENERGY = (1u << MS_S_ESURF) | (1u << MS_S_VOL) | (1u << MS_S_EBEND) |
-                                 (1u << MS_S_MINEDGE2) | (1u << MS_S_GUARD) | (1u << MS_S_ETILT);
+                                 (1u << MS_S_MINEDGE2) | (1u << MS_S_GUARD) | (1u << MS_S_ETILT) |
+                                 (1u << MS_S_EBT);
+constexpr uint32_t MS_TILT_MODS = MS_MOD_TILT | MS_MOD_BENDING_TILT;  // modules reading the tilt field
 
 // mode 0 energy / 1 energy+gradients read `src`; mode 2 projects `src` onto the tangent
 // planes of x (+ alpha d) and writes `dst`.
 int tilt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* src = nullptr,
-              double* dst = nullptr) {
+              double* dst = nullptr, bool shape_gradient = true) {
   if (!c->d_tilts) return fail(c, MS_ERR_STATE, "tilt module active but ms_set_tilts was never called");
   TiltArgs a;
   a.m = device_mesh(c);
@@ -172,10 +181,30 @@ int tilt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* src
   a.tilts = src ? src : c->d_tilts;
   a.tilts_out = dst ? dst : c->d_tilts;
   a.k_tilt = c->k_tilt;
-  a.g = c->buf[MS_BUF_G];
+  a.g = shape_gradient ? c->buf[MS_BUF_G] : nullptr;
   a.tilt_grad = c->d_tilt_grad;
   a.partials = c->d_partials;
   HIPCHK(c, launch_tilt(a, mode, c->cap, c->til.max_ent, c->stream));
+  return MS_OK;
+}
+// bending_tilt facet pass (mode 0 energy / 1 + factors / 2 + tilt gradient) on the positions of
+// the preceding energy pass; `tilts` = the tangent tilts belonging to those positions
+int bt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* tilts) {
+  if (!c->d_tilts) return fail(c, MS_ERR_STATE, "bending_tilt module active but ms_set_tilts was never called");
+  BtArgs a;
+  a.m = device_mesh(c);
+  a.tile0 = c->tile0;
+  a.tile1 = c->tile1;
+  a.x = c->buf[MS_BUF_X];
+  a.d = use_dir ? c->buf[MS_BUF_D] : nullptr;
+  a.alpha = alpha;
+  a.tilts = tilts;
+  a.bt_vert = c->d_bt_vert;
+  a.fK = c->buf[MS_BUF_FK];
+  a.fA = c->buf[MS_BUF_FA];
+  a.tilt_grad = c->d_tilt_grad;
+  a.partials = c->d_partials;
+  HIPCHK(c, launch_bt(a, mode, c->cap, c->til.max_ent, c->stream));
   return MS_OK;
 }
 constexpr uint32_t MASK_GRAD = (1u << MS_S_GGC) | (1u << MS_S_GCGC);
@@ -193,7 +222,7 @@ int reduce_slots(ms_ctx* c, uint32_t mask) {
 
 int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool write_trial,
                  bool guard, bool write_factors, bool reduce_now = true) {
-  c->carry_valid = c->grad_valid = false;
+  c->carry_valid = c->grad_valid = c->bt_valid = false;
   EnergyArgs a;
   a.m = device_mesh(c);
   a.tile0 = c->tile0;
@@ -202,9 +231,12 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   a.d = use_dir ? c->buf[MS_BUF_D] : nullptr;
   a.alpha = alpha;
   a.xt = write_trial ? c->buf[MS_BUF_XT] : nullptr;
-  const bool bend = (modules & MS_MOD_BENDING) != 0;
+  const bool bt = (modules & MS_MOD_BENDING_TILT) != 0;
+  const bool bend = (modules & MS_MOD_BENDING) != 0 || bt;
   a.fK = (bend && write_factors) ? c->buf[MS_BUF_FK] : nullptr;
   a.fA = (bend && write_factors) ? c->buf[MS_BUF_FA] : nullptr;
+  a.bt_vert = bt ? c->d_bt_vert : nullptr;
+  if (bt && !c->d_bt_vert) return fail(c, MS_ERR_STATE, "bending_tilt: ms_set_params did not allocate its buffers");
   a.partials = c->d_partials;
   a.bending_model = c->params.bending_model;
   a.modules = modules;
@@ -212,18 +244,20 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
     ProfScope ps(c, 0);
     HIPCHK(c, launch_energy(a, guard && use_dir, c->cap, c->til.max_ent, c->stream));
   }
-  if (modules & MS_MOD_TILT) {
-    int rc;
+  if (modules & MS_TILT_MODS) {
+    int rc = MS_OK;
+    const double* tilts = c->d_tilts;
     if (use_dir) {
       // minimizer.py:723-733: the trial energy is taken with the tilts projected onto the
       // TRIAL surface's vertex tangent planes (kept aside; they become the stored tilts
       // only if this trial is accepted)
       rc = tilt_pass(c, 2, true, alpha, c->d_tilts, c->d_tilts_trial);
       if (rc) return rc;
-      rc = tilt_pass(c, 0, true, alpha, c->d_tilts_trial);
-    } else {
-      rc = tilt_pass(c, 0, false, 0.0);
+      tilts = c->d_tilts_trial;
     }
+    if (modules & MS_MOD_TILT) rc = tilt_pass(c, 0, use_dir, alpha, tilts);
+    if (rc) return rc;
+    if (bt) rc = bt_pass(c, write_factors ? 1 : 0, use_dir, alpha, tilts);
     if (rc) return rc;
   }
   if (reduce_now) {
@@ -231,14 +265,18 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
     if (rc) return rc;
   }
   if (bend && write_factors) c->factors_valid = !use_dir;
+  c->bt_valid = bt && !use_dir;
   return MS_OK;
 }
 
 // dir_mode: 0 = plain gradient pass (+ <g,gC> partials); 1/2 = fused direction (GD / CG history)
-int phase_gradient(ms_ctx* c, uint32_t modules, double* g_out, bool accumulate, int dir_mode = 0,
+int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulate, int dir_mode = 0,
                    bool reduce_now = true) {
-  if ((modules & MS_MOD_BENDING) && !c->factors_valid)
+  uint32_t modules = modules_in;
+  if ((modules & (MS_MOD_BENDING | MS_MOD_BENDING_TILT)) && !c->factors_valid)
     return fail(c, MS_ERR_STATE, "gradient pass needs the bending factors of an energy pass at x");
+  if (modules & MS_MOD_BENDING_TILT)  // k_bt finished the factors: K_C is the plain bending back-prop
+    modules = (modules & ~MS_MOD_BENDING_TILT) | MS_MOD_BENDING;
   GradientArgs a;
   a.m = device_mesh(c);
   a.tile0 = c->tile0;
@@ -316,6 +354,7 @@ double penalty_energy(const ms_ctx* c, double V) {
 void energies_from_mailbox(const ms_ctx* c, double e[4]) {
   e[0] = (c->params.modules & MS_MOD_SURFACE) ? c->h_scal[MS_S_ESURF] : 0.0;
   e[1] = (c->params.modules & MS_MOD_BENDING) ? c->h_scal[MS_S_EBEND] : 0.0;
+  if (c->params.modules & MS_MOD_BENDING_TILT) e[1] += c->h_scal[MS_S_EBT];
   e[2] = penalty_energy(c, c->h_scal[MS_S_VOL]);
   e[3] = (c->params.modules & MS_MOD_TILT) ? c->h_scal[MS_S_ETILT] : 0.0;
 }
@@ -489,6 +528,7 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
       fl[i] = f;
     }
     CREATE_CHK(upload(c, &c->d_vflags, fl));
+    c->h_vflags = fl;
     std::vector<double> zeros((size_t)t.nvp, 0.0);
     CREATE_CHK(upload(c, &c->d_kappa, zeros));
     CREATE_CHK(upload(c, &c->d_c0, zeros));
@@ -572,7 +612,7 @@ void ms_destroy(ms_ctx* c) {
   if (!c->own_state) c->state = nullptr;
   void* ptrs[] = {c->d_perm, c->d_tile_facet_off, c->d_tile_facets, c->d_tf_gamma,
                   c->d_tile_halo_off, c->d_halo_ids, c->d_tile_ent_off, c->d_tile_voff, c->d_vent,
-                  c->d_vflags, c->d_kappa, c->d_c0, c->d_tilts, c->d_tilt_grad, c->d_tilts_trial,
+                  c->d_vflags, c->d_kappa, c->d_c0, c->d_tilts, c->d_tilt_grad, c->d_tilts_trial, c->d_bt_vert, c->d_tn, c->d_tdir, c->d_minv,
                   c->state, c->d_partials, c->d_scal, c->d_stage, c->d_bnd_rows, c->d_bnd_off,
                   c->d_halo_rows, c->d_scal_all};
   for (void* p : ptrs)
@@ -612,7 +652,7 @@ int ms_set_surface_tension(ms_ctx* c, const double* gamma) {
   for (size_t p = 0; p < g.size(); ++p) g[p] = gamma[t.tile_facet_ext[p]];
   if (!g.empty())
     HIPCHK(c, hipMemcpy(c->d_tf_gamma, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice));
-  c->carry_valid = c->grad_valid = false;
+  c->carry_valid = c->grad_valid = c->bt_valid = false;
   return MS_OK;
 }
 
@@ -628,7 +668,7 @@ int ms_set_bending_params(ms_ctx* c, const double* kappa, const double* c0) {
   HIPCHK(c, hipMemcpy(c->d_kappa, k.data(), k.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_c0, z.data(), z.size() * sizeof(double), hipMemcpyHostToDevice));
   c->factors_valid = false;
-  c->carry_valid = c->grad_valid = false;
+  c->carry_valid = c->grad_valid = c->bt_valid = false;
   return MS_OK;
 }
 
@@ -638,9 +678,18 @@ int ms_set_params(ms_ctx* c, const ms_params* p) {
     return fail(c, MS_ERR_INVALID, "ms_set_params: bad bending_model");
   if (p->bending_grad_mode != MS_GRAD_ANALYTIC && p->bending_grad_mode != MS_GRAD_APPROX)
     return fail(c, MS_ERR_INVALID, "ms_set_params: bad bending_grad_mode");
+  if ((p->modules & MS_MOD_BENDING) && (p->modules & MS_MOD_BENDING_TILT))
+    return fail(c, MS_ERR_INVALID, "ms_set_params: bending and bending_tilt are mutually exclusive");
+  if ((p->modules & MS_MOD_BENDING_TILT) && c->shard_count != 1)
+    return fail(c, MS_ERR_STATE, "the bending_tilt module is not sharded yet (single GPU only)");
+  if ((p->modules & MS_MOD_BENDING_TILT) && !c->d_bt_vert) {
+    const size_t bytes = sizeof(double) * 4 * (size_t)c->til.nvp;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_bt_vert), bytes));
+    HIPCHK(c, hipMemset(c->d_bt_vert, 0, bytes));
+  }
   c->params = *p;
   c->factors_valid = false;
-  c->carry_valid = c->grad_valid = false;
+  c->carry_valid = c->grad_valid = c->bt_valid = false;
   return MS_OK;
 }
 
@@ -656,7 +705,7 @@ int ms_set_tilts(ms_ctx* c, const double* tilts, double tilt_rigidity) {
     HIPCHK(c, hipMemset(c->d_tilt_grad, 0, bytes));
   }
   c->k_tilt = tilt_rigidity;
-  c->carry_valid = c->grad_valid = false;
+  c->carry_valid = c->grad_valid = c->bt_valid = false;
   return ext_to_patch(c, tilts, c->d_tilts, 3);
 }
 
@@ -678,10 +727,211 @@ int ms_project_tilts_to_tangent(ms_ctx* c) {
   return fetch(c);
 }
 
+int ms_set_tilt_fixed(ms_ctx* c, const uint8_t* tilt_fixed) {
+  if (!c) return fail(c, MS_ERR_INVALID, "ms_set_tilt_fixed: NULL context");
+  const Tiling& t = c->til;
+  for (int i = 0; i < t.nv; ++i) {
+    uint8_t f = c->h_vflags[(size_t)i] & (uint8_t)~VF_TILT_FIXED;
+    if (tilt_fixed && tilt_fixed[t.perm[i]]) f |= VF_TILT_FIXED;
+    c->h_vflags[(size_t)i] = f;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->d_vflags, c->h_vflags.data(), c->h_vflags.size(), hipMemcpyHostToDevice));
+  return MS_OK;
+}
+
+namespace {
+// energy of the tilt-reading modules (+ dense tilt gradient) for `tilts` on the current x
+// (runtime/evaluation_manager.py:303-462); needs d_bt_vert valid when bending_tilt is on
+int tilt_eval(ms_ctx* c, const double* tilts, bool gradient) {
+  const uint32_t mods = c->params.modules;
+  int rc = MS_OK;
+  uint32_t mask = 0;
+  if (mods & MS_MOD_TILT) {
+    rc = tilt_pass(c, gradient ? 1 : 0, false, 0.0, tilts, nullptr, /*shape_gradient=*/false);
+    if (rc) return rc;
+    mask |= 1u << MS_S_ETILT;
+  } else if (gradient) {
+    HIPCHK(c, hipMemsetAsync(c->d_tilt_grad, 0, sizeof(double) * 3 * (size_t)c->til.nvp, c->stream));
+  }
+  if (mods & MS_MOD_BENDING_TILT) {
+    rc = bt_pass(c, gradient ? 2 : 0, false, 0.0, tilts);
+    if (rc) return rc;
+    mask |= 1u << MS_S_EBT;
+  }
+  return mask ? reduce_slots(c, mask) : MS_OK;
+}
+double tilt_energy_from_mailbox(const ms_ctx* c) {
+  double e = 0.0;
+  if (c->params.modules & MS_MOD_TILT) e += c->h_scal[MS_S_ETILT];
+  if (c->params.modules & MS_MOD_BENDING_TILT) e += c->h_scal[MS_S_EBT];
+  return e;
+}
+int ensure_bt_record(ms_ctx* c) {
+  if (!(c->params.modules & MS_MOD_BENDING_TILT) || c->bt_valid) return MS_OK;
+  return phase_energy(c, c->params.modules, false, 0.0, false, false, false, /*reduce_now=*/false);
+}
+}  // namespace
+
+int ms_tilt_energy_and_gradient(ms_ctx* c, double* energy, double* tilt_grad) {
+  if (!c || !energy) return fail(c, MS_ERR_INVALID, "ms_tilt_energy_and_gradient: NULL argument");
+  if (!(c->params.modules & MS_TILT_MODS) || !c->d_tilts)
+    return fail(c, MS_ERR_STATE, "ms_tilt_energy_and_gradient: no tilt-reading module / no tilts set");
+  if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "tilt passes are single-shard only");
+  int rc = ensure_bt_record(c);
+  if (rc) return rc;
+  rc = tilt_eval(c, c->d_tilts, true);
+  if (rc) return rc;
+  rc = fetch(c);
+  if (rc) return rc;
+  *energy = tilt_energy_from_mailbox(c);
+  if (tilt_grad) return patch_to_ext(c, c->d_tilt_grad, tilt_grad, 3);
+  return MS_OK;
+}
+
+int ms_relax_tilts(ms_ctx* c, const ms_tilt_relax_params* rp, int* iters_out, int* evals_out) {
+  if (!c || !rp) return fail(c, MS_ERR_INVALID, "ms_relax_tilts: NULL argument");
+  if (iters_out) *iters_out = 0;
+  if (evals_out) *evals_out = 0;
+  const uint32_t mods = c->params.modules;
+  if (!(mods & MS_TILT_MODS) || !c->d_tilts)
+    return fail(c, MS_ERR_STATE, "ms_relax_tilts: no tilt-reading module / no tilts set");
+  if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "tilt passes are single-shard only");
+  if (rp->step_size <= 0.0 || rp->max_iters <= 0) return MS_OK;
+  const Tiling& t = c->til;
+  bool any_free = false;
+  for (int i = 0; i < t.nv && !any_free; ++i) any_free = !(c->h_vflags[(size_t)i] & VF_TILT_FIXED);
+  if (!any_free) return MS_OK;
+  const size_t b3 = sizeof(double) * 3 * (size_t)t.nvp;
+  if (!c->d_tn) {
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_tn), b3));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_tdir), b3));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_minv), sizeof(double) * (size_t)t.nvp));
+    HIPCHK(c, hipMemset(c->d_tn, 0, b3));
+    HIPCHK(c, hipMemset(c->d_tdir, 0, b3));
+    HIPCHK(c, hipMemset(c->d_minv, 0, sizeof(double) * (size_t)t.nvp));
+  }
+  int iters = 0, evals = 0;
+  int rc = ensure_bt_record(c);
+  if (rc) return rc;
+  {  // frozen geometry: unit vertex normals and the Jacobi diagonal
+    TiltArgs a;
+    a.m = device_mesh(c);
+    a.tile0 = c->tile0;
+    a.tile1 = c->tile1;
+    a.x = c->buf[MS_BUF_X];
+    a.d = nullptr;
+    a.alpha = 0.0;
+    a.tilts = c->d_tilts;
+    a.tilts_out = c->d_tn;
+    a.k_tilt = (rp->solver == 1 && rp->jacobi) ? c->k_tilt : 0.0;
+    a.g = nullptr;
+    a.tilt_grad = c->d_tilt_grad;
+    a.minv = c->d_minv;
+    a.partials = c->d_partials;
+    HIPCHK(c, launch_tilt(a, 3, c->cap, t.max_ent, c->stream));
+  }
+  auto tvec = [&](int mode, const double* src, double* out, double coef, int flag) -> int {
+    HIPCHK(c, launch_tvec(mode, c->tile0, c->tile1, t.nv, t.T, c->d_vflags, c->d_tilt_grad, c->d_minv,
+                          c->d_tdir, c->d_tilts, src, c->d_tn, out, coef, flag, c->d_partials, t.n_tiles,
+                          c->stream));
+    return MS_OK;
+  };
+  // tilts <- P(tilts) on every row (:303-305), fixed rows keep that value from now on
+  rc = tvec(2, c->d_tilts, c->d_tilts_trial, 0.0, 0);
+  if (rc) return rc;
+  std::swap(c->d_tilts, c->d_tilts_trial);
+  auto grad_at = [&](double* E, double* gnorm, double* rz) -> int {
+    int r = tilt_eval(c, c->d_tilts, true);
+    if (r) return r;
+    r = tvec(0, nullptr, nullptr, 0.0, 0);
+    if (r) return r;
+    r = reduce_slots(c, (1u << MS_S_TGNORM2) | (1u << MS_S_TRZ));
+    if (r) return r;
+    r = fetch(c);
+    if (r) return r;
+    ++evals;
+    *E = tilt_energy_from_mailbox(c);
+    *gnorm = std::sqrt(c->h_scal[MS_S_TGNORM2]);
+    *rz = c->h_scal[MS_S_TRZ];
+    return MS_OK;
+  };
+  // backtracking on E(P(t + step*src)) <= E0 (:330-347 / :380-398); accepts by pointer swap
+  auto search = [&](const double* src, double sign, double E0, double* E_acc, bool* accepted) -> int {
+    double step = rp->step_size;
+    *accepted = false;
+    for (int bt = 0; bt < 12; ++bt) {
+      int r = tvec(2, src, c->d_tilts_trial, sign * step, 1);
+      if (r) return r;
+      r = tilt_eval(c, c->d_tilts_trial, false);
+      if (r) return r;
+      r = fetch(c);
+      if (r) return r;
+      ++evals;
+      const double E1 = tilt_energy_from_mailbox(c);
+      if (E1 <= E0) {
+        std::swap(c->d_tilts, c->d_tilts_trial);
+        *E_acc = E1;
+        *accepted = true;
+        return MS_OK;
+      }
+      step *= 0.5;
+      if (step < 1e-16) break;
+    }
+    return MS_OK;
+  };
+  const double tol = rp->tol > 0.0 ? rp->tol : 0.0;
+  double E0 = 0.0, gnorm = 0.0, rz_old = 0.0;
+  if (rp->solver == 0) {  // gradient descent (:312-351)
+    for (int it = 0; it < rp->max_iters; ++it) {
+      rc = grad_at(&E0, &gnorm, &rz_old);
+      if (rc) return rc;
+      if (gnorm == 0.0 || (tol > 0.0 && gnorm < tol)) break;
+      bool acc = false;
+      double E1 = E0;
+      rc = search(c->d_tilt_grad, -1.0, E0, &E1, &acc);
+      if (rc) return rc;
+      ++iters;
+      if (!acc) break;
+    }
+  } else {  // (preconditioned) Fletcher-Reeves CG (:352-421)
+    rc = grad_at(&E0, &gnorm, &rz_old);
+    if (rc) return rc;
+    if (!(gnorm == 0.0 || (tol > 0.0 && gnorm < tol))) {
+      rc = tvec(1, nullptr, nullptr, 0.0, 1);
+      if (rc) return rc;
+      for (int it = 0; it < rp->max_iters; ++it) {
+        if (gnorm == 0.0 || (tol > 0.0 && gnorm < tol)) break;
+        bool acc = false;
+        double E1 = E0;
+        rc = search(c->d_tdir, 1.0, E0, &E1, &acc);
+        if (rc) return rc;
+        ++iters;
+        if (!acc) break;
+        double rz_new = 0.0;
+        rc = grad_at(&E0, &gnorm, &rz_new);
+        if (rc) return rc;
+        if (gnorm == 0.0 || (tol > 0.0 && gnorm < tol)) break;
+        if (rz_old == 0.0) break;
+        const double beta = rz_new / rz_old;
+        rc = tvec(1, nullptr, nullptr, beta, 0);
+        if (rc) return rc;
+        rz_old = rz_new;
+      }
+    }
+  }
+  if (iters_out) *iters_out = iters;
+  if (evals_out) *evals_out = evals;
+  // the tilt-dependent energies in the mailbox belong to whatever was evaluated last
+  c->carry_valid = c->grad_valid = false;
+  c->factors_valid = c->factors_valid && !(mods & MS_MOD_BENDING_TILT);
+  return MS_OK;
+}
+
 int ms_set_positions(ms_ctx* c, const double* positions) {
   if (!c || !positions) return fail(c, MS_ERR_INVALID, "ms_set_positions: NULL argument");
   c->factors_valid = false;
-  c->carry_valid = c->grad_valid = false;
+  c->carry_valid = c->grad_valid = c->bt_valid = false;
   return ext_to_patch(c, positions, c->buf[MS_BUF_X], 3);
 }
 
@@ -741,11 +991,11 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   const int restart = sp->restart_interval > 0 ? sp->restart_interval : 10;
   // conjugate_gradient.py:78-82: steepest descent on first call and every restart
   const bool use_history = cg && c->cg_have_history && (c->cg_iter_count % restart != 0);
-  const bool tilt = (c->params.modules & MS_MOD_TILT) != 0;
+  const bool tilt = (c->params.modules & MS_TILT_MODS) != 0;
   // reuse_energy0 == 2: an accepted trial doubles as the next step's energy/factor pass
   const bool carry_mode = sp->reuse_energy0 >= 2 && !tilt;
   const bool carried = carry_mode && c->carry_valid &&
-                       (c->factors_valid || !(c->params.modules & MS_MOD_BENDING));
+                       (c->factors_valid || !(c->params.modules & (MS_MOD_BENDING | MS_MOD_BENDING_TILT)));
   const bool constraint = (c->params.modules & (MS_CON_VOLUME | MS_MOD_TILT)) != 0;
   int rc;
   if (carried && c->grad_valid && !constraint && c->til.T <= 256) {
@@ -829,6 +1079,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       // minimizer.py:1415 re-projects the stored tilts onto the accepted surface: that is
       // exactly the trial projection computed above
       if (tilt) std::swap(c->d_tilts, c->d_tilts_trial);
+      c->bt_valid = (c->params.modules & MS_MOD_BENDING_TILT) != 0;  // the trial's record is x's now
       if (cg) {  // conjugate_gradient.py:114-117 history on success only
         std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
         std::swap(c->buf[MS_BUF_D], c->buf[MS_BUF_PD]);
@@ -905,7 +1156,7 @@ int ms_phase_accept(ms_ctx* c, int keep_history) {
   if (!c) return MS_ERR_INVALID;
   std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
   c->factors_valid = false;
-  c->carry_valid = c->grad_valid = false;
+  c->carry_valid = c->grad_valid = c->bt_valid = false;
   if (keep_history) {
     std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
     std::swap(c->buf[MS_BUF_D], c->buf[MS_BUF_PD]);
@@ -1047,7 +1298,7 @@ int ms_fetch_scalars(ms_ctx* c, double* out) {
 int ms_store_scalars(ms_ctx* c, const double* in) {
   if (!c || !in) return MS_ERR_INVALID;
   memcpy(c->h_scal, in, sizeof(double) * MS_NSCAL);
-  c->carry_valid = c->grad_valid = false;
+  c->carry_valid = c->grad_valid = c->bt_valid = false;
   HIPCHK(c, hipMemcpyAsync(c->d_scal, c->h_scal, sizeof(double) * MS_NSCAL, hipMemcpyHostToDevice,
                            c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -26,6 +26,7 @@ constexpr uint16_t TF_BODY = 2;
 
 constexpr uint8_t VF_FIXED = 1;
 constexpr uint8_t VF_BOUNDARY = 2;
+constexpr uint8_t VF_TILT_FIXED = 4;  // vertex.tilt_fixed (runtime/minimizer_helpers.py:49-75)
 
 // Host-side result of the tiling pass.
 struct Tiling {
@@ -87,6 +88,9 @@ struct EnergyArgs {
   double* partials;       // [n_tiles][MS_NSCAL]
   int bending_model;
   uint32_t modules;
+  // bending_tilt: per-vertex record {base = 2H - c0 (0 on boundary), A_eff, kappa*ratio*H, 0}
+  // written instead of the final factors; fK then holds K_dir * kappa * ratio (k_bt finishes)
+  double* bt_vert;
 };
 
 struct GradientArgs {
@@ -121,6 +125,21 @@ struct TiltArgs {
   double k_tilt;
   double* g;              // mode 1: shape gradient is ADDED into g
   double* tilt_grad;      // mode 1: k_t t_v A_v (written)
+  double* minv;           // mode 3: Jacobi preconditioner 1/(k_t A_v) (normals go to tilts_out)
+  double* partials;
+};
+
+struct BtArgs {
+  DeviceMesh m;
+  int tile0, tile1;
+  const double* x;
+  const double* d;         // direction or nullptr (energy at x + alpha d)
+  double alpha;
+  const double* tilts;     // (nvp,3) tangent tilts
+  const double* bt_vert;   // (nvp,4) from the energy pass at the same positions
+  double* fK;              // mode 1: in K_dir*kappa*ratio, out the back-prop factor
+  double* fA;              // mode 1: out {fA_eff, fA_vor}
+  double* tilt_grad;       // mode 2: dE/dt ADDED here
   double* partials;
 };
 
@@ -133,6 +152,14 @@ hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStrea
 // mode 0: energy partial (MS_S_ETILT); 1: energy + gradients; 2: project tilts to tangent
 size_t tilt_lds_bytes(int T, int cap, int max_ent);
 hipError_t launch_tilt(const TiltArgs& a, int mode, int cap, int max_ent, hipStream_t s);
+// bending_tilt facet pass.  mode 0: energy (MS_S_EBT); 1: energy + back-prop factors;
+// 2: energy + tilt gradient
+size_t bt_lds_bytes(int T, int cap, int max_ent);
+hipError_t launch_bt(const BtArgs& a, int mode, int cap, int max_ent, hipStream_t s);
+hipError_t launch_tvec(int mode, int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* tg,
+                       const double* minv, double* dir, const double* tilts, const double* src,
+                       const double* normals, double* out, double coef, int flag, double* partials,
+                       int n_tiles, hipStream_t s);
 hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
                          uint32_t slot_mask, double* scal, double* host_mirror,
                          unsigned long long* host_seq, unsigned long long ticket, hipStream_t s);

@@ -533,7 +533,19 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_
     const double H = k_mag / (2.0 * safe);
     const double ratio = safe > 1.0e-15 ? aAe / safe : 0.0;
     double scale_K, fe, fv;
-    if (a.bending_model == MS_BEND_HELFRICH) {
+    if (a.bt_vert) {
+      // bending_tilt.py:217-233: the energy and the factors need div t, which k_bt adds;
+      // leave the per-vertex pieces: base term, A_eff, kappa*ratio*H and K_dir*kappa*ratio
+      double base = (2.0 * H) - c0;
+      if (!interior) base = 0.0;
+      scale_K = kappa * ratio;
+      fe = fv = 0.0;
+      double* rec = a.bt_vert + 4 * (size_t)v;
+      rec[0] = base;
+      rec[1] = aAe;
+      rec[2] = kappa * ratio * H;
+      rec[3] = 0.0;
+    } else if (a.bending_model == MS_BEND_HELFRICH) {
       double term = (2.0 * H) - c0;
       if (!interior) term = 0.0;
       e_bend = 0.5 * (kappa * (term * term) * aAe);
@@ -613,7 +625,7 @@ constexpr int FAST_CAP = 0;  // patch capacity stays a runtime value: a fixed 51
 hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, hipStream_t s) {
   const int nb = a.tile1 - a.tile0;
   if (nb <= 0) return hipSuccess;
-  const bool bend = (a.modules & MS_MOD_BENDING) != 0;
+  const bool bend = (a.modules & (MS_MOD_BENDING | MS_MOD_BENDING_TILT)) != 0;
   const bool fast = a.m.T == FAST_T;
   const size_t lds = energy_lds_bytes(a.m.T, cap, max_ent, bend, guard, a.m.has_boundary != 0);
   hipError_t e;
@@ -1088,7 +1100,7 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
     const V3 th = mk(a.tilts[g], a.tilts[g + 1], a.tilts[g + 2]);
     tq[sl] = dot(th, th);
   }
-  if (MODE != 0) {
+  if (MODE != 0) {  // (modes 1-3 gather per vertex)
     const uint16_t* gv = a.m.tile_voff + (size_t)t.tile * (T + 1);
     voff[tid] = gv[tid];
     if (tid == 0) voff[T] = gv[T];
@@ -1113,10 +1125,11 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
       const V3 n = cross(e2, -e1);
       const double A2 = norm(n);
       double* s = stg + tid;
-      if (MODE == 2) {
+      if (MODE == 2 || MODE == 3) {
         s[0 * T] = n.x;
         s[1 * T] = n.y;
         s[2 * T] = n.z;
+        if (MODE == 3) s[9 * T] = (0.5 * A2) / 3.0;
       } else {
         V3 G0 = mk(0, 0, 0), G1 = mk(0, 0, 0), G2 = mk(0, 0, 0);
         double a3 = 0.0;
@@ -1148,10 +1161,11 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
         const int fl = ent >> 2;
         if (fl >= hi) break;
         const double* s = stg + (fl - lo);
-        if (MODE == 2) {
+        if (MODE == 2 || MODE == 3) {
           ax += s[0];
           ay += s[T];
           az += s[2 * T];
+          if (MODE == 3) aw += s[9 * T];
         } else {
           const int k = ent & 3;
           ax += s[(3 * k) * T];
@@ -1167,9 +1181,11 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
   if (tid < t.n_owned) {
     const size_t o = 3 * (size_t)(t.v_lo + tid);
     if (MODE == 1) {
-      a.g[o] += ax;
-      a.g[o + 1] += ay;
-      a.g[o + 2] += az;
+      if (a.g) {
+        a.g[o] += ax;
+        a.g[o + 1] += ay;
+        a.g[o + 2] += az;
+      }
       a.tilt_grad[o] = a.k_tilt * tv.x * aw;
       a.tilt_grad[o + 1] = a.k_tilt * tv.y * aw;
       a.tilt_grad[o + 2] = a.k_tilt * tv.z * aw;
@@ -1181,9 +1197,22 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
       a.tilts_out[o] = tv.x - dt * nrm.x;
       a.tilts_out[o + 1] = tv.y - dt * nrm.y;
       a.tilts_out[o + 2] = tv.z - dt * nrm.z;
+    } else if (MODE == 3) {
+      // relaxation geometry: unit vertex normals (triangle_ops.py:55-73) and the Jacobi
+      // preconditioner 1/(k_t A_v) of runtime/preconditioners.py:15-59 (1 where <= 1e-12,
+      // on tilt-fixed rows, or when switched off)
+      V3 nrm = mk(ax, ay, az);
+      const double len = norm(nrm);
+      if (len >= 1.0e-12) nrm = mk(nrm.x / len, nrm.y / len, nrm.z / len);
+      a.tilts_out[o] = nrm.x;
+      a.tilts_out[o + 1] = nrm.y;
+      a.tilts_out[o + 2] = nrm.z;
+      double diag = a.k_tilt * aw;
+      if (!(diag > 1.0e-12) || (a.m.vflags[t.v_lo + tid] & VF_TILT_FIXED)) diag = 1.0;
+      a.minv[t.v_lo + tid] = 1.0 / diag;
     }
   }
-  if (MODE != 2) {
+  if (MODE != 2 && MODE != 3) {
     const double vals[1] = {e_tilt};
     const int ops[1] = {0};
     const int slots[1] = {MS_S_ETILT};
@@ -1206,8 +1235,285 @@ hipError_t launch_tilt(const TiltArgs& a, int mode, int cap, int max_ent, hipStr
     if (e != hipSuccess) return e;                                                      \
     hipLaunchKernelGGL((k_tilt<M>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);    \
   } while (0)
-  if (mode == 0) MS_LAUNCH_T(0); else if (mode == 1) MS_LAUNCH_T(1); else MS_LAUNCH_T(2);
+  if (mode == 0) MS_LAUNCH_T(0); else if (mode == 1) MS_LAUNCH_T(1); else if (mode == 2) MS_LAUNCH_T(2); else MS_LAUNCH_T(3);
 #undef MS_LAUNCH_T
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// k_bt: Helfrich bending with Kozlov-Hamm tilt-splay coupling
+// (modules/energy/bending_tilt.py:151-482), the facet pass that follows an energy pass run
+// with EnergyArgs.bt_vert:  E = 1/2 sum_f sum_k kappa_k (base_k + div_f t)^2 va_eff[f,k].
+//   div_f t = t0.g0 + t1.g1 + t2.g2, g_k = n x e_k / max(|n|^2, 1e-20)
+//             (geometry/tilt_operators.py:191-330, fortran_kernels/tilt_kernels.f90:26-86)
+//   va_eff  = mixed-Voronoi corner areas with the boundary->interior redistribution
+//             (bending_utils.py:37-171), recomputed exactly as the energy pass does
+//   MODE 1: div_eff_v = sum va_eff div / A_eff (:243-253), term = base + div_eff (0 on the
+//           boundary), then fK = K_dir kappa ratio term, fA_eff = kappa term^2/2,
+//           fA_vor = -2 kappa term ratio H (:279-283) for the unchanged gradient pass
+//   MODE 2: tilt gradient dE/dt_k = (sum_j kappa_j term_j va_eff_j) g_k ADDED to tilt_grad
+// LDS: px[3][cap] | tl[3][cap] | bs[cap] | kp[cap] | stg[9][T] (red aliases it) | vent | fl
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
+  extern __shared__ double lds[];
+  const int T = a.m.T;
+  double* px = lds;
+  double* tl = px + 3 * cap;
+  double* bs = tl + 3 * cap;
+  double* kp = bs + cap;
+  double* stg = kp + cap;
+  double* red = stg;
+  uint16_t* vent = reinterpret_cast<uint16_t*>(stg + 9 * T);
+  uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + ((max_ent + 3) & ~3));
+
+  const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
+  const int tid = threadIdx.x;
+  const bool have_d = a.d != nullptr;
+
+  int cur = 0, end = 0;
+  uint8_t own_fl = 0;
+  {
+    const bool own = tid < t.n_owned;
+    const int v_own = t.v_lo + tid;
+    CsrStage cs;
+    if (MODE != 0) csr_issue(cs, a.m, t, T, tid);
+    // rows this thread stages: its owned row and the halo rows h = tid, tid + T, ...
+    for (int r = own ? -1 : 0; ; ++r) {
+      const int h = r < 0 ? -1 : tid + r * T;
+      if (r >= 0 && h >= t.nh) break;
+      const int v = r < 0 ? v_own : a.m.halo_ids[t.h0 + h];
+      const int sl = r < 0 ? tid : t.n_owned + h;
+      const size_t g = 3 * (size_t)v;
+      const uint8_t fl = a.m.vflags[v];
+      double x0 = a.x[g], x1 = a.x[g + 1], x2 = a.x[g + 2];
+      if (have_d && !(fl & VF_FIXED)) {
+        x0 = x0 + a.alpha * a.d[g];
+        x1 = x1 + a.alpha * a.d[g + 1];
+        x2 = x2 + a.alpha * a.d[g + 2];
+      }
+      px[sl] = x0;
+      px[cap + sl] = x1;
+      px[2 * cap + sl] = x2;
+      tl[sl] = a.tilts[g];
+      tl[cap + sl] = a.tilts[g + 1];
+      tl[2 * cap + sl] = a.tilts[g + 2];
+      bs[sl] = a.bt_vert[4 * (size_t)v];
+      kp[sl] = a.m.kappa[v];
+      lfl[sl] = fl;
+      if (r < 0) own_fl = fl;
+    }
+    if (MODE != 0) {
+      csr_commit(cs, a.m, t, T, tid, vent);
+      if (own) {
+        cur = cs.vo0;
+        end = cs.vo1;
+      }
+    }
+  }
+  __syncthreads();
+
+  double e_bt = 0.0;
+  double ax = 0, ay = 0, az = 0;  // MODE 1: ax = sum va_eff div ; MODE 2: tilt gradient
+  for (int c0f = t.f0; c0f < t.f1; c0f += T) {
+    const int p = c0f + tid;
+    if (p < t.f1) {
+      const TileFacet tf = a.m.tile_facets[p];
+      const V3 v0 = lds_v3(px, cap, tf.l0), v1 = lds_v3(px, cap, tf.l1), v2 = lds_v3(px, cap, tf.l2);
+      const V3 e0 = v2 - v1, e1 = v0 - v2, e2 = v1 - v0;
+      const double l0 = dot(e0, e0), l1 = dot(e1, e1), l2 = dot(e2, e2);
+      const V3 n = cross(e2, -e1);
+      const double n2 = dot(n, n);
+      const double A2 = sqrt(n2);
+      // P1 basis gradients and the facet divergence
+      const double denom = n2 > 1.0e-20 ? n2 : 1.0e-20;
+      const V3 c0v = cross(n, e0), c1v = cross(n, e1), c2v = cross(n, e2);
+      const V3 g0 = mk(c0v.x / denom, c0v.y / denom, c0v.z / denom);
+      const V3 g1 = mk(c1v.x / denom, c1v.y / denom, c1v.z / denom);
+      const V3 g2 = mk(c2v.x / denom, c2v.y / denom, c2v.z / denom);
+      const double dv = dot(lds_v3(tl, cap, tf.l0), g0) + dot(lds_v3(tl, cap, tf.l1), g1) +
+                        dot(lds_v3(tl, cap, tf.l2), g2);
+      // cotans and effective corner areas, as in the energy pass
+      const double ad = A2 < 1.0e-12 ? 1.0e-12 : A2;
+      const double inv_ad = 1.0 / ad;
+      const double cc0 = dot(-e1, e2) * inv_ad, cc1 = dot(-e2, e0) * inv_ad, cc2 = dot(-e0, e1) * inv_ad;
+      double ve0, ve1, ve2;
+      corner_areas(cc0, cc1, cc2, l0, l1, l2, fmax(0.5 * A2, 1.0e-12), ve0, ve1, ve2);
+      int b0 = 0, b1 = 0, b2 = 0;
+      if (a.m.has_boundary) {
+        b0 = (lfl[tf.l0] & VF_BOUNDARY) ? 1 : 0;
+        b1 = (lfl[tf.l1] & VF_BOUNDARY) ? 1 : 0;
+        b2 = (lfl[tf.l2] & VF_BOUNDARY) ? 1 : 0;
+      }
+      const int n_int = 3 - (b0 + b1 + b2);
+      if (n_int > 0 && n_int < 3) {
+        const double b_sum = ve0 * b0 + ve1 * b1 + ve2 * b2;
+        const double extra = b_sum / (double)n_int;
+        const double m0 = b0 ? 0.0 : 1.0, m1 = b1 ? 0.0 : 1.0, m2 = b2 ? 0.0 : 1.0;
+        ve0 = ve0 * m0 + m0 * extra;
+        ve1 = ve1 * m1 + m1 * extra;
+        ve2 = ve2 * m2 + m2 * extra;
+      }
+      const double t0 = bs[tf.l0] + dv, t1 = bs[tf.l1] + dv, t2 = bs[tf.l2] + dv;
+      const double k0 = kp[tf.l0], k1 = kp[tf.l1], k2 = kp[tf.l2];
+      if (tf.flags & TF_OWNER) e_bt += 0.5 * ((k0 * (t0 * t0) * ve0 + k1 * (t1 * t1) * ve1) + k2 * (t2 * t2) * ve2);
+      double* s = stg + tid;
+      if (MODE == 1) {
+        s[0 * T] = ve0 * dv;
+        s[1 * T] = ve1 * dv;
+        s[2 * T] = ve2 * dv;
+      } else if (MODE == 2) {
+        const double dE = (k0 * t0 * ve0 + k1 * t1 * ve1) + k2 * t2 * ve2;
+        s[0 * T] = dE * g0.x; s[1 * T] = dE * g0.y; s[2 * T] = dE * g0.z;
+        s[3 * T] = dE * g1.x; s[4 * T] = dE * g1.y; s[5 * T] = dE * g1.z;
+        s[6 * T] = dE * g2.x; s[7 * T] = dE * g2.y; s[8 * T] = dE * g2.z;
+      }
+    }
+    if (MODE != 0) {
+      __syncthreads();
+      const int lo = c0f - t.f0, hi = min(c0f + T, t.f1) - t.f0;
+      while (cur < end) {
+        const int ent = vent[cur];
+        const int fl = ent >> 2;
+        if (fl >= hi) break;
+        const int k = ent & 3;
+        const double* s = stg + (fl - lo);
+        if (MODE == 1) {
+          ax += s[k * T];
+        } else {
+          ax += s[(3 * k) * T];
+          ay += s[(3 * k + 1) * T];
+          az += s[(3 * k + 2) * T];
+        }
+        ++cur;
+      }
+      __syncthreads();
+    }
+  }
+  if (MODE != 0 && tid < t.n_owned) {
+    const int v = t.v_lo + tid;
+    const size_t o = 3 * (size_t)v;
+    if (MODE == 1) {
+      const double* rec = a.bt_vert + 4 * (size_t)v;
+      const double base = rec[0], A_eff = rec[1], krH = rec[2];
+      const double div_eff = A_eff > 1.0e-20 ? ax / A_eff : 0.0;
+      double term = base + div_eff;
+      if (own_fl & VF_BOUNDARY) term = 0.0;
+      const double kappa = kp[tid];
+      a.fK[o] = a.fK[o] * term;
+      a.fK[o + 1] = a.fK[o + 1] * term;
+      a.fK[o + 2] = a.fK[o + 2] * term;
+      a.fA[2 * (size_t)v] = 0.5 * kappa * (term * term);
+      a.fA[2 * (size_t)v + 1] = -2.0 * term * krH;
+    } else {
+      a.tilt_grad[o] += ax;
+      a.tilt_grad[o + 1] += ay;
+      a.tilt_grad[o + 2] += az;
+    }
+  }
+  if (MODE != 0) __syncthreads();  // red aliases the staging block
+  {
+    const double vals[1] = {e_bt};
+    const int ops[1] = {0};
+    const int slots[1] = {MS_S_EBT};
+    block_reduce_store<1>(vals, ops, slots, red, a.partials + t.tile, (size_t)a.m.n_tiles);
+  }
+}
+
+size_t bt_lds_bytes(int T, int cap, int max_ent) {
+  return (8 * (size_t)cap + 9 * (size_t)T) * sizeof(double) + 2 * ((size_t)((max_ent + 3) & ~3)) +
+         (((size_t)cap + 15) / 16) * 16;
+}
+
+hipError_t launch_bt(const BtArgs& a, int mode, int cap, int max_ent, hipStream_t s) {
+  const int nb = a.tile1 - a.tile0;
+  if (nb <= 0) return hipSuccess;
+  const size_t lds = bt_lds_bytes(a.m.T, cap, max_ent);
+  hipError_t e;
+#define MS_LAUNCH_B(M)                                                                      \
+  do {                                                                                      \
+    e = ensure_lds(k_bt<M>, lds);                                                           \
+    if (e != hipSuccess) return e;                                                          \
+    hipLaunchKernelGGL((k_bt<M>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);          \
+  } while (0)
+  if (mode == 0) MS_LAUNCH_B(0); else if (mode == 1) MS_LAUNCH_B(1); else MS_LAUNCH_B(2);
+#undef MS_LAUNCH_B
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Tilt relaxation vector ops (runtime/steppers/tilt_relaxation.py:237-424), one workgroup per
+// tile so the partials line up with k_reduce.
+//   mode 0 PREP : tg[tilt-fixed] = 0 ; partials |tg|^2 (free rows) and <r, M^-1 r>, r = -tg
+//   mode 1 DIR  : dir = z (first) or z + beta dir, z = -tg * Minv            (:360-368,:410-421)
+//   mode 2 TRIAL: out = P(t + step*src) with P = tangent projection on the frozen normals;
+//                 tilt-fixed rows keep t unless keep_fixed == 0 (the initial projection)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_tvec(int mode, int tile0, int nv, int T, const uint8_t* vflags,
+                                                double* tg, const double* minv, double* dir,
+                                                const double* tilts, const double* src,
+                                                const double* normals, double* out, double coef,
+                                                int flag, double* partials, int n_tiles) {
+  __shared__ double red[16];
+  const int tile = tile0 + blockIdx.x;
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = threadIdx.x; i < T; i += BLOCK) {
+    const int v = tile * T + i;
+    if (v >= nv) break;
+    const size_t o = 3 * (size_t)v;
+    const bool tfix = vflags[v] & VF_TILT_FIXED;
+    if (mode == 0) {
+      V3 g = mk(tg[o], tg[o + 1], tg[o + 2]);
+      if (tfix) {
+        g = mk(0, 0, 0);
+        tg[o] = tg[o + 1] = tg[o + 2] = 0.0;
+      }
+      const double gg = dot_pinned(g, g);
+      s0 += gg;
+      s1 += gg * minv[v];
+    } else if (mode == 1) {
+      const double m = minv[v];
+      const V3 z = mk(-tg[o] * m, -tg[o + 1] * m, -tg[o + 2] * m);
+      if (flag) {
+        dir[o] = z.x;
+        dir[o + 1] = z.y;
+        dir[o + 2] = z.z;
+      } else {
+        dir[o] = z.x + coef * dir[o];
+        dir[o + 1] = z.y + coef * dir[o + 1];
+        dir[o + 2] = z.z + coef * dir[o + 2];
+      }
+    } else {
+      const V3 t0 = mk(tilts[o], tilts[o + 1], tilts[o + 2]);
+      V3 r = t0;
+      if (!(tfix && flag)) {
+        const V3 q = mk(t0.x + coef * src[o], t0.y + coef * src[o + 1], t0.z + coef * src[o + 2]);
+        const V3 n = mk(normals[o], normals[o + 1], normals[o + 2]);
+        const double dt = dot(q, n);
+        r = mk(q.x - dt * n.x, q.y - dt * n.y, q.z - dt * n.z);
+      }
+      out[o] = r.x;
+      out[o + 1] = r.y;
+      out[o + 2] = r.z;
+    }
+  }
+  if (mode == 0) {
+    double* po = partials + tile;
+    const size_t ps = (size_t)n_tiles;
+    double r = block_reduce(s0, 0, red);
+    if (threadIdx.x == 0) po[MS_S_TGNORM2 * ps] = r;
+    r = block_reduce(s1, 0, red);
+    if (threadIdx.x == 0) po[MS_S_TRZ * ps] = r;
+  }
+}
+
+hipError_t launch_tvec(int mode, int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* tg,
+                       const double* minv, double* dir, const double* tilts, const double* src,
+                       const double* normals, double* out, double coef, int flag, double* partials,
+                       int n_tiles, hipStream_t s) {
+  if (tile1 <= tile0) return hipSuccess;
+  hipLaunchKernelGGL(k_tvec, dim3(tile1 - tile0), dim3(BLOCK), 0, s, mode, tile0, nv, T, vflags, tg, minv,
+                     dir, tilts, src, normals, out, coef, flag, partials, n_tiles);
   return hipGetLastError();
 }
 

@@ -152,6 +152,35 @@ class DeviceMesh:
         self._chk(L.lib().ms_get_tilt_gradient(self._h, _pd(out)), "ms_get_tilt_gradient")
         return out
 
+    def set_tilt_fixed(self, tilt_fixed=None):
+        """vertex.tilt_fixed flags of the reference (None clears them)."""
+        if tilt_fixed is None:
+            ptr = None
+        else:
+            arr = np.ascontiguousarray(np.asarray(tilt_fixed, dtype=bool).astype(np.uint8))
+            if arr.shape != (self.nv,):
+                raise ValueError("tilt_fixed must have shape (nv,)")
+            ptr = arr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+        self._chk(L.lib().ms_set_tilt_fixed(self._h, ptr), "ms_set_tilt_fixed")
+
+    def tilt_energy_and_gradient(self, want_gradient: bool = True):
+        """-> (energy of the tilt-reading modules, dE/dt (nv,3) or None) at the stored tilts."""
+        e = ctypes.c_double(0.0)
+        out = np.empty((self.nv, 3), dtype=np.float64) if want_gradient else None
+        self._chk(L.lib().ms_tilt_energy_and_gradient(self._h, ctypes.byref(e), _pd(out) if want_gradient else None),
+                  "ms_tilt_energy_and_gradient")
+        return float(e.value), out
+
+    def relax_tilts(self, *, solver: str = "cg", max_iters: int, step_size: float, tol: float = 0.0,
+                    jacobi: bool = True):
+        """TiltRelaxationManager.relax_tilts on the device -> (iterations, energy evaluations)."""
+        rp = L.ms_tilt_relax_params(1 if solver == "cg" else 0, int(max_iters), float(step_size), float(tol),
+                                    1 if jacobi else 0)
+        it, ev = ctypes.c_int(0), ctypes.c_int(0)
+        self._chk(L.lib().ms_relax_tilts(self._h, ctypes.byref(rp), ctypes.byref(it), ctypes.byref(ev)),
+                  "ms_relax_tilts")
+        return int(it.value), int(ev.value)
+
     def project_tilts_to_tangent(self):
         self._chk(L.lib().ms_project_tilts_to_tangent(self._h), "ms_project_tilts_to_tangent")
 

@@ -38,7 +38,7 @@ class ArrayBody:
 class ArrayMesh:
     def __init__(self, positions, tri_rows, *, fixed=None, surface_tension=None,
                  bending_modulus=None, spontaneous_curvature=None, bodies=None, tilts=None,
-                 global_parameters=None, energy_modules=None, constraint_modules=None):
+                 tilt_fixed=None, global_parameters=None, energy_modules=None, constraint_modules=None):
         self._positions = np.array(positions, dtype=np.float64, order="C", copy=True)
         self._tri_rows = np.ascontiguousarray(tri_rows, dtype=np.int32)
         nv, nf = self._positions.shape[0], self._tri_rows.shape[0]
@@ -73,6 +73,8 @@ class ArrayMesh:
         self._tilts = (np.zeros_like(self._positions) if tilts is None
                        else np.array(tilts, dtype=np.float64, order="C", copy=True))
         self._tilts_version = 0
+        self.tilt_fixed = (np.zeros(nv, dtype=bool) if tilt_fixed is None
+                           else np.asarray(tilt_fixed, dtype=bool).copy())
         self._version = 0
         self._facet_loops_version = 0
         self._vertex_ids_version = 0
@@ -291,6 +293,14 @@ class HipMirror:
             self.dm.set_tilts(tilts, k_t)
             self._tilt_key = key
 
+    def upload_tilt_fixed(self):
+        """vertex.tilt_fixed flags (runtime/minimizer_helpers.py:49-75)."""
+        mask = tilt_fixed_mask(self.mesh)
+        key = (self._topo_key, mask.tobytes())
+        if key != getattr(self, "_tilt_fixed_key", None):
+            self.dm.set_tilt_fixed(mask if mask.any() else None)
+            self._tilt_fixed_key = key
+
     def mark_device_tilts_current(self):
         self._tilt_key = (self._topo_key, getattr(self.mesh, "_tilts_version", None),
                           self._tilt_key[2] if getattr(self, "_tilt_key", None) else 0.0, None)
@@ -301,6 +311,18 @@ class HipMirror:
         if key != self._bend_key:
             self.dm.set_bending_params(kappa, c0)
             self._bend_key = key
+
+
+def tilt_fixed_mask(mesh) -> np.ndarray:
+    """(nv,) bool: ArrayMesh.tilt_fixed, or the reference Mesh's per-vertex ``tilt_fixed`` attribute."""
+    own = getattr(mesh, "tilt_fixed", None)
+    if own is not None and not callable(own):
+        return np.asarray(own, dtype=bool)
+    verts = getattr(mesh, "vertices", None)
+    ids = getattr(mesh, "vertex_ids", None)
+    if verts is not None and ids is not None and isinstance(verts, dict):
+        return np.array([bool(getattr(verts[int(v)], "tilt_fixed", False)) for v in ids], dtype=bool)
+    return np.zeros(len(mesh.positions_view()), dtype=bool)
 
 
 def mirror_for(mesh, device: int = 0, tile_vertices: int = 0) -> HipMirror:

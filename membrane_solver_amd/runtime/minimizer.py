@@ -42,8 +42,8 @@ from .steppers.base import write_back_positions
 logger = logging.getLogger("membrane_solver")
 
 _ENERGY_BITS = {"surface": L.MS_MOD_SURFACE, "bending": L.MS_MOD_BENDING, "volume": L.MS_MOD_VOLUME_PENALTY,
-                "tilt": L.MS_MOD_TILT}
-_ENERGY_SLOT = {"surface": 0, "bending": 1, "volume": 2, "tilt": 3}
+                "tilt": L.MS_MOD_TILT, "bending_tilt": L.MS_MOD_BENDING_TILT}
+_ENERGY_SLOT = {"surface": 0, "bending": 1, "volume": 2, "tilt": 3, "bending_tilt": 1}
 
 
 class GradientRows:
@@ -118,7 +118,8 @@ class Minimizer:
                 raise TypeError(f"energy module {name!r} lacks compute_energy_and_gradient_array")
             if name not in _ENERGY_BITS:
                 raise L.MembraneHipError(
-                    f"energy module {name!r} is outside the HIP hot path (surface, bending, volume, tilt)")
+                    f"energy module {name!r} is outside the HIP hot path (surface, bending, volume, tilt, "
+                    "bending_tilt)")
         self.constraint_modules = [self.constraint_manager.get_constraint(c)
                                    for c in self.constraint_module_names]
         for name in self.constraint_module_names:
@@ -152,9 +153,6 @@ class Minimizer:
     # -- device configuration --------------------------------------------------
     def _device(self):
         gp = self.global_params
-        tilt_mode = gp.get("tilt_solve_mode", "fixed")
-        if tilt_mode not in (None, "fixed"):
-            raise L.MembraneHipError(f"tilt_solve_mode={tilt_mode!r} is outside the HIP hot path")
         mir = mirror_for(self.mesh, device=self.device, tile_vertices=self.tile_vertices)
         dm = mir.sync()
         mods = 0
@@ -185,7 +183,18 @@ class Minimizer:
                 and not gp.get("volume_projection_during_minimization", True):
             mods |= L.MS_TRACK_VOLUME  # drift check of minimizer.py:1478-1513
         model = bending_model(gp)
-        mode = bending_gradient_mode(gp) if (mods & L.MS_MOD_BENDING) else "analytic"
+        if (mods & L.MS_MOD_BENDING) and (mods & L.MS_MOD_BENDING_TILT):
+            raise L.MembraneHipError("bending and bending_tilt together are outside the HIP hot path")
+        if mods & L.MS_MOD_BENDING_TILT:
+            model = "helfrich"  # bending_tilt.py:212-215
+        any_bend = mods & (L.MS_MOD_BENDING | L.MS_MOD_BENDING_TILT)
+        mode = bending_gradient_mode(gp) if any_bend else "analytic"
+        if mode == "approx" and (mods & L.MS_MOD_BENDING_TILT) and np.any(_boundary(self.mesh)) \
+                and self.energy_module_names.index("bending_tilt") != len(self.energy_module_names) - 1:
+            raise L.MembraneHipError(
+                "bending_gradient_mode=approx with modules listed AFTER bending_tilt on an open mesh is "
+                "not on the fused device path (bending_tilt.py:297-299 zeroes boundary rows of what was "
+                "accumulated so far); list bending_tilt last")
         if mode == "approx" and (mods & L.MS_MOD_BENDING):
             order = self.energy_module_names
             if order.index("bending") != len(order) - 1 and np.any(_boundary(self.mesh)):
@@ -195,10 +204,11 @@ class Minimizer:
                     "rows of what was accumulated so far); list bending last")
         if mods & L.MS_MOD_SURFACE:
             mir.upload_surface_tension()
-        if mods & L.MS_MOD_BENDING:
+        if any_bend:
             mir.upload_bending_params(gp, model)
-        if mods & L.MS_MOD_TILT:
+        if mods & (L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT):
             mir.upload_tilts(gp)
+            mir.upload_tilt_fixed()
         key = (mods, model, mode, stiffness, target, id(dm))
         if key != self._configured_key:
             dm.set_params(modules=mods,
@@ -258,6 +268,39 @@ class Minimizer:
         iters, _v = dm.project_volume(target, tol=1e-12, max_iter=max_iter)
         return iters > 0
 
+    # -- tilt relaxation (runtime/steppers/tilt_relaxation.py:237-300 parameter handling) --
+    def _relax_tilts(self, dm) -> bool:
+        gp = self.global_params
+        mode = str(gp.get("tilt_solve_mode", "fixed") or "").strip().lower()
+        if mode in ("", "none", "off", "false", "fixed"):
+            return False
+        if mode not in ("nested", "coupled"):
+            logger.warning("Unknown tilt_solve_mode=%r; treating as 'fixed'.", mode)
+            return False
+        step = float(gp.get("tilt_step_size", 0.0) or 0.0)
+        if step <= 0.0:
+            return False
+        tol = float(gp.get("tilt_tol", 0.0) or 0.0)
+        if mode == "nested":
+            n_inner = int(gp.get("tilt_inner_steps", 0) or 0)
+        else:
+            n_inner = int(gp.get("tilt_coupled_steps", gp.get("tilt_inner_steps", 0)) or 0)
+        if n_inner <= 0:
+            return False
+        solver = str(gp.get("tilt_solver", "cg") or "cg").strip().lower()
+        if solver not in ("gd", "cg"):
+            logger.warning("Unknown tilt_solver=%r; using gradient descent.", solver)
+            solver = "gd"
+        max_iters = int(gp.get("tilt_cg_max_iters", n_inner) or 0) if solver == "cg" else n_inner
+        if max_iters <= 0:
+            return False
+        if float(gp.get("tilt_smoothness_rigidity", 0.0) or 0.0) != 0.0:
+            raise L.MembraneHipError("tilt_smoothness is outside the HIP hot path")
+        pre = str(gp.get("tilt_cg_preconditioner", "jacobi") or "jacobi").strip().lower()
+        dm.relax_tilts(solver=solver, max_iters=max_iters, step_size=step, tol=max(tol, 0.0),
+                       jacobi=(pre == "jacobi"))
+        return True
+
     # -- the loop -------------------------------------------------------------------
     def minimize(self, n_steps: int = 1, callback: Optional[Callable] = None, *, sync_mesh: bool = True):
         """Run ``n_steps`` iterations (minimizer.py:1189-1535).
@@ -297,7 +340,7 @@ class Minimizer:
             if dirty_box[0] or self._device_ahead:
                 if sync_mesh:
                     write_back_positions(self.mesh, dm, mir)
-                    if dm.modules & L.MS_MOD_TILT:  # tilts were re-projected on the device
+                    if dm.modules & (L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT):  # tilts changed on the device
                         self.mesh.set_tilts_from_array(dm.get_tilts())
                         mir.mark_device_tilts_current()
                     self._device_ahead = False
@@ -313,6 +356,9 @@ class Minimizer:
                     dirty_box[0] = False
                 callback(self.mesh, i)
                 mir, dm = self._device()
+            if dm.modules & (L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT):
+                if self._relax_tilts(dm):  # minimizer.py:1237-1307, before the convergence check
+                    dirty_box[0] = True
             step_mode = str(gp.get("step_size_mode", "adaptive") or "adaptive").lower()
             fixed_step = float(gp.get("step_size", self.step_size) or self.step_size)
             step_size_in = fixed_step if step_mode == "fixed" else self.step_size
