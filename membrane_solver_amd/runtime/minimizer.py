@@ -207,6 +207,9 @@ class Minimizer:
         if any_bend:
             mir.upload_bending_params(gp, model)
         if mods & (L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT):
+            if gp.get("line_search_reduced_energy", False):
+                raise L.MembraneHipError("line_search_reduced_energy (inner tilt relaxation inside every "
+                                         "line-search trial, minimizer.py:568-608) is outside the HIP hot path")
             mir.upload_tilts(gp)
             mir.upload_tilt_fixed()
         key = (mods, model, mode, stiffness, target, id(dm))
