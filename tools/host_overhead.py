@@ -1,0 +1,43 @@
+"""Where does a step's wall time go: Minimizer (Python bookkeeping) vs a bare ms_step loop."""
+import ctypes
+import time
+
+import numpy as np
+
+from membrane_solver_amd import _lib as L
+from membrane_solver_amd import meshgen
+from membrane_solver_amd.device import DeviceMesh
+
+P, T = meshgen.icosphere(320)
+P = meshgen.smooth_displace(P, 0.05)
+nv, nf = P.shape[0], T.shape[0]
+dm = DeviceMesh(P, T)
+dm.set_surface_tension(np.ones(nf))
+dm.set_bending_params(np.ones(nv), np.zeros(nv))
+dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING)
+lib = L.lib()
+sp = L.ms_stepper_params(L.MS_STEPPER_CG, 10, 0.7, 1e-4, 1.5, 10.0, 10, 0.0, 2)
+r = L.ms_step_result()
+step = 1e-6
+
+
+def run(n):
+    global step
+    for _ in range(n):
+        lib.ms_step(dm._h, ctypes.byref(sp), step, 1e-6, ctypes.byref(r))
+        step = r.next_step
+        if not r.success:
+            lib.ms_reset_stepper(dm._h)
+
+
+run(40)
+t0 = time.perf_counter()
+run(200)
+dt = time.perf_counter() - t0
+print("bare ms_step loop: %.1f us/step" % (1e6 * dt / 200))
+dm.profile_enable(True)
+dm.profile_read()
+run(100)
+prof = dm.profile_read()
+tot = sum(ms for ms, n in prof.values())
+print("kernel time per step (HIP events): %.1f us" % (1e3 * tot / 100), {k: (round(1e3 * ms / max(n, 1), 1), n) for k, (ms, n) in prof.items()})
