@@ -289,10 +289,13 @@ int ms_tile_stats(ms_ctx *ctx, int64_t *n_tiles, int64_t *facet_instances,
 /* Per-kernel device timing with HIP events on the context's stream.  While
  * enabled every energy / gradient / direction / reduce launch is bracketed by
  * an event pair; ms_profile_read synchronises, returns the summed milliseconds
- * and launch counts per kind {0 energy, 1 gradient, 2 direction, 3 reduce} and
- * resets the counters.  Used by bench.py for the roofline figure. */
+ * and launch counts per kind {0 energy, 1 gradient, 2 direction, 3 reduce,
+ * 4 tilt, 5 bending_tilt facet pass, 6 tilt vector ops, 7 unused} and resets the
+ * counters.  Used by bench.py for the roofline figure. */
+#define MS_PROF_KINDS 8
 int ms_profile_enable(ms_ctx *ctx, int on);
-int ms_profile_read(ms_ctx *ctx, double total_ms[4], int64_t launches[4]);
+int ms_profile_read(ms_ctx *ctx, double total_ms[MS_PROF_KINDS],
+                    int64_t launches[MS_PROF_KINDS]);
 
 /* Host-only planning pass (no GPU needed): runs the same tiling ms_create
  * uses and reports stats[0..7] = {n_tiles, facet_instances, max_halo,

@@ -90,8 +90,8 @@ struct ms_ctx {
   };
   std::vector<ProfRec> prof_pending;
   std::vector<hipEvent_t> prof_pool;
-  double prof_ms[4] = {0, 0, 0, 0};
-  int64_t prof_n[4] = {0, 0, 0, 0};
+  double prof_ms[MS_PROF_KINDS] = {0};
+  int64_t prof_n[MS_PROF_KINDS] = {0};
   std::string err;
 };
 
@@ -184,7 +184,10 @@ int tilt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* src
   a.g = shape_gradient ? c->buf[MS_BUF_G] : nullptr;
   a.tilt_grad = c->d_tilt_grad;
   a.partials = c->d_partials;
-  HIPCHK(c, launch_tilt(a, mode, c->cap, c->til.max_ent, c->stream));
+  {
+    ProfScope ps(c, 4);
+    HIPCHK(c, launch_tilt(a, mode, c->cap, c->til.max_ent, c->stream));
+  }
   return MS_OK;
 }
 // bending_tilt facet pass (mode 0 energy / 1 + factors / 2 + tilt gradient) on the positions of
@@ -204,7 +207,10 @@ int bt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* tilts
   a.fA = c->buf[MS_BUF_FA];
   a.tilt_grad = c->d_tilt_grad;
   a.partials = c->d_partials;
-  HIPCHK(c, launch_bt(a, mode, c->cap, c->til.max_ent, c->stream));
+  {
+    ProfScope ps(c, 5);
+    HIPCHK(c, launch_bt(a, mode, c->cap, c->til.max_ent, c->stream));
+  }
   return MS_OK;
 }
 constexpr uint32_t MASK_GRAD = (1u << MS_S_GGC) | (1u << MS_S_GCGC);
@@ -832,6 +838,7 @@ int ms_relax_tilts(ms_ctx* c, const ms_tilt_relax_params* rp, int* iters_out, in
     HIPCHK(c, launch_tilt(a, 3, c->cap, t.max_ent, c->stream));
   }
   auto tvec = [&](int mode, const double* src, double* out, double coef, int flag) -> int {
+    ProfScope ps(c, 6);
     HIPCHK(c, launch_tvec(mode, c->tile0, c->tile1, t.nv, t.T, c->d_vflags, c->d_tilt_grad, c->d_minv,
                           c->d_tdir, c->d_tilts, src, c->d_tn, out, coef, flag, c->d_partials, t.n_tiles,
                           c->stream));
@@ -1348,7 +1355,7 @@ int ms_profile_enable(ms_ctx* c, int on) {
   return MS_OK;
 }
 
-int ms_profile_read(ms_ctx* c, double total_ms[4], int64_t launches[4]) {
+int ms_profile_read(ms_ctx* c, double total_ms[MS_PROF_KINDS], int64_t launches[MS_PROF_KINDS]) {
   if (!c || !total_ms || !launches) return MS_ERR_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (auto& r : c->prof_pending) {
@@ -1361,7 +1368,7 @@ int ms_profile_read(ms_ctx* c, double total_ms[4], int64_t launches[4]) {
     c->prof_pool.push_back(r.b);
   }
   c->prof_pending.clear();
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < MS_PROF_KINDS; ++k) {
     total_ms[k] = c->prof_ms[k];
     launches[k] = c->prof_n[k];
     c->prof_ms[k] = 0.0;

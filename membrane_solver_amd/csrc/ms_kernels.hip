@@ -1278,31 +1278,56 @@ __global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
     const int v_own = t.v_lo + tid;
     CsrStage cs;
     if (MODE != 0) csr_issue(cs, a.m, t, T, tid);
-    // rows this thread stages: its owned row and the halo rows h = tid, tid + T, ...
-    for (int r = own ? -1 : 0; ; ++r) {
-      const int h = r < 0 ? -1 : tid + r * T;
-      if (r >= 0 && h >= t.nh) break;
-      const int v = r < 0 ? v_own : a.m.halo_ids[t.h0 + h];
-      const int sl = r < 0 ? tid : t.n_owned + h;
+    // all loads of a row set are issued before the first LDS write (two HBM round trips)
+    struct Row {
+      double x0, x1, x2, t0, t1, t2, b, k;
+      uint8_t fl;
+    };
+    auto load_row = [&](int v) {
+      Row r;
       const size_t g = 3 * (size_t)v;
-      const uint8_t fl = a.m.vflags[v];
-      double x0 = a.x[g], x1 = a.x[g + 1], x2 = a.x[g + 2];
-      if (have_d && !(fl & VF_FIXED)) {
-        x0 = x0 + a.alpha * a.d[g];
-        x1 = x1 + a.alpha * a.d[g + 1];
-        x2 = x2 + a.alpha * a.d[g + 2];
+      r.fl = a.m.vflags[v];
+      r.x0 = a.x[g];
+      r.x1 = a.x[g + 1];
+      r.x2 = a.x[g + 2];
+      if (have_d) {
+        const double d0 = a.d[g], d1 = a.d[g + 1], d2 = a.d[g + 2];
+        if (!(r.fl & VF_FIXED)) {
+          r.x0 = r.x0 + a.alpha * d0;
+          r.x1 = r.x1 + a.alpha * d1;
+          r.x2 = r.x2 + a.alpha * d2;
+        }
       }
-      px[sl] = x0;
-      px[cap + sl] = x1;
-      px[2 * cap + sl] = x2;
-      tl[sl] = a.tilts[g];
-      tl[cap + sl] = a.tilts[g + 1];
-      tl[2 * cap + sl] = a.tilts[g + 2];
-      bs[sl] = a.bt_vert[4 * (size_t)v];
-      kp[sl] = a.m.kappa[v];
-      lfl[sl] = fl;
-      if (r < 0) own_fl = fl;
+      r.t0 = a.tilts[g];
+      r.t1 = a.tilts[g + 1];
+      r.t2 = a.tilts[g + 2];
+      r.b = a.bt_vert[4 * (size_t)v];
+      r.k = a.m.kappa[v];
+      return r;
+    };
+    auto put_row = [&](const Row& r, int sl) {
+      px[sl] = r.x0;
+      px[cap + sl] = r.x1;
+      px[2 * cap + sl] = r.x2;
+      tl[sl] = r.t0;
+      tl[cap + sl] = r.t1;
+      tl[2 * cap + sl] = r.t2;
+      bs[sl] = r.b;
+      kp[sl] = r.k;
+      lfl[sl] = r.fl;
+    };
+    const bool has_h = tid < t.nh;
+    int hv = 0;
+    if (has_h) hv = a.m.halo_ids[t.h0 + tid];
+    Row ro{}, rh{};
+    if (own) ro = load_row(v_own);
+    if (has_h) rh = load_row(hv);
+    if (own) {
+      put_row(ro, tid);
+      own_fl = ro.fl;
     }
+    if (has_h) put_row(rh, t.n_owned + tid);
+    for (int h = tid + T; h < t.nh; h += T) put_row(load_row(a.m.halo_ids[t.h0 + h]), t.n_owned + h);
     if (MODE != 0) {
       csr_commit(cs, a.m, t, T, tid, vent);
       if (own) {

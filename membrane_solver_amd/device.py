@@ -298,11 +298,11 @@ class DeviceMesh:
         self._chk(L.lib().ms_profile_enable(self._h, int(on)), "ms_profile_enable")
 
     def profile_read(self):
-        """-> {kind: (total_ms, launches)} for energy / gradient / direction / reduce."""
-        ms = np.zeros(4)
-        n = np.zeros(4, dtype=np.int64)
+        """-> {kind: (total_ms, launches)} per kernel kind (include/membrane_hip.h, ms_profile_read)."""
+        ms = np.zeros(8)
+        n = np.zeros(8, dtype=np.int64)
         self._chk(L.lib().ms_profile_read(self._h, _pd(ms), n.ctypes.data_as(L._I64)), "ms_profile_read")
-        names = ("energy", "gradient", "direction", "reduce")
+        names = ("energy", "gradient", "direction", "reduce", "tilt", "bending_tilt", "tilt_vec", "other")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
     def shard_info(self):
