@@ -222,6 +222,43 @@ int ms_step(ms_ctx *ctx, const ms_stepper_params *sp, double step_size,
             double tol, ms_step_result *out);
 /* ConjugateGradient.reset (conjugate_gradient.py:44-50) */
 int ms_reset_stepper(ms_ctx *ctx);
+
+/* Minimizer.minimize loop body (runtime/minimizer.py:1230-1535) for n_steps
+ * iterations without returning to the host language: [tilt relaxation] ->
+ * ms_step -> step-size bookkeeping (fixed mode, zero-step counter, stepper
+ * reset on failure, :1425-1476) -> Lagrange volume-drift check with device
+ * projection (:1478-1513).  step_log (n_steps x 8, may be NULL) receives per
+ * iteration {success, next_step, energy, energy_eval, grad_norm, g_dot_d,
+ * alpha, trials}.  Identical to driving ms_step from the caller. */
+typedef struct ms_minimize_params {
+  ms_stepper_params stepper;
+  double step_size;        /* in: first step size                              */
+  double tol;              /* convergence |g| < tol                            */
+  int fixed_step_mode;     /* gp["step_size_mode"] == "fixed"                  */
+  double fixed_step;       /* gp["step_size"]                                  */
+  int max_zero_steps;      /* gp["max_zero_steps"], 10                         */
+  double step_size_floor;  /* gp["step_size_floor"], 1e-8                      */
+  int drift_check;         /* Lagrange mode, no per-trial projection, target set */
+  double target_volume;
+  double volume_tolerance; /* gp["volume_tolerance"], 1e-3                     */
+  int project_on_drift;    /* an enforceable volume constraint module exists   */
+  int relax_tilts;         /* tilt_solve_mode nested/coupled                   */
+  ms_tilt_relax_params relax;
+} ms_minimize_params;
+
+typedef struct ms_minimize_result {
+  int iterations;          /* iterations executed                              */
+  int converged;           /* stopped on |g| < tol                             */
+  int zero_step_exit;      /* stopped after max_zero_steps failed tiny steps   */
+  int step_success;        /* success flag of the last line search            */
+  int accepted, trials, guard_rejects, moved;  /* totals; moved: x changed     */
+  double step_size;        /* out: step size for the next call                 */
+  double energy_eval;      /* energy of the last gradient evaluation           */
+  double grad_norm;
+} ms_minimize_result;
+
+int ms_minimize(ms_ctx *ctx, const ms_minimize_params *params, int n_steps,
+                ms_minimize_result *out, double *step_log);
 /* modules/constraints/volume.enforce_constraint projection loop (:117-149) */
 int ms_project_volume(ms_ctx *ctx, double target, double tol, int max_iter,
                       int *iters_out, double *volume_out);

@@ -59,6 +59,22 @@ class ms_tilt_relax_params(ctypes.Structure):
                 ("tol", ctypes.c_double), ("jacobi", ctypes.c_int)]
 
 
+class ms_minimize_params(ctypes.Structure):
+    _fields_ = [("stepper", ms_stepper_params), ("step_size", ctypes.c_double), ("tol", ctypes.c_double),
+                ("fixed_step_mode", ctypes.c_int), ("fixed_step", ctypes.c_double),
+                ("max_zero_steps", ctypes.c_int), ("step_size_floor", ctypes.c_double),
+                ("drift_check", ctypes.c_int), ("target_volume", ctypes.c_double),
+                ("volume_tolerance", ctypes.c_double), ("project_on_drift", ctypes.c_int),
+                ("relax_tilts", ctypes.c_int), ("relax", ms_tilt_relax_params)]
+
+
+class ms_minimize_result(ctypes.Structure):
+    _fields_ = [("iterations", ctypes.c_int), ("converged", ctypes.c_int), ("zero_step_exit", ctypes.c_int),
+                ("step_success", ctypes.c_int), ("accepted", ctypes.c_int), ("trials", ctypes.c_int),
+                ("guard_rejects", ctypes.c_int), ("moved", ctypes.c_int), ("step_size", ctypes.c_double),
+                ("energy_eval", ctypes.c_double), ("grad_norm", ctypes.c_double)]
+
+
 class ms_step_result(ctypes.Structure):
     _fields_ = [("success", ctypes.c_int), ("converged", ctypes.c_int), ("trials", ctypes.c_int),
                 ("guard_rejects", ctypes.c_int), ("next_step", ctypes.c_double),
@@ -102,6 +118,8 @@ SIGNATURES = {
     "ms_step": (ctypes.c_int, [_P, ctypes.POINTER(ms_stepper_params), ctypes.c_double,
                                ctypes.c_double, ctypes.POINTER(ms_step_result)]),
     "ms_reset_stepper": (ctypes.c_int, [_P]),
+    "ms_minimize": (ctypes.c_int, [_P, ctypes.POINTER(ms_minimize_params), ctypes.c_int,
+                                   ctypes.POINTER(ms_minimize_result), _D]),
     "ms_project_volume": (ctypes.c_int, [_P, ctypes.c_double, ctypes.c_double, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_int), _D]),
     "ms_phase_energy": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_double, ctypes.c_int,

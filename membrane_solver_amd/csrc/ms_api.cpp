@@ -1138,6 +1138,84 @@ int ms_project_volume(ms_ctx* c, double target, double tol, int max_iter, int* i
   return MS_OK;
 }
 
+int ms_minimize(ms_ctx* c, const ms_minimize_params* mp, int n_steps, ms_minimize_result* out,
+                double* step_log) {
+  if (!c || !mp || !out) return fail(c, MS_ERR_INVALID, "ms_minimize: NULL argument");
+  memset(out, 0, sizeof(*out));
+  double step_size = mp->step_size;
+  int zero_steps = 0;
+  out->step_success = 1;
+  out->step_size = step_size;
+  for (int i = 0; i < n_steps; ++i) {
+    int rc;
+    if (mp->relax_tilts) {  // minimizer.py:1237-1307: before the convergence check
+      rc = ms_relax_tilts(c, &mp->relax, nullptr, nullptr);
+      if (rc) return rc;
+      out->moved = 1;
+    }
+    const double step_in = mp->fixed_step_mode ? mp->fixed_step : step_size;
+    ms_step_result r;
+    rc = ms_step(c, &mp->stepper, step_in, mp->tol, &r);
+    if (rc) return rc;
+    out->iterations = i + 1;
+    out->energy_eval = r.energy_eval;
+    out->grad_norm = r.grad_norm;
+    if (step_log) {
+      double* row = step_log + 8 * (size_t)i;
+      row[0] = r.success;
+      row[1] = r.next_step;
+      row[2] = r.energy;
+      row[3] = r.energy_eval;
+      row[4] = r.grad_norm;
+      row[5] = r.g_dot_d;
+      row[6] = r.alpha;
+      row[7] = r.trials;
+    }
+    if (r.converged) {  // :1324-1337
+      out->converged = 1;
+      out->step_success = 1;
+      out->step_size = step_size;
+      return MS_OK;
+    }
+    out->step_success = r.success;
+    out->trials += r.trials;
+    out->guard_rejects += r.guard_rejects;
+    step_size = r.next_step;
+    if (r.success) {
+      ++out->accepted;
+      out->moved = 1;
+    }
+    if (mp->fixed_step_mode) step_size = mp->fixed_step;
+    out->step_size = step_size;
+    if (!r.success) {  // :1425-1476
+      if (step_size <= mp->step_size_floor) {
+        if (++zero_steps >= mp->max_zero_steps) {
+          out->zero_step_exit = 1;
+          return MS_OK;
+        }
+      } else {
+        zero_steps = 0;
+      }
+      ms_reset_stepper(c);
+    } else {
+      zero_steps = 0;
+      if (mp->drift_check) {  // :1478-1513
+        const double denom = std::max(std::fabs(mp->target_volume), 1.0);
+        if (std::fabs(r.volume - mp->target_volume) / denom > mp->volume_tolerance) {
+          if (mp->project_on_drift) {
+            int iters = 0;
+            rc = ms_project_volume(c, mp->target_volume, 1e-12, 12, &iters, nullptr);
+            if (rc) return rc;
+          }
+          ms_reset_stepper(c);
+        }
+      }
+    }
+  }
+  return MS_OK;
+}
+
+
 // ---- phase-level API -------------------------------------------------------
 int ms_phase_energy(ms_ctx* c, int use_direction, double alpha, int write_trial, int guard,
                     int write_bending_factors) {

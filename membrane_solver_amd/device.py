@@ -32,7 +32,7 @@ def _pu8(a):
     return None if a is None else a.ctypes.data_as(L._U8)
 
 
-@dataclass
+@dataclass(slots=True)
 class StepResult:
     success: bool
     converged: bool
@@ -201,15 +201,33 @@ class DeviceMesh:
              beta: float = 0.7, c: float = 1e-4, gamma: float = 1.5, alpha_max_factor: float = 10.0,
              restart_interval: int = 10, edge_fraction: float = 0.0,
              reuse_energy0: int = 0) -> StepResult:
-        sp = L.ms_stepper_params(int(stepper), int(max_iter), float(beta), float(c), float(gamma),
-                                 float(alpha_max_factor), int(restart_interval), float(edge_fraction),
-                                 int(reuse_energy0))
-        r = L.ms_step_result()
-        self._chk(L.lib().ms_step(self._h, ctypes.byref(sp), float(step_size), float(tol),
-                                  ctypes.byref(r)), "ms_step")
-        return StepResult(bool(r.success), bool(r.converged), int(r.trials), int(r.guard_rejects),
-                          float(r.next_step), float(r.energy), float(r.alpha), float(r.energy_eval),
-                          float(r.grad_norm), float(r.g_dot_d), float(r.volume))
+        # the parameter block and the result struct are reused between calls: at ~140 us per
+        # step every microsecond of ctypes marshalling shows
+        key = (stepper, max_iter, beta, c, gamma, alpha_max_factor, restart_interval, edge_fraction,
+               reuse_energy0)
+        cache = self.__dict__.get("_step_cache")
+        if cache is None or cache[0] != key:
+            sp = L.ms_stepper_params(int(stepper), int(max_iter), float(beta), float(c), float(gamma),
+                                     float(alpha_max_factor), int(restart_interval), float(edge_fraction),
+                                     int(reuse_energy0))
+            r = L.ms_step_result()
+            cache = (key, sp, r, ctypes.byref(sp), ctypes.byref(r), L.lib().ms_step)
+            self._step_cache = cache
+        _k, sp, r, sp_ref, r_ref, fn = cache
+        rc = fn(self._h, sp_ref, step_size, tol, r_ref)
+        if rc != 0:
+            self._chk(rc, "ms_step")
+        return StepResult(r.success != 0, r.converged != 0, r.trials, r.guard_rejects, r.next_step, r.energy,
+                          r.alpha, r.energy_eval, r.grad_norm, r.g_dot_d, r.volume)
+
+    def minimize(self, params: "L.ms_minimize_params", n_steps: int, want_log: bool = False):
+        """ms_minimize: n_steps iterations of the minimizer loop inside the library.
+        -> (ms_minimize_result, step_log (iterations,8) | None)"""
+        out = L.ms_minimize_result()
+        log = np.zeros((int(n_steps), 8)) if want_log else None
+        self._chk(L.lib().ms_minimize(self._h, ctypes.byref(params), int(n_steps), ctypes.byref(out),
+                                      _pd(log) if want_log else None), "ms_minimize")
+        return out, (log[: out.iterations] if want_log else None)
 
     def reset_stepper(self):
         self._chk(L.lib().ms_reset_stepper(self._h), "ms_reset_stepper")

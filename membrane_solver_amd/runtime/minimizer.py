@@ -34,6 +34,7 @@ import numpy as np
 
 from .. import _lib as L
 from ..core.parameters import ParameterResolver
+from .steppers.base import BaseStepper
 from ..geometry.mesh import mirror_for
 from ..modules.energy._common import bending_gradient_mode, bending_model
 from ..modules.energy.volume import body_penalty_params
@@ -50,10 +51,21 @@ class GradientRows:
     """Lazy stand-in for the reference's ``{vertex_id: grad_row}`` dict of non-zero rows
     (minimizer.py:1067-1073); materialised on first dict-style access."""
 
-    def __init__(self, mesh, grad_arr: np.ndarray):
-        self.array = grad_arr
+    def __init__(self, mesh, grad_arr):
+        """grad_arr: the (nv,3) array, or a zero-argument callable that downloads it on first use
+        (minimize(sync_mesh=False) keeps the 24 B/vertex D2H copy out of the loop that way; read
+        it before stepping again: it fetches the gradient then resident on the device)."""
+        self._array = None if callable(grad_arr) else grad_arr
+        self._fetch = grad_arr if callable(grad_arr) else None
         self._mesh = mesh
         self._dict = None
+
+    @property
+    def array(self) -> np.ndarray:
+        if self._array is None:
+            self._array = self._fetch()
+            self._fetch = None
+        return self._array
 
     def _materialise(self):
         if self._dict is None:
@@ -272,37 +284,88 @@ class Minimizer:
         return iters > 0
 
     # -- tilt relaxation (runtime/steppers/tilt_relaxation.py:237-300 parameter handling) --
-    def _relax_tilts(self, dm) -> bool:
+    def _tilt_relax_params(self):
+        """Resolved relaxation parameters or None when tilt_solve_mode leaves the tilts alone."""
         gp = self.global_params
         mode = str(gp.get("tilt_solve_mode", "fixed") or "").strip().lower()
         if mode in ("", "none", "off", "false", "fixed"):
-            return False
+            return None
         if mode not in ("nested", "coupled"):
             logger.warning("Unknown tilt_solve_mode=%r; treating as 'fixed'.", mode)
-            return False
+            return None
         step = float(gp.get("tilt_step_size", 0.0) or 0.0)
         if step <= 0.0:
-            return False
+            return None
         tol = float(gp.get("tilt_tol", 0.0) or 0.0)
         if mode == "nested":
             n_inner = int(gp.get("tilt_inner_steps", 0) or 0)
         else:
             n_inner = int(gp.get("tilt_coupled_steps", gp.get("tilt_inner_steps", 0)) or 0)
         if n_inner <= 0:
-            return False
+            return None
         solver = str(gp.get("tilt_solver", "cg") or "cg").strip().lower()
         if solver not in ("gd", "cg"):
             logger.warning("Unknown tilt_solver=%r; using gradient descent.", solver)
             solver = "gd"
         max_iters = int(gp.get("tilt_cg_max_iters", n_inner) or 0) if solver == "cg" else n_inner
         if max_iters <= 0:
-            return False
+            return None
         if float(gp.get("tilt_smoothness_rigidity", 0.0) or 0.0) != 0.0:
             raise L.MembraneHipError("tilt_smoothness is outside the HIP hot path")
         pre = str(gp.get("tilt_cg_preconditioner", "jacobi") or "jacobi").strip().lower()
-        dm.relax_tilts(solver=solver, max_iters=max_iters, step_size=step, tol=max(tol, 0.0),
-                       jacobi=(pre == "jacobi"))
+        return {"solver": solver, "max_iters": max_iters, "step_size": step, "tol": max(tol, 0.0),
+                "jacobi": pre == "jacobi"}
+
+    def _relax_tilts(self, dm) -> bool:
+        rp = self._tilt_relax_params()
+        if rp is None:
+            return False
+        dm.relax_tilts(**rp)
         return True
+
+    def _fast_path_ok(self, callback) -> bool:
+        """The whole loop can run inside the library (ms_minimize) when nothing on the Python side
+        wants to see individual steps: no callback, quiet, and the stepper's device_step is the
+        stock one (tests and tools wrap it to log steps)."""
+        st = self.stepper
+        return (callback is None and self.quiet and isinstance(st, BaseStepper)
+                and "device_step" not in vars(st) and type(st).device_step is BaseStepper.device_step)
+
+    def _minimize_in_library(self, mir, dm, n_steps, sync_mesh):
+        gp = self.global_params
+        st = self.stepper
+        st._dm = dm
+        edge_fraction = float(gp.get("shape_step_edge_fraction", 0.0) or 0.0)
+        extra = st._extra()
+        mp = L.ms_minimize_params()
+        mp.stepper = L.ms_stepper_params(int(st.stepper_id), int(st._max_iter_for(self.mesh)), float(st.beta),
+                                         float(st.c), float(st.gamma), float(st.alpha_max_factor),
+                                         int(extra.get("restart_interval", 10)), edge_fraction,
+                                         int(st.reuse_energy0))
+        step_mode = str(gp.get("step_size_mode", "adaptive") or "adaptive").lower()
+        mp.step_size = float(self.step_size)
+        mp.tol = float(self.tol)
+        mp.fixed_step_mode = 1 if step_mode == "fixed" else 0
+        mp.fixed_step = float(gp.get("step_size", self.step_size) or self.step_size)
+        mp.max_zero_steps = int(self.max_zero_steps)
+        mp.step_size_floor = float(self.step_size_floor)
+        target = self._target_volume()
+        mp.drift_check = 1 if (gp.get("volume_constraint_mode", "lagrange") == "lagrange"
+                               and not gp.get("volume_projection_during_minimization", True)
+                               and target is not None) else 0
+        mp.target_volume = float(target) if target is not None else 0.0
+        mp.volume_tolerance = float(gp.get("volume_tolerance", 1e-3))
+        mp.project_on_drift = 1 if self._has_enforceable_constraints else 0
+        rp = self._tilt_relax_params() if dm.modules & (L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT) else None
+        mp.relax_tilts = 0 if rp is None else 1
+        if rp is not None:
+            mp.relax = L.ms_tilt_relax_params(1 if rp["solver"] == "cg" else 0, rp["max_iters"], rp["step_size"],
+                                              rp["tol"], 1 if rp["jacobi"] else 0)
+        out, _log = dm.minimize(mp, n_steps)
+        self.step_size = float(out.step_size)
+        self.last_run = {"accepted": out.accepted, "trials": out.trials, "guard_rejects": out.guard_rejects,
+                         "iterations": out.iterations}
+        return out
 
     # -- the loop -------------------------------------------------------------------
     def minimize(self, n_steps: int = 1, callback: Optional[Callable] = None, *, sync_mesh: bool = True):
@@ -330,6 +393,33 @@ class Minimizer:
         dirty = False
         if self._has_enforceable_constraints:
             dirty |= self._enforce(dm, "mesh_operation")
+
+        if self._fast_path_ok(callback):
+            out = self._minimize_in_library(mir, dm, n_steps, sync_mesh)
+            moved = bool(out.moved) or dirty
+            early = bool(out.converged or out.zero_step_exit)
+            if out.converged:
+                logger.info("Converged in %d iterations; |grad E|=%.3e", out.iterations - 1, out.grad_norm)
+            if not out.zero_step_exit:  # minimizer.py:1324-1337 / :1516-1535 finalize the constraints
+                moved |= self._enforce(dm, "finalize")
+            if out.converged:
+                energy = float(out.energy_eval)
+            else:
+                energy = float(dm.energy().sum())
+            if moved or self._device_ahead:
+                if sync_mesh:
+                    write_back_positions(self.mesh, dm, mir)
+                    if dm.modules & (L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT):
+                        self.mesh.set_tilts_from_array(dm.get_tilts())
+                        mir.mark_device_tilts_current()
+                    self._device_ahead = False
+                else:
+                    self._device_ahead = True
+            return {"energy": energy, "gradient": GradientRows(self.mesh, dm.get_gradient() if sync_mesh
+                                                               else dm.get_gradient),
+                    "mesh": self.mesh, "step_success": bool(out.step_success) if not out.zero_step_exit else False,
+                    "iterations": int(out.iterations), "terminated_early": early,
+                    "steps_accepted": int(out.accepted), "line_search_trials": int(out.trials)}
 
         zero_step_counter = 0
         step_success = True
@@ -403,7 +493,7 @@ class Minimizer:
                         self.stepper.reset()
         dirty_box[0] |= self._enforce(dm, "finalize")
         final_energy = float(dm.energy().sum())
-        grad = GradientRows(self.mesh, dm.get_gradient()) if have_grad else {}
+        grad = GradientRows(self.mesh, dm.get_gradient() if sync_mesh else dm.get_gradient) if have_grad else {}
         return finish({"energy": final_energy, "gradient": grad, "mesh": self.mesh,
                        "step_success": step_success, "iterations": n_steps, "terminated_early": False})
 

@@ -41,3 +41,24 @@ run(100)
 prof = dm.profile_read()
 tot = sum(ms for ms, n in prof.values())
 print("kernel time per step (HIP events): %.1f us" % (1e3 * tot / 100), {k: (round(1e3 * ms / max(n, 1), 1), n) for k, (ms, n) in prof.items()})
+
+# the same loop through the reference-shaped Python Minimizer
+from membrane_solver_amd.geometry.mesh import ArrayMesh  # noqa: E402
+from membrane_solver_amd.runtime.constraint_manager import ConstraintModuleManager  # noqa: E402
+from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager  # noqa: E402
+from membrane_solver_amd.runtime.minimizer import Minimizer  # noqa: E402
+from membrane_solver_amd.runtime.steppers import ConjugateGradient  # noqa: E402
+
+dm.close()
+gp = {"surface_tension": 1.0, "bending_modulus": 1.0, "spontaneous_curvature": 0.0,
+      "bending_gradient_mode": "analytic", "volume_constraint_mode": "lagrange",
+      "volume_projection_during_minimization": False}
+mods = ["surface", "bending"]
+mesh = ArrayMesh(P, T, global_parameters=gp, energy_modules=mods, constraint_modules=[])
+mz = Minimizer(mesh, mesh.global_parameters, ConjugateGradient(), EnergyModuleManager(mods),
+               ConstraintModuleManager([]), quiet=True, step_size=1e-6)
+mz.minimize(40, sync_mesh=False)
+t0 = time.perf_counter()
+mz.minimize(200, sync_mesh=False)
+dt = time.perf_counter() - t0
+print("Minimizer.minimize: %.1f us/step" % (1e6 * dt / 200))
