@@ -316,7 +316,7 @@ int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulat
   return MS_OK;
 }
 
-int phase_direction(ms_ctx* c, int stepper, bool use_history) {
+int phase_direction(ms_ctx* c, int stepper, bool use_history, bool g_finalized = false) {
   const bool use_con = (c->params.modules & MS_CON_VOLUME) != 0;
   {
   ProfScope ps(c, 2);
@@ -324,7 +324,7 @@ int phase_direction(ms_ctx* c, int stepper, bool use_history) {
                              c->buf[MS_BUF_GC], c->buf[MS_BUF_D], c->buf[MS_BUF_PG],
                              c->buf[MS_BUF_PD], c->d_scal, use_con ? 1 : 0,
                              (stepper == MS_STEPPER_CG && use_history) ? 1 : 0, c->d_partials,
-                             c->til.n_tiles, c->stream));
+                             c->til.n_tiles, (g_finalized && !use_con) ? 0 : 1, c->stream));
   }
   c->last_g = c->buf[MS_BUF_G];
   return reduce_slots(c, MASK_DIR);
@@ -1009,7 +1009,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     // x has not moved since the last gradient pass (failed search, stepper reset): only the
     // direction changes.  k_direction on the finalized g repeats the fused epilogue's
     // arithmetic and reduction order exactly.
-    rc = phase_direction(c, sp->stepper, use_history);
+    rc = phase_direction(c, sp->stepper, use_history, /*g_finalized=*/true);
   } else {
     rc = queue_energy_and_gradient(c, sp->stepper, use_history, carried);
   }

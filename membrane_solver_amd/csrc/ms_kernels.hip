@@ -1616,7 +1616,7 @@ __global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, c
                                                      const double* pg, const double* pd,
                                                      const double* scal, int use_constraint,
                                                      int cg_history, double* partials,
-                                                     int n_tiles) {
+                                                     int n_tiles, int write_g) {
   __shared__ double red[16];
   const int tile = tile0 + blockIdx.x;
   double lam = 0.0;
@@ -1650,9 +1650,11 @@ __global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, c
       }
     }
     if (fixed) di = mk(0, 0, 0);
-    g[o] = gi.x;
-    g[o + 1] = gi.y;
-    g[o + 2] = gi.z;
+    if (write_g) {  // (a finalized g -- restart after a failed search -- is left as it is)
+      g[o] = gi.x;
+      g[o + 1] = gi.y;
+      g[o + 2] = gi.z;
+    }
     d[o] = di.x;
     d[o + 1] = di.y;
     d[o + 2] = di.z;
@@ -1673,10 +1675,10 @@ __global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, c
 hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* g,
                             const double* gC, double* d, const double* pg, const double* pd,
                             const double* scal, int use_constraint, int cg_history,
-                            double* partials, int n_tiles, hipStream_t s) {
+                            double* partials, int n_tiles, int write_g, hipStream_t s) {
   if (tile1 <= tile0) return hipSuccess;
   hipLaunchKernelGGL(k_direction, dim3(tile1 - tile0), dim3(BLOCK), 0, s, tile0, nv, T, vflags, g,
-                     gC, d, pg, pd, scal, use_constraint, cg_history, partials, n_tiles);
+                     gC, d, pg, pd, scal, use_constraint, cg_history, partials, n_tiles, write_g);
   return hipGetLastError();
 }
 
