@@ -49,18 +49,21 @@ GRAD_SLOTS = (L.MS_S_GGC, L.MS_S_GCGC)
 DIR_SLOTS = (L.MS_S_GNORM2, L.MS_S_GDOTD, L.MS_S_MAXD2)
 
 
+_SUM_IDX = np.array(SUM_SLOTS)
+_MIN_IDX = np.array(MIN_SLOTS)
+_MAX_IDX = np.array(MAX_SLOTS)
+
+
 def fold_scalars(per_rank: np.ndarray) -> np.ndarray:
-    """(world, MS_NSCAL) -> (MS_NSCAL,), folded in rank order (deterministic)."""
+    """(world, MS_NSCAL) -> (MS_NSCAL,), folded in rank order (deterministic: every rank adds the
+    same doubles in the same order)."""
     out = np.zeros(L.MS_NSCAL)
-    for s in SUM_SLOTS:
-        acc = 0.0
-        for r in range(per_rank.shape[0]):
-            acc += float(per_rank[r, s])
-        out[s] = acc
-    for s in MIN_SLOTS:
-        out[s] = float(np.min(per_rank[:, s]))
-    for s in MAX_SLOTS:
-        out[s] = float(np.max(per_rank[:, s]))
+    acc = per_rank[0, _SUM_IDX].copy()
+    for r in range(1, per_rank.shape[0]):
+        acc += per_rank[r, _SUM_IDX]
+    out[_SUM_IDX] = acc
+    out[_MIN_IDX] = per_rank[:, _MIN_IDX].min(axis=0)
+    out[_MAX_IDX] = per_rank[:, _MAX_IDX].max(axis=0)
     return out
 
 
@@ -262,6 +265,7 @@ class HipShardBackend:
         n_max = L.MS_NSCAL + 8 * self.boundary["max_rows"]
         self._send = torch.zeros(n_max, dtype=torch.float64, device=self.device)
         self._recv = torch.zeros(world * n_max, dtype=torch.float64, device=self.device)
+        self._plans = {}
 
     def configure(self, *, modules, gamma=None, kappa=None, c0=None, **params):
         if gamma is not None:
@@ -321,11 +325,16 @@ class HipShardBackend:
                 v = self._view(bid)
                 v[:r0] = float("nan")
                 v[r1:] = float("nan")
-        n = self.dm.exchange_bytes(buffers) // 8
-        send, recv = self._send[:n], self._recv[: self.world * n]
-        self.dm.pack_boundary(buffers, send.data_ptr(), n * 8)
+        plan = self._plans.get(buffers)
+        if plan is None:  # message size and tensor views per buffer set, resolved once
+            n = self.dm.exchange_bytes(buffers) // 8
+            send, recv = self._send[:n], self._recv[: self.world * n]
+            plan = (n * 8, send, recv, send.data_ptr(), recv.data_ptr())
+            self._plans[buffers] = plan
+        nbytes, send, recv, send_ptr, recv_ptr = plan
+        self.dm.pack_boundary(buffers, send_ptr, nbytes)
         self.dist.all_gather_into_tensor(recv, send)
-        return self.dm.unpack_boundary(buffers, recv.data_ptr(), n * 8, self.world)
+        return self.dm.unpack_boundary(buffers, recv_ptr, nbytes, self.world)
 
 
 def bench_main(args, rank: int, world: int, local_rank: int):
