@@ -149,3 +149,48 @@ def test_minimizer_reproduces_bending_tilt_trajectory(fname):
     assert relerr(mesh.positions_view(), g["positions_final"]) < 1e-8
     assert relerr(mesh.tilts_view(), g["tilts_final"]) < 1e-8
     assert abs(res["energy"] - g["E_final"]) <= 1e-9 * abs(g["E_final"])
+
+
+def test_bending_tilt_midsize_matches_oracle():
+    """131 220 facets (config C2 size), many tiles: HIP vs the CPU oracle for the energy, the shape
+    gradient and the tilt gradient of tilt + bending_tilt; plus size-independent properties
+    (quadratic scaling in the tilt amplitude of the pure tilt part, translation invariance)."""
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+    from oracle import minimizer_port as mp
+    from oracle import ms_oracle as orc
+
+    P, T = meshgen.icosphere(81)
+    P = meshgen.smooth_displace(P, 0.05)
+    nv, nf = P.shape[0], T.shape[0]
+    rng = np.random.default_rng(11)
+    nrm = mp.unit_vertex_normals(P, T)
+    tl = 0.02 * rng.normal(size=P.shape)
+    tl -= np.einsum("ij,ij->i", tl, nrm)[:, None] * nrm
+    kappa, c0 = np.full(nv, 1.1), np.full(nv, 0.3)
+    dm = DeviceMesh(P, T)
+    dm.set_surface_tension(np.ones(nf))
+    dm.set_bending_params(kappa, c0)
+    dm.set_tilts(tl, 1.7)
+    dm.set_params(modules=L.MS_MOD_BENDING_TILT | L.MS_MOD_TILT)
+    e, grad = dm.energy_and_gradient()
+    E_t, tg = dm.tilt_energy_and_gradient()
+    g_ref, tg_ref = np.zeros_like(P), np.zeros_like(P)
+    isb = np.zeros(nv, bool)
+    E_bt = orc.bending_tilt_energy_and_gradient(P, tl, T, kappa, c0, isb, grad=g_ref, tilt_grad=tg_ref)
+    E_tilt = orc.tilt_energy_and_gradient(P, tl, T, 1.7, g_ref, tg_ref)
+    assert abs(e[1] - E_bt) <= 1e-11 * abs(E_bt)
+    assert abs(e[3] - E_tilt) <= 1e-11 * abs(E_tilt)
+    assert abs(E_t - (E_bt + E_tilt)) <= 1e-11 * abs(E_t)
+    assert relerr(grad, g_ref) < 1e-9  # same conditioning caveat as the bending gradient at this size
+    assert relerr(tg, tg_ref) < 1e-10
+    # pure tilt energy is quadratic in the amplitude
+    dm.set_tilts(2.0 * tl, 1.7)
+    assert abs(dm.energy()[3] - 4.0 * e[3]) <= 1e-12 * abs(4.0 * e[3])
+    # rigid translation leaves both energies unchanged
+    dm.set_tilts(tl, 1.7)
+    dm.set_positions(P + np.array([0.3, -0.2, 0.1]))
+    e2 = dm.energy()
+    assert abs(e2[1] - e[1]) <= 1e-9 * abs(e[1]) and abs(e2[3] - e[3]) <= 1e-11 * abs(e[3])
+    dm.close()
