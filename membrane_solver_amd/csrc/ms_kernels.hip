@@ -154,21 +154,6 @@ __device__ __forceinline__ void grad_cotan(V3 u, V3 v, V3& gu, V3& gv) {
   gv = mk(u.x * invS - k * wxu.x, u.y * invS - k * wxu.y, u.z * invS - k * wxu.z);
 }
 
-// geometry/bending_derivatives.py:82-102
-__device__ __forceinline__ void grad_triangle_area(V3 u, V3 v, V3& gu, V3& gv) {
-  const V3 w = cross(u, v);
-  const double S = norm(w);
-  if (!(S > 1.0e-15)) {
-    gu = mk(0, 0, 0);
-    gv = mk(0, 0, 0);
-    return;
-  }
-  const double invS = 1.0 / S;
-  const V3 vxw = cross(v, w), wxu = cross(w, u);
-  gu = mk(0.5 * vxw.x * invS, 0.5 * vxw.y * invS, 0.5 * vxw.z * invS);
-  gv = mk(0.5 * wxu.x * invS, 0.5 * wxu.y * invS, 0.5 * wxu.z * invS);
-}
-
 // dot product with the contraction spelled out: the direction scalars (|g|^2, <g,d>,
 // max|d_i|^2) are produced at two code sites (k_gradient's fused epilogue, k_direction) that
 // must agree to the last bit.
@@ -178,11 +163,6 @@ __device__ __forceinline__ double dot_pinned(V3 a, V3 b) {
 
 __device__ __forceinline__ V3 lds_v3(const double* base, int cap, int slot) {
   return mk(base[slot], base[cap + slot], base[2 * cap + slot]);
-}
-__device__ __forceinline__ void lds_add3(double* base, int stride, int slot, V3 v) {
-  atomicAdd(&base[slot], v.x);
-  atomicAdd(&base[stride + slot], v.y);
-  atomicAdd(&base[2 * stride + slot], v.z);
 }
 
 // ---------------------------------------------------------------------------
@@ -257,8 +237,8 @@ __device__ __forceinline__ void csr_commit(const CsrStage& r, const DeviceMesh& 
 //   alpha d, line_search.py:362-368) and can write that trial block to xt.
 // One normal n = (v1-v0)x(v2-v0) and one sqrt per facet serve the surface term,
 // the cotans (|e1 x e2| is the same vector) and both area clamps.
-// LDS: px[3][cap] | (GUARD) ox[3][cap] | (BEND) stg[18][T] | red[16]
-//      | (BEND) voff[T+1], vent[max_ent] (u16) | fl[cap] (u8)
+// LDS: px[3][cap] | (GUARD) ox[3][cap] | (BEND) stg[9][T] (the reduction scratch aliases it)
+//      | (BEND) vent[max_ent] (u16) | fl[cap] (u8, only with boundary vertices / GUARD)
 // ---------------------------------------------------------------------------
 // TT / CAPC: compile-time tile size and LDS patch capacity (0 = take the runtime values);
 // with constants every LDS address becomes base + immediate offset.
@@ -663,8 +643,8 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
 // S = |n| (the same vector for all corners of a triangle), so a facet costs one
 // sqrt and two divides.
 // BENDMODE: 0 none, 1 analytic, 2 approx (bending.py:163-167).
-// LDS: px[3][cap] | (BEND) fk[3][cap] fae[cap] fav[cap] | stg[9 or 18][T] | red[16]
-//      | voff[T+2] vent[max_ent] (u16) | fl[cap] (u8)
+// LDS: px[3][cap] | (BEND) fk[3][cap] fae[cap] fav[cap] | stg[9 or 18][T] | red[3*16]
+//      | vent[max_ent] (u16) | fl[cap] (u8)
 // ---------------------------------------------------------------------------
 template <int BENDMODE, bool VOLROW, int TT, int CAPC>
 __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
