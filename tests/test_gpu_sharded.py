@@ -41,9 +41,11 @@ class ThreadGroup:
         self.bar.wait()
 
 
-@pytest.mark.parametrize("with_volume,world,level", [(False, 2, 2), (True, 2, 2), (False, 3, 2), (False, 2, 0),
-                                                     (True, 3, 0)])
-def test_shards_match_single_context(with_volume, world, level):
+@pytest.mark.parametrize("with_volume,world,level,freq,tile", [
+    (False, 2, 2, 16, 64), (True, 2, 2, 16, 64), (False, 3, 2, 16, 64), (False, 2, 0, 16, 64), (True, 3, 0, 16, 64),
+    (False, 4, 2, 160, 256),  # 512 000 facets, default tile size, 4 shards: sizes near the headline
+])
+def test_shards_match_single_context(with_volume, world, level, freq, tile):
     import torch
 
     from membrane_solver_amd import _lib as L
@@ -51,7 +53,7 @@ def test_shards_match_single_context(with_volume, world, level):
     from membrane_solver_amd.device import DeviceMesh
     from membrane_solver_amd.parallel import HipShardBackend, ShardedStepper
 
-    P, T = meshgen.icosphere(16)
+    P, T = meshgen.icosphere(freq)
     P = meshgen.smooth_displace(P, 0.06)
     nv, nf = P.shape[0], T.shape[0]
     fixed = np.zeros(nv, bool)
@@ -59,10 +61,10 @@ def test_shards_match_single_context(with_volume, world, level):
     kappa, c0, gamma = np.full(nv, 0.9), np.full(nv, 0.1), np.full(nf, 1.1)
     mods = L.MS_MOD_SURFACE | L.MS_MOD_BENDING | (L.MS_CON_VOLUME if with_volume else 0)
     V0 = 4.0
-    n_steps, step0 = 9, 1e-3
+    n_steps, step0 = (9, 1e-3) if freq < 100 else (6, 1e-6)
 
     # single context reference
-    dm = DeviceMesh(P, T, fixed=fixed, tile_vertices=64)
+    dm = DeviceMesh(P, T, fixed=fixed, tile_vertices=tile)
     dm.set_surface_tension(gamma)
     dm.set_bending_params(kappa, c0)
     dm.set_params(modules=mods, target_volume=V0)
@@ -82,7 +84,7 @@ def test_shards_match_single_context(with_volume, world, level):
     def run(rank):
         try:
             grp.bind(rank)
-            be = HipShardBackend(P, T, rank=rank, world=world, device=0, tile_vertices=64, fixed=fixed, group=grp,
+            be = HipShardBackend(P, T, rank=rank, world=world, device=0, tile_vertices=tile, fixed=fixed, group=grp,
                                  debug_poison=True)
             be.configure(modules=mods, gamma=gamma, kappa=kappa, c0=c0, target_volume=V0)
             drv = ShardedStepper(be, stepper=L.MS_STEPPER_CG, reuse_energy0=level)
