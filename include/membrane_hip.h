@@ -306,6 +306,25 @@ int ms_unpack_boundary(ms_ctx *ctx, int n_buffers, const int *buffer_ids,
                        const void *recv_dev, size_t stride_bytes,
                        double *scal_all_host);
 
+/* ---- library-side multi-GPU driver -------------------------------------------
+ * The sharded step (the control flow of membrane_solver_amd/parallel.py's
+ * ShardedStepper, i.e. ms_step with the exchanges of DESIGN.md section 6) run inside
+ * the library: per exchange pack -> all-gather -> unpack -> mailbox poll, with no
+ * interpreter in the loop.  The all-gather is RCCL's ncclAllGather on the
+ * context's stream (ms_shard_comm_init; librccl is resolved from the process,
+ * i.e. the copy torch.distributed already loaded) or a caller-supplied function
+ * (tests use an in-process stand-in).  ms_shard_unique_id fills the 128-byte
+ * ncclUniqueId on one rank; the caller broadcasts it to the others. */
+typedef int (*ms_allgather_fn)(void *user, const void *send_dev, void *recv_dev,
+                               size_t bytes_per_rank);
+int ms_shard_unique_id(void *id128);
+int ms_shard_comm_init(ms_ctx *ctx, const void *id128);
+int ms_shard_set_allgather(ms_ctx *ctx, ms_allgather_fn fn, void *user);
+int ms_shard_step(ms_ctx *ctx, const ms_stepper_params *params, double step_size,
+                  double tol, ms_step_result *out);
+/* number of exchanges done so far by ms_shard_step on this context */
+int64_t ms_shard_exchange_count(const ms_ctx *ctx);
+
 /* Per-vertex state in caller-owned device memory (e.g. a torch tensor, so RCCL
  * collectives can run on it in place).  ms_state_bytes gives the size;
  * ms_rebind_state copies the current state there and uses it from then on.

@@ -90,6 +90,9 @@ _U8 = ctypes.POINTER(ctypes.c_uint8)
 _I64 = ctypes.POINTER(ctypes.c_int64)
 
 # name -> (restype, argtypes): every symbol include/membrane_hip.h declares.
+# ms_allgather_fn(user, send_dev, recv_dev, bytes_per_rank) -> int
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+
 SIGNATURES = {
     "ms_version": (ctypes.c_char_p, []),
     "ms_device_count": (ctypes.c_int, []),
@@ -136,6 +139,12 @@ SIGNATURES = {
                                         ctypes.c_size_t]),
     "ms_unpack_boundary": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _P,
                                           ctypes.c_size_t, _D]),
+    "ms_shard_unique_id": (ctypes.c_int, [_P]),
+    "ms_shard_comm_init": (ctypes.c_int, [_P, _P]),
+    "ms_shard_set_allgather": (ctypes.c_int, [_P, ALLGATHER_FN, _P]),
+    "ms_shard_step": (ctypes.c_int, [_P, ctypes.POINTER(ms_stepper_params), ctypes.c_double, ctypes.c_double,
+                                     ctypes.POINTER(ms_step_result)]),
+    "ms_shard_exchange_count": (ctypes.c_int64, [_P]),
     "ms_state_bytes": (ctypes.c_size_t, [_P]),
     "ms_rebind_state": (ctypes.c_int, [_P, _P, ctypes.c_size_t]),
     "ms_fetch_scalars": (ctypes.c_int, [_P, _D]),

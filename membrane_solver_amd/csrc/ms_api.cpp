@@ -8,7 +8,11 @@
 #include <cstring>
 #include <new>
 
+#include <dlfcn.h>
+
 #include "ms_internal.h"
+
+static void shard_comm_destroy(void* comm);  // (RCCL binding further down)
 
 using namespace ms;
 
@@ -78,6 +82,21 @@ struct ms_ctx {
   int32_t* d_halo_rows = nullptr;  // rows of other ranks that THIS rank's tiles read
   int n_halo_rows = 0;
   double* d_scal_all = nullptr;    // shard_count x MS_NSCAL, filled by unpack
+  // library-side sharded driver (ms_shard_*): RCCL communicator or a caller-supplied all-gather,
+  // message buffers, pinned mailbox for the gathered scalar headers
+  void* comm = nullptr;
+  ms_allgather_fn allgather_cb = nullptr;
+  void* allgather_user = nullptr;
+  double* d_xsend = nullptr;
+  double* d_xrecv = nullptr;
+  double* h_scal_all = nullptr;    // pinned + mapped, shard_count x MS_NSCAL
+  double* d_h_scal_all = nullptr;
+  unsigned long long* h_xseq = nullptr;
+  unsigned long long* d_h_xseq = nullptr;
+  unsigned long long xticket = 0;
+  double sh_scal[MS_NSCAL] = {0};  // rank-ordered fold of the last exchanges
+  bool sh_carry_valid = false, sh_grad_valid = false;
+  long sh_exchanges = 0;
   bool carry_valid = false;
   // true while buffer G holds the finalized gradient of the current x (set by ms_step's fused
   // gradient pass, survives a failed line search, cleared together with carry_valid)
@@ -229,6 +248,7 @@ int reduce_slots(ms_ctx* c, uint32_t mask) {
 int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool write_trial,
                  bool guard, bool write_factors, bool reduce_now = true) {
   c->carry_valid = c->grad_valid = c->bt_valid = false;
+  c->sh_carry_valid = c->sh_grad_valid = false;
   EnergyArgs a;
   a.m = device_mesh(c);
   a.tile0 = c->tile0;
@@ -623,6 +643,11 @@ void ms_destroy(ms_ctx* c) {
                   c->d_halo_rows, c->d_scal_all};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (c->comm) shard_comm_destroy(c->comm);
+  if (c->d_xsend) (void)hipFree(c->d_xsend);
+  if (c->d_xrecv) (void)hipFree(c->d_xrecv);
+  if (c->h_scal_all) (void)hipHostFree(c->h_scal_all);
+  if (c->h_xseq) (void)hipHostFree(c->h_xseq);
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->h_seq) (void)hipHostFree(c->h_seq);
   for (auto& r : c->prof_pending) {
@@ -659,6 +684,7 @@ int ms_set_surface_tension(ms_ctx* c, const double* gamma) {
   if (!g.empty())
     HIPCHK(c, hipMemcpy(c->d_tf_gamma, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice));
   c->carry_valid = c->grad_valid = c->bt_valid = false;
+  c->sh_carry_valid = c->sh_grad_valid = false;
   return MS_OK;
 }
 
@@ -675,6 +701,7 @@ int ms_set_bending_params(ms_ctx* c, const double* kappa, const double* c0) {
   HIPCHK(c, hipMemcpy(c->d_c0, z.data(), z.size() * sizeof(double), hipMemcpyHostToDevice));
   c->factors_valid = false;
   c->carry_valid = c->grad_valid = c->bt_valid = false;
+  c->sh_carry_valid = c->sh_grad_valid = false;
   return MS_OK;
 }
 
@@ -696,6 +723,7 @@ int ms_set_params(ms_ctx* c, const ms_params* p) {
   c->params = *p;
   c->factors_valid = false;
   c->carry_valid = c->grad_valid = c->bt_valid = false;
+  c->sh_carry_valid = c->sh_grad_valid = false;
   return MS_OK;
 }
 
@@ -712,6 +740,7 @@ int ms_set_tilts(ms_ctx* c, const double* tilts, double tilt_rigidity) {
   }
   c->k_tilt = tilt_rigidity;
   c->carry_valid = c->grad_valid = c->bt_valid = false;
+  c->sh_carry_valid = c->sh_grad_valid = false;
   return ext_to_patch(c, tilts, c->d_tilts, 3);
 }
 
@@ -939,6 +968,7 @@ int ms_set_positions(ms_ctx* c, const double* positions) {
   if (!c || !positions) return fail(c, MS_ERR_INVALID, "ms_set_positions: NULL argument");
   c->factors_valid = false;
   c->carry_valid = c->grad_valid = c->bt_valid = false;
+  c->sh_carry_valid = c->sh_grad_valid = false;
   return ext_to_patch(c, positions, c->buf[MS_BUF_X], 3);
 }
 
@@ -1155,7 +1185,8 @@ int ms_minimize(ms_ctx* c, const ms_minimize_params* mp, int n_steps, ms_minimiz
     }
     const double step_in = mp->fixed_step_mode ? mp->fixed_step : step_size;
     ms_step_result r;
-    rc = ms_step(c, &mp->stepper, step_in, mp->tol, &r);
+    rc = (c->shard_count > 1 || c->comm || c->allgather_cb) ? ms_shard_step(c, &mp->stepper, step_in, mp->tol, &r)
+                                                            : ms_step(c, &mp->stepper, step_in, mp->tol, &r);
     if (rc) return rc;
     out->iterations = i + 1;
     out->energy_eval = r.energy_eval;
@@ -1242,6 +1273,7 @@ int ms_phase_accept(ms_ctx* c, int keep_history) {
   std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
   c->factors_valid = false;
   c->carry_valid = c->grad_valid = c->bt_valid = false;
+  c->sh_carry_valid = c->sh_grad_valid = false;
   if (keep_history) {
     std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
     std::swap(c->buf[MS_BUF_D], c->buf[MS_BUF_PD]);
@@ -1352,6 +1384,292 @@ int ms_unpack_boundary(ms_ctx* c, int n_buffers, const int* buffer_ids, const vo
   return MS_OK;
 }
 
+// ---- library-side sharded driver ------------------------------------------------
+namespace {
+struct NcclUniqueId {
+  char internal[128];
+};
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+  int (*CommInitRank)(void**, int, NcclUniqueId, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_bind() {
+  if (g_rccl.lib) return MS_OK;
+  // the copy the process already uses (torch.distributed's) first, then the ROCm one
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void* lib = nullptr;
+  for (const char* n : names) {
+    lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (lib) break;
+  }
+  for (size_t i = 0; !lib && i < sizeof(names) / sizeof(names[0]); ++i) lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return fail(nullptr, MS_ERR_STATE, std::string("librccl not found: ") + dlerror());
+  g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+  g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+  g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(lib, "ncclAllGather"));
+  g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+  g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather)
+    return fail(nullptr, MS_ERR_STATE, "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather");
+  g_rccl.lib = lib;
+  return MS_OK;
+}
+
+int shard_buffers(ms_ctx* c) {
+  if (c->d_xsend) return MS_OK;
+  const size_t n_max = (size_t)MS_NSCAL + 8 * (size_t)c->bnd_max;  // fK 3 + fA 2 + d 3 per boundary row
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xsend), sizeof(double) * n_max));
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xrecv), sizeof(double) * n_max * (size_t)c->shard_count));
+  HIPCHK(c, hipMemset(c->d_xsend, 0, sizeof(double) * n_max));
+  HIPCHK(c, hipMemset(c->d_xrecv, 0, sizeof(double) * n_max * (size_t)c->shard_count));
+  const size_t sb = sizeof(double) * MS_NSCAL * (size_t)c->shard_count;
+  HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_scal_all), sb, hipHostMallocMapped));
+  memset(c->h_scal_all, 0, sb);
+  HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_scal_all), c->h_scal_all, 0));
+  HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_xseq), sizeof(unsigned long long), hipHostMallocMapped));
+  *c->h_xseq = 0;
+  HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_xseq), c->h_xseq, 0));
+  return MS_OK;
+}
+
+const int SH_SUM[] = {MS_S_ESURF, MS_S_VOL, MS_S_EBEND, MS_S_GGC, MS_S_GCGC, MS_S_GNORM2, MS_S_GDOTD, MS_S_ETILT};
+constexpr uint32_t SH_ENERGY = (1u << MS_S_ESURF) | (1u << MS_S_VOL) | (1u << MS_S_EBEND) |
+                               (1u << MS_S_MINEDGE2) | (1u << MS_S_GUARD);
+constexpr uint32_t SH_GRAD = (1u << MS_S_GGC) | (1u << MS_S_GCGC);
+constexpr uint32_t SH_DIR = (1u << MS_S_GNORM2) | (1u << MS_S_GDOTD) | (1u << MS_S_MAXD2);
+
+// One exchange: boundary rows of `ids` + the 16 scalars of every rank; `slots` of the
+// rank-ordered fold go to c->sh_scal (push: also to the device scalars).
+int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push) {
+  double* p[4];
+  int nc[4], comps = 0;
+  int rc = row_buffers(c, n, ids, p, nc, &comps);
+  if (rc) return rc;
+  rc = shard_buffers(c);
+  if (rc) return rc;
+  const size_t count = (size_t)MS_NSCAL + (size_t)c->bnd_max * comps;
+  const int me = c->shard_rank, W = c->shard_count;
+  HIPCHK(c, launch_pack_boundary(c->d_bnd_rows + c->bnd_off[(size_t)me],
+                                 c->bnd_off[(size_t)me + 1] - c->bnd_off[(size_t)me], p, nc, n, c->d_scal,
+                                 c->d_xsend, c->stream));
+  if (c->allgather_cb) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->allgather_cb(c->allgather_user, c->d_xsend, c->d_xrecv, count * sizeof(double)) != 0)
+      return fail(c, MS_ERR_STATE, "caller-supplied all-gather failed");
+  } else if (c->comm) {
+    const int r = g_rccl.AllGather(c->d_xsend, c->d_xrecv, count, /*ncclDouble*/ 8, c->comm, c->stream);
+    if (r != 0)
+      return fail(c, MS_ERR_HIP, std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+  } else if (W == 1) {
+    HIPCHK(c, hipMemcpyAsync(c->d_xrecv, c->d_xsend, count * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  } else {
+    return fail(c, MS_ERR_STATE, "ms_shard_step: no communicator (ms_shard_comm_init / ms_shard_set_allgather)");
+  }
+  HIPCHK(c, launch_unpack_boundary(c->d_bnd_rows, c->d_bnd_off, me, W, c->bnd_max, p, nc, n, c->d_xrecv, count,
+                                   c->d_h_scal_all, c->stream));
+  ++c->xticket;
+  HIPCHK(c, launch_post_seq(c->d_h_xseq, c->xticket, c->stream));
+  bool seen = false;
+  for (long spin = 0; spin < 20000000L; ++spin) {
+    if (__atomic_load_n(c->h_xseq, __ATOMIC_ACQUIRE) >= c->xticket) {
+      seen = true;
+      break;
+    }
+    __builtin_ia32_pause();
+  }
+  if (!seen) HIPCHK(c, hipStreamSynchronize(c->stream));
+  // fold in rank order: every rank adds the same doubles in the same order
+  for (int sl : SH_SUM)
+    if (slots & (1u << sl)) {
+      double acc = 0.0;
+      for (int r = 0; r < W; ++r) acc += c->h_scal_all[(size_t)r * MS_NSCAL + sl];
+      c->sh_scal[sl] = acc;
+    }
+  if (slots & (1u << MS_S_MINEDGE2)) {
+    double m = c->h_scal_all[MS_S_MINEDGE2];
+    for (int r = 1; r < W; ++r) m = std::min(m, c->h_scal_all[(size_t)r * MS_NSCAL + MS_S_MINEDGE2]);
+    c->sh_scal[MS_S_MINEDGE2] = m;
+  }
+  for (int sl : {(int)MS_S_GUARD, (int)MS_S_MAXD2})
+    if (slots & (1u << sl)) {
+      double m = c->h_scal_all[sl];
+      for (int r = 1; r < W; ++r) m = std::max(m, c->h_scal_all[(size_t)r * MS_NSCAL + sl]);
+      c->sh_scal[sl] = m;
+    }
+  if (push)
+    HIPCHK(c, hipMemcpyAsync(c->d_scal, c->sh_scal, sizeof(double) * MS_NSCAL, hipMemcpyHostToDevice, c->stream));
+  ++c->sh_exchanges;
+  return MS_OK;
+}
+
+double shard_energy(const ms_ctx* c) {
+  const uint32_t m = c->params.modules;
+  double e = 0.0;
+  if (m & MS_MOD_SURFACE) e += c->sh_scal[MS_S_ESURF];
+  if (m & MS_MOD_BENDING) e += c->sh_scal[MS_S_EBEND];
+  e += penalty_energy(c, c->sh_scal[MS_S_VOL]);
+  return e;
+}
+}  // namespace
+
+static void shard_comm_destroy(void* comm) {
+  if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
+}
+
+int ms_shard_unique_id(void* id128) {
+  if (!id128) return MS_ERR_INVALID;
+  int rc = rccl_bind();
+  if (rc) return rc;
+  NcclUniqueId id;
+  const int r = g_rccl.GetUniqueId(&id);
+  if (r != 0) return fail(nullptr, MS_ERR_HIP, "ncclGetUniqueId failed");
+  memcpy(id128, id.internal, 128);
+  return MS_OK;
+}
+
+int ms_shard_comm_init(ms_ctx* c, const void* id128) {
+  if (!c || !id128) return fail(c, MS_ERR_INVALID, "ms_shard_comm_init: NULL argument");
+  int rc = rccl_bind();
+  if (rc) return fail(c, rc, g_last_error);
+  (void)hipSetDevice(c->device);
+  NcclUniqueId id;
+  memcpy(id.internal, id128, 128);
+  const int r = g_rccl.CommInitRank(&c->comm, c->shard_count, id, c->shard_rank);
+  if (r != 0) {
+    c->comm = nullptr;
+    return fail(c, MS_ERR_HIP, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
+  }
+  return shard_buffers(c);
+}
+
+int ms_shard_set_allgather(ms_ctx* c, ms_allgather_fn fn, void* user) {
+  if (!c) return MS_ERR_INVALID;
+  c->allgather_cb = fn;
+  c->allgather_user = user;
+  return shard_buffers(c);
+}
+
+int64_t ms_shard_exchange_count(const ms_ctx* c) { return c ? (int64_t)c->sh_exchanges : 0; }
+
+// The control flow of parallel.ShardedStepper.step (itself a restatement of ms_step).
+int ms_shard_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol, ms_step_result* out) {
+  if (!c || !sp || !out) return fail(c, MS_ERR_INVALID, "ms_shard_step: NULL argument");
+  const uint32_t mods = c->params.modules;
+  if (mods & MS_TILT_MODS) return fail(c, MS_ERR_STATE, "the tilt modules are not sharded yet (single GPU only)");
+  memset(out, 0, sizeof(*out));
+  const bool cg = sp->stepper == MS_STEPPER_CG;
+  const int restart = sp->restart_interval > 0 ? sp->restart_interval : 10;
+  const bool use_history = cg && c->cg_have_history && (c->cg_iter_count % restart != 0);
+  const bool bend = (mods & MS_MOD_BENDING) != 0;
+  const bool constraint = (mods & MS_CON_VOLUME) != 0;
+  const bool penalty = (mods & MS_MOD_VOLUME_PENALTY) != 0;
+  const bool carry_mode = sp->reuse_energy0 >= 2;
+  const int fbufs[2] = {MS_BUF_FK, MS_BUF_FA};
+  const int n_fb = bend ? 2 : 0;
+  const int dbuf[1] = {MS_BUF_D};
+  const bool carried = carry_mode && c->sh_carry_valid;
+  int rc;
+  if (!carried) {
+    rc = phase_energy(c, mods, false, 0.0, false, false, true);
+    if (rc) return rc;
+    rc = shard_exchange(c, n_fb, fbufs, SH_ENERGY, penalty);
+    if (rc) return rc;
+    c->sh_grad_valid = false;
+  }
+  if (carried && c->sh_grad_valid && !constraint) {
+    rc = phase_direction(c, sp->stepper, use_history, /*g_finalized=*/true);
+  } else if (constraint) {
+    rc = phase_gradient(c, mods, c->buf[MS_BUF_G], false);
+    if (rc) return rc;
+    rc = shard_exchange(c, 0, nullptr, SH_GRAD, true);
+    if (rc) return rc;
+    rc = phase_direction(c, sp->stepper, use_history);
+  } else {
+    const int dir_mode = (cg && use_history) ? 2 : 1;
+    rc = phase_gradient(c, mods, c->buf[MS_BUF_G], false, dir_mode);
+  }
+  if (rc) return rc;
+  rc = shard_exchange(c, 1, dbuf, SH_DIR, false);
+  if (rc) return rc;
+  c->sh_carry_valid = carry_mode;
+  c->sh_grad_valid = carry_mode && !constraint;
+  const double E_eval = shard_energy(c);
+  const double grad_norm = std::sqrt(c->sh_scal[MS_S_GNORM2]);
+  const double g_dot_d = c->sh_scal[MS_S_GDOTD];
+  const double max_dir = std::sqrt(c->sh_scal[MS_S_MAXD2]);
+  out->energy_eval = E_eval;
+  out->grad_norm = grad_norm;
+  out->g_dot_d = g_dot_d;
+  out->volume = c->sh_scal[MS_S_VOL];
+  out->next_step = step_size;
+  out->energy = E_eval;
+  if (grad_norm < tol) {
+    out->converged = out->success = 1;
+    return MS_OK;
+  }
+  double energy0 = E_eval;
+  if (sp->reuse_energy0 == 0) {
+    rc = phase_energy(c, mods, false, 0.0, false, false, false);
+    if (rc) return rc;
+    rc = shard_exchange(c, 0, nullptr, SH_ENERGY, false);
+    if (rc) return rc;
+    energy0 = shard_energy(c);
+  }
+  const double min_edge = c->til.nf > 0 ? std::sqrt(c->sh_scal[MS_S_MINEDGE2]) : 0.0;
+  out->energy = energy0;
+  const double safe_limit = min_edge > 0.0 ? 0.3 * min_edge : INFINITY;
+  if (g_dot_d >= 0.0) return MS_OK;
+  double alpha = step_size;
+  if (sp->edge_fraction > 0.0 && min_edge > 0.0 && max_dir > 0.0)
+    alpha = std::min(alpha, sp->edge_fraction * min_edge / max_dir);
+  const double alpha_max = sp->alpha_max_factor * step_size;
+  const int max_iter = sp->max_iter > 0 ? sp->max_iter : 10;
+  for (int it = 0; it < max_iter; ++it) {
+    const bool safe_small = alpha * max_dir < safe_limit;
+    rc = phase_energy(c, mods, true, alpha, false, !safe_small, carry_mode);
+    if (rc) return rc;
+    if (carry_mode) c->sh_carry_valid = false;  // the factor buffers now belong to the trial point
+    rc = shard_exchange(c, carry_mode ? n_fb : 0, fbufs, SH_ENERGY, false);
+    if (rc) return rc;
+    if (!safe_small && c->sh_scal[MS_S_GUARD] > 0.0) {
+      ++out->guard_rejects;
+      alpha *= sp->beta;
+      if (alpha < 1e-8) break;
+      continue;
+    }
+    ++out->trials;
+    const double E_t = shard_energy(c);
+    if (E_t <= energy0 + sp->c * alpha * g_dot_d) {
+      rc = ms_phase_commit_trial(c, alpha, cg ? 1 : 0);
+      if (rc) return rc;
+      c->sh_grad_valid = false;
+      if (carry_mode) {
+        c->factors_valid = true;
+        if (penalty)
+          HIPCHK(c, hipMemcpyAsync(c->d_scal, c->sh_scal, sizeof(double) * MS_NSCAL, hipMemcpyHostToDevice,
+                                   c->stream));
+        c->sh_carry_valid = true;
+      }
+      out->success = 1;
+      out->alpha = alpha;
+      out->energy = E_t;
+      out->volume = c->sh_scal[MS_S_VOL];
+      out->next_step = std::min(alpha * sp->gamma, alpha_max);
+      return MS_OK;
+    }
+    alpha *= sp->beta;
+    if (alpha < 1e-8) break;
+  }
+  out->next_step = std::max(std::max(alpha * sp->beta, 0.0), step_size * sp->beta);
+  return MS_OK;
+}
+
 size_t ms_state_bytes(const ms_ctx* c) {
   if (!c) return 0;
   return sizeof(double) * (8 * 3 * (size_t)c->til.nvp + 2 * (size_t)c->til.nvp);
@@ -1384,6 +1702,7 @@ int ms_store_scalars(ms_ctx* c, const double* in) {
   if (!c || !in) return MS_ERR_INVALID;
   memcpy(c->h_scal, in, sizeof(double) * MS_NSCAL);
   c->carry_valid = c->grad_valid = c->bt_valid = false;
+  c->sh_carry_valid = c->sh_grad_valid = false;
   HIPCHK(c, hipMemcpyAsync(c->d_scal, c->h_scal, sizeof(double) * MS_NSCAL, hipMemcpyHostToDevice,
                            c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

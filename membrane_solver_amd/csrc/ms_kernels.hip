@@ -1732,6 +1732,18 @@ hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_of
   return hipGetLastError();
 }
 
+// One word to the pinned mailbox after everything queued before it on the stream has completed
+// (a kernel boundary orders the earlier kernels' host writes before this one).
+__global__ void k_post_seq(unsigned long long* host_seq, unsigned long long ticket) {
+  __threadfence_system();
+  *reinterpret_cast<volatile unsigned long long*>(host_seq) = ticket;
+}
+
+hipError_t launch_post_seq(unsigned long long* host_seq, unsigned long long ticket, hipStream_t s) {
+  hipLaunchKernelGGL(k_post_seq, dim3(1), dim3(1), 0, s, host_seq, ticket);
+  return hipGetLastError();
+}
+
 // x[i] += coef * y[i] on movable rows of [row0, row1) and of an explicit row list (shard commit)
 __global__ void k_axpy_rows(int64_t row0, int64_t row1, const int32_t* extra, int n_extra,
                             const uint8_t* vflags, double* x, const double* y, double coef) {

@@ -265,6 +265,49 @@ class DeviceMesh:
     def phase_set_factors_valid(self, valid: bool):
         self._chk(L.lib().ms_phase_set_factors_valid(self._h, int(valid)), "ms_phase_set_factors_valid")
 
+    # -- library-side sharded driver ----------------------------------------------
+    @staticmethod
+    def shard_unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        L.check(L.lib().ms_shard_unique_id(buf), None, "ms_shard_unique_id")
+        return buf.raw
+
+    def shard_comm_init(self, unique_id: bytes):
+        if len(unique_id) != 128:
+            raise ValueError("ncclUniqueId is 128 bytes")
+        self._chk(L.lib().ms_shard_comm_init(self._h, ctypes.create_string_buffer(unique_id, 128)),
+                  "ms_shard_comm_init")
+
+    def shard_set_allgather(self, fn):
+        """fn(send_ptr, recv_ptr, bytes_per_rank) -> None: in-process stand-in for ncclAllGather."""
+        def thunk(_user, send, recv, nbytes):
+            try:
+                fn(int(send), int(recv), int(nbytes))
+                return 0
+            except Exception:  # pragma: no cover - surfaced as MS_ERR_STATE
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        self._allgather_cb = L.ALLGATHER_FN(thunk)  # keep the trampoline alive
+        self._chk(L.lib().ms_shard_set_allgather(self._h, self._allgather_cb, None), "ms_shard_set_allgather")
+
+    def shard_step(self, *, stepper: int, step_size: float, tol: float = 1e-6, max_iter: int = 10,
+                   beta: float = 0.7, c: float = 1e-4, gamma: float = 1.5, alpha_max_factor: float = 10.0,
+                   restart_interval: int = 10, edge_fraction: float = 0.0, reuse_energy0: int = 2) -> StepResult:
+        sp = L.ms_stepper_params(int(stepper), int(max_iter), float(beta), float(c), float(gamma),
+                                 float(alpha_max_factor), int(restart_interval), float(edge_fraction),
+                                 int(reuse_energy0))
+        r = L.ms_step_result()
+        self._chk(L.lib().ms_shard_step(self._h, ctypes.byref(sp), float(step_size), float(tol), ctypes.byref(r)),
+                  "ms_shard_step")
+        return StepResult(r.success != 0, r.converged != 0, r.trials, r.guard_rejects, r.next_step, r.energy,
+                          r.alpha, r.energy_eval, r.grad_norm, r.g_dot_d, r.volume)
+
+    def shard_exchange_count(self) -> int:
+        return int(L.lib().ms_shard_exchange_count(self._h))
+
     # -- shard boundary exchange ------------------------------------------------
     def boundary_info(self):
         v = np.zeros(4, dtype=np.int64)

@@ -31,7 +31,10 @@ RCCL and on a NumPy/oracle backend under gloo in the CPU tests.
 
 from __future__ import annotations
 
+import ctypes
 import json
+import os
+import sys
 import math
 import time
 from dataclasses import dataclass
@@ -230,6 +233,29 @@ class ShardedStepper:
         return res
 
 
+class LibraryShardedStepper:
+    """ShardedStepper's control flow run inside the library (ms_shard_step): per exchange
+    pack -> ncclAllGather on the context's stream -> unpack -> mailbox poll, nothing of the
+    interpreter in the loop.  Needs ``HipShardBackend.enable_library_driver()`` first."""
+
+    def __init__(self, backend, *, stepper: int = L.MS_STEPPER_CG, reuse_energy0: int = 2, **params):
+        self.b = backend
+        self.stepper = stepper
+        self.reuse_energy0 = int(reuse_energy0)
+        self.params = params
+
+    @property
+    def exchanges(self) -> int:
+        return self.b.dm.shard_exchange_count()
+
+    def reset(self):
+        self.b.dm.reset_stepper()
+
+    def step(self, step_size: float, tol: float = 0.0):
+        return self.b.dm.shard_step(stepper=self.stepper, step_size=step_size, tol=tol,
+                                    reuse_energy0=self.reuse_energy0, **self.params)
+
+
 class HipShardBackend:
     """HIP kernels on this rank's tile range; collectives through torch.distributed."""
 
@@ -309,6 +335,37 @@ class HipShardBackend:
     def set_factors_valid(self, valid):
         self.dm.phase_set_factors_valid(valid)
 
+    def enable_library_driver(self):
+        """Give the context its own RCCL communicator (ncclUniqueId from rank 0, broadcast over
+        the existing torch.distributed group) or, for an in-process group, an all-gather callback."""
+        dist = self.dist
+        if hasattr(dist, "all_gather_into_tensor") and not hasattr(dist, "broadcast"):
+            # in-process stand-in (tests): route the library's all-gather through the group
+            torch = self.torch
+            n_max = self._send.numel()
+
+            def gather(send_ptr, recv_ptr, nbytes):
+                n = nbytes // 8
+                assert n <= n_max
+                hip = ctypes.CDLL(L.HIP_RUNTIME_PATH)
+                hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+                send, recv = self._send[:n], self._recv[: self.world * n]
+                hip.hipMemcpy(send.data_ptr(), send_ptr, nbytes, 3)
+                dist.all_gather_into_tensor(recv, send)
+                hip.hipMemcpy(recv_ptr, recv.data_ptr(), nbytes * self.world, 3)
+                torch.cuda.synchronize()
+
+            self.dm.shard_set_allgather(gather)
+            return
+        torch = self.torch
+        backend = dist.get_backend()
+        dev = self.device if backend == "nccl" else torch.device("cpu")
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if self.rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(self.dm.shard_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, src=0)
+        self.dm.shard_comm_init(bytes(idt.cpu().numpy().tobytes()))
+
     def gather_positions(self) -> np.ndarray:
         """Assemble the full position array (owner rows of x from every rank) -- between steps a
         rank only keeps the rows it reads (own + halo) current."""
@@ -354,7 +411,17 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     be = HipShardBackend(P, T, rank=rank, world=world, device=local_rank, tile_vertices=args.tile)
     be.configure(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING, gamma=np.ones(nf), kappa=np.ones(nv),
                  c0=np.zeros(nv))
-    drv = ShardedStepper(be, stepper=L.MS_STEPPER_CG)
+    driver = "library (ms_shard_step, direct ncclAllGather)"
+    try:
+        if os.environ.get("MS_SHARD_PYTHON_DRIVER"):
+            raise RuntimeError("MS_SHARD_PYTHON_DRIVER set")
+        be.enable_library_driver()
+        drv = LibraryShardedStepper(be, stepper=L.MS_STEPPER_CG)
+    except Exception as exc:  # fall back to the torch.distributed driver, loudly
+        print(f"[bench] library shard driver unavailable ({exc}); using the Python/torch.distributed driver",
+              file=sys.stderr)
+        driver = "python (ShardedStepper, torch.distributed all_gather_into_tensor)"
+        drv = ShardedStepper(be, stepper=L.MS_STEPPER_CG)
     step = args.step_size
 
     def run(n):
@@ -370,7 +437,7 @@ def bench_main(args, rank: int, world: int, local_rank: int):
         return acc, trials, r
 
     run(args.warmup)
-    drv.exchanges = 0
+    ex0 = drv.exchanges
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -392,7 +459,7 @@ def bench_main(args, rank: int, world: int, local_rank: int):
                                    f"evaluation reuse level {drv.reuse_energy0}",
                        "parallelism": f"tiles (facet blocks) sharded over {world} GPUs; per exchange one RCCL "
                                       f"all-gather of [16 scalars | <= {be.boundary['max_rows']} boundary rows] "
-                                      f"per rank ({drv.exchanges} exchanges in the timed steps)",
+                                      f"per rank ({drv.exchanges - ex0} exchanges in the timed steps); driver: {driver}",
                        "tile_vertices": args.tile or 256, "initial_step_size": args.step_size},
             "steps_accepted": acc, "line_search_trials": trials, "energy_end": r.energy,
         }))

@@ -41,17 +41,21 @@ class ThreadGroup:
         self.bar.wait()
 
 
+@pytest.mark.parametrize("driver", ["python", "library"])
 @pytest.mark.parametrize("with_volume,world,level,freq,tile", [
     (False, 2, 2, 16, 64), (True, 2, 2, 16, 64), (False, 3, 2, 16, 64), (False, 2, 0, 16, 64), (True, 3, 0, 16, 64),
     (False, 4, 2, 160, 256),  # 512 000 facets, default tile size, 4 shards: sizes near the headline
 ])
-def test_shards_match_single_context(with_volume, world, level, freq, tile):
+def test_shards_match_single_context(with_volume, world, level, freq, tile, driver):
+    """driver "python": parallel.ShardedStepper drives the phase API; "library": the same control
+    flow inside the library (ms_shard_step) with the in-process all-gather plugged in where
+    ncclAllGather goes."""
     import torch
 
     from membrane_solver_amd import _lib as L
     from membrane_solver_amd import meshgen
     from membrane_solver_amd.device import DeviceMesh
-    from membrane_solver_amd.parallel import HipShardBackend, ShardedStepper
+    from membrane_solver_amd.parallel import HipShardBackend, LibraryShardedStepper, ShardedStepper
 
     P, T = meshgen.icosphere(freq)
     P = meshgen.smooth_displace(P, 0.06)
@@ -85,9 +89,13 @@ def test_shards_match_single_context(with_volume, world, level, freq, tile):
         try:
             grp.bind(rank)
             be = HipShardBackend(P, T, rank=rank, world=world, device=0, tile_vertices=tile, fixed=fixed, group=grp,
-                                 debug_poison=True)
+                                 debug_poison=(driver == "python"))
             be.configure(modules=mods, gamma=gamma, kappa=kappa, c0=c0, target_volume=V0)
-            drv = ShardedStepper(be, stepper=L.MS_STEPPER_CG, reuse_energy0=level)
+            if driver == "library":
+                be.enable_library_driver()
+                drv = LibraryShardedStepper(be, stepper=L.MS_STEPPER_CG, reuse_energy0=level)
+            else:
+                drv = ShardedStepper(be, stepper=L.MS_STEPPER_CG, reuse_energy0=level)
             log, step = [], step0
             for _ in range(n_steps):
                 r = drv.step(step, tol=1e-9)
