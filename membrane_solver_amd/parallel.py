@@ -255,6 +255,22 @@ class LibraryShardedStepper:
         return self.b.dm.shard_step(stepper=self.stepper, step_size=step_size, tol=tol,
                                     reuse_energy0=self.reuse_energy0, **self.params)
 
+    def run(self, n_steps: int, step_size: float, tol: float = 0.0):
+        """n_steps iterations of the minimizer loop (step, stepper reset on failure, zero-step
+        exit) inside the library: ms_minimize over ms_shard_step.  -> ms_minimize_result"""
+        p = self.params
+        mp = L.ms_minimize_params()
+        mp.stepper = L.ms_stepper_params(int(self.stepper), int(p.get("max_iter", 10)), float(p.get("beta", 0.7)),
+                                         float(p.get("c", 1e-4)), float(p.get("gamma", 1.5)),
+                                         float(p.get("alpha_max_factor", 10.0)),
+                                         int(p.get("restart_interval", 10)), float(p.get("edge_fraction", 0.0)),
+                                         self.reuse_energy0)
+        mp.step_size, mp.tol = float(step_size), float(tol)
+        mp.fixed_step_mode, mp.fixed_step = 0, float(step_size)
+        mp.max_zero_steps, mp.step_size_floor = 10, 1e-8
+        out, _log = self.b.dm.minimize(mp, n_steps)
+        return out
+
 
 class HipShardBackend:
     """HIP kernels on this rank's tile range; collectives through torch.distributed."""
@@ -427,6 +443,10 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     def run(n):
         nonlocal step
         acc = trials = 0
+        if isinstance(drv, LibraryShardedStepper):
+            out = drv.run(n, step, tol=1e-6)
+            step = float(out.step_size)
+            return int(out.accepted), int(out.trials), out
         for _ in range(n):
             r = drv.step(step, tol=1e-6)
             step = r.next_step
@@ -461,6 +481,7 @@ def bench_main(args, rank: int, world: int, local_rank: int):
                                       f"all-gather of [16 scalars | <= {be.boundary['max_rows']} boundary rows] "
                                       f"per rank ({drv.exchanges - ex0} exchanges in the timed steps); driver: {driver}",
                        "tile_vertices": args.tile or 256, "initial_step_size": args.step_size},
-            "steps_accepted": acc, "line_search_trials": trials, "energy_end": r.energy,
+            "steps_accepted": acc, "line_search_trials": trials,
+            "energy_end": float(getattr(r, "energy", getattr(r, "energy_eval", float("nan")))),
         }))
     dist.destroy_process_group()
