@@ -376,9 +376,20 @@ class HipShardBackend:
         torch = self.torch
         backend = dist.get_backend()
         dev = self.device if backend == "nccl" else torch.device("cpu")
+        # every rank first checks, locally, that librccl binds (ncclCommInitRank below is a
+        # collective: a rank that cannot take part must be known to all before anyone enters it)
+        try:
+            my_id = self.dm.shard_unique_id()
+            ok = 1
+        except L.MembraneHipError:
+            my_id, ok = bytes(128), 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            raise L.MembraneHipError("librccl could not be bound on every rank")
         idt = torch.zeros(128, dtype=torch.uint8, device=dev)
         if self.rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(self.dm.shard_unique_id()), dtype=torch.uint8))
+            idt.copy_(torch.frombuffer(bytearray(my_id), dtype=torch.uint8))
         dist.broadcast(idt, src=0)
         self.dm.shard_comm_init(bytes(idt.cpu().numpy().tobytes()))
 
