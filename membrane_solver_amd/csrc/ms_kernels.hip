@@ -1551,9 +1551,23 @@ __global__ __launch_bounds__(BLOCK) void k_reduce(const double* partials, int n_
   const int op = (slot == MS_S_MINEDGE2) ? 1 : ((slot == MS_S_GUARD || slot == MS_S_MAXD2) ? 2 : 0);
   const double* p = partials + (size_t)slot * n_tiles;
   double v = op == 1 ? 1.0e300 : 0.0;
-  for (int t = tile0 + threadIdx.x; t < tile1; t += BLOCK) {
-    const double q = p[t];
-    v = op == 0 ? v + q : (op == 1 ? fmin(v, q) : fmax(v, q));
+  // RU loads in flight per thread (the order of the additions is unchanged)
+  constexpr int RU = 8;
+  const double neutral = op == 1 ? 1.0e300 : 0.0;
+  for (int t = tile0 + threadIdx.x; t < tile1; t += RU * BLOCK) {
+    double q[RU];
+#pragma unroll
+    for (int k = 0; k < RU; ++k) q[k] = t + k * BLOCK < tile1 ? p[t + k * BLOCK] : neutral;
+#pragma unroll
+    for (int k = 0; k < RU; ++k) {
+      if (op == 0) {
+        if (t + k * BLOCK < tile1) v = v + q[k];
+      } else if (op == 1) {
+        v = fmin(v, q[k]);
+      } else {
+        v = fmax(v, q[k]);
+      }
+    }
   }
   v = block_reduce(v, op, red);
   if (threadIdx.x == 0) {
