@@ -96,6 +96,7 @@ enum ms_scalar {
   MS_S_EBT = 11,    /* bending + tilt-splay energy, modules/energy/bending_tilt.py */
   MS_S_TGNORM2 = 12, /* |tilt gradient|^2 over free rows (tilt_relaxation.py:318) */
   MS_S_TRZ = 13,    /* <r, M^-1 r> of the tilt CG (tilt_relaxation.py:369,416) */
+  MS_S_MAXG2 = 14,  /* max_i |g_i|^2 over movable rows (= max|d_i|^2 of a steepest-descent restart) */
   MS_NSCAL = 16
 };
 

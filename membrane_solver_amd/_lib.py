@@ -33,7 +33,7 @@ MS_STEPPER_GD, MS_STEPPER_CG = 0, 1
 (MS_BUF_X, MS_BUF_XT, MS_BUF_G, MS_BUF_GC, MS_BUF_D, MS_BUF_PG, MS_BUF_PD, MS_BUF_FK,
  MS_BUF_FA, MS_BUF_SCAL) = range(10)
 (MS_S_ESURF, MS_S_VOL, MS_S_EBEND, MS_S_MINEDGE2, MS_S_GUARD, MS_S_GGC, MS_S_GCGC,
- MS_S_GNORM2, MS_S_GDOTD, MS_S_MAXD2, MS_S_ETILT, MS_S_EBT, MS_S_TGNORM2, MS_S_TRZ) = range(14)
+ MS_S_GNORM2, MS_S_GDOTD, MS_S_MAXD2, MS_S_ETILT, MS_S_EBT, MS_S_TGNORM2, MS_S_TRZ, MS_S_MAXG2) = range(15)
 MS_NSCAL = 16
 
 

@@ -101,6 +101,7 @@ struct ms_ctx {
   // true while buffer G holds the finalized gradient of the current x (set by ms_step's fused
   // gradient pass, survives a failed line search, cleared together with carry_valid)
   bool grad_valid = false;
+  bool maxg2_valid = false;  // the mailbox holds |g|^2 and max|g_i|^2 of the gradient in buffer G
   // optional per-kernel timing (ms_profile_*)
   bool profiling = false;
   struct ProfRec {
@@ -233,7 +234,7 @@ int bt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* tilts
   return MS_OK;
 }
 constexpr uint32_t MASK_GRAD = (1u << MS_S_GGC) | (1u << MS_S_GCGC);
-constexpr uint32_t MASK_DIR = (1u << MS_S_GNORM2) | (1u << MS_S_GDOTD) | (1u << MS_S_MAXD2);
+constexpr uint32_t MASK_DIR = (1u << MS_S_GNORM2) | (1u << MS_S_GDOTD) | (1u << MS_S_MAXD2) | (1u << MS_S_MAXG2);
 
 int reduce_slots(ms_ctx* c, uint32_t mask) {
   ProfScope ps(c, 3);
@@ -247,7 +248,7 @@ int reduce_slots(ms_ctx* c, uint32_t mask) {
 
 int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool write_trial,
                  bool guard, bool write_factors, bool reduce_now = true) {
-  c->carry_valid = c->grad_valid = c->bt_valid = false;
+  c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
   c->sh_carry_valid = c->sh_grad_valid = false;
   EnergyArgs a;
   a.m = device_mesh(c);
@@ -683,7 +684,7 @@ int ms_set_surface_tension(ms_ctx* c, const double* gamma) {
   for (size_t p = 0; p < g.size(); ++p) g[p] = gamma[t.tile_facet_ext[p]];
   if (!g.empty())
     HIPCHK(c, hipMemcpy(c->d_tf_gamma, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice));
-  c->carry_valid = c->grad_valid = c->bt_valid = false;
+  c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
   c->sh_carry_valid = c->sh_grad_valid = false;
   return MS_OK;
 }
@@ -700,7 +701,7 @@ int ms_set_bending_params(ms_ctx* c, const double* kappa, const double* c0) {
   HIPCHK(c, hipMemcpy(c->d_kappa, k.data(), k.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_c0, z.data(), z.size() * sizeof(double), hipMemcpyHostToDevice));
   c->factors_valid = false;
-  c->carry_valid = c->grad_valid = c->bt_valid = false;
+  c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
   c->sh_carry_valid = c->sh_grad_valid = false;
   return MS_OK;
 }
@@ -722,7 +723,7 @@ int ms_set_params(ms_ctx* c, const ms_params* p) {
   }
   c->params = *p;
   c->factors_valid = false;
-  c->carry_valid = c->grad_valid = c->bt_valid = false;
+  c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
   c->sh_carry_valid = c->sh_grad_valid = false;
   return MS_OK;
 }
@@ -739,7 +740,7 @@ int ms_set_tilts(ms_ctx* c, const double* tilts, double tilt_rigidity) {
     HIPCHK(c, hipMemset(c->d_tilt_grad, 0, bytes));
   }
   c->k_tilt = tilt_rigidity;
-  c->carry_valid = c->grad_valid = c->bt_valid = false;
+  c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
   c->sh_carry_valid = c->sh_grad_valid = false;
   return ext_to_patch(c, tilts, c->d_tilts, 3);
 }
@@ -967,7 +968,7 @@ int ms_relax_tilts(ms_ctx* c, const ms_tilt_relax_params* rp, int* iters_out, in
 int ms_set_positions(ms_ctx* c, const double* positions) {
   if (!c || !positions) return fail(c, MS_ERR_INVALID, "ms_set_positions: NULL argument");
   c->factors_valid = false;
-  c->carry_valid = c->grad_valid = c->bt_valid = false;
+  c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
   c->sh_carry_valid = c->sh_grad_valid = false;
   return ext_to_patch(c, positions, c->buf[MS_BUF_X], 3);
 }
@@ -1035,17 +1036,35 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
                        (c->factors_valid || !(c->params.modules & (MS_MOD_BENDING | MS_MOD_BENDING_TILT)));
   const bool constraint = (c->params.modules & (MS_CON_VOLUME | MS_MOD_TILT)) != 0;
   int rc;
+  bool restart_sd = false;
   if (carried && c->grad_valid && !constraint && c->til.T <= 256) {
     // x has not moved since the last gradient pass (failed search, stepper reset): only the
     // direction changes.  k_direction on the finalized g repeats the fused epilogue's
     // arithmetic and reduction order exactly.
-    rc = phase_direction(c, sp->stepper, use_history, /*g_finalized=*/true);
+    restart_sd = !use_history && c->maxg2_valid;
+    if (restart_sd) {
+      // steepest-descent restart: d = -g, whose scalars the gradient pass already reduced
+      // (|g|^2; <g,d> = -|g|^2 and max|d_i|^2 = max|g_i|^2 exactly) -- no fold, no host round trip
+      ProfScope ps(c, 2);
+      HIPCHK(c, launch_direction(c->tile0, c->tile1, c->til.nv, c->til.T, c->d_vflags, c->buf[MS_BUF_G],
+                                 c->buf[MS_BUF_GC], c->buf[MS_BUF_D], c->buf[MS_BUF_PG], c->buf[MS_BUF_PD],
+                                 c->d_scal, 0, 0, c->d_partials, c->til.n_tiles, 0, c->stream));
+      c->last_g = c->buf[MS_BUF_G];
+      c->h_scal[MS_S_GDOTD] = -c->h_scal[MS_S_GNORM2];
+      c->h_scal[MS_S_MAXD2] = c->h_scal[MS_S_MAXG2];
+      rc = MS_OK;
+    } else {
+      rc = phase_direction(c, sp->stepper, use_history, /*g_finalized=*/true);
+    }
   } else {
     rc = queue_energy_and_gradient(c, sp->stepper, use_history, carried);
+    c->maxg2_valid = !constraint;  // the fused epilogue reduced max|g_i|^2 as well
   }
   if (rc) return rc;
-  rc = fetch(c);
-  if (rc) return rc;
+  if (!restart_sd) {
+    rc = fetch(c);
+    if (rc) return rc;
+  }
   // factors, mailbox energies and G now describe x (until a trial pass overwrites them)
   c->carry_valid = carry_mode;
   c->grad_valid = carry_mode && !constraint;
@@ -1272,7 +1291,7 @@ int ms_phase_accept(ms_ctx* c, int keep_history) {
   if (!c) return MS_ERR_INVALID;
   std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
   c->factors_valid = false;
-  c->carry_valid = c->grad_valid = c->bt_valid = false;
+  c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
   c->sh_carry_valid = c->sh_grad_valid = false;
   if (keep_history) {
     std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
@@ -1701,7 +1720,7 @@ int ms_fetch_scalars(ms_ctx* c, double* out) {
 int ms_store_scalars(ms_ctx* c, const double* in) {
   if (!c || !in) return MS_ERR_INVALID;
   memcpy(c->h_scal, in, sizeof(double) * MS_NSCAL);
-  c->carry_valid = c->grad_valid = c->bt_valid = false;
+  c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
   c->sh_carry_valid = c->sh_grad_valid = false;
   HIPCHK(c, hipMemcpyAsync(c->d_scal, c->h_scal, sizeof(double) * MS_NSCAL, hipMemcpyHostToDevice,
                            c->stream));

@@ -643,7 +643,7 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
 // S = |n| (the same vector for all corners of a triangle), so a facet costs one
 // sqrt and two divides.
 // BENDMODE: 0 none, 1 analytic, 2 approx (bending.py:163-167).
-// LDS: px[3][cap] | (BEND) fk[3][cap] fae[cap] fav[cap] | stg[9 or 18][T] | red[3*16]
+// LDS: px[3][cap] | (BEND) fk[3][cap] fae[cap] fav[cap] | stg[9 or 18][T] | red[4*16]
 //      | vent[max_ent] (u16) | fl[cap] (u8)
 // ---------------------------------------------------------------------------
 template <int BENDMODE, bool VOLROW, int TT, int CAPC>
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
   double* fav = fae + (BEND ? cap : 0);
   double* stg = fav + (BEND ? cap : 0);
   double* red = stg + (VOLROW ? 18 : 9) * T;
-  uint16_t* vent = reinterpret_cast<uint16_t*>(red + 3 * 16);
+  uint16_t* vent = reinterpret_cast<uint16_t*>(red + 4 * 16);
   uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + ((max_ent + 3) & ~3));
 
   const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
     __syncthreads();
   }
 
-  double ggc = 0.0, gcgc = 0.0, gn2 = 0.0, gdd = 0.0, md2 = 0.0;
+  double ggc = 0.0, gcgc = 0.0, gn2 = 0.0, gdd = 0.0, md2 = 0.0, mg2 = 0.0;
   if (tid < t.n_owned) {
     const size_t o = 3 * (size_t)(t.v_lo + tid);
     // bending.py:165-166: approx mode zeroes the boundary rows of what was accumulated
@@ -956,6 +956,7 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
       gn2 = dot_pinned(gi, gi);
       gdd = dot_pinned(gi, di);
       md2 = fixed ? 0.0 : dot_pinned(di, di);
+      mg2 = gn2;  // (gi is zero on fixed rows) what max|d_i|^2 becomes if the stepper restarts with d = -g
     } else if (a.g) {
       if (a.accumulate) {
         gx += a.g[o];
@@ -981,10 +982,10 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
     }
   }
   if (a.dir_mode) {
-    const double vals[3] = {gn2, gdd, md2};
-    const int ops[3] = {0, 0, 2};
-    const int slots[3] = {MS_S_GNORM2, MS_S_GDOTD, MS_S_MAXD2};
-    block_reduce_store<3>(vals, ops, slots, red, a.partials + t.tile, (size_t)a.m.n_tiles);
+    const double vals[4] = {gn2, gdd, md2, mg2};
+    const int ops[4] = {0, 0, 2, 2};
+    const int slots[4] = {MS_S_GNORM2, MS_S_GDOTD, MS_S_MAXD2, MS_S_MAXG2};
+    block_reduce_store<4>(vals, ops, slots, red, a.partials + t.tile, (size_t)a.m.n_tiles);
   } else {
     const double vals[2] = {ggc, gcgc};
     const int ops[2] = {0, 0};
@@ -994,7 +995,7 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
 }
 
 size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow) {
-  size_t d = 3 * (size_t)cap + (bend ? 5 * (size_t)cap : 0) + (volrow ? 18 : 9) * (size_t)T + 3 * 16;
+  size_t d = 3 * (size_t)cap + (bend ? 5 * (size_t)cap : 0) + (volrow ? 18 : 9) * (size_t)T + 4 * 16;
   return d * sizeof(double) + u16_bytes(T, max_ent) + (((size_t)cap + 15) / 16) * 16;
 }
 
@@ -1548,7 +1549,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce(const double* partials, int n_
       }
   }
   if (slot < 0) return;
-  const int op = (slot == MS_S_MINEDGE2) ? 1 : ((slot == MS_S_GUARD || slot == MS_S_MAXD2) ? 2 : 0);
+  const int op = (slot == MS_S_MINEDGE2) ? 1 : ((slot == MS_S_GUARD || slot == MS_S_MAXD2 || slot == MS_S_MAXG2) ? 2 : 0);
   const double* p = partials + (size_t)slot * n_tiles;
   double v = op == 1 ? 1.0e300 : 0.0;
   // RU loads in flight per thread (the order of the additions is unchanged)
