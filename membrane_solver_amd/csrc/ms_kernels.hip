@@ -767,6 +767,13 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
 
   double gx = 0, gy = 0, gz = 0, cx = 0, cy = 0, cz = 0;
   if (tid >= t.n_owned) cur = end = 0;
+  // CG history rows of the fused direction pass: requested now, consumed in the epilogue
+  V3 h_pg = mk(0, 0, 0), h_pd = mk(0, 0, 0);
+  if (a.dir_mode == 2 && tid < t.n_owned) {
+    const size_t o = 3 * (size_t)(t.v_lo + tid);
+    h_pg = mk(a.pg[o], a.pg[o + 1], a.pg[o + 2]);
+    h_pd = mk(a.pd[o], a.pd[o + 1], a.pd[o + 2]);
+  }
 
   for (int c0f = t.f0; c0f < t.f1; c0f += T) {
     const int p = c0f + tid;
@@ -939,10 +946,10 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
       V3 gi = fixed ? mk(0, 0, 0) : mk(gx, gy, gz);
       V3 di = -gi;
       if (a.dir_mode == 2) {
-        const V3 pgv = mk(a.pg[o], a.pg[o + 1], a.pg[o + 2]);
+        const V3 pgv = h_pg;
         const double beta = dot_pinned(gi, gi - pgv) / (dot_pinned(pgv, pgv) + 1.0e-20);
         if (!(beta < 0.0)) {
-          const V3 q = mk(a.pd[o], a.pd[o + 1], a.pd[o + 2]);
+          const V3 q = h_pd;
           di = mk(fma(beta, q.x, -gi.x), fma(beta, q.y, -gi.y), fma(beta, q.z, -gi.z));
         }
       }
