@@ -30,6 +30,7 @@ ap.add_argument("--reference", default="/root/reference")
 ap.add_argument("--fortran-dir", default="/tmp/fprobe/f2py_try")
 ap.add_argument("--only-tilt", action="store_true")
 ap.add_argument("--only-bt", action="store_true", help="bending_tilt + tilt relaxation vectors only")
+ap.add_argument("--only-ts", action="store_true", help="tilt_smoothness vectors only")
 args = ap.parse_args()
 
 sys.dont_write_bytecode = True
@@ -300,7 +301,7 @@ def gen_mesh_cases():
 # ---------------------------------------------------------------------------
 # (c) minimizer trajectories
 # ---------------------------------------------------------------------------
-def run_trajectory(name, m, stepper, n_steps, step_size=1e-3):
+def run_trajectory(name, m, stepper, n_steps, step_size=1e-3, mesh_path=False):
     em = EnergyModuleManager(m.energy_modules)
     cm = ConstraintModuleManager(m.constraint_modules)
     mz = Minimizer(m, m.global_parameters, stepper, em, cm, quiet=True, step_size=step_size)
@@ -308,10 +309,20 @@ def run_trajectory(name, m, stepper, n_steps, step_size=1e-3):
     log = []
     orig_step = stepper.step
 
-    def logged_step(*a, **kw):
-        r = orig_step(*a, **kw)
+    # keep the stepper's signature: the minimizer passes ``trial_energy_fn`` (the array fast path of
+    # the line search, line_search.py:357-421) only to steppers whose ``step`` names it
+    # (minimizer.py:257-269); a (*a, **kw) wrapper would silently select the mesh-mutating path
+    def logged_step(mesh, grad, step_size, energy_fn, constraint_enforcer=None, trial_energy_fn=None):
+        r = orig_step(mesh, grad, step_size, energy_fn, constraint_enforcer=constraint_enforcer,
+                      trial_energy_fn=trial_energy_fn)
         log.append((float(bool(r[0])), float(r[1]), float(r[2])))
         return r
+
+    if mesh_path:  # tilt modules: see run_tilt_trajectory
+        def logged_step(mesh, grad, step_size, energy_fn, constraint_enforcer=None):  # noqa: F811
+            r = orig_step(mesh, grad, step_size, energy_fn, constraint_enforcer=constraint_enforcer)
+            log.append((float(bool(r[0])), float(r[1]), float(r[2])))
+            return r
 
     stepper.step = logged_step
     snaps = []
@@ -407,7 +418,7 @@ def gen_tilt_trajectory():
     mm = build_mesh(P, T, gp, tilts=tl)
     mm.energy_modules = ["surface", "tilt"]
     mm.constraint_modules = []
-    out = run_trajectory("ico4_gd_tilt", mm, GradientDescent(), 6, step_size=2e-3)
+    out = run_trajectory("ico4_gd_tilt", mm, GradientDescent(), 6, step_size=2e-3, mesh_path=True)
     out["tilts0"] = tl
     out["tilts_final"] = np.ascontiguousarray(mm.tilts_view())
     out["k_tilt"] = np.array(2.5)
@@ -498,8 +509,16 @@ def run_tilt_trajectory(fname, P, T, gp, mods, stepper, n_steps, step_size, tilt
     log = []
     orig_step = stepper.step
 
-    def logged_step(*a, **kw):
-        r = orig_step(*a, **kw)
+    # DELIBERATELY without ``trial_energy_fn`` in the signature: the minimizer then does not pass
+    # the array trial-energy callback (minimizer.py:257-269) and the line search takes its
+    # mesh-mutating path (line_search.py:428-487), which evaluates every trial consistently.  The
+    # array fast path (:357-421) evaluates bending_tilt through the EnergyContext's P1-gradient
+    # cache, which is keyed to the mesh and therefore STALE for a trial position array (measured
+    # here: bending_tilt 40.5908 via the manager vs 40.7643 direct at the same trial point), so it
+    # is not a usable oracle for the tilt modules.  For the shape-only modules both paths give
+    # identical numbers (run_trajectory above keeps the fast path).
+    def logged_step(mesh, grad, step_size, energy_fn, constraint_enforcer=None):
+        r = orig_step(mesh, grad, step_size, energy_fn, constraint_enforcer=constraint_enforcer)
         log.append((float(bool(r[0])), float(r[1]), float(r[2])))
         return r
 
@@ -569,10 +588,68 @@ def run_tilt_trajectory_disk(fname, P, T, gp, fixed):
         build_mesh = orig
 
 
+# ---------------------------------------------------------------------------
+# (e) tilt_smoothness (modules/energy/tilt_smoothness.py, ambient_v1 transport)
+# ---------------------------------------------------------------------------
+def gen_tilt_smoothness():
+    from modules.energy import tilt_smoothness
+    from runtime.preconditioners import build_tilt_cg_preconditioner
+
+    out = {"meta_fortran": META}
+    meshes = {}
+    rng = np.random.default_rng(41)
+    P, T = meshgen.icosphere(5)
+    P = meshgen.smooth_displace(P, 0.08) + 4e-3 * rng.normal(size=P.shape)
+    meshes["ico5"] = (P, T)
+    Pd, Td, _isb = meshgen.disk_patch(5, bulge=0.35, jitter=0.03, seed=5)
+    meshes["disk5"] = (Pd, Td)
+    for name, (P, T) in meshes.items():
+        gp = {"surface_tension": 1.0, "tilt_rigidity": 2.0, "tilt_smoothness_rigidity": 0.7}
+        m = build_mesh(P, T, gp)
+        pos, tri, isb, fixed = mesh_arrays(m)
+        tl = _tangent_tilts(m, np.random.default_rng(9), 0.25)
+        res = ParameterResolver(m.global_parameters)
+        g = np.zeros_like(pos)
+        tg = np.zeros_like(pos)
+        E = tilt_smoothness.compute_energy_and_gradient_array(
+            m, m.global_parameters, res, positions=pos, index_map=m.vertex_index_to_row, grad_arr=g,
+            tilts=tl, tilt_grad_arr=tg)
+        out[name + "_positions"], out[name + "_tri"], out[name + "_is_boundary"] = pos, tri, isb
+        out[name + "_tilts"], out[name + "_E"], out[name + "_grad"], out[name + "_tilt_grad"] = tl, np.array(E), g, tg
+        em = EnergyModuleManager(["tilt", "tilt_smoothness"])
+        mz = Minimizer(m, m.global_parameters, GradientDescent(), em, ConstraintModuleManager([]), quiet=True)
+        out[name + "_jacobi_Minv"] = build_tilt_cg_preconditioner(
+            m, mz.param_resolver, mz.energy_context(), positions=pos, index_map=m.vertex_index_to_row,
+            fixed_mask=np.zeros(len(pos), bool))
+        print("tilt_smoothness", name, "E=%.16g" % E, "shape grad max", np.abs(g).max())
+    np.savez_compressed(os.path.join(OUT, "tilt_smoothness_cases.npz"), **out)
+    base = {"surface_tension": 1.0, "bending_modulus": 1.0, "spontaneous_curvature": 0.1,
+            "bending_energy_model": "helfrich", "bending_gradient_mode": "analytic",
+            "tilt_rigidity": 2.5, "tilt_smoothness_rigidity": 0.6, "volume_constraint_mode": "lagrange",
+            "volume_projection_during_minimization": False, "mesh_quality_auto_repair_enabled": False}
+    P, T = meshgen.icosphere(4)
+    P = meshgen.smooth_displace(P, 0.08)
+    run_tilt_trajectory("traj_ico4_gd_ts_nested_cg.npz", P, T,
+                        dict(base, tilt_solve_mode="nested", tilt_solver="cg", tilt_step_size=0.1,
+                             tilt_inner_steps=6),
+                        ["surface", "tilt", "tilt_smoothness", "bending_tilt"], GradientDescent(), 5, 1e-3)
+    run_tilt_trajectory("traj_ico4_cg_ts_fixed.npz", P, T, dict(base, tilt_solve_mode="fixed"),
+                        ["surface", "tilt", "tilt_smoothness"], ConjugateGradient(), 6, 2e-3)
+    # over-long first step: rejected trials.  ConjugateGradient has no trial_energy_fn, so its line
+    # search mutates the mesh per trial and the stored tilts keep the projection of a rejected trial
+    run_tilt_trajectory("traj_ico4_cg_ts_backtrack.npz", P, T, dict(base, tilt_solve_mode="fixed"),
+                        ["surface", "tilt", "tilt_smoothness", "bending_tilt"], ConjugateGradient(), 5, 8e-2)
+    run_tilt_trajectory("traj_ico4_gd_ts_backtrack.npz", P, T, dict(base, tilt_solve_mode="fixed"),
+                        ["surface", "tilt", "tilt_smoothness", "bending_tilt"], GradientDescent(), 5, 8e-2)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if "--only-tilt" in sys.argv:
         gen_tilt_trajectory()
+        sys.exit(0)
+    if "--only-ts" in sys.argv:
+        gen_tilt_smoothness()
         sys.exit(0)
     if "--only-bt" in sys.argv:
         gen_bending_tilt_cases()
@@ -584,3 +661,4 @@ if __name__ == "__main__":
     gen_tilt_trajectory()
     gen_bending_tilt_cases()
     gen_bending_tilt_trajectories()
+    gen_tilt_smoothness()

@@ -108,6 +108,8 @@ def energy_and_gradient(p: Problem, pos: np.ndarray):
             # modules/energy/bending_tilt.py:151-482 (always the Helfrich form, :212-215)
             E += orc.bending_tilt_energy_and_gradient(pos, p.tilts, p.tri, p.kappa, p.c0, p.is_boundary,
                                                       mode=p.grad_mode, grad=grad)
+        elif name == "tilt_smoothness":
+            E += _smoothness(p, pos, p.tilts)
         else:
             raise ValueError(f"module {name!r} is outside the hot-path scope")
     # constraint_manager.apply_gradient_modifications_array (k == 1 dense branch :293-301)
@@ -145,12 +147,22 @@ def energy_total(p: Problem, pos: np.ndarray, tilts=None) -> float:
                 E += orc.tilt_energy_and_gradient(pos, tilts, p.tri, k_t, None, None)
         elif name == "bending_tilt":
             E += orc.bending_tilt_energy_and_gradient(pos, tilts, p.tri, p.kappa, p.c0, p.is_boundary)
+        elif name == "tilt_smoothness":
+            E += _smoothness(p, pos, tilts)
         else:
             raise ValueError(name)
     return float(E)
 
 
-TILT_MODULES = ("tilt", "bending_tilt")  # modules with USES_TILT = True in scope
+def _smoothness(p: Problem, pos, tilts, tilt_grad=None) -> float:
+    """modules/energy/tilt_smoothness.py:246-283; cotans of the positions being evaluated."""
+    k_s = float(p.gp.get("tilt_smoothness_rigidity", 0.0) or 0.0)
+    if k_s == 0.0:
+        return 0.0
+    return orc.tilt_smoothness_energy_and_gradient(pos, tilts, p.tri, k_s, tilt_grad)
+
+
+TILT_MODULES = ("tilt", "bending_tilt", "tilt_smoothness")  # modules with USES_TILT = True in scope
 
 
 # runtime/evaluation_manager.py:386-462 (energy of the USES_TILT modules + dense tilt gradient)
@@ -165,6 +177,8 @@ def energy_and_tilt_gradient(p: Problem, pos: np.ndarray, tilts: np.ndarray):
         elif name == "bending_tilt":
             E += orc.bending_tilt_energy_and_gradient(pos, tilts, p.tri, p.kappa, p.c0, p.is_boundary,
                                                       tilt_grad=tg)
+        elif name == "tilt_smoothness":
+            E += _smoothness(p, pos, tilts, tg)
     return float(E), tg
 
 
@@ -178,6 +192,8 @@ def tilt_dependent_energy(p: Problem, pos: np.ndarray, tilts: np.ndarray) -> flo
                 E += orc.tilt_energy_and_gradient(pos, tilts, p.tri, k_t, None, None)
         elif name == "bending_tilt":
             E += orc.bending_tilt_energy_and_gradient(pos, tilts, p.tri, p.kappa, p.c0, p.is_boundary)
+        elif name == "tilt_smoothness":
+            E += _smoothness(p, pos, tilts)
     return float(E)
 
 
@@ -207,8 +223,13 @@ def tilt_cg_preconditioner(p: Problem, pos: np.ndarray, fixed_mask: np.ndarray) 
         for kcol in range(3):
             np.add.at(va, tri[:, kcol], thirds)
         diag += k_t * va
-    if float(p.gp.get("tilt_smoothness_rigidity", 0.0) or 0.0) != 0.0:
-        raise ValueError("tilt_smoothness is outside the hot-path scope")
+    k_s = float(p.gp.get("tilt_smoothness_rigidity", 0.0) or 0.0)
+    if k_s != 0.0 and p.tri.shape[0]:  # :42-57
+        _k, _a, w = orc.compute_curvature_data(pos, p.tri)
+        f = 0.5 * k_s
+        np.add.at(diag, p.tri[:, 0], f * (w[:, 1] + w[:, 2]))
+        np.add.at(diag, p.tri[:, 1], f * (w[:, 2] + w[:, 0]))
+        np.add.at(diag, p.tri[:, 2], f * (w[:, 0] + w[:, 1]))
     diag = np.where(diag > 1e-12, diag, 1.0)
     diag[fixed_mask] = 1.0
     return 1.0 / diag
@@ -409,7 +430,18 @@ class LineSearchResult:
 
 # runtime/steppers/line_search.py:267-541 backtracking_line_search_array
 def line_search(p: Problem, direction, gradient, step_size, *, max_iter=10, beta=0.7,
-                c=1e-4, gamma=1.5, alpha_max_factor=10.0, enforcer=None) -> LineSearchResult:
+                c=1e-4, gamma=1.5, alpha_max_factor=10.0, enforcer=None,
+                array_trials=True) -> LineSearchResult:
+    """Trial evaluation follows the line search's mesh-mutating path (line_search.py:428-487) whenever a
+    tilt-reading module or a constraint enforcer is active: every trial is written into the mesh,
+    ``energy_fn`` projects the STORED tilts onto the trial surface, and a rejected trial restores
+    the positions but not the tilts (those are restored only with an enforcer / reduced energy,
+    :300-312).  The array fast path (:357-421, taken when the stepper names ``trial_energy_fn``)
+    gives the same numbers for the shape-only modules; for bending_tilt it reads a P1-gradient
+    cache keyed to the mesh, i.e. stale for a trial array, so the consistent path is the one
+    restated and pinned (oracle/gen_golden.py: run_tilt_trajectory)."""
+    has_tilt = any(m in p.energy_modules for m in TILT_MODULES)
+    array_trials = array_trials and enforcer is None and not has_tilt
     movable = ~p.fixed
     baseline = p.positions.copy()
     project_tilts_to_tangent(p, baseline)  # energy_fn projects first (minimizer.py:581-588)
@@ -438,14 +470,24 @@ def line_search(p: Problem, direction, gradient, step_size, *, max_iter=10, beta
                 continue
         if enforcer is not None:
             trial = enforcer(trial)
-        # vertex-tilt modules: the trial energy uses the tilts projected onto the TRIAL
-        # surface's tangent planes, without storing them (minimizer.py:723-733)
-        E_t = energy_total(p, trial, tilts=projected_tilts(p, trial)
-                           if any(m in p.energy_modules for m in TILT_MODULES) else None)
+        if array_trials:
+            # vertex-tilt modules: the trial energy uses the tilts projected onto the TRIAL
+            # surface's tangent planes, without storing them (minimizer.py:723-733)
+            E_t = energy_total(p, trial, tilts=projected_tilts(p, trial) if has_tilt else None)
+        else:
+            tilts_before = None if p.tilts is None else p.tilts.copy()
+            p.positions = trial
+            if has_tilt:
+                project_tilts_to_tangent(p, trial)
+            E_t = energy_total(p, trial)
         trials += 1
         if E_t <= energy0 + c * alpha * g_dot_d:
             p.positions = trial
             return LineSearchResult(True, min(alpha * gamma, alpha_max), float(E_t), alpha, trials)
+        if not array_trials:
+            p.positions = baseline
+            if enforcer is not None and tilts_before is not None:
+                p.tilts = tilts_before  # needs_tilt_restore (line_search.py:300-312)
         alpha *= beta
         if alpha < 1e-8:
             break

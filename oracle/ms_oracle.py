@@ -312,3 +312,27 @@ def bending_tilt_energy_and_gradient(pos, tilts, tri, kappa, c0, is_boundary, *,
     else:
         bending_backprop(pos, tri, isb, fA_eff, fA_vor, fK, grad)        # :300-436
     return E
+
+
+# --- tilt smoothness --------------------------------------------------------------
+def tilt_smoothness_energy_and_gradient(pos, tilts, tri, k_smooth, tilt_grad=None) -> float:
+    """modules/energy/tilt_smoothness.py:84-198 (ambient_v1 transport): cotangent Dirichlet energy
+    E = k_s/4 sum_f [c0|t1-t2|^2 + c1|t2-t0|^2 + c2|t0-t1|^2] with the cotans of
+    compute_curvature_data at `pos`; exact tilt gradient, NO shape gradient (:21-23)."""
+    pos, tilts, tri = _f64(pos), _f64(tilts), _i32(tri)
+    if k_smooth == 0.0 or tri.shape[0] == 0:
+        return 0.0
+    _k, _a, w = compute_curvature_data(pos, tri)
+    c0, c1, c2 = w[:, 0], w[:, 1], w[:, 2]
+    t0, t1, t2 = tilts[tri[:, 0]], tilts[tri[:, 1]], tilts[tri[:, 2]]
+    d12, d20, d01 = t1 - t2, t2 - t0, t0 - t1
+    n12 = np.einsum("ij,ij->i", d12, d12)
+    n20 = np.einsum("ij,ij->i", d20, d20)
+    n01 = np.einsum("ij,ij->i", d01, d01)
+    E = float(0.25 * k_smooth * np.sum(c0 * n12 + c1 * n20 + c2 * n01))
+    if tilt_grad is not None:
+        f = 0.5 * k_smooth
+        np.add.at(tilt_grad, tri[:, 0], f * (c1[:, None] * (t0 - t2) + c2[:, None] * (t0 - t1)))
+        np.add.at(tilt_grad, tri[:, 1], f * (c2[:, None] * (t1 - t0) + c0[:, None] * (t1 - t2)))
+        np.add.at(tilt_grad, tri[:, 2], f * (c0[:, None] * (t2 - t1) + c1[:, None] * (t2 - t0)))
+    return E

@@ -247,3 +247,56 @@ def test_port_reproduces_bending_tilt_trajectory(fname):
     assert relerr(p.positions, g["positions_final"]) < 1e-8
     assert relerr(p.tilts, g["tilts_final"]) < 1e-8
     assert abs(res["energy"] - g["E_final"]) <= 1e-9 * abs(g["E_final"])
+
+
+# ---- tilt_smoothness (cotangent Dirichlet energy of the tilt field) ---------------------
+@pytest.mark.parametrize("name", ["ico5", "disk5"])
+def test_tilt_smoothness_matches_reference(name):
+    g = load_golden("tilt_smoothness_cases.npz")
+    pos, tri, tl = g[name + "_positions"], g[name + "_tri"], g[name + "_tilts"]
+    tg = np.zeros_like(pos)
+    E = orc.tilt_smoothness_energy_and_gradient(pos, tl, tri, 0.7, tg)
+    assert abs(E - g[name + "_E"]) <= 1e-12 * abs(g[name + "_E"])
+    assert relerr(tg, g[name + "_tilt_grad"]) < 1e-11
+    assert not np.any(g[name + "_grad"])  # the reference module has no shape gradient
+    p = mp.Problem(positions=pos, tri=tri, is_boundary=g[name + "_is_boundary"], tilts=tl,
+                   gp={"tilt_rigidity": 2.0, "tilt_smoothness_rigidity": 0.7})
+    assert relerr(mp.tilt_cg_preconditioner(p, pos, np.zeros(len(pos), bool)), g[name + "_jacobi_Minv"]) < 1e-12
+
+
+TS_BASE = dict(BT_BASE, tilt_smoothness_rigidity=0.6)
+TS_TRAJ = {
+    "traj_ico4_gd_ts_nested_cg.npz": ("gd", ["surface", "tilt", "tilt_smoothness", "bending_tilt"],
+                                      dict(TS_BASE, tilt_solve_mode="nested", tilt_solver="cg",
+                                           tilt_step_size=0.1, tilt_inner_steps=6)),
+    "traj_ico4_cg_ts_fixed.npz": ("cg", ["surface", "tilt", "tilt_smoothness"],
+                                  dict(TS_BASE, tilt_solve_mode="fixed")),
+    # rejected trials: the CG stepper's mesh-mutating line search compounds the tilt projections,
+    # the GD stepper's array line search does not
+    "traj_ico4_cg_ts_backtrack.npz": ("cg", ["surface", "tilt", "tilt_smoothness", "bending_tilt"],
+                                      dict(TS_BASE, tilt_solve_mode="fixed")),
+    "traj_ico4_gd_ts_backtrack.npz": ("gd", ["surface", "tilt", "tilt_smoothness", "bending_tilt"],
+                                      dict(TS_BASE, tilt_solve_mode="fixed")),
+}
+
+
+@pytest.mark.parametrize("fname", sorted(TS_TRAJ))
+def test_port_reproduces_tilt_smoothness_trajectory(fname):
+    kind, mods, gp = TS_TRAJ[fname]
+    g = load_golden(fname)
+    p = mp.Problem(positions=g["positions0"], tri=g["tri"], gamma=g["gamma"], is_boundary=g["is_boundary"],
+                   fixed=g["fixed"], tilts=g["tilts0"], tilt_fixed=g["tilt_fixed"], energy_modules=list(mods),
+                   constraint_modules=[], gp=dict(gp))
+    E0, grad0 = mp.energy_and_gradient(p, p.positions)
+    assert abs(E0 - g["E0"]) <= 1e-12 * abs(g["E0"])
+    assert relerr(grad0, g["grad0"]) < 1e-11
+    stepper = mp.GradientDescent() if kind == "gd" else mp.ConjugateGradient()
+    res = mp.minimize(p, stepper, int(g["n_steps"]), step_size=float(g["step_size0"]))
+    log = g["step_log"]
+    got = np.array([[float(t["success"]), t["next_step"], t["E_accepted"]] for t in res["trace"]])
+    assert got.shape == log.shape
+    assert np.array_equal(got[:, 0], log[:, 0])
+    assert np.allclose(got[:, 1], log[:, 1], rtol=1e-12, atol=0)
+    assert np.allclose(got[:, 2], log[:, 2], rtol=1e-9, atol=0)
+    assert relerr(p.positions, g["positions_final"]) < 1e-8
+    assert relerr(p.tilts, g["tilts_final"]) < 1e-8
