@@ -53,6 +53,7 @@ extern "C" {
 /* vertex-tilt magnitude energy 1/2 k_t sum |t_v|^2 A_v (modules/energy/tilt.py:99-172) */
 #define MS_MOD_TILT 32u
 #define MS_MOD_BENDING_TILT 64u /* modules/energy/bending_tilt.py (replaces MS_MOD_BENDING) */
+#define MS_MOD_TILT_SMOOTH 128u /* modules/energy/tilt_smoothness.py (ambient_v1 transport) */
 
 /* bending_params.py:19-33 */
 #define MS_BEND_HELFRICH 0
@@ -97,6 +98,7 @@ enum ms_scalar {
   MS_S_TGNORM2 = 12, /* |tilt gradient|^2 over free rows (tilt_relaxation.py:318) */
   MS_S_TRZ = 13,    /* <r, M^-1 r> of the tilt CG (tilt_relaxation.py:369,416) */
   MS_S_MAXG2 = 14,  /* max_i |g_i|^2 over movable rows (= max|d_i|^2 of a steepest-descent restart) */
+  MS_S_ETS = 15,    /* tilt smoothness (Dirichlet) energy, modules/energy/tilt_smoothness.py */
   MS_NSCAL = 16
 };
 
@@ -195,6 +197,8 @@ typedef struct ms_tilt_relax_params {
   int jacobi;        /* CG: "tilt_cg_preconditioner" == jacobi */
 } ms_tilt_relax_params;
 int ms_set_tilt_fixed(ms_ctx *ctx, const uint8_t *tilt_fixed /* nv or NULL */);
+/* gp["tilt_smoothness_rigidity"] of the tilt_smoothness module */
+int ms_set_tilt_smoothness(ms_ctx *ctx, double k_smooth);
 int ms_tilt_energy_and_gradient(ms_ctx *ctx, double *energy, double *tilt_grad);
 int ms_relax_tilts(ms_ctx *ctx, const ms_tilt_relax_params *params,
                    int *iters_out, int *evals_out);

@@ -26,6 +26,7 @@ MS_CON_VOLUME = 8
 MS_TRACK_VOLUME = 16
 MS_MOD_TILT = 32
 MS_MOD_BENDING_TILT = 64
+MS_MOD_TILT_SMOOTH = 128
 MS_BEND_HELFRICH, MS_BEND_WILLMORE = 0, 1
 MS_GRAD_ANALYTIC, MS_GRAD_APPROX = 0, 1
 MS_STEPPER_GD, MS_STEPPER_CG = 0, 1
@@ -33,7 +34,8 @@ MS_STEPPER_GD, MS_STEPPER_CG = 0, 1
 (MS_BUF_X, MS_BUF_XT, MS_BUF_G, MS_BUF_GC, MS_BUF_D, MS_BUF_PG, MS_BUF_PD, MS_BUF_FK,
  MS_BUF_FA, MS_BUF_SCAL) = range(10)
 (MS_S_ESURF, MS_S_VOL, MS_S_EBEND, MS_S_MINEDGE2, MS_S_GUARD, MS_S_GGC, MS_S_GCGC,
- MS_S_GNORM2, MS_S_GDOTD, MS_S_MAXD2, MS_S_ETILT, MS_S_EBT, MS_S_TGNORM2, MS_S_TRZ, MS_S_MAXG2) = range(15)
+ MS_S_GNORM2, MS_S_GDOTD, MS_S_MAXD2, MS_S_ETILT, MS_S_EBT, MS_S_TGNORM2, MS_S_TRZ, MS_S_MAXG2,
+ MS_S_ETS) = range(16)
 MS_NSCAL = 16
 
 
@@ -109,6 +111,7 @@ SIGNATURES = {
     "ms_get_tilt_gradient": (ctypes.c_int, [_P, _D]),
     "ms_project_tilts_to_tangent": (ctypes.c_int, [_P]),
     "ms_set_tilt_fixed": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint8)]),
+    "ms_set_tilt_smoothness": (ctypes.c_int, [_P, ctypes.c_double]),
     "ms_tilt_energy_and_gradient": (ctypes.c_int, [_P, _D, _D]),
     "ms_relax_tilts": (ctypes.c_int, [_P, ctypes.POINTER(ms_tilt_relax_params),
                                       ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),

@@ -45,6 +45,7 @@ struct ms_ctx {
   double* d_tilts_trial = nullptr;  // tilts projected onto a trial surface (line search)
   double* d_tilt_grad = nullptr;  // (nvp,3) dE/dt of the last gradient evaluation
   double* d_bt_vert = nullptr;    // (nvp,4) bending_tilt per-vertex record of the last energy pass
+  double k_smooth = 0.0;          // gp["tilt_smoothness_rigidity"]
   bool bt_valid = false;          // d_bt_vert describes the current x
   // tilt relaxation work space (positions frozen): unit vertex normals, CG direction, Jacobi M^-1
   double* d_tn = nullptr;
@@ -183,8 +184,8 @@ struct ProfScope {
 
 constexpr uint32_t MASK_ENERGY = (1u << MS_S_ESURF) | (1u << MS_S_VOL) | (1u << MS_S_EBEND) |
                                  (1u << MS_S_MINEDGE2) | (1u << MS_S_GUARD) | (1u << MS_S_ETILT) |
-                                 (1u << MS_S_EBT);
-constexpr uint32_t MS_TILT_MODS = MS_MOD_TILT | MS_MOD_BENDING_TILT;  // modules reading the tilt field
+                                 (1u << MS_S_EBT) | (1u << MS_S_ETS);
+constexpr uint32_t MS_TILT_MODS = MS_MOD_TILT | MS_MOD_BENDING_TILT | MS_MOD_TILT_SMOOTH;  // modules reading the tilt field
 
 // mode 0 energy / 1 energy+gradients read `src`; mode 2 projects `src` onto the tangent
 // planes of x (+ alpha d) and writes `dst`.
@@ -230,6 +231,27 @@ int bt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* tilts
   {
     ProfScope ps(c, 5);
     HIPCHK(c, launch_bt(a, mode, c->cap, c->til.max_ent, c->stream));
+  }
+  return MS_OK;
+}
+// tilt smoothness pass (mode 0 energy / 1 + tilt gradient / 2 Jacobi diagonal into `diag`)
+int ts_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* tilts, double* diag = nullptr) {
+  if (!c->d_tilts) return fail(c, MS_ERR_STATE, "tilt_smoothness module active but ms_set_tilts was never called");
+  TsArgs a;
+  a.m = device_mesh(c);
+  a.tile0 = c->tile0;
+  a.tile1 = c->tile1;
+  a.x = c->buf[MS_BUF_X];
+  a.d = use_dir ? c->buf[MS_BUF_D] : nullptr;
+  a.alpha = alpha;
+  a.tilts = tilts;
+  a.k_smooth = c->k_smooth;
+  a.tilt_grad = c->d_tilt_grad;
+  a.diag = diag;
+  a.partials = c->d_partials;
+  {
+    ProfScope ps(c, 7);
+    HIPCHK(c, launch_ts(a, mode, c->cap, c->til.max_ent, c->stream));
   }
   return MS_OK;
 }
@@ -285,6 +307,8 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
     if (modules & MS_MOD_TILT) rc = tilt_pass(c, 0, use_dir, alpha, tilts);
     if (rc) return rc;
     if (bt) rc = bt_pass(c, write_factors ? 1 : 0, use_dir, alpha, tilts);
+    if (rc) return rc;
+    if (modules & MS_MOD_TILT_SMOOTH) rc = ts_pass(c, 0, use_dir, alpha, tilts);
     if (rc) return rc;
   }
   if (reduce_now) {
@@ -384,6 +408,7 @@ void energies_from_mailbox(const ms_ctx* c, double e[4]) {
   if (c->params.modules & MS_MOD_BENDING_TILT) e[1] += c->h_scal[MS_S_EBT];
   e[2] = penalty_energy(c, c->h_scal[MS_S_VOL]);
   e[3] = (c->params.modules & MS_MOD_TILT) ? c->h_scal[MS_S_ETILT] : 0.0;
+  if (c->params.modules & MS_MOD_TILT_SMOOTH) e[3] += c->h_scal[MS_S_ETS];
 }
 
 // gradient assembly at x: energy pass (+factors), gradient pass, finalize via
@@ -763,6 +788,13 @@ int ms_project_tilts_to_tangent(ms_ctx* c) {
   return fetch(c);
 }
 
+int ms_set_tilt_smoothness(ms_ctx* c, double k_smooth) {
+  if (!c) return MS_ERR_INVALID;
+  c->k_smooth = k_smooth;
+  c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
+  return MS_OK;
+}
+
 int ms_set_tilt_fixed(ms_ctx* c, const uint8_t* tilt_fixed) {
   if (!c) return fail(c, MS_ERR_INVALID, "ms_set_tilt_fixed: NULL context");
   const Tiling& t = c->til;
@@ -795,12 +827,18 @@ int tilt_eval(ms_ctx* c, const double* tilts, bool gradient) {
     if (rc) return rc;
     mask |= 1u << MS_S_EBT;
   }
+  if (mods & MS_MOD_TILT_SMOOTH) {
+    rc = ts_pass(c, gradient ? 1 : 0, false, 0.0, tilts);
+    if (rc) return rc;
+    mask |= 1u << MS_S_ETS;
+  }
   return mask ? reduce_slots(c, mask) : MS_OK;
 }
 double tilt_energy_from_mailbox(const ms_ctx* c) {
   double e = 0.0;
   if (c->params.modules & MS_MOD_TILT) e += c->h_scal[MS_S_ETILT];
   if (c->params.modules & MS_MOD_BENDING_TILT) e += c->h_scal[MS_S_EBT];
+  if (c->params.modules & MS_MOD_TILT_SMOOTH) e += c->h_scal[MS_S_ETS];
   return e;
 }
 int ensure_bt_record(ms_ctx* c) {
@@ -874,6 +912,12 @@ int ms_relax_tilts(ms_ctx* c, const ms_tilt_relax_params* rp, int* iters_out, in
                           c->stream));
     return MS_OK;
   };
+  if (rp->solver == 1 && rp->jacobi && c->k_smooth != 0.0) {  // (the parameter alone decides, :42-43)
+    rc = ts_pass(c, 2, false, 0.0, c->d_tilts, c->d_minv);  // + 1/2 k_s sum (c_a + c_b)
+    if (rc) return rc;
+  }
+  rc = tvec(3, nullptr, c->d_minv, 0.0, 0);  // diagonal -> clamped inverse
+  if (rc) return rc;
   // tilts <- P(tilts) on every row (:303-305), fixed rows keep that value from now on
   rc = tvec(2, c->d_tilts, c->d_tilts_trial, 0.0, 0);
   if (rc) return rc;
@@ -1150,6 +1194,9 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       out->next_step = std::min(alpha * sp->gamma, alpha_max);
       return MS_OK;
     }
+    // a rejected trial restores the positions, not the tilts: energy_fn stored their projection
+    // onto the trial surface (line_search.py:456-487 without an enforcer)
+    if (tilt) std::swap(c->d_tilts, c->d_tilts_trial);
     alpha *= sp->beta;
     if (alpha < 1e-8) break;
   }

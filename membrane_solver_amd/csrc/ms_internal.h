@@ -143,6 +143,19 @@ struct BtArgs {
   double* partials;
 };
 
+struct TsArgs {
+  DeviceMesh m;
+  int tile0, tile1;
+  const double* x;
+  const double* d;         // direction or nullptr (cotans at x + alpha d)
+  double alpha;
+  const double* tilts;     // (nvp,3)
+  double k_smooth;
+  double* tilt_grad;       // mode 1: dE/dt ADDED here
+  double* diag;            // mode 2: Jacobi diagonal 1/2 k_s sum (c_a + c_b) ADDED here
+  double* partials;
+};
+
 // kernel launchers (ms_kernels.hip).  cap = T + max halo (LDS patch slots),
 // max_ent = largest per-tile vertex->corner entry count.
 size_t energy_lds_bytes(int T, int cap, int max_ent, bool bend, bool guard, bool flags);
@@ -156,6 +169,9 @@ hipError_t launch_tilt(const TiltArgs& a, int mode, int cap, int max_ent, hipStr
 // 2: energy + tilt gradient
 size_t bt_lds_bytes(int T, int cap, int max_ent);
 hipError_t launch_bt(const BtArgs& a, int mode, int cap, int max_ent, hipStream_t s);
+// tilt smoothness (Dirichlet) pass.  mode 0: energy (MS_S_ETS); 1: energy + tilt gradient; 2: Jacobi diagonal
+size_t ts_lds_bytes(int T, int cap, int max_ent);
+hipError_t launch_ts(const TsArgs& a, int mode, int cap, int max_ent, hipStream_t s);
 hipError_t launch_tvec(int mode, int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* tg,
                        const double* minv, double* dir, const double* tilts, const double* src,
                        const double* normals, double* out, double coef, int flag, double* partials,

@@ -1186,18 +1186,15 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
       a.tilts_out[o + 1] = tv.y - dt * nrm.y;
       a.tilts_out[o + 2] = tv.z - dt * nrm.z;
     } else if (MODE == 3) {
-      // relaxation geometry: unit vertex normals (triangle_ops.py:55-73) and the Jacobi
-      // preconditioner 1/(k_t A_v) of runtime/preconditioners.py:15-59 (1 where <= 1e-12,
-      // on tilt-fixed rows, or when switched off)
+      // relaxation geometry: unit vertex normals (triangle_ops.py:55-73) and the tilt-rigidity
+      // part k_t A_v of the Jacobi diagonal (runtime/preconditioners.py:27-40)
       V3 nrm = mk(ax, ay, az);
       const double len = norm(nrm);
       if (len >= 1.0e-12) nrm = mk(nrm.x / len, nrm.y / len, nrm.z / len);
       a.tilts_out[o] = nrm.x;
       a.tilts_out[o + 1] = nrm.y;
       a.tilts_out[o + 2] = nrm.z;
-      double diag = a.k_tilt * aw;
-      if (!(diag > 1.0e-12) || (a.m.vflags[t.v_lo + tid] & VF_TILT_FIXED)) diag = 1.0;
-      a.minv[t.v_lo + tid] = 1.0 / diag;
+      a.minv[t.v_lo + tid] = a.k_tilt * aw;  // raw diagonal; k_tvec mode 3 clamps and inverts
     }
   }
   if (MODE != 2 && MODE != 3) {
@@ -1455,12 +1452,184 @@ hipError_t launch_bt(const BtArgs& a, int mode, int cap, int max_ent, hipStream_
 }
 
 // ---------------------------------------------------------------------------
+// k_tsmooth: cotangent Dirichlet energy of the tilt field (modules/energy/tilt_smoothness.py:84-198,
+// ambient_v1 transport):  E = k_s/4 sum_f [c0|t1-t2|^2 + c1|t2-t0|^2 + c2|t0-t1|^2] with the
+// cotans of compute_curvature_data (tilt_kernels.f90:140-151).  No shape gradient (:21-23).
+//   MODE 1: tilt gradient k_s/2 [c1 (t0-t2) + c2 (t0-t1)] (cyclic), ADDED to tilt_grad
+//   MODE 2: Jacobi diagonal k_s/2 (c_a + c_b) per corner (runtime/preconditioners.py:42-57), ADDED
+// LDS: px[3][cap] | tl[3][cap] | stg[9][T] (red aliases it) | vent
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(512) void k_tsmooth(TsArgs a, int cap, int max_ent) {
+  extern __shared__ double lds[];
+  const int T = a.m.T;
+  double* px = lds;
+  double* tl = px + 3 * cap;
+  double* stg = tl + 3 * cap;
+  double* red = stg;
+  uint16_t* vent = reinterpret_cast<uint16_t*>(stg + 9 * T);
+
+  const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
+  const int tid = threadIdx.x;
+  const bool have_d = a.d != nullptr;
+  int cur = 0, end = 0;
+  {
+    const bool own = tid < t.n_owned;
+    CsrStage cs;
+    if (MODE != 0) csr_issue(cs, a.m, t, T, tid);
+    struct Row {
+      double x0, x1, x2, t0, t1, t2;
+    };
+    auto load_row = [&](int v) {
+      Row r;
+      const size_t g = 3 * (size_t)v;
+      r.x0 = a.x[g];
+      r.x1 = a.x[g + 1];
+      r.x2 = a.x[g + 2];
+      if (have_d) {
+        const double d0 = a.d[g], d1 = a.d[g + 1], d2 = a.d[g + 2];
+        if (!(a.m.vflags[v] & VF_FIXED)) {
+          r.x0 = r.x0 + a.alpha * d0;
+          r.x1 = r.x1 + a.alpha * d1;
+          r.x2 = r.x2 + a.alpha * d2;
+        }
+      }
+      r.t0 = a.tilts[g];
+      r.t1 = a.tilts[g + 1];
+      r.t2 = a.tilts[g + 2];
+      return r;
+    };
+    auto put_row = [&](const Row& r, int sl) {
+      px[sl] = r.x0;
+      px[cap + sl] = r.x1;
+      px[2 * cap + sl] = r.x2;
+      tl[sl] = r.t0;
+      tl[cap + sl] = r.t1;
+      tl[2 * cap + sl] = r.t2;
+    };
+    const bool has_h = tid < t.nh;
+    int hv = 0;
+    if (has_h) hv = a.m.halo_ids[t.h0 + tid];
+    Row ro{}, rh{};
+    if (own) ro = load_row(t.v_lo + tid);
+    if (has_h) rh = load_row(hv);
+    if (own) put_row(ro, tid);
+    if (has_h) put_row(rh, t.n_owned + tid);
+    for (int h = tid + T; h < t.nh; h += T) put_row(load_row(a.m.halo_ids[t.h0 + h]), t.n_owned + h);
+    if (MODE != 0) {
+      csr_commit(cs, a.m, t, T, tid, vent);
+      if (own) {
+        cur = cs.vo0;
+        end = cs.vo1;
+      }
+    }
+  }
+  __syncthreads();
+
+  double e_ts = 0.0;
+  double ax = 0, ay = 0, az = 0;
+  const double hk = 0.5 * a.k_smooth;
+  for (int c0f = t.f0; c0f < t.f1; c0f += T) {
+    const int p = c0f + tid;
+    if (p < t.f1) {
+      const TileFacet tf = a.m.tile_facets[p];
+      const V3 v0 = lds_v3(px, cap, tf.l0), v1 = lds_v3(px, cap, tf.l1), v2 = lds_v3(px, cap, tf.l2);
+      const V3 e0 = v2 - v1, e1 = v0 - v2, e2 = v1 - v0;
+      const V3 n = cross(e2, -e1);
+      const double A2 = norm(n);
+      const double ad = A2 < 1.0e-12 ? 1.0e-12 : A2;
+      const double inv_ad = 1.0 / ad;
+      const double c0 = dot(-e1, e2) * inv_ad, c1 = dot(-e2, e0) * inv_ad, c2 = dot(-e0, e1) * inv_ad;
+      double* s = stg + tid;
+      if (MODE == 2) {
+        s[0 * T] = hk * (c1 + c2);
+        s[1 * T] = hk * (c2 + c0);
+        s[2 * T] = hk * (c0 + c1);
+      } else {
+        const V3 t0 = lds_v3(tl, cap, tf.l0), t1 = lds_v3(tl, cap, tf.l1), t2 = lds_v3(tl, cap, tf.l2);
+        const V3 d12 = t1 - t2, d20 = t2 - t0, d01 = t0 - t1;
+        if (tf.flags & TF_OWNER)
+          e_ts += 0.25 * a.k_smooth * ((c0 * dot(d12, d12) + c1 * dot(d20, d20)) + c2 * dot(d01, d01));
+        if (MODE == 1) {
+          // g0 = k/2 (c1 (t0-t2) + c2 (t0-t1)), g1 = k/2 (c2 (t1-t0) + c0 (t1-t2)), g2 = k/2 (c0 (t2-t1) + c1 (t2-t0))
+          const V3 g0 = hk * (c2 * d01 - c1 * d20);
+          const V3 g1 = hk * (c0 * d12 - c2 * d01);
+          const V3 g2 = hk * (c1 * d20 - c0 * d12);
+          s[0 * T] = g0.x; s[1 * T] = g0.y; s[2 * T] = g0.z;
+          s[3 * T] = g1.x; s[4 * T] = g1.y; s[5 * T] = g1.z;
+          s[6 * T] = g2.x; s[7 * T] = g2.y; s[8 * T] = g2.z;
+        }
+      }
+    }
+    if (MODE != 0) {
+      __syncthreads();
+      const int lo = c0f - t.f0, hi = min(c0f + T, t.f1) - t.f0;
+      while (cur < end) {
+        const int ent = vent[cur];
+        const int fl = ent >> 2;
+        if (fl >= hi) break;
+        const int k = ent & 3;
+        const double* s = stg + (fl - lo);
+        if (MODE == 2) {
+          ax += s[k * T];
+        } else {
+          ax += s[(3 * k) * T];
+          ay += s[(3 * k + 1) * T];
+          az += s[(3 * k + 2) * T];
+        }
+        ++cur;
+      }
+      __syncthreads();
+    }
+  }
+  if (MODE != 0 && tid < t.n_owned) {
+    const int v = t.v_lo + tid;
+    if (MODE == 1) {
+      const size_t o = 3 * (size_t)v;
+      a.tilt_grad[o] += ax;
+      a.tilt_grad[o + 1] += ay;
+      a.tilt_grad[o + 2] += az;
+    } else {
+      a.diag[v] += ax;
+    }
+  }
+  if (MODE != 2) {
+    if (MODE != 0) __syncthreads();  // red aliases the staging block
+    const double vals[1] = {e_ts};
+    const int ops[1] = {0};
+    const int slots[1] = {MS_S_ETS};
+    block_reduce_store<1>(vals, ops, slots, red, a.partials + t.tile, (size_t)a.m.n_tiles);
+  }
+}
+
+size_t ts_lds_bytes(int T, int cap, int max_ent) {
+  return (6 * (size_t)cap + 9 * (size_t)T) * sizeof(double) + 2 * ((size_t)((max_ent + 3) & ~3)) + 64;
+}
+
+hipError_t launch_ts(const TsArgs& a, int mode, int cap, int max_ent, hipStream_t s) {
+  const int nb = a.tile1 - a.tile0;
+  if (nb <= 0) return hipSuccess;
+  const size_t lds = ts_lds_bytes(a.m.T, cap, max_ent);
+  hipError_t e;
+#define MS_LAUNCH_S(M)                                                                      \
+  do {                                                                                      \
+    e = ensure_lds(k_tsmooth<M>, lds);                                                      \
+    if (e != hipSuccess) return e;                                                          \
+    hipLaunchKernelGGL((k_tsmooth<M>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);     \
+  } while (0)
+  if (mode == 0) MS_LAUNCH_S(0); else if (mode == 1) MS_LAUNCH_S(1); else MS_LAUNCH_S(2);
+#undef MS_LAUNCH_S
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // Tilt relaxation vector ops (runtime/steppers/tilt_relaxation.py:237-424), one workgroup per
 // tile so the partials line up with k_reduce.
 //   mode 0 PREP : tg[tilt-fixed] = 0 ; partials |tg|^2 (free rows) and <r, M^-1 r>, r = -tg
 //   mode 1 DIR  : dir = z (first) or z + beta dir, z = -tg * Minv            (:360-368,:410-421)
 //   mode 2 TRIAL: out = P(t + step*src) with P = tangent projection on the frozen normals;
 //                 tilt-fixed rows keep t unless keep_fixed == 0 (the initial projection)
+//   mode 3 MINV : out[v] (the accumulated Jacobi diagonal) -> its clamped inverse
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_tvec(int mode, int tile0, int nv, int T, const uint8_t* vflags,
                                                 double* tg, const double* minv, double* dir,
@@ -1475,7 +1644,13 @@ __global__ __launch_bounds__(BLOCK) void k_tvec(int mode, int tile0, int nv, int
     if (v >= nv) break;
     const size_t o = 3 * (size_t)v;
     const bool tfix = vflags[v] & VF_TILT_FIXED;
-    if (mode == 0) {
+    if (mode == 3) {
+      // Jacobi preconditioner from the accumulated diagonal: 1 where <= 1e-12 and on tilt-fixed
+      // rows (runtime/preconditioners.py:57-59)
+      double dg = out[v];
+      if (!(dg > 1.0e-12) || tfix) dg = 1.0;
+      out[v] = 1.0 / dg;
+    } else if (mode == 0) {
       V3 g = mk(tg[o], tg[o + 1], tg[o + 2]);
       if (tfix) {
         g = mk(0, 0, 0);

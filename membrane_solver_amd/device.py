@@ -163,6 +163,9 @@ class DeviceMesh:
             ptr = arr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
         self._chk(L.lib().ms_set_tilt_fixed(self._h, ptr), "ms_set_tilt_fixed")
 
+    def set_tilt_smoothness(self, k_smooth: float):
+        self._chk(L.lib().ms_set_tilt_smoothness(self._h, float(k_smooth)), "ms_set_tilt_smoothness")
+
     def tilt_energy_and_gradient(self, want_gradient: bool = True):
         """-> (energy of the tilt-reading modules, dE/dt (nv,3) or None) at the stored tilts."""
         e = ctypes.c_double(0.0)

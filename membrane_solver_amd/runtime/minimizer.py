@@ -43,8 +43,10 @@ from .steppers.base import write_back_positions
 logger = logging.getLogger("membrane_solver")
 
 _ENERGY_BITS = {"surface": L.MS_MOD_SURFACE, "bending": L.MS_MOD_BENDING, "volume": L.MS_MOD_VOLUME_PENALTY,
-                "tilt": L.MS_MOD_TILT, "bending_tilt": L.MS_MOD_BENDING_TILT}
-_ENERGY_SLOT = {"surface": 0, "bending": 1, "volume": 2, "tilt": 3, "bending_tilt": 1}
+                "tilt": L.MS_MOD_TILT, "bending_tilt": L.MS_MOD_BENDING_TILT,
+                "tilt_smoothness": L.MS_MOD_TILT_SMOOTH}
+_ENERGY_SLOT = {"surface": 0, "bending": 1, "volume": 2, "tilt": 3, "bending_tilt": 1, "tilt_smoothness": 3}
+_TILT_BITS = L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT | L.MS_MOD_TILT_SMOOTH
 
 
 class GradientRows:
@@ -131,7 +133,7 @@ class Minimizer:
             if name not in _ENERGY_BITS:
                 raise L.MembraneHipError(
                     f"energy module {name!r} is outside the HIP hot path (surface, bending, volume, tilt, "
-                    "bending_tilt)")
+                    "bending_tilt, tilt_smoothness)")
         self.constraint_modules = [self.constraint_manager.get_constraint(c)
                                    for c in self.constraint_module_names]
         for name in self.constraint_module_names:
@@ -176,6 +178,9 @@ class Minimizer:
             elif name == "tilt":
                 if float(gp.get("tilt_rigidity", 0.0) or 0.0) != 0.0:  # tilt.py:110-112
                     mods |= L.MS_MOD_TILT
+            elif name == "tilt_smoothness":
+                if float(gp.get("tilt_smoothness_rigidity", 0.0) or 0.0) != 0.0:  # tilt_smoothness.py:258-260
+                    mods |= L.MS_MOD_TILT_SMOOTH
             else:
                 mods |= _ENERGY_BITS[name]
         target = 0.0
@@ -218,12 +223,15 @@ class Minimizer:
             mir.upload_surface_tension()
         if any_bend:
             mir.upload_bending_params(gp, model)
-        if mods & (L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT):
+        if mods & (_TILT_BITS):
             if gp.get("line_search_reduced_energy", False):
                 raise L.MembraneHipError("line_search_reduced_energy (inner tilt relaxation inside every "
                                          "line-search trial, minimizer.py:568-608) is outside the HIP hot path")
+            if str(gp.get("tilt_transport_model", "ambient_v1") or "ambient_v1").strip().lower() != "ambient_v1":
+                raise L.MembraneHipError("tilt_transport_model other than ambient_v1 is outside the HIP hot path")
             mir.upload_tilts(gp)
             mir.upload_tilt_fixed()
+            dm.set_tilt_smoothness(float(gp.get("tilt_smoothness_rigidity", 0.0) or 0.0))
         key = (mods, model, mode, stiffness, target, id(dm))
         if key != self._configured_key:
             dm.set_params(modules=mods,
@@ -266,6 +274,10 @@ class Minimizer:
         out = {}
         for name in self.energy_module_names:
             out[name] = float(e[_ENERGY_SLOT[name]])
+        if "tilt" in out and "tilt_smoothness" in out:  # the two share slot 3: split via the scalars
+            sc = dm.fetch_scalars()
+            out["tilt"] = float(sc[L.MS_S_ETILT]) if dm.modules & L.MS_MOD_TILT else 0.0
+            out["tilt_smoothness"] = float(sc[L.MS_S_ETS]) if dm.modules & L.MS_MOD_TILT_SMOOTH else 0.0
         return out
 
     # -- constraint enforcement (minimizer.py:1103-1188) ---------------------------
@@ -310,8 +322,6 @@ class Minimizer:
         max_iters = int(gp.get("tilt_cg_max_iters", n_inner) or 0) if solver == "cg" else n_inner
         if max_iters <= 0:
             return None
-        if float(gp.get("tilt_smoothness_rigidity", 0.0) or 0.0) != 0.0:
-            raise L.MembraneHipError("tilt_smoothness is outside the HIP hot path")
         pre = str(gp.get("tilt_cg_preconditioner", "jacobi") or "jacobi").strip().lower()
         return {"solver": solver, "max_iters": max_iters, "step_size": step, "tol": max(tol, 0.0),
                 "jacobi": pre == "jacobi"}
@@ -356,7 +366,7 @@ class Minimizer:
         mp.target_volume = float(target) if target is not None else 0.0
         mp.volume_tolerance = float(gp.get("volume_tolerance", 1e-3))
         mp.project_on_drift = 1 if self._has_enforceable_constraints else 0
-        rp = self._tilt_relax_params() if dm.modules & (L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT) else None
+        rp = self._tilt_relax_params() if dm.modules & (_TILT_BITS) else None
         mp.relax_tilts = 0 if rp is None else 1
         if rp is not None:
             mp.relax = L.ms_tilt_relax_params(1 if rp["solver"] == "cg" else 0, rp["max_iters"], rp["step_size"],
@@ -409,7 +419,7 @@ class Minimizer:
             if moved or self._device_ahead:
                 if sync_mesh:
                     write_back_positions(self.mesh, dm, mir)
-                    if dm.modules & (L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT):
+                    if dm.modules & (_TILT_BITS):
                         self.mesh.set_tilts_from_array(dm.get_tilts())
                         mir.mark_device_tilts_current()
                     self._device_ahead = False
@@ -433,7 +443,7 @@ class Minimizer:
             if dirty_box[0] or self._device_ahead:
                 if sync_mesh:
                     write_back_positions(self.mesh, dm, mir)
-                    if dm.modules & (L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT):  # tilts changed on the device
+                    if dm.modules & (_TILT_BITS):  # tilts changed on the device
                         self.mesh.set_tilts_from_array(dm.get_tilts())
                         mir.mark_device_tilts_current()
                     self._device_ahead = False
@@ -449,7 +459,7 @@ class Minimizer:
                     dirty_box[0] = False
                 callback(self.mesh, i)
                 mir, dm = self._device()
-            if dm.modules & (L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT):
+            if dm.modules & (_TILT_BITS):
                 if self._relax_tilts(dm):  # minimizer.py:1237-1307, before the convergence check
                     dirty_box[0] = True
             step_mode = str(gp.get("step_size_mode", "adaptive") or "adaptive").lower()

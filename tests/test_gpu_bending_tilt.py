@@ -194,3 +194,107 @@ def test_bending_tilt_midsize_matches_oracle():
     e2 = dm.energy()
     assert abs(e2[1] - e[1]) <= 1e-9 * abs(e[1]) and abs(e2[3] - e[3]) <= 1e-11 * abs(e[3])
     dm.close()
+
+
+# ---- tilt_smoothness ------------------------------------------------------------------------
+@pytest.mark.parametrize("tile", [64, 256])
+@pytest.mark.parametrize("name", ["ico5", "disk5"])
+def test_tilt_smoothness_kernel_cases(name, tile):
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd.device import DeviceMesh
+
+    g = load_golden("tilt_smoothness_cases.npz")
+    pos, tri, isb, tl = g[name + "_positions"], g[name + "_tri"], g[name + "_is_boundary"], g[name + "_tilts"]
+    dm = DeviceMesh(pos, tri, boundary=isb, tile_vertices=tile)
+    dm.set_tilts(tl, 2.0)
+    dm.set_tilt_smoothness(0.7)
+    dm.set_params(modules=L.MS_MOD_TILT_SMOOTH)
+    E, tg = dm.tilt_energy_and_gradient()
+    assert abs(E - g[name + "_E"]) <= 1e-12 * abs(g[name + "_E"])
+    assert relerr(tg, g[name + "_tilt_grad"]) < 1e-10
+    assert abs(dm.energy()[3] - g[name + "_E"]) <= 1e-12 * abs(g[name + "_E"])
+    e, grad = dm.energy_and_gradient()
+    assert not np.any(grad)  # no shape gradient (tilt_smoothness.py:21-23)
+    dm.close()
+
+
+def test_relax_with_smoothness_matches_oracle():
+    """Jacobi diagonal with both terms (k_t A_v + k_s/2 sum(c_a + c_b)) and the three tilt modules."""
+    from membrane_solver_amd import _lib as L
+    from oracle import minimizer_port as mp
+
+    g = load_golden("tilt_smoothness_cases.npz")
+    pos, tri, isb, tl = g["disk5_positions"], g["disk5_tri"], g["disk5_is_boundary"], g["disk5_tilts"]
+    nv = pos.shape[0]
+    tfix = np.zeros(nv, bool)
+    tfix[::11] = True
+    gp = {"bending_modulus": 1.3, "spontaneous_curvature": 0.2, "tilt_rigidity": 2.0, "tilt_smoothness_rigidity": 0.7,
+          "tilt_solve_mode": "nested", "tilt_solver": "cg", "tilt_step_size": 0.15, "tilt_inner_steps": 8}
+    p = mp.Problem(positions=pos, tri=tri, is_boundary=isb, tilts=tl, tilt_fixed=tfix,
+                   energy_modules=["tilt", "tilt_smoothness", "bending_tilt"], gp=gp)
+    st = mp.relax_tilts(p, p.positions)
+    dm = _dm(pos, tri, isb, tl, "analytic", 64, tilt_module=True)
+    dm.set_tilt_smoothness(0.7)
+    dm.set_params(modules=L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT | L.MS_MOD_TILT_SMOOTH)
+    dm.set_tilt_fixed(tfix)
+    iters, evals = dm.relax_tilts(solver="cg", max_iters=8, step_size=0.15, jacobi=True)
+    assert (iters, evals) == (st["iters"], st["evals"])
+    assert relerr(dm.get_tilts(), p.tilts) < 1e-10
+    dm.close()
+
+
+TS_BASE = dict(BT_BASE, tilt_smoothness_rigidity=0.6)
+TS_TRAJ = {
+    "traj_ico4_gd_ts_nested_cg.npz": ("gd", ["surface", "tilt", "tilt_smoothness", "bending_tilt"],
+                                      dict(TS_BASE, tilt_solve_mode="nested", tilt_solver="cg",
+                                           tilt_step_size=0.1, tilt_inner_steps=6)),
+    "traj_ico4_cg_ts_fixed.npz": ("cg", ["surface", "tilt", "tilt_smoothness"],
+                                  dict(TS_BASE, tilt_solve_mode="fixed")),
+    # rejected trials: a rejected trial keeps the tilts projected onto its surface (line search's
+    # mesh-mutating path, the one the tilt goldens pin)
+    "traj_ico4_cg_ts_backtrack.npz": ("cg", ["surface", "tilt", "tilt_smoothness", "bending_tilt"],
+                                      dict(TS_BASE, tilt_solve_mode="fixed")),
+    "traj_ico4_gd_ts_backtrack.npz": ("gd", ["surface", "tilt", "tilt_smoothness", "bending_tilt"],
+                                      dict(TS_BASE, tilt_solve_mode="fixed")),
+}
+
+
+@pytest.mark.parametrize("fname", sorted(TS_TRAJ))
+def test_minimizer_reproduces_tilt_smoothness_trajectory(fname):
+    from membrane_solver_amd.geometry.mesh import ArrayMesh
+    from membrane_solver_amd.runtime.constraint_manager import ConstraintModuleManager
+    from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
+    from membrane_solver_amd.runtime.minimizer import Minimizer
+    from membrane_solver_amd.runtime.steppers import ConjugateGradient, GradientDescent
+
+    kind, mods, gp = TS_TRAJ[fname]
+    g = load_golden(fname)
+    mesh = ArrayMesh(g["positions0"], g["tri"], fixed=g["fixed"], surface_tension=g["gamma"], tilts=g["tilts0"],
+                     tilt_fixed=g["tilt_fixed"], global_parameters=dict(gp), energy_modules=list(mods),
+                     constraint_modules=[])
+    stepper = GradientDescent() if kind == "gd" else ConjugateGradient()
+    log = []
+    orig = stepper.device_step
+
+    def logged(dm, m, step_size, tol=0.0):
+        r = orig(dm, m, step_size, tol=tol)
+        log.append((float(r.success), r.next_step, r.energy))
+        return r
+
+    stepper.device_step = logged
+    mz = Minimizer(mesh, mesh.global_parameters, stepper, EnergyModuleManager(mods), ConstraintModuleManager([]),
+                   quiet=True, step_size=float(g["step_size0"]))
+    E0, grad0 = mz.compute_energy_and_gradient_array()
+    assert abs(E0 - g["E0"]) <= 1e-12 * abs(g["E0"])
+    assert relerr(grad0, g["grad0"]) < 1e-10
+    res = mz.minimize(int(g["n_steps"]))
+    got, ref = np.array(log), g["step_log"]
+    assert got.shape == ref.shape
+    assert np.array_equal(got[:, 0], ref[:, 0]), "accept/reject sequence differs from the reference"
+    assert np.allclose(got[:, 1], ref[:, 1], rtol=1e-12, atol=0)
+    assert np.allclose(got[:, 2], ref[:, 2], rtol=1e-9, atol=0)
+    assert relerr(mesh.positions_view(), g["positions_final"]) < 1e-8
+    assert relerr(mesh.tilts_view(), g["tilts_final"]) < 1e-8
+    assert abs(res["energy"] - g["E_final"]) <= 1e-9 * abs(g["E_final"])
+    bd = mz.compute_energy_breakdown()
+    assert abs(sum(bd.values()) - g["E_final"]) <= 1e-9 * abs(g["E_final"])
