@@ -129,6 +129,28 @@ class ArrayMesh:
     def increment_version(self):
         self._version += 1
 
+    def replace_topology(self, positions, tri_rows, *, fixed=None, tilts=None) -> None:
+        """Stand-in for the reference's refinement / equiangulation (runtime/refinement.py:287,
+        runtime/equiangulation.py:81): new vertex and facet sets, version counters bumped the way
+        ``Mesh.increment_topology_version`` does, so the device mirror re-tiles on its next use."""
+        self._positions = np.array(positions, dtype=np.float64, order="C", copy=True)
+        self._tri_rows = np.ascontiguousarray(tri_rows, dtype=np.int32)
+        nv = self._positions.shape[0]
+        self.vertex_ids = np.arange(nv, dtype=np.int64)
+        self._index_map = None
+        self._fixed = np.zeros(nv, dtype=bool) if fixed is None else np.asarray(fixed, dtype=bool).copy()
+        self._facet_params = {}
+        self._vertex_params = {}
+        self._boundary_mask = None
+        self._tilts = (np.zeros_like(self._positions) if tilts is None
+                       else np.array(tilts, dtype=np.float64, order="C", copy=True))
+        self.tilt_fixed = np.zeros(nv, dtype=bool)
+        self._tilts_version += 1
+        self._version += 1
+        self._facet_loops_version += 1
+        self._vertex_ids_version += 1
+        self._topology_version += 1
+
     # vertex tilt field (geometry/mesh.py:391-430, :516-530 of the reference)
     def tilts_view(self) -> np.ndarray:
         return self._tilts

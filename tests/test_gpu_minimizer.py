@@ -387,3 +387,40 @@ def test_library_loop_equals_python_loop(fname):
     a, b = outs
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[6], b[6])
     assert a[1:6] == b[1:6]
+
+
+def test_topology_change_rebuilds_the_device_mirror():
+    """SURVEY 8(f)-3, the refinement re-upload hook: after the mesh's topology counters change the
+    next call re-tiles and re-uploads; the run continues exactly like a fresh Minimizer on the new mesh."""
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.geometry.mesh import ArrayMesh
+    from membrane_solver_amd.runtime.constraint_manager import ConstraintModuleManager
+    from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
+    from membrane_solver_amd.runtime.minimizer import Minimizer
+    from membrane_solver_amd.runtime.steppers import ConjugateGradient
+
+    gp = {"surface_tension": 1.0, "bending_modulus": 0.8, "spontaneous_curvature": 0.1,
+          "volume_constraint_mode": "lagrange", "volume_projection_during_minimization": False}
+    mods = ["surface", "bending"]
+    P4, T4 = meshgen.icosphere(4)
+    P4 = meshgen.smooth_displace(P4, 0.06)
+    P9, T9 = meshgen.icosphere(9)
+    P9 = meshgen.smooth_displace(P9, 0.06)
+
+    def make(P, T):
+        mesh = ArrayMesh(P, T, global_parameters=dict(gp), energy_modules=mods, constraint_modules=[])
+        return mesh, Minimizer(mesh, mesh.global_parameters, ConjugateGradient(), EnergyModuleManager(mods),
+                               ConstraintModuleManager([]), quiet=True, step_size=1e-3)
+
+    mesh, mz = make(P4, T4)
+    mz.minimize(4)
+    first_dm = mesh._hip_mirror.dm
+    mesh.replace_topology(P9, T9)       # "refine"
+    mz.stepper.reset()
+    mz.step_size = 1e-3
+    res = mz.minimize(5)
+    assert mesh._hip_mirror.dm is not first_dm and mesh._hip_mirror.dm.nv == P9.shape[0]
+    mesh_b, mz_b = make(P9, T9)
+    res_b = mz_b.minimize(5)
+    assert np.array_equal(mesh.positions_view(), mesh_b.positions_view())
+    assert res["energy"] == res_b["energy"] and mz.step_size == mz_b.step_size
