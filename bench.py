@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--reuse-level", type=int, default=2, choices=(0, 1, 2),
                     help="ms_stepper_params.reuse_energy0: 0 repeats every pass the reference repeats, "
                          "2 (library default) never repeats a pass whose result is already on the device")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="fixed-order per-vertex sums (ms_set_deterministic): bitwise reproducible run to "
+                         "run, slower than the default LDS-atomic accumulation")
     return ap.parse_args()
 
 
@@ -136,7 +139,7 @@ def main():
     stepper.reuse_energy0 = args.reuse_level
     mz = Minimizer(mesh, mesh.global_parameters, stepper, EnergyModuleManager(mods),
                    ConstraintModuleManager(cons), quiet=True, step_size=args.step_size,
-                   device=local_rank, tile_vertices=args.tile)
+                   device=local_rank, tile_vertices=args.tile, deterministic=bool(args.deterministic))
     E_start = mz.compute_energy()
 
     # the whole loop runs inside the library (ms_minimize); it reports what the steps did
@@ -161,10 +164,13 @@ def main():
                                "bending (analytic cotan gradient), CG stepper, Armijo line search, "
                                f"evaluation reuse level {stepper.reuse_energy0} (0 = every pass the "
                                "reference re-runs, 2 = passes already on the device are not repeated; "
-                               "bitwise identical trajectories)"
+                               "same trajectories), per-vertex sums "
+                               + ("in fixed order (bitwise reproducible)" if args.deterministic
+                                  else "by LDS atomics (default; --deterministic for fixed-order sums)")
                                + (", volume Lagrange row" if args.volume else ""),
                    "stepper": "conjugate_gradient", "tile_vertices": args.tile or 256,
-                   "initial_step_size": args.step_size, "parallelism": "1 GPU"},
+                   "initial_step_size": args.step_size, "parallelism": "1 GPU",
+                   "deterministic": bool(args.deterministic)},
         "steps_accepted": timed["accepted"], "line_search_trials": timed["trials"],
         "energy_start": E_start, "energy_end": res["energy"],
     }
@@ -184,9 +190,23 @@ def main():
                                                 "ms_per_step": 1e3 * dt0 / args.steps, "reuse_level": 0}
         stepper.reuse_energy0 = args.reuse_level
 
-    # -- roofline of the dominant kernel: HIP events inside the library --------
+    # -- the same K steps with fixed-order (bitwise reproducible) vertex sums -------------------
     mir = mesh._hip_mirror
     dm = mir.dm
+    if not args.deterministic:
+        mz.deterministic = True
+        mz.minimize(5, sync_mesh=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mz.minimize(args.steps, sync_mesh=False)
+        torch.cuda.synchronize()
+        dtd = time.perf_counter() - t0
+        out["deterministic_mode"] = {"value": args.steps / dtd, "unit": "steps/s",
+                                     "ms_per_step": 1e3 * dtd / args.steps}
+        mz.deterministic = False
+        mz.minimize(2, sync_mesh=False)
+
+    # -- roofline of the dominant kernel: HIP events inside the library --------
     if not args.no_roofline:
         n_prof = min(args.steps, 40)
         dm.profile_enable(True)

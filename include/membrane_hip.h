@@ -172,6 +172,12 @@ int ms_set_surface_tension(ms_ctx *ctx, const double *gamma /* nf */);
 int ms_set_bending_params(ms_ctx *ctx, const double *kappa /* nv */,
                           const double *c0 /* nv */);
 int ms_set_params(ms_ctx *ctx, const ms_params *p);
+/* Per-vertex accumulation in the two big tile kernels (energy pass, gradient pass):
+ * 0 (default) LDS atomic adds -- fastest, the floating-point summation order (hence the
+ * last bits) may differ between runs; 1 staged CSR gather in a fixed order -- bitwise
+ * reproducible run to run, ~20 % slower.  Environment MS_DETERMINISTIC=1 makes 1 the
+ * default for new contexts. */
+int ms_set_deterministic(ms_ctx *ctx, int on);
 /* Mesh.tilts_view() (geometry/mesh.py:391-430) + gp["tilt_rigidity"]; tilts (nv,3) row-major */
 int ms_set_tilts(ms_ctx *ctx, const double *tilts /* nv*3 */, double tilt_rigidity);
 int ms_get_tilts(ms_ctx *ctx, double *tilts /* nv*3 */);

@@ -112,6 +112,7 @@ SIGNATURES = {
     "ms_project_tilts_to_tangent": (ctypes.c_int, [_P]),
     "ms_set_tilt_fixed": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint8)]),
     "ms_set_tilt_smoothness": (ctypes.c_int, [_P, ctypes.c_double]),
+    "ms_set_deterministic": (ctypes.c_int, [_P, ctypes.c_int]),
     "ms_tilt_energy_and_gradient": (ctypes.c_int, [_P, _D, _D]),
     "ms_relax_tilts": (ctypes.c_int, [_P, ctypes.POINTER(ms_tilt_relax_params),
                                       ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),

@@ -101,6 +101,7 @@ struct ms_ctx {
   bool carry_valid = false;
   // true while buffer G holds the finalized gradient of the current x (set by ms_step's fused
   // gradient pass, survives a failed line search, cleared together with carry_valid)
+  bool deterministic = false;  // ms_set_deterministic: staged CSR gather instead of LDS atomics
   bool grad_valid = false;
   bool maxg2_valid = false;  // the mailbox holds |g|^2 and max|g_i|^2 of the gradient in buffer G
   // optional per-kernel timing (ms_profile_*)
@@ -285,6 +286,7 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   a.fK = (bend && write_factors) ? c->buf[MS_BUF_FK] : nullptr;
   a.fA = (bend && write_factors) ? c->buf[MS_BUF_FA] : nullptr;
   a.bt_vert = bt ? c->d_bt_vert : nullptr;
+  a.atomic = c->deterministic ? 0 : 1;
   if (bt && !c->d_bt_vert) return fail(c, MS_ERR_STATE, "bending_tilt: ms_set_params did not allocate its buffers");
   a.partials = c->d_partials;
   a.bending_model = c->params.bending_model;
@@ -348,6 +350,7 @@ int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulat
   a.d = c->buf[MS_BUF_D];
   a.pg = c->buf[MS_BUF_PG];
   a.pd = c->buf[MS_BUF_PD];
+  a.atomic = c->deterministic ? 0 : 1;
   {
     ProfScope ps(c, 1);
     HIPCHK(c, launch_gradient(a, c->cap, c->til.max_ent, c->stream));
@@ -644,6 +647,7 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
     CREATE_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_scal_all), sizeof(double) * MS_NSCAL * (size_t)W));
     CREATE_HIP(hipMemset(c->d_scal_all, 0, sizeof(double) * MS_NSCAL * (size_t)W));
   }
+  c->deterministic = getenv("MS_DETERMINISTIC") != nullptr && atoi(getenv("MS_DETERMINISTIC")) != 0;
   c->params.modules = MS_MOD_SURFACE;
   c->params.bending_model = MS_BEND_HELFRICH;
   c->params.bending_grad_mode = MS_GRAD_ANALYTIC;
@@ -786,6 +790,15 @@ int ms_project_tilts_to_tangent(ms_ctx* c) {
   int rc = tilt_pass(c, 2, false, 0.0);
   if (rc) return rc;
   return fetch(c);
+}
+
+int ms_set_deterministic(ms_ctx* c, int on) {
+  if (!c) return MS_ERR_INVALID;
+  if (c->deterministic == (on != 0)) return MS_OK;
+  c->deterministic = on != 0;
+  c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
+  c->factors_valid = false;
+  return MS_OK;
 }
 
 int ms_set_tilt_smoothness(ms_ctx* c, double k_smooth) {

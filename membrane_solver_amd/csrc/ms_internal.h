@@ -91,6 +91,7 @@ struct EnergyArgs {
   // bending_tilt: per-vertex record {base = 2H - c0 (0 on boundary), A_eff, kappa*ratio*H, 0}
   // written instead of the final factors; fK then holds K_dir * kappa * ratio (k_bt finishes)
   double* bt_vert;
+  int atomic;             // accumulate per-vertex sums with LDS atomics (not bitwise reproducible)
 };
 
 struct GradientArgs {
@@ -112,6 +113,7 @@ struct GradientArgs {
   double* d;
   const double* pg;
   const double* pd;
+  int atomic;
 };
 
 struct TiltArgs {

@@ -242,7 +242,7 @@ __device__ __forceinline__ void csr_commit(const CsrStage& r, const DeviceMesh& 
 // ---------------------------------------------------------------------------
 // TT / CAPC: compile-time tile size and LDS patch capacity (0 = take the runtime values);
 // with constants every LDS address becomes base + immediate offset.
-template <bool BEND, bool GUARD, int TT, int CAPC>
+template <bool BEND, bool GUARD, int TT, int CAPC, bool ATOMIC>
 __global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_rt, int max_ent) {
   extern __shared__ double lds[];
   const int T = TT ? TT : a.m.T;  // == blockDim.x
@@ -254,8 +254,9 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_
   // barrier); the vertex offsets stay in registers; the flag bytes are staged only when
   // some vertex carries VF_BOUNDARY
   double* red = stg;
-  uint16_t* vent = reinterpret_cast<uint16_t*>(stg + (BEND ? 9 * T : 5 * 16));
-  uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + (BEND ? ((max_ent + 3) & ~3) : 0));
+  // ATOMIC: stg holds the five per-vertex accumulators K(3), A_vor, A_eff (ds_add_f64), no CSR
+  uint16_t* vent = reinterpret_cast<uint16_t*>(stg + (BEND ? (ATOMIC ? 5 : 9) * T : 5 * 16));
+  uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + ((BEND && !ATOMIC) ? ((max_ent + 3) & ~3) : 0));
   const bool stage_flags = a.m.has_boundary || GUARD;
 
   const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
@@ -304,7 +305,10 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_
       }
     }
     CsrStage cs;
-    if (BEND) csr_issue(cs, a.m, t, T, tid);
+    if (BEND && !ATOMIC) csr_issue(cs, a.m, t, T, tid);
+    if (BEND && ATOMIC) {
+      for (int j = tid; j < 5 * T; j += T) stg[j] = 0.0;
+    }
     own_fl = fl;
     // second round trip: the halo row this thread covers
     double h0 = 0, h1 = 0, h2 = 0, e0 = 0, e1 = 0, e2 = 0;
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_
         a.xt[g + 2] = x2;
       }
     }
-    if (BEND) {
+    if (BEND && !ATOMIC) {
       csr_commit(cs, a.m, t, T, tid, vent);
       cur = cs.vo0;
       end = cs.vo1;
@@ -462,14 +466,30 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_
           const V3 K0 = 0.5 * (c1 * (-e1) + c2 * e2);
           const V3 K1 = 0.5 * (c2 * (-e2) + c0 * e0);
           const V3 K2 = 0.5 * (c0 * (-e0) + c1 * e1);
-          double* s = stg + tid;
-          s[0 * T] = K0.x; s[1 * T] = K0.y; s[2 * T] = K0.z;
-          s[3 * T] = K1.x; s[4 * T] = K1.y; s[5 * T] = K1.z;
-          s[6 * T] = K2.x; s[7 * T] = K2.y; s[8 * T] = K2.z;
+          if (ATOMIC) {
+            const int no = t.n_owned;
+            if (tf.l0 < no) {
+              atomicAdd(&stg[tf.l0], K0.x); atomicAdd(&stg[T + tf.l0], K0.y); atomicAdd(&stg[2 * T + tf.l0], K0.z);
+              atomicAdd(&stg[3 * T + tf.l0], va0); atomicAdd(&stg[4 * T + tf.l0], ve0);
+            }
+            if (tf.l1 < no) {
+              atomicAdd(&stg[tf.l1], K1.x); atomicAdd(&stg[T + tf.l1], K1.y); atomicAdd(&stg[2 * T + tf.l1], K1.z);
+              atomicAdd(&stg[3 * T + tf.l1], va1); atomicAdd(&stg[4 * T + tf.l1], ve1);
+            }
+            if (tf.l2 < no) {
+              atomicAdd(&stg[tf.l2], K2.x); atomicAdd(&stg[T + tf.l2], K2.y); atomicAdd(&stg[2 * T + tf.l2], K2.z);
+              atomicAdd(&stg[3 * T + tf.l2], va2); atomicAdd(&stg[4 * T + tf.l2], ve2);
+            }
+          } else {
+            double* s = stg + tid;
+            s[0 * T] = K0.x; s[1 * T] = K0.y; s[2 * T] = K0.z;
+            s[3 * T] = K1.x; s[4 * T] = K1.y; s[5 * T] = K1.z;
+            s[6 * T] = K2.x; s[7 * T] = K2.y; s[8 * T] = K2.z;
+          }
         }
       }
     }
-    if (BEND) {
+    if (BEND && !ATOMIC) {
       // sub-phase A: curvature vectors; sub-phase B: corner areas (same 9*T buffer)
       const int lo = c0 - t.f0, hi = min(c0 + T, t.f1) - t.f0;
       __syncthreads();
@@ -501,6 +521,17 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_
     }
   }
 
+  if (BEND && ATOMIC) {
+    __syncthreads();
+    if (tid < t.n_owned) {
+      aKx = stg[tid];
+      aKy = stg[T + tid];
+      aKz = stg[2 * T + tid];
+      aAv = stg[3 * T + tid];
+      aAe = stg[4 * T + tid];
+    }
+    __syncthreads();  // red aliases stg
+  }
   double e_bend = 0.0;
   if (BEND && tid < t.n_owned) {
     // modules/energy/bending.py:111-161 on this thread's owned vertex
@@ -547,8 +578,16 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_
         // bending.py:154-158 falls back to the vertex normal (bending_utils.py:13-34)
         // where K vanishes (flat patches): sum the incident facet normals now.
         V3 N = mk(0, 0, 0);
-        for (int q = ent_begin; q < end; ++q) {
-          const TileFacet f = a.m.tile_facets[t.f0 + (vent[q] >> 2)];
+        int qb = ent_begin, qe = end;
+        const uint16_t* ve = vent;
+        if (ATOMIC) {  // (rare path) the CSR was not staged: read it where it lives
+          const uint16_t* gv = a.m.tile_voff + (size_t)t.tile * (T + 1);
+          qb = gv[tid];
+          qe = gv[tid + 1];
+          ve = a.m.vent + t.e0;
+        }
+        for (int q = qb; q < qe; ++q) {
+          const TileFacet f = a.m.tile_facets[t.f0 + (ve[q] >> 2)];
           const V3 q0 = lds_v3(px, cap, f.l0), q1 = lds_v3(px, cap, f.l1), q2 = lds_v3(px, cap, f.l2);
           N = N + cross(q1 - q0, q2 - q0);
         }
@@ -609,11 +648,22 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
   const bool fast = a.m.T == FAST_T;
   const size_t lds = energy_lds_bytes(a.m.T, cap, max_ent, bend, guard, a.m.has_boundary != 0);
   hipError_t e;
+  if (a.atomic && bend && !guard && fast) {
+    // per-vertex sums by LDS ds_add_f64 instead of the staged CSR gather: one barrier per tile
+    // instead of twelve and half the LDS traffic, at the price of a summation order that varies
+    // from run to run (ms_set_deterministic)
+    const size_t lds_a = (3 * (size_t)cap + 5 * (size_t)a.m.T) * sizeof(double) +
+                         (a.m.has_boundary ? (((size_t)cap + 15) / 16) * 16 : 0);
+    e = ensure_lds(k_energy<true, false, FAST_T, FAST_CAP, true>, lds_a);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_energy<true, false, FAST_T, FAST_CAP, true>), dim3(nb), dim3(a.m.T), lds_a, s, a, cap, max_ent);
+    return hipGetLastError();
+  }
 #define MS_LAUNCH_E(B, G, TT, CC)                                                                     \
   do {                                                                                                \
-    e = ensure_lds(k_energy<B, G, TT, CC>, lds);                                                      \
+    e = ensure_lds(k_energy<B, G, TT, CC, false>, lds);                                               \
     if (e != hipSuccess) return e;                                                                    \
-    hipLaunchKernelGGL((k_energy<B, G, TT, CC>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);     \
+    hipLaunchKernelGGL((k_energy<B, G, TT, CC, false>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent); \
   } while (0)
 #define MS_PICK_E(B, G)                                   \
   do {                                                    \
@@ -646,7 +696,7 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
 // LDS: px[3][cap] | (BEND) fk[3][cap] fae[cap] fav[cap] | stg[9 or 18][T] | red[4*16]
 //      | vent[max_ent] (u16) | fl[cap] (u8)
 // ---------------------------------------------------------------------------
-template <int BENDMODE, bool VOLROW, int TT, int CAPC>
+template <int BENDMODE, bool VOLROW, int TT, int CAPC, bool ATOMIC>
 __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
   extern __shared__ double lds[];
   constexpr bool BEND = BENDMODE != 0;
@@ -657,9 +707,10 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
   double* fae = fk + (BEND ? 3 * cap : 0);
   double* fav = fae + (BEND ? cap : 0);
   double* stg = fav + (BEND ? cap : 0);
-  double* red = stg + (VOLROW ? 18 : 9) * T;
+  // ATOMIC (only without the volume row): stg holds the three per-vertex gradient accumulators
+  double* red = stg + (ATOMIC ? 3 : (VOLROW ? 18 : 9)) * T;
   uint16_t* vent = reinterpret_cast<uint16_t*>(red + 4 * 16);
-  uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + ((max_ent + 3) & ~3));
+  uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + (ATOMIC ? 0 : ((max_ent + 3) & ~3)));
 
   const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
   const int tid = threadIdx.x;
@@ -696,7 +747,10 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
       }
     }
     CsrStage cs;
-    csr_issue(cs, a.m, t, T, tid);
+    if (!ATOMIC) csr_issue(cs, a.m, t, T, tid);
+    if (ATOMIC) {
+      for (int j = tid; j < 3 * T; j += T) stg[j] = 0.0;
+    }
     double hx0 = 0, hx1 = 0, hx2 = 0, hk0 = 0, hk1 = 0, hk2 = 0, hae = 0, hav = 0;
     uint8_t hfl = 0;
     if (has_h) {
@@ -726,9 +780,11 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
         fav[tid] = av;
       }
     }
-    csr_commit(cs, a.m, t, T, tid, vent);
-    cur = cs.vo0;
-    end = cs.vo1;
+    if (!ATOMIC) {
+      csr_commit(cs, a.m, t, T, tid, vent);
+      cur = cs.vo0;
+      end = cs.vo1;
+    }
     if (has_h) {
       const int s = t.n_owned + tid;
       lfl[s] = hfl;
@@ -901,11 +957,19 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
           }
         }
       }
-      double* s = stg + tid;
-      s[0 * T] = G0.x; s[1 * T] = G0.y; s[2 * T] = G0.z;
-      s[3 * T] = G1.x; s[4 * T] = G1.y; s[5 * T] = G1.z;
-      s[6 * T] = G2.x; s[7 * T] = G2.y; s[8 * T] = G2.z;
+      if (ATOMIC) {
+        const int no = t.n_owned;
+        if (tf.l0 < no) { atomicAdd(&stg[tf.l0], G0.x); atomicAdd(&stg[T + tf.l0], G0.y); atomicAdd(&stg[2 * T + tf.l0], G0.z); }
+        if (tf.l1 < no) { atomicAdd(&stg[tf.l1], G1.x); atomicAdd(&stg[T + tf.l1], G1.y); atomicAdd(&stg[2 * T + tf.l1], G1.z); }
+        if (tf.l2 < no) { atomicAdd(&stg[tf.l2], G2.x); atomicAdd(&stg[T + tf.l2], G2.y); atomicAdd(&stg[2 * T + tf.l2], G2.z); }
+      } else {
+        double* s = stg + tid;
+        s[0 * T] = G0.x; s[1 * T] = G0.y; s[2 * T] = G0.z;
+        s[3 * T] = G1.x; s[4 * T] = G1.y; s[5 * T] = G1.z;
+        s[6 * T] = G2.x; s[7 * T] = G2.y; s[8 * T] = G2.z;
+      }
     }
+    if (ATOMIC) continue;
     __syncthreads();
     {
       const int lo = c0f - t.f0, hi = min(c0f + T, t.f1) - t.f0;
@@ -929,6 +993,14 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
     __syncthreads();
   }
 
+  if (ATOMIC) {
+    __syncthreads();
+    if (tid < t.n_owned) {
+      gx = stg[tid];
+      gy = stg[T + tid];
+      gz = stg[2 * T + tid];
+    }
+  }
   double ggc = 0.0, gcgc = 0.0, gn2 = 0.0, gdd = 0.0, md2 = 0.0, mg2 = 0.0;
   if (tid < t.n_owned) {
     const size_t o = 3 * (size_t)(t.v_lo + tid);
@@ -1014,11 +1086,18 @@ hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStrea
   const bool fast = a.m.T == FAST_T;
   const size_t lds = gradient_lds_bytes(a.m.T, cap, max_ent, bend, volrow);
   hipError_t e;
+  if (a.atomic && bend && !volrow && fast && a.bending_grad_mode != MS_GRAD_APPROX) {
+    const size_t lds_a = (8 * (size_t)cap + 3 * (size_t)a.m.T + 4 * 16) * sizeof(double) + (((size_t)cap + 15) / 16) * 16;
+    e = ensure_lds(k_gradient<1, false, FAST_T, FAST_CAP, true>, lds_a);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_gradient<1, false, FAST_T, FAST_CAP, true>), dim3(nb), dim3(a.m.T), lds_a, s, a, cap, max_ent);
+    return hipGetLastError();
+  }
 #define MS_LAUNCH_G(M, V, TT, CC)                                                                       \
   do {                                                                                                  \
-    e = ensure_lds(k_gradient<M, V, TT, CC>, lds);                                                      \
+    e = ensure_lds(k_gradient<M, V, TT, CC, false>, lds);                                               \
     if (e != hipSuccess) return e;                                                                      \
-    hipLaunchKernelGGL((k_gradient<M, V, TT, CC>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);     \
+    hipLaunchKernelGGL((k_gradient<M, V, TT, CC, false>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent); \
   } while (0)
 #define MS_PICK_G(M, V)                                   \
   do {                                                    \

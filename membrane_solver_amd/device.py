@@ -163,6 +163,10 @@ class DeviceMesh:
             ptr = arr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
         self._chk(L.lib().ms_set_tilt_fixed(self._h, ptr), "ms_set_tilt_fixed")
 
+    def set_deterministic(self, on: bool = True):
+        """Fixed-order (bitwise reproducible) per-vertex sums instead of LDS atomics (~20 % slower)."""
+        self._chk(L.lib().ms_set_deterministic(self._h, int(bool(on))), "ms_set_deterministic")
+
     def set_tilt_smoothness(self, k_smooth: float):
         self._chk(L.lib().ms_set_tilt_smoothness(self._h, float(k_smooth)), "ms_set_tilt_smoothness")
 

@@ -436,6 +436,8 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     P = meshgen.smooth_displace(P, 0.05)
     nv, nf = P.shape[0], T.shape[0]
     be = HipShardBackend(P, T, rank=rank, world=world, device=local_rank, tile_vertices=args.tile)
+    if getattr(args, "deterministic", False):
+        be.dm.set_deterministic(True)
     be.configure(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING, gamma=np.ones(nf), kappa=np.ones(nv),
                  c0=np.zeros(nv))
     driver = "library (ms_shard_step, direct ncclAllGather)"
@@ -491,7 +493,8 @@ def bench_main(args, rank: int, world: int, local_rank: int):
                        "parallelism": f"tiles (facet blocks) sharded over {world} GPUs; per exchange one RCCL "
                                       f"all-gather of [16 scalars | <= {be.boundary['max_rows']} boundary rows] "
                                       f"per rank ({drv.exchanges - ex0} exchanges in the timed steps); driver: {driver}",
-                       "tile_vertices": args.tile or 256, "initial_step_size": args.step_size},
+                       "tile_vertices": args.tile or 256, "initial_step_size": args.step_size,
+                       "deterministic": bool(getattr(args, "deterministic", False))},
             "steps_accepted": acc, "line_search_trials": trials,
             "energy_end": float(getattr(r, "energy", getattr(r, "energy_eval", float("nan")))),
         }))

@@ -104,7 +104,8 @@ class Minimizer:
     def __init__(self, mesh, global_params, stepper, energy_manager, constraint_manager,
                  energy_modules: Optional[List[str]] = None,
                  constraint_modules: Optional[List[str]] = None, step_size: float = 1e-3,
-                 tol: float = 1e-6, quiet: bool = False, *, device: int = 0, tile_vertices: int = 0):
+                 tol: float = 1e-6, quiet: bool = False, *, device: int = 0, tile_vertices: int = 0,
+                 deterministic: Optional[bool] = None):
         self.mesh = mesh
         self.global_params = global_params
         self.energy_manager = energy_manager
@@ -115,6 +116,9 @@ class Minimizer:
         self.quiet = quiet
         self.device = device
         self.tile_vertices = tile_vertices
+        # None: library default (LDS-atomic vertex sums unless MS_DETERMINISTIC=1); True: fixed-order
+        # sums, bitwise reproducible run to run (ms_set_deterministic)
+        self.deterministic = deterministic
         self.max_zero_steps = int(global_params.get("max_zero_steps", 10))
         self.step_size_floor = float(global_params.get("step_size_floor", 1e-8))
         self.param_resolver = ParameterResolver(global_params)
@@ -169,6 +173,8 @@ class Minimizer:
         gp = self.global_params
         mir = mirror_for(self.mesh, device=self.device, tile_vertices=self.tile_vertices)
         dm = mir.sync()
+        if self.deterministic is not None:
+            dm.set_deterministic(self.deterministic)
         mods = 0
         vol_mode = gp.get("volume_constraint_mode", "lagrange")
         for name in self.energy_module_names:

@@ -29,3 +29,10 @@ def relerr(a, b):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture
+def deterministic(monkeypatch):
+    """Contexts created inside the test use the fixed-order vertex sums (ms_set_deterministic):
+    what the bitwise-equality tests need.  Everything else runs the default LDS-atomic mode."""
+    monkeypatch.setenv("MS_DETERMINISTIC", "1")

@@ -170,7 +170,7 @@ def test_oversized_valence_and_bad_arguments_are_errors_not_crashes(L):
     dm.close()
 
 
-def test_set_positions_and_reevaluate_is_consistent(L):
+def test_set_positions_and_reevaluate_is_consistent(L, deterministic):
     from membrane_solver_amd import meshgen
     from membrane_solver_amd.device import DeviceMesh
 
@@ -186,4 +186,50 @@ def test_set_positions_and_reevaluate_is_consistent(L):
     e3, g3 = dm.energy_and_gradient()
     assert e2.sum() != e1.sum()
     assert np.array_equal(e1, e3) and np.array_equal(g1, g3)  # bitwise reproducible
+    dm.close()
+
+
+@pytest.mark.parametrize("shape", ["sphere", "disk"])
+def test_atomic_and_fixed_order_vertex_sums_agree(L, shape):
+    """The default LDS-atomic accumulation and the fixed-order gather (ms_set_deterministic) are
+    the same sums in a different order: energies/gradients agree to rounding (1e-12 relative here),
+    the mode can be switched on a live context, and the fixed-order mode repeats bitwise."""
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+
+    if shape == "sphere":
+        P, T = meshgen.icosphere(24)
+        P = meshgen.smooth_displace(P, 0.05)
+    else:
+        P, T, _ = meshgen.disk_patch(40)
+        P = P + 0.02 * np.sin(3.0 * P[:, [1, 2, 0]] + 0.3)
+    nv, nf = len(P), len(T)
+    rng = np.random.default_rng(5)
+    dm = DeviceMesh(P, T)
+    dm.set_surface_tension(rng.uniform(0.5, 1.5, nf))
+    dm.set_bending_params(rng.uniform(0.5, 1.5, nv), rng.uniform(-0.2, 0.2, nv))
+    for model in (L.MS_BEND_HELFRICH, L.MS_BEND_WILLMORE):
+        dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING, bending_model=model)
+        dm.set_deterministic(False)
+        ea, ga = dm.energy_and_gradient()
+        dm.set_deterministic(True)
+        ed, gd = dm.energy_and_gradient()
+        ed2, gd2 = dm.energy_and_gradient()
+        assert np.array_equal(ed, ed2) and np.array_equal(gd, gd2)
+        assert relerr(ea, ed) < 1e-12 and relerr(ga, gd) < 1e-12
+        # a short CG run in either mode lands on the same trajectory to rounding
+        out = []
+        for det in (False, True):
+            dm.set_positions(P)
+            dm.reset_stepper()
+            dm.set_deterministic(det)
+            step, log = 1e-3, []
+            for _ in range(5):
+                r = dm.step(stepper=L.MS_STEPPER_CG, step_size=step, tol=1e-12)
+                log.append((r.success, r.energy, r.grad_norm))
+                step = r.next_step
+            out.append(np.array(log, dtype=np.float64))
+        assert np.array_equal(out[0][:, 0], out[1][:, 0])
+        assert np.allclose(out[0][:, 1], out[1][:, 1], rtol=1e-11)
+        assert np.allclose(out[0][:, 2], out[1][:, 2], rtol=1e-8)
     dm.close()

@@ -281,7 +281,7 @@ def test_full_size_properties(freq, kind):
 
 
 @pytest.mark.parametrize("fname", sorted(CASES))
-def test_evaluation_reuse_levels_are_bitwise_identical(fname):
+def test_evaluation_reuse_levels_are_bitwise_identical(fname, deterministic):
     """ms_stepper_params.reuse_energy0 = 0 (re-evaluate everything the reference re-evaluates),
     1 (reuse energy0) and 2 (an accepted trial is the next step's energy/factor pass) must give
     the SAME doubles: the skipped passes are the same kernel on the same inputs."""
@@ -320,7 +320,7 @@ def test_evaluation_reuse_levels_are_bitwise_identical(fname):
         assert np.array_equal(pos, runs[0][1])
 
 
-def test_reuse_levels_bitwise_identical_multitile_with_rejections():
+def test_reuse_levels_bitwise_identical_multitile_with_rejections(deterministic):
     """Same, straight on DeviceMesh.step for a multi-tile noisy sphere with an over-long first
     step (forces backtracking / failed searches, i.e. the carried state must be invalidated)."""
     from membrane_solver_amd import _lib as L
@@ -355,7 +355,7 @@ def test_reuse_levels_bitwise_identical_multitile_with_rejections():
 
 @pytest.mark.parametrize("fname", ["traj_ico8_cg_surface_bending_volume.npz", "traj_cube_gd.npz",
                                    "traj_ico4_gd_surface_tilt.npz"])
-def test_library_loop_equals_python_loop(fname):
+def test_library_loop_equals_python_loop(fname, deterministic):
     """Minimizer.minimize runs the loop inside the library (ms_minimize) when nobody watches the
     individual steps; wrapping stepper.device_step (as the parity tests do) selects the Python
     loop.  Both must leave bit-identical state."""
@@ -389,7 +389,7 @@ def test_library_loop_equals_python_loop(fname):
     assert a[1:6] == b[1:6]
 
 
-def test_topology_change_rebuilds_the_device_mirror():
+def test_topology_change_rebuilds_the_device_mirror(deterministic):
     """SURVEY 8(f)-3, the refinement re-upload hook: after the mesh's topology counters change the
     next call re-tiles and re-uploads; the run continues exactly like a fresh Minimizer on the new mesh."""
     from membrane_solver_amd import meshgen

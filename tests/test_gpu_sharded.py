@@ -46,7 +46,7 @@ class ThreadGroup:
     (False, 2, 2, 16, 64), (True, 2, 2, 16, 64), (False, 3, 2, 16, 64), (False, 2, 0, 16, 64), (True, 3, 0, 16, 64),
     (False, 4, 2, 160, 256),  # 512 000 facets, default tile size, 4 shards: sizes near the headline
 ])
-def test_shards_match_single_context(with_volume, world, level, freq, tile, driver):
+def test_shards_match_single_context(with_volume, world, level, freq, tile, driver, monkeypatch):
     """driver "python": parallel.ShardedStepper drives the phase API; "library": the same control
     flow inside the library (ms_shard_step) with the in-process all-gather plugged in where
     ncclAllGather goes."""
@@ -57,6 +57,10 @@ def test_shards_match_single_context(with_volume, world, level, freq, tile, driv
     from membrane_solver_amd.device import DeviceMesh
     from membrane_solver_amd.parallel import HipShardBackend, LibraryShardedStepper, ShardedStepper
 
+    if freq >= 100:
+        # six CG steps on 512k facets amplify last-bit differences beyond the tolerances below;
+        # the big case compares fixed-order sums, the small ones run the default atomic mode
+        monkeypatch.setenv("MS_DETERMINISTIC", "1")
     P, T = meshgen.icosphere(freq)
     P = meshgen.smooth_displace(P, 0.06)
     nv, nf = P.shape[0], T.shape[0]
