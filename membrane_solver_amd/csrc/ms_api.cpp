@@ -1818,10 +1818,10 @@ int ms_tile_stats(ms_ctx* c, int64_t* n_tiles, int64_t* facet_instances, int64_t
   if (n_tiles) *n_tiles = t.n_tiles;
   if (facet_instances) *facet_instances = (int64_t)t.tile_facets.size();
   if (max_halo) *max_halo = t.max_halo;
-  if (lds_bytes_energy) *lds_bytes_energy = (int64_t)energy_lds_bytes(t.T, c->cap, t.max_ent, bend, false, c->has_boundary);
+  if (lds_bytes_energy) *lds_bytes_energy = (int64_t)energy_lds_bytes(t.T, c->cap, t.max_ent, bend, false, c->has_boundary, !c->deterministic);
   if (lds_bytes_gradient)
     *lds_bytes_gradient = (int64_t)gradient_lds_bytes(t.T, c->cap, t.max_ent, bend,
-                                                      (c->params.modules & MS_CON_VOLUME) != 0);
+                                                      (c->params.modules & MS_CON_VOLUME) != 0, !c->deterministic);
   return MS_OK;
 }
 

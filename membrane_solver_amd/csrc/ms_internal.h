@@ -160,8 +160,8 @@ struct TsArgs {
 
 // kernel launchers (ms_kernels.hip).  cap = T + max halo (LDS patch slots),
 // max_ent = largest per-tile vertex->corner entry count.
-size_t energy_lds_bytes(int T, int cap, int max_ent, bool bend, bool guard, bool flags);
-size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow);
+size_t energy_lds_bytes(int T, int cap, int max_ent, bool bend, bool guard, bool flags, bool atomic = false);
+size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow, bool atomic = false);
 hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, hipStream_t s);
 hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStream_t s);
 // mode 0: energy partial (MS_S_ETILT); 1: energy + gradients; 2: project tilts to tangent

@@ -624,9 +624,9 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_
 
 static size_t u16_bytes(int T, int max_ent) { return 2 * ((size_t)((max_ent + 3) & ~3)); }
 
-size_t energy_lds_bytes(int T, int cap, int max_ent, bool bend, bool guard, bool flags) {
-  size_t d = 3 * (size_t)cap + (guard ? 3 * (size_t)cap : 0) + (bend ? 9 * (size_t)T : 5 * 16);
-  return d * sizeof(double) + (bend ? u16_bytes(T, max_ent) : 0) +
+size_t energy_lds_bytes(int T, int cap, int max_ent, bool bend, bool guard, bool flags, bool atomic) {
+  size_t d = 3 * (size_t)cap + (guard ? 3 * (size_t)cap : 0) + (bend ? (atomic ? 5 : 9) * (size_t)T : 5 * 16);
+  return d * sizeof(double) + ((bend && !atomic) ? u16_bytes(T, max_ent) : 0) +
          ((flags || guard) ? (((size_t)cap + 15) / 16) * 16 : 0);
 }
 
@@ -646,34 +646,29 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
   if (nb <= 0) return hipSuccess;
   const bool bend = (a.modules & (MS_MOD_BENDING | MS_MOD_BENDING_TILT)) != 0;
   const bool fast = a.m.T == FAST_T;
-  const size_t lds = energy_lds_bytes(a.m.T, cap, max_ent, bend, guard, a.m.has_boundary != 0);
+  // atomic: per-vertex sums by LDS ds_add_f64 instead of the staged CSR gather -- one barrier per
+  // tile instead of twelve and half the LDS traffic, at the price of a summation order that
+  // varies from run to run (ms_set_deterministic).  Without bending there are no vertex sums.
+  const bool atomic = a.atomic != 0 && bend;
+  const size_t lds = energy_lds_bytes(a.m.T, cap, max_ent, bend, guard, a.m.has_boundary != 0, atomic);
   hipError_t e;
-  if (a.atomic && bend && !guard && fast) {
-    // per-vertex sums by LDS ds_add_f64 instead of the staged CSR gather: one barrier per tile
-    // instead of twelve and half the LDS traffic, at the price of a summation order that varies
-    // from run to run (ms_set_deterministic)
-    const size_t lds_a = (3 * (size_t)cap + 5 * (size_t)a.m.T) * sizeof(double) +
-                         (a.m.has_boundary ? (((size_t)cap + 15) / 16) * 16 : 0);
-    e = ensure_lds(k_energy<true, false, FAST_T, FAST_CAP, true>, lds_a);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_energy<true, false, FAST_T, FAST_CAP, true>), dim3(nb), dim3(a.m.T), lds_a, s, a, cap, max_ent);
-    return hipGetLastError();
-  }
-#define MS_LAUNCH_E(B, G, TT, CC)                                                                     \
-  do {                                                                                                \
-    e = ensure_lds(k_energy<B, G, TT, CC, false>, lds);                                               \
-    if (e != hipSuccess) return e;                                                                    \
-    hipLaunchKernelGGL((k_energy<B, G, TT, CC, false>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent); \
+#define MS_LAUNCH_E(B, G, TT, CC, AT)                                                              \
+  do {                                                                                             \
+    e = ensure_lds(k_energy<B, G, TT, CC, AT>, lds);                                               \
+    if (e != hipSuccess) return e;                                                                 \
+    hipLaunchKernelGGL((k_energy<B, G, TT, CC, AT>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent); \
   } while (0)
-#define MS_PICK_E(B, G)                                   \
+#define MS_PICK_E(B, G, AT)                               \
   do {                                                    \
-    if (fast) MS_LAUNCH_E(B, G, FAST_T, FAST_CAP);        \
-    else MS_LAUNCH_E(B, G, 0, 0);                         \
+    if (fast) MS_LAUNCH_E(B, G, FAST_T, FAST_CAP, AT);    \
+    else MS_LAUNCH_E(B, G, 0, 0, AT);                     \
   } while (0)
-  if (bend) {
-    if (guard) MS_PICK_E(true, true); else MS_PICK_E(true, false);
+  if (bend && atomic) {
+    if (guard) MS_PICK_E(true, true, true); else MS_PICK_E(true, false, true);
+  } else if (bend) {
+    if (guard) MS_PICK_E(true, true, false); else MS_PICK_E(true, false, false);
   } else {
-    if (guard) MS_PICK_E(false, true); else MS_PICK_E(false, false);
+    if (guard) MS_PICK_E(false, true, false); else MS_PICK_E(false, false, false);
   }
 #undef MS_PICK_E
 #undef MS_LAUNCH_E
@@ -707,8 +702,9 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
   double* fae = fk + (BEND ? 3 * cap : 0);
   double* fav = fae + (BEND ? cap : 0);
   double* stg = fav + (BEND ? cap : 0);
-  // ATOMIC (only without the volume row): stg holds the three per-vertex gradient accumulators
-  double* red = stg + (ATOMIC ? 3 : (VOLROW ? 18 : 9)) * T;
+  // ATOMIC: stg holds the per-vertex accumulators (ds_add_f64) instead of per-corner columns
+  constexpr int NACC = VOLROW ? 6 : 3;  // ATOMIC: gradient (and constraint-row) accumulator columns
+  double* red = stg + (ATOMIC ? NACC : (VOLROW ? 18 : 9)) * T;
   uint16_t* vent = reinterpret_cast<uint16_t*>(red + 4 * 16);
   uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + (ATOMIC ? 0 : ((max_ent + 3) & ~3)));
 
@@ -749,7 +745,7 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
     CsrStage cs;
     if (!ATOMIC) csr_issue(cs, a.m, t, T, tid);
     if (ATOMIC) {
-      for (int j = tid; j < 3 * T; j += T) stg[j] = 0.0;
+      for (int j = tid; j < NACC * T; j += T) stg[j] = 0.0;
     }
     double hx0 = 0, hx1 = 0, hx2 = 0, hk0 = 0, hk1 = 0, hk2 = 0, hae = 0, hav = 0;
     uint8_t hfl = 0;
@@ -860,14 +856,21 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
           G1 = G1 + pen_factor * w1;
           G2 = G2 + pen_factor * w2;
         }
-        if (VOLROW) {
+        if (VOLROW && ATOMIC) {
+          const double s6 = 1.0 / 6.0;
+          const int no = t.n_owned;
+          double* c = stg + 3 * T;
+          if (tf.l0 < no) { atomicAdd(&c[tf.l0], s6 * w0.x); atomicAdd(&c[T + tf.l0], s6 * w0.y); atomicAdd(&c[2 * T + tf.l0], s6 * w0.z); }
+          if (tf.l1 < no) { atomicAdd(&c[tf.l1], s6 * w1.x); atomicAdd(&c[T + tf.l1], s6 * w1.y); atomicAdd(&c[2 * T + tf.l1], s6 * w1.z); }
+          if (tf.l2 < no) { atomicAdd(&c[tf.l2], s6 * w2.x); atomicAdd(&c[T + tf.l2], s6 * w2.y); atomicAdd(&c[2 * T + tf.l2], s6 * w2.z); }
+        } else if (VOLROW) {
           const double s6 = 1.0 / 6.0;
           double* s = stg + 9 * T + tid;
           s[0 * T] = s6 * w0.x; s[1 * T] = s6 * w0.y; s[2 * T] = s6 * w0.z;
           s[3 * T] = s6 * w1.x; s[4 * T] = s6 * w1.y; s[5 * T] = s6 * w1.z;
           s[6 * T] = s6 * w2.x; s[7 * T] = s6 * w2.y; s[8 * T] = s6 * w2.z;
         }
-      } else if (VOLROW) {
+      } else if (VOLROW && !ATOMIC) {
         double* s = stg + 9 * T + tid;
 #pragma unroll
         for (int k = 0; k < 9; ++k) s[k * T] = 0.0;
@@ -999,6 +1002,11 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
       gx = stg[tid];
       gy = stg[T + tid];
       gz = stg[2 * T + tid];
+      if (VOLROW) {
+        cx = stg[3 * T + tid];
+        cy = stg[4 * T + tid];
+        cz = stg[5 * T + tid];
+      }
     }
   }
   double ggc = 0.0, gcgc = 0.0, gn2 = 0.0, gdd = 0.0, md2 = 0.0, mg2 = 0.0;
@@ -1073,9 +1081,10 @@ __global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int 
   }
 }
 
-size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow) {
-  size_t d = 3 * (size_t)cap + (bend ? 5 * (size_t)cap : 0) + (volrow ? 18 : 9) * (size_t)T + 4 * 16;
-  return d * sizeof(double) + u16_bytes(T, max_ent) + (((size_t)cap + 15) / 16) * 16;
+size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow, bool atomic) {
+  const size_t cols = atomic ? (volrow ? 6 : 3) : (volrow ? 18 : 9);
+  size_t d = 3 * (size_t)cap + (bend ? 5 * (size_t)cap : 0) + cols * (size_t)T + 4 * 16;
+  return d * sizeof(double) + (atomic ? 0 : u16_bytes(T, max_ent)) + (((size_t)cap + 15) / 16) * 16;
 }
 
 hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStream_t s) {
@@ -1084,25 +1093,21 @@ hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStrea
   const bool bend = (a.modules & MS_MOD_BENDING) != 0;
   const bool volrow = a.gC != nullptr && (a.modules & MS_CON_VOLUME);
   const bool fast = a.m.T == FAST_T;
-  const size_t lds = gradient_lds_bytes(a.m.T, cap, max_ent, bend, volrow);
+  const bool atomic = a.atomic != 0;
+  const size_t lds = gradient_lds_bytes(a.m.T, cap, max_ent, bend, volrow, atomic);
   hipError_t e;
-  if (a.atomic && bend && !volrow && fast && a.bending_grad_mode != MS_GRAD_APPROX) {
-    const size_t lds_a = (8 * (size_t)cap + 3 * (size_t)a.m.T + 4 * 16) * sizeof(double) + (((size_t)cap + 15) / 16) * 16;
-    e = ensure_lds(k_gradient<1, false, FAST_T, FAST_CAP, true>, lds_a);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_gradient<1, false, FAST_T, FAST_CAP, true>), dim3(nb), dim3(a.m.T), lds_a, s, a, cap, max_ent);
-    return hipGetLastError();
-  }
-#define MS_LAUNCH_G(M, V, TT, CC)                                                                       \
-  do {                                                                                                  \
-    e = ensure_lds(k_gradient<M, V, TT, CC, false>, lds);                                               \
-    if (e != hipSuccess) return e;                                                                      \
-    hipLaunchKernelGGL((k_gradient<M, V, TT, CC, false>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent); \
+#define MS_LAUNCH_G(M, V, TT, CC, AT)                                                                \
+  do {                                                                                               \
+    e = ensure_lds(k_gradient<M, V, TT, CC, AT>, lds);                                               \
+    if (e != hipSuccess) return e;                                                                   \
+    hipLaunchKernelGGL((k_gradient<M, V, TT, CC, AT>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent); \
   } while (0)
-#define MS_PICK_G(M, V)                                   \
-  do {                                                    \
-    if (fast) MS_LAUNCH_G(M, V, FAST_T, FAST_CAP);        \
-    else MS_LAUNCH_G(M, V, 0, 0);                         \
+#define MS_PICK_G(M, V)                                           \
+  do {                                                            \
+    if (fast && atomic) MS_LAUNCH_G(M, V, FAST_T, FAST_CAP, true); \
+    else if (fast) MS_LAUNCH_G(M, V, FAST_T, FAST_CAP, false);    \
+    else if (atomic) MS_LAUNCH_G(M, V, 0, 0, true);               \
+    else MS_LAUNCH_G(M, V, 0, 0, false);                          \
   } while (0)
   const int mode = !bend ? 0 : (a.bending_grad_mode == MS_GRAD_APPROX ? 2 : 1);
   if (volrow) {
