@@ -68,7 +68,7 @@ def algorithmic_bytes(nv, nf, volume=False):
     }
 
 
-def pmc_traffic(kernel_prefix):
+def pmc_traffic(kernel_prefix, deterministic=False):
     """HBM bytes per launch of one kernel from the committed rocprofv3 PMC summary
     (profiles/<tag>_pmc_summary.csv; separate FETCH_SIZE / WRITE_SIZE passes of this same
     bench command).  gfx950 correction: FETCH_SIZE counts 1/2 of the fetched bytes
@@ -84,6 +84,9 @@ def pmc_traffic(kernel_prefix):
     with open(files[-1]) as f:
         for row in csv.reader(line for line in f if not line.startswith("#")):
             if len(row) < 4 or kernel_prefix not in row[1] or row[0] not in acc:
+                continue
+            # the last template argument selects the accumulation mode (true = LDS atomics)
+            if row[1].count(",") >= 4 and not row[1].rstrip().endswith(", false>" if deterministic else ", true>"):
                 continue
             n = float(row[2])
             acc[row[0]][0] += n * float(row[3])
@@ -244,9 +247,10 @@ def main():
         dom = max((k for k in ("energy", "gradient") if k in kernels),
                   key=lambda k: kernels[k]["share_of_profiled_ms"])
         ach = kernels[dom]["GBps"]
-        traffic, traffic_src = pmc_traffic({"energy": "ms::k_energy", "gradient": "ms::k_gradient"}[dom])
+        traffic, traffic_src = pmc_traffic({"energy": "ms::k_energy", "gradient": "ms::k_gradient"}[dom],
+                                           deterministic=bool(args.deterministic))
         out["roofline"] = {"bound": "hbm", "kernel": {"energy": "ms::k_energy* (energy pass)",
-                                                     "gradient": "ms::k_gradient<1,false,256,0>"}[dom],
+                                                     "gradient": "ms::k_gradient* (gradient pass)"}[dom],
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                            "avg_launch_us": kernels[dom]["avg_us"],

@@ -12,7 +12,7 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libmembrane_hip.so")
+LIB_PATH = os.environ.get("MEMBRANE_HIP_LIB") or os.path.join(_PKG, "libmembrane_hip.so")  # override: A/B builds
 _CSRC = os.path.join(_PKG, "csrc")
 
 MS_OK = 0

@@ -197,6 +197,12 @@ __device__ __forceinline__ TileCtx tile_ctx(const DeviceMesh& m, int tile) {
 // Per-tile CSR words held in registers between "issue" and "commit": every global load of a
 // tile's stage-in is issued before the first LDS write, so the whole prologue costs two HBM
 // round trips (ids/rows/CSR, then the halo rows the ids name) instead of one per array.
+#ifndef MS_WPE_ENERGY
+#define MS_WPE_ENERGY
+#endif
+#ifndef MS_WPE_GRADIENT
+#define MS_WPE_GRADIENT
+#endif
 constexpr int CSR_REGS = 12;  // entries per thread held in registers (T=256: 3072 entries)
 struct CsrStage {
   uint16_t vo0, vo1;  // this vertex's entry range [vo0, vo1) (offset row of the tile)
@@ -243,7 +249,7 @@ __device__ __forceinline__ void csr_commit(const CsrStage& r, const DeviceMesh& 
 // TT / CAPC: compile-time tile size and LDS patch capacity (0 = take the runtime values);
 // with constants every LDS address becomes base + immediate offset.
 template <bool BEND, bool GUARD, int TT, int CAPC, bool ATOMIC>
-__global__ __launch_bounds__(TT ? TT : 512) void k_energy(EnergyArgs a, int cap_rt, int max_ent) {
+__global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyArgs a, int cap_rt, int max_ent) {
   extern __shared__ double lds[];
   const int T = TT ? TT : a.m.T;  // == blockDim.x
   const int cap = CAPC ? CAPC : cap_rt;
@@ -692,7 +698,7 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
 //      | vent[max_ent] (u16) | fl[cap] (u8)
 // ---------------------------------------------------------------------------
 template <int BENDMODE, bool VOLROW, int TT, int CAPC, bool ATOMIC>
-__global__ __launch_bounds__(TT ? TT : 512) void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
+__global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
   extern __shared__ double lds[];
   constexpr bool BEND = BENDMODE != 0;
   const int T = TT ? TT : a.m.T;
