@@ -54,6 +54,15 @@ extern "C" {
 #define MS_MOD_TILT 32u
 #define MS_MOD_BENDING_TILT 64u /* modules/energy/bending_tilt.py (replaces MS_MOD_BENDING) */
 #define MS_MOD_TILT_SMOOTH 128u /* modules/energy/tilt_smoothness.py (ambient_v1 transport) */
+/* two-leaflet tilt fields (Mesh.tilts_in_view / tilts_out_view): tilt magnitude
+ * (modules/energy/tilt_in.py, tilt_out.py -> tilt_leaflet.py:26-169) and tilt smoothness
+ * (tilt_smoothness_in.py, tilt_smoothness_out.py -> tilt_smoothness_leaflet.py:17-79) */
+#define MS_MOD_TILT_IN 256u
+#define MS_MOD_TILT_OUT 512u
+#define MS_MOD_TILT_SMOOTH_IN 1024u
+#define MS_MOD_TILT_SMOOTH_OUT 2048u
+#define MS_LEAFLET_IN 0
+#define MS_LEAFLET_OUT 1
 
 /* bending_params.py:19-33 */
 #define MS_BEND_HELFRICH 0
@@ -99,7 +108,15 @@ enum ms_scalar {
   MS_S_TRZ = 13,    /* <r, M^-1 r> of the tilt CG (tilt_relaxation.py:369,416) */
   MS_S_MAXG2 = 14,  /* max_i |g_i|^2 over movable rows (= max|d_i|^2 of a steepest-descent restart) */
   MS_S_ETS = 15,    /* tilt smoothness (Dirichlet) energy, modules/energy/tilt_smoothness.py */
-  MS_NSCAL = 16
+  MS_S_ETILT_IN = 16,  /* leaflet energies: tilt_in / tilt_out / tilt_smoothness_in / _out */
+  MS_S_ETILT_OUT = 17,
+  MS_S_ETS_IN = 18,
+  MS_S_ETS_OUT = 19,
+  MS_S_TGNORM2_IN = 20, /* leaflet relaxation: |grad|^2 and <r, M^-1 r> per leaflet; the driver */
+  MS_S_TGNORM2_OUT = 21, /* adds the two (tilt_relaxation.py:862-868, 1139-1141)               */
+  MS_S_TRZ_IN = 22,
+  MS_S_TRZ_OUT = 23,
+  MS_NSCAL = 24
 };
 
 typedef struct ms_params {
@@ -208,6 +225,35 @@ int ms_set_tilt_smoothness(ms_ctx *ctx, double k_smooth);
 int ms_tilt_energy_and_gradient(ms_ctx *ctx, double *energy, double *tilt_grad);
 int ms_relax_tilts(ms_ctx *ctx, const ms_tilt_relax_params *params,
                    int *iters_out, int *evals_out);
+
+/* ---- two-leaflet tilt fields (tilts_in / tilts_out) ----
+ * ms_set_leaflet_tilts: Mesh.tilts_in_view()/tilts_out_view() (nv,3 row-major), the
+ *   vertex.tilt_fixed_in / tilt_fixed_out flags (minimizer.py:460-486; NULL = none) and the
+ *   leaflet's module parameters.  Modules are switched on by the MS_MOD_*_IN/_OUT bits of
+ *   ms_params.modules; both leaflets must be set before the first evaluation.
+ * Energies and the shape gradient (coeff_f dA/dx, tilt_leaflet.py:152-166) join the ordinary
+ *   evaluation; every line-search trial projects both fields onto the trial surface's tangent
+ *   planes like the single field (Mesh.project_tilts_to_tangent, geometry/mesh.py:788-814).
+ * ms_leaflet_tilt_energy_and_gradient: EvaluationManager.compute_energy_and_leaflet_tilt_
+ *   gradients_array with tilt_vertex_areas given (runtime/evaluation_manager.py:630-742): the
+ *   magnitude modules take the lumped vertex-area form 1/2 k sum |t_v|^2 A_v there.
+ * ms_relax_leaflet_tilts: TiltRelaxationManager.relax_leaflet_tilts
+ *   (runtime/steppers/tilt_relaxation.py:426-1478), default options: GD or Jacobi/plain
+ *   Fletcher-Reeves CG over the concatenated (in, out) field, <= 12 halvings, accept on
+ *   E1 <= E0, fixed rows keep their projected start value. */
+typedef struct ms_leaflet_params {
+  double tilt_modulus;        /* "tilt_modulus_in|out" (tilt_params.py:6-12); 0 = no contribution */
+  int tilt_mass_consistent;   /* "tilt_mass_mode_in|out" == consistent (tilt_params.py:15-23)  */
+  double smoothness;          /* tilt_smoothness_in|out rigidity (tilt_smoothness_utils.py:95-100) */
+  double precond_smoothness;  /* rigidity in the Jacobi diagonal (preconditioners.py:111-120)   */
+} ms_leaflet_params;
+int ms_set_leaflet_tilts(ms_ctx *ctx, int leaflet, const double *tilts /* nv*3 */,
+                         const uint8_t *tilt_fixed /* nv or NULL */, const ms_leaflet_params *params);
+int ms_get_leaflet_tilts(ms_ctx *ctx, int leaflet, double *tilts /* nv*3 */);
+int ms_leaflet_tilt_energy_and_gradient(ms_ctx *ctx, double *energy, double *grad_in /* nv*3 or NULL */,
+                                        double *grad_out /* nv*3 or NULL */);
+int ms_relax_leaflet_tilts(ms_ctx *ctx, const ms_tilt_relax_params *params,
+                           int *iters_out, int *evals_out);
 
 /* Mesh.project_tilts_to_tangent (geometry/mesh.py:788-814): t <- t - (t.n) n with the
  * unit vertex normals of the current positions (triangle_ops.py:55-73) */

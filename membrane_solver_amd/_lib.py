@@ -27,6 +27,8 @@ MS_TRACK_VOLUME = 16
 MS_MOD_TILT = 32
 MS_MOD_BENDING_TILT = 64
 MS_MOD_TILT_SMOOTH = 128
+MS_MOD_TILT_IN, MS_MOD_TILT_OUT, MS_MOD_TILT_SMOOTH_IN, MS_MOD_TILT_SMOOTH_OUT = 256, 512, 1024, 2048
+MS_LEAFLET_IN, MS_LEAFLET_OUT = 0, 1
 MS_BEND_HELFRICH, MS_BEND_WILLMORE = 0, 1
 MS_GRAD_ANALYTIC, MS_GRAD_APPROX = 0, 1
 MS_STEPPER_GD, MS_STEPPER_CG = 0, 1
@@ -35,8 +37,9 @@ MS_STEPPER_GD, MS_STEPPER_CG = 0, 1
  MS_BUF_FA, MS_BUF_SCAL) = range(10)
 (MS_S_ESURF, MS_S_VOL, MS_S_EBEND, MS_S_MINEDGE2, MS_S_GUARD, MS_S_GGC, MS_S_GCGC,
  MS_S_GNORM2, MS_S_GDOTD, MS_S_MAXD2, MS_S_ETILT, MS_S_EBT, MS_S_TGNORM2, MS_S_TRZ, MS_S_MAXG2,
- MS_S_ETS) = range(16)
-MS_NSCAL = 16
+ MS_S_ETS, MS_S_ETILT_IN, MS_S_ETILT_OUT, MS_S_ETS_IN, MS_S_ETS_OUT, MS_S_TGNORM2_IN, MS_S_TGNORM2_OUT,
+ MS_S_TRZ_IN, MS_S_TRZ_OUT) = range(24)
+MS_NSCAL = 24
 
 
 class MembraneHipError(RuntimeError):
@@ -59,6 +62,11 @@ class ms_stepper_params(ctypes.Structure):
 class ms_tilt_relax_params(ctypes.Structure):
     _fields_ = [("solver", ctypes.c_int), ("max_iters", ctypes.c_int), ("step_size", ctypes.c_double),
                 ("tol", ctypes.c_double), ("jacobi", ctypes.c_int)]
+
+
+class ms_leaflet_params(ctypes.Structure):
+    _fields_ = [("tilt_modulus", ctypes.c_double), ("tilt_mass_consistent", ctypes.c_int),
+                ("smoothness", ctypes.c_double), ("precond_smoothness", ctypes.c_double)]
 
 
 class ms_minimize_params(ctypes.Structure):
@@ -116,6 +124,12 @@ SIGNATURES = {
     "ms_tilt_energy_and_gradient": (ctypes.c_int, [_P, _D, _D]),
     "ms_relax_tilts": (ctypes.c_int, [_P, ctypes.POINTER(ms_tilt_relax_params),
                                       ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "ms_set_leaflet_tilts": (ctypes.c_int, [_P, ctypes.c_int, _D, ctypes.POINTER(ctypes.c_uint8),
+                                            ctypes.POINTER(ms_leaflet_params)]),
+    "ms_get_leaflet_tilts": (ctypes.c_int, [_P, ctypes.c_int, _D]),
+    "ms_leaflet_tilt_energy_and_gradient": (ctypes.c_int, [_P, _D, _D, _D]),
+    "ms_relax_leaflet_tilts": (ctypes.c_int, [_P, ctypes.POINTER(ms_tilt_relax_params),
+                                              ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "ms_set_positions": (ctypes.c_int, [_P, _D]),
     "ms_get_positions": (ctypes.c_int, [_P, _D]),
     "ms_get_gradient": (ctypes.c_int, [_P, _D]),

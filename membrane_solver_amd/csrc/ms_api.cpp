@@ -41,18 +41,27 @@ struct ms_ctx {
   uint8_t* d_vflags = nullptr;
   double* d_kappa = nullptr;
   double* d_c0 = nullptr;
-  double* d_tilts = nullptr;      // (nvp,3) vertex tilts, patch order (ms_set_tilts)
-  double* d_tilts_trial = nullptr;  // tilts projected onto a trial surface (line search)
-  double* d_tilt_grad = nullptr;  // (nvp,3) dE/dt of the last gradient evaluation
+  // vertex tilt fields: [0] the single field (ms_set_tilts), [1]/[2] inner / outer leaflet
+  // (ms_set_leaflet_tilts).  All arrays (nvp,3) in patch order.
+  struct TiltField {
+    double* tilts = nullptr;   // current tangent tilts
+    double* trial = nullptr;   // tilts projected onto a trial surface / relaxation trial
+    double* grad = nullptr;    // dE/dt of the last tilt-gradient evaluation
+    double* dir = nullptr;     // relaxation: CG direction
+    double* minv = nullptr;    // relaxation: Jacobi M^-1 (nvp)
+    double k_tilt = 0.0;       // tilt modulus (0 = magnitude module contributes nothing)
+    int consistent = 0;        // tilt_mass_mode: consistent P1 mass instead of lumped
+    double k_smooth = 0.0;     // smoothness rigidity of the energy
+    double k_smooth_precond = 0.0;  // rigidity entering the Jacobi diagonal
+    uint8_t fixed_bit = 0;     // vertex flag bit that clamps a row of this field
+    uint32_t mod_tilt = 0, mod_smooth = 0;  // module bits that read this field
+    int s_etilt = 0, s_ets = 0, s_gn2 = 0, s_rz = 0;  // reduction slots
+  } tf[3];
   double* d_bt_vert = nullptr;    // (nvp,4) bending_tilt per-vertex record of the last energy pass
-  double k_smooth = 0.0;          // gp["tilt_smoothness_rigidity"]
   bool bt_valid = false;          // d_bt_vert describes the current x
   // tilt relaxation work space (positions frozen): unit vertex normals, CG direction, Jacobi M^-1
   double* d_tn = nullptr;
-  double* d_tdir = nullptr;
-  double* d_minv = nullptr;
   std::vector<uint8_t> h_vflags;  // host copy of the vertex flag bytes (patch order)
-  double k_tilt = 0.0;
   // per-vertex state (one allocation), patch order, nvp rows
   double* state = nullptr;
   bool own_state = true;
@@ -185,14 +194,31 @@ struct ProfScope {
 
 constexpr uint32_t MASK_ENERGY = (1u << MS_S_ESURF) | (1u << MS_S_VOL) | (1u << MS_S_EBEND) |
                                  (1u << MS_S_MINEDGE2) | (1u << MS_S_GUARD) | (1u << MS_S_ETILT) |
-                                 (1u << MS_S_EBT) | (1u << MS_S_ETS);
-constexpr uint32_t MS_TILT_MODS = MS_MOD_TILT | MS_MOD_BENDING_TILT | MS_MOD_TILT_SMOOTH;  // modules reading the tilt field
+                                 (1u << MS_S_EBT) | (1u << MS_S_ETS) | (1u << MS_S_ETILT_IN) |
+                                 (1u << MS_S_ETILT_OUT) | (1u << MS_S_ETS_IN) | (1u << MS_S_ETS_OUT);
+constexpr uint32_t MS_TILT_MODS = MS_MOD_TILT | MS_MOD_BENDING_TILT | MS_MOD_TILT_SMOOTH;  // modules reading the single tilt field
+constexpr uint32_t MS_LEAFLET_MODS = MS_MOD_TILT_IN | MS_MOD_TILT_OUT | MS_MOD_TILT_SMOOTH_IN | MS_MOD_TILT_SMOOTH_OUT;
+constexpr uint32_t MS_ANY_TILT_MODS = MS_TILT_MODS | MS_LEAFLET_MODS;
+// modules whose shape gradient is added into g by a pass after K_C (so the direction cannot be fused)
+constexpr uint32_t MS_TILT_SHAPE_MODS = MS_MOD_TILT | MS_MOD_TILT_IN | MS_MOD_TILT_OUT;
+using TiltField = ms_ctx::TiltField;
+
+// the tilt fields the module set reads: [0] single field, [1] inner, [2] outer leaflet
+int active_fields(ms_ctx* c, uint32_t mods, TiltField* out[3]) {
+  int n = 0;
+  for (int k = 0; k < 3; ++k) {
+    TiltField& f = c->tf[k];
+    const uint32_t reads = k == 0 ? MS_TILT_MODS : (f.mod_tilt | f.mod_smooth);
+    if (mods & reads) out[n++] = &f;
+  }
+  return n;
+}
 
 // mode 0 energy / 1 energy+gradients read `src`; mode 2 projects `src` onto the tangent
 // planes of x (+ alpha d) and writes `dst`.
-int tilt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* src = nullptr,
-              double* dst = nullptr, bool shape_gradient = true) {
-  if (!c->d_tilts) return fail(c, MS_ERR_STATE, "tilt module active but ms_set_tilts was never called");
+int tilt_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, const double* src = nullptr,
+                double* dst = nullptr, bool shape_gradient = true, bool lumped = false) {
+  if (!f.tilts) return fail(c, MS_ERR_STATE, "tilt module active but its tilt field was never set (ms_set_tilts / ms_set_leaflet_tilts)");
   TiltArgs a;
   a.m = device_mesh(c);
   a.tile0 = c->tile0;
@@ -200,22 +226,29 @@ int tilt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* src
   a.x = c->buf[MS_BUF_X];
   a.d = use_dir ? c->buf[MS_BUF_D] : nullptr;
   a.alpha = alpha;
-  a.tilts = src ? src : c->d_tilts;
-  a.tilts_out = dst ? dst : c->d_tilts;
-  a.k_tilt = c->k_tilt;
+  a.tilts = src ? src : f.tilts;
+  a.tilts_out = dst ? dst : f.tilts;
+  a.k_tilt = f.k_tilt;
   a.g = shape_gradient ? c->buf[MS_BUF_G] : nullptr;
-  a.tilt_grad = c->d_tilt_grad;
+  a.tilt_grad = f.grad;
+  a.minv = nullptr;
   a.partials = c->d_partials;
+  a.e_slot = f.s_etilt;
+  a.consistent = (f.consistent && !lumped) ? 1 : 0;
   {
     ProfScope ps(c, 4);
     HIPCHK(c, launch_tilt(a, mode, c->cap, c->til.max_ent, c->stream));
   }
   return MS_OK;
 }
+int tilt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* src = nullptr,
+              double* dst = nullptr, bool shape_gradient = true) {
+  return tilt_pass_f(c, c->tf[0], mode, use_dir, alpha, src, dst, shape_gradient);
+}
 // bending_tilt facet pass (mode 0 energy / 1 + factors / 2 + tilt gradient) on the positions of
 // the preceding energy pass; `tilts` = the tangent tilts belonging to those positions
 int bt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* tilts) {
-  if (!c->d_tilts) return fail(c, MS_ERR_STATE, "bending_tilt module active but ms_set_tilts was never called");
+  if (!c->tf[0].tilts) return fail(c, MS_ERR_STATE, "bending_tilt module active but ms_set_tilts was never called");
   BtArgs a;
   a.m = device_mesh(c);
   a.tile0 = c->tile0;
@@ -227,7 +260,7 @@ int bt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* tilts
   a.bt_vert = c->d_bt_vert;
   a.fK = c->buf[MS_BUF_FK];
   a.fA = c->buf[MS_BUF_FA];
-  a.tilt_grad = c->d_tilt_grad;
+  a.tilt_grad = c->tf[0].grad;
   a.partials = c->d_partials;
   {
     ProfScope ps(c, 5);
@@ -236,8 +269,9 @@ int bt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* tilts
   return MS_OK;
 }
 // tilt smoothness pass (mode 0 energy / 1 + tilt gradient / 2 Jacobi diagonal into `diag`)
-int ts_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* tilts, double* diag = nullptr) {
-  if (!c->d_tilts) return fail(c, MS_ERR_STATE, "tilt_smoothness module active but ms_set_tilts was never called");
+int ts_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, const double* tilts,
+              double* diag = nullptr, double k_override = -1.0) {
+  if (!f.tilts) return fail(c, MS_ERR_STATE, "tilt_smoothness module active but its tilt field was never set");
   TsArgs a;
   a.m = device_mesh(c);
   a.tile0 = c->tile0;
@@ -246,15 +280,19 @@ int ts_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* tilts
   a.d = use_dir ? c->buf[MS_BUF_D] : nullptr;
   a.alpha = alpha;
   a.tilts = tilts;
-  a.k_smooth = c->k_smooth;
-  a.tilt_grad = c->d_tilt_grad;
+  a.k_smooth = k_override >= 0.0 ? k_override : f.k_smooth;
+  a.tilt_grad = f.grad;
   a.diag = diag;
   a.partials = c->d_partials;
+  a.e_slot = f.s_ets;
   {
     ProfScope ps(c, 7);
     HIPCHK(c, launch_ts(a, mode, c->cap, c->til.max_ent, c->stream));
   }
   return MS_OK;
+}
+int ts_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* tilts, double* diag = nullptr) {
+  return ts_pass_f(c, c->tf[0], mode, use_dir, alpha, tilts, diag);
 }
 constexpr uint32_t MASK_GRAD = (1u << MS_S_GGC) | (1u << MS_S_GCGC);
 constexpr uint32_t MASK_DIR = (1u << MS_S_GNORM2) | (1u << MS_S_GDOTD) | (1u << MS_S_MAXD2) | (1u << MS_S_MAXG2);
@@ -297,20 +335,35 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   }
   if (modules & MS_TILT_MODS) {
     int rc = MS_OK;
-    const double* tilts = c->d_tilts;
+    const double* tilts = c->tf[0].tilts;
     if (use_dir) {
       // minimizer.py:723-733: the trial energy is taken with the tilts projected onto the
       // TRIAL surface's vertex tangent planes (kept aside; they become the stored tilts
       // only if this trial is accepted)
-      rc = tilt_pass(c, 2, true, alpha, c->d_tilts, c->d_tilts_trial);
+      rc = tilt_pass(c, 2, true, alpha, c->tf[0].tilts, c->tf[0].trial);
       if (rc) return rc;
-      tilts = c->d_tilts_trial;
+      tilts = c->tf[0].trial;
     }
     if (modules & MS_MOD_TILT) rc = tilt_pass(c, 0, use_dir, alpha, tilts);
     if (rc) return rc;
     if (bt) rc = bt_pass(c, write_factors ? 1 : 0, use_dir, alpha, tilts);
     if (rc) return rc;
     if (modules & MS_MOD_TILT_SMOOTH) rc = ts_pass(c, 0, use_dir, alpha, tilts);
+    if (rc) return rc;
+  }
+  for (int l = 1; l <= 2 && (modules & MS_LEAFLET_MODS); ++l) {  // leaflet fields, same protocol
+    TiltField& f = c->tf[l];
+    if (!(modules & (f.mod_tilt | f.mod_smooth))) continue;
+    int rc = MS_OK;
+    const double* tilts = f.tilts;
+    if (use_dir) {
+      rc = tilt_pass_f(c, f, 2, true, alpha, f.tilts, f.trial);
+      if (rc) return rc;
+      tilts = f.trial;
+    }
+    if (modules & f.mod_tilt) rc = tilt_pass_f(c, f, 0, use_dir, alpha, tilts);
+    if (rc) return rc;
+    if (modules & f.mod_smooth) rc = ts_pass_f(c, f, 0, use_dir, alpha, tilts);
     if (rc) return rc;
   }
   if (reduce_now) {
@@ -356,8 +409,10 @@ int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulat
     HIPCHK(c, launch_gradient(a, c->cap, c->til.max_ent, c->stream));
   }
   if (dir_mode) c->last_g = g_out;
-  if ((modules & MS_MOD_TILT) && g_out) {  // module loop: tilt adds its shape gradient into g
-    int rc = tilt_pass(c, 1, false, 0.0);
+  for (int k = 0; k < 3 && g_out; ++k) {  // module loop: the tilt magnitude modules add their shape gradient into g
+    TiltField& f = c->tf[k];
+    if (!(modules & f.mod_tilt)) continue;
+    int rc = tilt_pass_f(c, f, 1, false, 0.0);
     if (rc) return rc;
   }
   if (reduce_now) return reduce_slots(c, dir_mode ? MASK_DIR : MASK_GRAD);
@@ -412,6 +467,11 @@ void energies_from_mailbox(const ms_ctx* c, double e[4]) {
   e[2] = penalty_energy(c, c->h_scal[MS_S_VOL]);
   e[3] = (c->params.modules & MS_MOD_TILT) ? c->h_scal[MS_S_ETILT] : 0.0;
   if (c->params.modules & MS_MOD_TILT_SMOOTH) e[3] += c->h_scal[MS_S_ETS];
+  for (int l = 1; l <= 2; ++l) {
+    const TiltField& f = c->tf[l];
+    if (c->params.modules & f.mod_tilt) e[3] += c->h_scal[f.s_etilt];
+    if (c->params.modules & f.mod_smooth) e[3] += c->h_scal[f.s_ets];
+  }
 }
 
 // gradient assembly at x: energy pass (+factors), gradient pass, finalize via
@@ -421,7 +481,7 @@ void energies_from_mailbox(const ms_ctx* c, double e[4]) {
 int queue_energy_and_gradient(ms_ctx* c, int stepper, bool use_history, bool skip_energy = false) {
   const uint32_t mods = c->params.modules;
   // lambda needs a global reduction first; the tilt module adds into g after K_C
-  const bool constraint = (mods & (MS_CON_VOLUME | MS_MOD_TILT)) != 0;
+  const bool constraint = (mods & (MS_CON_VOLUME | MS_TILT_SHAPE_MODS)) != 0;
   // K_C reads the reduced volume (already reduced when the energy pass is skipped)
   const bool penalty = skip_energy || (mods & MS_MOD_VOLUME_PENALTY) != 0;
   int rc = MS_OK;
@@ -647,6 +707,17 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
     CREATE_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_scal_all), sizeof(double) * MS_NSCAL * (size_t)W));
     CREATE_HIP(hipMemset(c->d_scal_all, 0, sizeof(double) * MS_NSCAL * (size_t)W));
   }
+  {
+    TiltField& f0 = c->tf[0];
+    f0.fixed_bit = VF_TILT_FIXED; f0.mod_tilt = MS_MOD_TILT; f0.mod_smooth = MS_MOD_TILT_SMOOTH;
+    f0.s_etilt = MS_S_ETILT; f0.s_ets = MS_S_ETS; f0.s_gn2 = MS_S_TGNORM2; f0.s_rz = MS_S_TRZ;
+    TiltField& f1 = c->tf[1];
+    f1.fixed_bit = VF_TILT_FIXED_IN; f1.mod_tilt = MS_MOD_TILT_IN; f1.mod_smooth = MS_MOD_TILT_SMOOTH_IN;
+    f1.s_etilt = MS_S_ETILT_IN; f1.s_ets = MS_S_ETS_IN; f1.s_gn2 = MS_S_TGNORM2_IN; f1.s_rz = MS_S_TRZ_IN;
+    TiltField& f2 = c->tf[2];
+    f2.fixed_bit = VF_TILT_FIXED_OUT; f2.mod_tilt = MS_MOD_TILT_OUT; f2.mod_smooth = MS_MOD_TILT_SMOOTH_OUT;
+    f2.s_etilt = MS_S_ETILT_OUT; f2.s_ets = MS_S_ETS_OUT; f2.s_gn2 = MS_S_TGNORM2_OUT; f2.s_rz = MS_S_TRZ_OUT;
+  }
   c->deterministic = getenv("MS_DETERMINISTIC") != nullptr && atoi(getenv("MS_DETERMINISTIC")) != 0;
   c->params.modules = MS_MOD_SURFACE;
   c->params.bending_model = MS_BEND_HELFRICH;
@@ -668,7 +739,9 @@ void ms_destroy(ms_ctx* c) {
   if (!c->own_state) c->state = nullptr;
   void* ptrs[] = {c->d_perm, c->d_tile_facet_off, c->d_tile_facets, c->d_tf_gamma,
                   c->d_tile_halo_off, c->d_halo_ids, c->d_tile_ent_off, c->d_tile_voff, c->d_vent,
-                  c->d_vflags, c->d_kappa, c->d_c0, c->d_tilts, c->d_tilt_grad, c->d_tilts_trial, c->d_bt_vert, c->d_tn, c->d_tdir, c->d_minv,
+                  c->d_vflags, c->d_kappa, c->d_c0, c->tf[0].tilts, c->tf[0].grad, c->tf[0].trial, c->d_bt_vert, c->d_tn, c->tf[0].dir, c->tf[0].minv,
+                  c->tf[1].tilts, c->tf[1].grad, c->tf[1].trial, c->tf[1].dir, c->tf[1].minv,
+                  c->tf[2].tilts, c->tf[2].grad, c->tf[2].trial, c->tf[2].dir, c->tf[2].minv,
                   c->state, c->d_partials, c->d_scal, c->d_stage, c->d_bnd_rows, c->d_bnd_off,
                   c->d_halo_rows, c->d_scal_all};
   for (void* p : ptrs)
@@ -760,35 +833,43 @@ int ms_set_params(ms_ctx* c, const ms_params* p) {
 int ms_set_tilts(ms_ctx* c, const double* tilts, double tilt_rigidity) {
   if (!c || !tilts) return fail(c, MS_ERR_INVALID, "ms_set_tilts: NULL argument");
   const size_t bytes = sizeof(double) * 3 * (size_t)c->til.nvp;
-  if (!c->d_tilts) {
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_tilts), bytes));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_tilt_grad), bytes));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_tilts_trial), bytes));
-    HIPCHK(c, hipMemset(c->d_tilts_trial, 0, bytes));
-    HIPCHK(c, hipMemset(c->d_tilts, 0, bytes));
-    HIPCHK(c, hipMemset(c->d_tilt_grad, 0, bytes));
+  if (!c->tf[0].tilts) {
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->tf[0].tilts), bytes));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->tf[0].grad), bytes));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->tf[0].trial), bytes));
+    HIPCHK(c, hipMemset(c->tf[0].trial, 0, bytes));
+    HIPCHK(c, hipMemset(c->tf[0].tilts, 0, bytes));
+    HIPCHK(c, hipMemset(c->tf[0].grad, 0, bytes));
   }
-  c->k_tilt = tilt_rigidity;
+  c->tf[0].k_tilt = tilt_rigidity;
   c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
   c->sh_carry_valid = c->sh_grad_valid = false;
-  return ext_to_patch(c, tilts, c->d_tilts, 3);
+  return ext_to_patch(c, tilts, c->tf[0].tilts, 3);
 }
 
 int ms_get_tilts(ms_ctx* c, double* tilts) {
-  if (!c || !tilts || !c->d_tilts) return fail(c, MS_ERR_INVALID, "ms_get_tilts: no tilts set");
-  return patch_to_ext(c, c->d_tilts, tilts, 3);
+  if (!c || !tilts || !c->tf[0].tilts) return fail(c, MS_ERR_INVALID, "ms_get_tilts: no tilts set");
+  return patch_to_ext(c, c->tf[0].tilts, tilts, 3);
 }
 
 int ms_get_tilt_gradient(ms_ctx* c, double* tilt_grad) {
-  if (!c || !tilt_grad || !c->d_tilt_grad) return fail(c, MS_ERR_INVALID, "ms_get_tilt_gradient: no tilts set");
-  return patch_to_ext(c, c->d_tilt_grad, tilt_grad, 3);
+  if (!c || !tilt_grad || !c->tf[0].grad) return fail(c, MS_ERR_INVALID, "ms_get_tilt_gradient: no tilts set");
+  return patch_to_ext(c, c->tf[0].grad, tilt_grad, 3);
 }
 
 int ms_project_tilts_to_tangent(ms_ctx* c) {
   if (!c) return MS_ERR_INVALID;
   if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "tilt passes are single-shard only");
-  int rc = tilt_pass(c, 2, false, 0.0);
-  if (rc) return rc;
+  TiltField* fl[3];
+  const int n = active_fields(c, c->params.modules, fl);
+  for (int k = 0; k < n; ++k) {  // every field the module set reads (geometry/mesh.py:788-814)
+    int rc = tilt_pass_f(c, *fl[k], 2, false, 0.0);
+    if (rc) return rc;
+  }
+  if (n == 0) {
+    int rc = tilt_pass(c, 2, false, 0.0);
+    if (rc) return rc;
+  }
   return fetch(c);
 }
 
@@ -803,7 +884,7 @@ int ms_set_deterministic(ms_ctx* c, int on) {
 
 int ms_set_tilt_smoothness(ms_ctx* c, double k_smooth) {
   if (!c) return MS_ERR_INVALID;
-  c->k_smooth = k_smooth;
+  c->tf[0].k_smooth = k_smooth;
   c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
   return MS_OK;
 }
@@ -822,28 +903,52 @@ int ms_set_tilt_fixed(ms_ctx* c, const uint8_t* tilt_fixed) {
 }
 
 namespace {
-// energy of the tilt-reading modules (+ dense tilt gradient) for `tilts` on the current x
-// (runtime/evaluation_manager.py:303-462); needs d_bt_vert valid when bending_tilt is on
-int tilt_eval(ms_ctx* c, const double* tilts, bool gradient) {
+// Energy of the tilt-reading modules (+ dense tilt gradients) on the current x, reading each
+// field's `trial` or stored tilts (runtime/evaluation_manager.py:303-462 for the single field,
+// :537-742 for the leaflets; needs d_bt_vert valid when bending_tilt is on).  With positions
+// frozen the leaflet magnitude modules take the lumped vertex-area form whatever their mass mode
+// (evaluation_manager.py:565-581, 663-695: the relaxation always passes tilt_vertex_areas).
+int tilt_eval(ms_ctx* c, bool trial, bool gradient) {
   const uint32_t mods = c->params.modules;
   int rc = MS_OK;
   uint32_t mask = 0;
-  if (mods & MS_MOD_TILT) {
-    rc = tilt_pass(c, gradient ? 1 : 0, false, 0.0, tilts, nullptr, /*shape_gradient=*/false);
-    if (rc) return rc;
-    mask |= 1u << MS_S_ETILT;
-  } else if (gradient) {
-    HIPCHK(c, hipMemsetAsync(c->d_tilt_grad, 0, sizeof(double) * 3 * (size_t)c->til.nvp, c->stream));
+  const size_t b3 = sizeof(double) * 3 * (size_t)c->til.nvp;
+  if (mods & MS_TILT_MODS) {
+    const double* tilts = trial ? c->tf[0].trial : c->tf[0].tilts;
+    if (mods & MS_MOD_TILT) {
+      rc = tilt_pass(c, gradient ? 1 : 0, false, 0.0, tilts, nullptr, /*shape_gradient=*/false);
+      if (rc) return rc;
+      mask |= 1u << MS_S_ETILT;
+    } else if (gradient) {
+      HIPCHK(c, hipMemsetAsync(c->tf[0].grad, 0, b3, c->stream));
+    }
+    if (mods & MS_MOD_BENDING_TILT) {
+      rc = bt_pass(c, gradient ? 2 : 0, false, 0.0, tilts);
+      if (rc) return rc;
+      mask |= 1u << MS_S_EBT;
+    }
+    if (mods & MS_MOD_TILT_SMOOTH) {
+      rc = ts_pass(c, gradient ? 1 : 0, false, 0.0, tilts);
+      if (rc) return rc;
+      mask |= 1u << MS_S_ETS;
+    }
   }
-  if (mods & MS_MOD_BENDING_TILT) {
-    rc = bt_pass(c, gradient ? 2 : 0, false, 0.0, tilts);
-    if (rc) return rc;
-    mask |= 1u << MS_S_EBT;
-  }
-  if (mods & MS_MOD_TILT_SMOOTH) {
-    rc = ts_pass(c, gradient ? 1 : 0, false, 0.0, tilts);
-    if (rc) return rc;
-    mask |= 1u << MS_S_ETS;
+  for (int l = 1; l <= 2; ++l) {
+    TiltField& f = c->tf[l];
+    if (!(mods & (f.mod_tilt | f.mod_smooth))) continue;
+    const double* tilts = trial ? f.trial : f.tilts;
+    if (mods & f.mod_tilt) {
+      rc = tilt_pass_f(c, f, gradient ? 1 : 0, false, 0.0, tilts, nullptr, /*shape_gradient=*/false, /*lumped=*/true);
+      if (rc) return rc;
+      mask |= 1u << f.s_etilt;
+    } else if (gradient) {
+      HIPCHK(c, hipMemsetAsync(f.grad, 0, b3, c->stream));
+    }
+    if (mods & f.mod_smooth) {
+      rc = ts_pass_f(c, f, gradient ? 1 : 0, false, 0.0, tilts);
+      if (rc) return rc;
+      mask |= 1u << f.s_ets;
+    }
   }
   return mask ? reduce_slots(c, mask) : MS_OK;
 }
@@ -852,119 +957,130 @@ double tilt_energy_from_mailbox(const ms_ctx* c) {
   if (c->params.modules & MS_MOD_TILT) e += c->h_scal[MS_S_ETILT];
   if (c->params.modules & MS_MOD_BENDING_TILT) e += c->h_scal[MS_S_EBT];
   if (c->params.modules & MS_MOD_TILT_SMOOTH) e += c->h_scal[MS_S_ETS];
+  for (int l = 1; l <= 2; ++l) {
+    const TiltField& f = c->tf[l];
+    if (c->params.modules & f.mod_tilt) e += c->h_scal[f.s_etilt];
+    if (c->params.modules & f.mod_smooth) e += c->h_scal[f.s_ets];
+  }
   return e;
 }
 int ensure_bt_record(ms_ctx* c) {
   if (!(c->params.modules & MS_MOD_BENDING_TILT) || c->bt_valid) return MS_OK;
   return phase_energy(c, c->params.modules, false, 0.0, false, false, false, /*reduce_now=*/false);
 }
-}  // namespace
 
-int ms_tilt_energy_and_gradient(ms_ctx* c, double* energy, double* tilt_grad) {
-  if (!c || !energy) return fail(c, MS_ERR_INVALID, "ms_tilt_energy_and_gradient: NULL argument");
-  if (!(c->params.modules & MS_TILT_MODS) || !c->d_tilts)
-    return fail(c, MS_ERR_STATE, "ms_tilt_energy_and_gradient: no tilt-reading module / no tilts set");
-  if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "tilt passes are single-shard only");
-  int rc = ensure_bt_record(c);
-  if (rc) return rc;
-  rc = tilt_eval(c, c->d_tilts, true);
-  if (rc) return rc;
-  rc = fetch(c);
-  if (rc) return rc;
-  *energy = tilt_energy_from_mailbox(c);
-  if (tilt_grad) return patch_to_ext(c, c->d_tilt_grad, tilt_grad, 3);
-  return MS_OK;
-}
-
-int ms_relax_tilts(ms_ctx* c, const ms_tilt_relax_params* rp, int* iters_out, int* evals_out) {
-  if (!c || !rp) return fail(c, MS_ERR_INVALID, "ms_relax_tilts: NULL argument");
-  if (iters_out) *iters_out = 0;
-  if (evals_out) *evals_out = 0;
+// TiltRelaxationManager.relax_tilts (tilt_relaxation.py:237-424) for one field and
+// relax_leaflet_tilts (:426-1478, default options) for the (in, out) pair: the same driver over
+// the concatenated free rows of `fl[0..nf)` -- one energy, |grad|^2 and <r, M^-1 r> summed over
+// the fields, one step length for all of them.
+int relax_fields(ms_ctx* c, const ms_tilt_relax_params* rp, TiltField** fl, int nf, bool jacobi_smooth_by_param,
+                 int* iters_out, int* evals_out) {
   const uint32_t mods = c->params.modules;
-  if (!(mods & MS_TILT_MODS) || !c->d_tilts)
-    return fail(c, MS_ERR_STATE, "ms_relax_tilts: no tilt-reading module / no tilts set");
-  if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "tilt passes are single-shard only");
-  if (rp->step_size <= 0.0 || rp->max_iters <= 0) return MS_OK;
   const Tiling& t = c->til;
   bool any_free = false;
-  for (int i = 0; i < t.nv && !any_free; ++i) any_free = !(c->h_vflags[(size_t)i] & VF_TILT_FIXED);
+  for (int k = 0; k < nf && !any_free; ++k)
+    for (int i = 0; i < t.nv && !any_free; ++i) any_free = !(c->h_vflags[(size_t)i] & fl[k]->fixed_bit);
   if (!any_free) return MS_OK;
   const size_t b3 = sizeof(double) * 3 * (size_t)t.nvp;
   if (!c->d_tn) {
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_tn), b3));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_tdir), b3));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_minv), sizeof(double) * (size_t)t.nvp));
     HIPCHK(c, hipMemset(c->d_tn, 0, b3));
-    HIPCHK(c, hipMemset(c->d_tdir, 0, b3));
-    HIPCHK(c, hipMemset(c->d_minv, 0, sizeof(double) * (size_t)t.nvp));
+  }
+  for (int k = 0; k < nf; ++k) {
+    TiltField& f = *fl[k];
+    if (f.dir) continue;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&f.dir), b3));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&f.minv), sizeof(double) * (size_t)t.nvp));
+    HIPCHK(c, hipMemset(f.dir, 0, b3));
+    HIPCHK(c, hipMemset(f.minv, 0, sizeof(double) * (size_t)t.nvp));
   }
   int iters = 0, evals = 0;
   int rc = ensure_bt_record(c);
   if (rc) return rc;
-  {  // frozen geometry: unit vertex normals and the Jacobi diagonal
-    TiltArgs a;
-    a.m = device_mesh(c);
-    a.tile0 = c->tile0;
-    a.tile1 = c->tile1;
-    a.x = c->buf[MS_BUF_X];
-    a.d = nullptr;
-    a.alpha = 0.0;
-    a.tilts = c->d_tilts;
-    a.tilts_out = c->d_tn;
-    a.k_tilt = (rp->solver == 1 && rp->jacobi) ? c->k_tilt : 0.0;
-    a.g = nullptr;
-    a.tilt_grad = c->d_tilt_grad;
-    a.minv = c->d_minv;
-    a.partials = c->d_partials;
-    HIPCHK(c, launch_tilt(a, 3, c->cap, t.max_ent, c->stream));
-  }
-  auto tvec = [&](int mode, const double* src, double* out, double coef, int flag) -> int {
+  auto tvec = [&](TiltField& f, int mode, const double* src, double* out, double coef, int flag) -> int {
     ProfScope ps(c, 6);
-    HIPCHK(c, launch_tvec(mode, c->tile0, c->tile1, t.nv, t.T, c->d_vflags, c->d_tilt_grad, c->d_minv,
-                          c->d_tdir, c->d_tilts, src, c->d_tn, out, coef, flag, c->d_partials, t.n_tiles,
-                          c->stream));
+    HIPCHK(c, launch_tvec(mode, c->tile0, c->tile1, t.nv, t.T, c->d_vflags, f.grad, f.minv, f.dir, f.tilts, src,
+                          c->d_tn, out, coef, flag, c->d_partials, t.n_tiles, c->stream, f.fixed_bit, f.s_gn2,
+                          f.s_rz));
     return MS_OK;
   };
-  if (rp->solver == 1 && rp->jacobi && c->k_smooth != 0.0) {  // (the parameter alone decides, :42-43)
-    rc = ts_pass(c, 2, false, 0.0, c->d_tilts, c->d_minv);  // + 1/2 k_s sum (c_a + c_b)
+  uint32_t norm_mask = 0;
+  for (int k = 0; k < nf; ++k) {
+    TiltField& f = *fl[k];
+    norm_mask |= (1u << f.s_gn2) | (1u << f.s_rz);
+    {  // frozen geometry: unit vertex normals and the tilt-rigidity part of the Jacobi diagonal
+      TiltArgs a;
+      a.m = device_mesh(c);
+      a.tile0 = c->tile0;
+      a.tile1 = c->tile1;
+      a.x = c->buf[MS_BUF_X];
+      a.d = nullptr;
+      a.alpha = 0.0;
+      a.tilts = f.tilts;
+      a.tilts_out = c->d_tn;
+      a.k_tilt = (rp->solver == 1 && rp->jacobi) ? f.k_tilt : 0.0;
+      a.g = nullptr;
+      a.tilt_grad = f.grad;
+      a.minv = f.minv;
+      a.partials = c->d_partials;
+      a.e_slot = f.s_etilt;
+      a.consistent = 0;
+      HIPCHK(c, launch_tilt(a, 3, c->cap, t.max_ent, c->stream));
+    }
+    // + 1/2 k_s sum (c_a + c_b): the parameter alone decides, loaded module or not
+    // (preconditioners.py:42-57 single field, :111-139 leaflets)
+    const double ks = jacobi_smooth_by_param ? f.k_smooth_precond : f.k_smooth;
+    if (rp->solver == 1 && rp->jacobi && ks != 0.0) {
+      rc = ts_pass_f(c, f, 2, false, 0.0, f.tilts, f.minv, ks);
+      if (rc) return rc;
+    }
+    rc = tvec(f, 3, nullptr, f.minv, 0.0, 0);  // diagonal -> clamped inverse
     if (rc) return rc;
+    // tilts <- P(tilts) on every row (:303-305 / :640-663), fixed rows keep that value from now on
+    rc = tvec(f, 2, f.tilts, f.trial, 0.0, 0);
+    if (rc) return rc;
+    std::swap(f.tilts, f.trial);
   }
-  rc = tvec(3, nullptr, c->d_minv, 0.0, 0);  // diagonal -> clamped inverse
-  if (rc) return rc;
-  // tilts <- P(tilts) on every row (:303-305), fixed rows keep that value from now on
-  rc = tvec(2, c->d_tilts, c->d_tilts_trial, 0.0, 0);
-  if (rc) return rc;
-  std::swap(c->d_tilts, c->d_tilts_trial);
   auto grad_at = [&](double* E, double* gnorm, double* rz) -> int {
-    int r = tilt_eval(c, c->d_tilts, true);
+    int r = tilt_eval(c, false, true);
     if (r) return r;
-    r = tvec(0, nullptr, nullptr, 0.0, 0);
-    if (r) return r;
-    r = reduce_slots(c, (1u << MS_S_TGNORM2) | (1u << MS_S_TRZ));
+    for (int k = 0; k < nf; ++k) {
+      r = tvec(*fl[k], 0, nullptr, nullptr, 0.0, 0);
+      if (r) return r;
+    }
+    r = reduce_slots(c, norm_mask);
     if (r) return r;
     r = fetch(c);
     if (r) return r;
     ++evals;
     *E = tilt_energy_from_mailbox(c);
-    *gnorm = std::sqrt(c->h_scal[MS_S_TGNORM2]);
-    *rz = c->h_scal[MS_S_TRZ];
+    double g2 = 0.0, z = 0.0;
+    for (int k = 0; k < nf; ++k) {
+      g2 += c->h_scal[fl[k]->s_gn2];
+      z += c->h_scal[fl[k]->s_rz];
+    }
+    *gnorm = std::sqrt(g2);
+    *rz = z;
     return MS_OK;
   };
-  // backtracking on E(P(t + step*src)) <= E0 (:330-347 / :380-398); accepts by pointer swap
-  auto search = [&](const double* src, double sign, double E0, double* E_acc, bool* accepted) -> int {
+  // backtracking on E(P(t + step*src)) <= E0 (:330-347 / :380-398 / :918-973); accepts by pointer swap
+  auto search = [&](bool along_dir, double sign, double E0, double* E_acc, bool* accepted) -> int {
     double step = rp->step_size;
     *accepted = false;
     for (int bt = 0; bt < 12; ++bt) {
-      int r = tvec(2, src, c->d_tilts_trial, sign * step, 1);
-      if (r) return r;
-      r = tilt_eval(c, c->d_tilts_trial, false);
+      for (int k = 0; k < nf; ++k) {
+        TiltField& f = *fl[k];
+        int r = tvec(f, 2, along_dir ? f.dir : f.grad, f.trial, sign * step, 1);
+        if (r) return r;
+      }
+      int r = tilt_eval(c, true, false);
       if (r) return r;
       r = fetch(c);
       if (r) return r;
       ++evals;
       const double E1 = tilt_energy_from_mailbox(c);
       if (E1 <= E0) {
-        std::swap(c->d_tilts, c->d_tilts_trial);
+        for (int k = 0; k < nf; ++k) std::swap(fl[k]->tilts, fl[k]->trial);
         *E_acc = E1;
         *accepted = true;
         return MS_OK;
@@ -976,29 +1092,31 @@ int ms_relax_tilts(ms_ctx* c, const ms_tilt_relax_params* rp, int* iters_out, in
   };
   const double tol = rp->tol > 0.0 ? rp->tol : 0.0;
   double E0 = 0.0, gnorm = 0.0, rz_old = 0.0;
-  if (rp->solver == 0) {  // gradient descent (:312-351)
+  if (rp->solver == 0) {  // gradient descent (:312-351 / :892-1058)
     for (int it = 0; it < rp->max_iters; ++it) {
       rc = grad_at(&E0, &gnorm, &rz_old);
       if (rc) return rc;
       if (gnorm == 0.0 || (tol > 0.0 && gnorm < tol)) break;
       bool acc = false;
       double E1 = E0;
-      rc = search(c->d_tilt_grad, -1.0, E0, &E1, &acc);
+      rc = search(false, -1.0, E0, &E1, &acc);
       if (rc) return rc;
       ++iters;
       if (!acc) break;
     }
-  } else {  // (preconditioned) Fletcher-Reeves CG (:352-421)
+  } else {  // (preconditioned) Fletcher-Reeves CG (:352-421 / :1059-1398)
     rc = grad_at(&E0, &gnorm, &rz_old);
     if (rc) return rc;
     if (!(gnorm == 0.0 || (tol > 0.0 && gnorm < tol))) {
-      rc = tvec(1, nullptr, nullptr, 0.0, 1);
-      if (rc) return rc;
+      for (int k = 0; k < nf; ++k) {
+        rc = tvec(*fl[k], 1, nullptr, nullptr, 0.0, 1);
+        if (rc) return rc;
+      }
       for (int it = 0; it < rp->max_iters; ++it) {
         if (gnorm == 0.0 || (tol > 0.0 && gnorm < tol)) break;
         bool acc = false;
         double E1 = E0;
-        rc = search(c->d_tdir, 1.0, E0, &E1, &acc);
+        rc = search(true, 1.0, E0, &E1, &acc);
         if (rc) return rc;
         ++iters;
         if (!acc) break;
@@ -1008,8 +1126,10 @@ int ms_relax_tilts(ms_ctx* c, const ms_tilt_relax_params* rp, int* iters_out, in
         if (gnorm == 0.0 || (tol > 0.0 && gnorm < tol)) break;
         if (rz_old == 0.0) break;
         const double beta = rz_new / rz_old;
-        rc = tvec(1, nullptr, nullptr, beta, 0);
-        if (rc) return rc;
+        for (int k = 0; k < nf; ++k) {
+          rc = tvec(*fl[k], 1, nullptr, nullptr, beta, 0);
+          if (rc) return rc;
+        }
         rz_old = rz_new;
       }
     }
@@ -1020,6 +1140,136 @@ int ms_relax_tilts(ms_ctx* c, const ms_tilt_relax_params* rp, int* iters_out, in
   c->carry_valid = c->grad_valid = false;
   c->factors_valid = c->factors_valid && !(mods & MS_MOD_BENDING_TILT);
   return MS_OK;
+}
+}  // namespace
+
+int ms_tilt_energy_and_gradient(ms_ctx* c, double* energy, double* tilt_grad) {
+  if (!c || !energy) return fail(c, MS_ERR_INVALID, "ms_tilt_energy_and_gradient: NULL argument");
+  if (!(c->params.modules & MS_TILT_MODS) || !c->tf[0].tilts)
+    return fail(c, MS_ERR_STATE, "ms_tilt_energy_and_gradient: no tilt-reading module / no tilts set");
+  if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "tilt passes are single-shard only");
+  int rc = ensure_bt_record(c);
+  if (rc) return rc;
+  rc = tilt_eval(c, false, true);
+  if (rc) return rc;
+  rc = fetch(c);
+  if (rc) return rc;
+  *energy = tilt_energy_from_mailbox(c);
+  if (tilt_grad) return patch_to_ext(c, c->tf[0].grad, tilt_grad, 3);
+  return MS_OK;
+}
+
+int ms_relax_tilts(ms_ctx* c, const ms_tilt_relax_params* rp, int* iters_out, int* evals_out) {
+  if (!c || !rp) return fail(c, MS_ERR_INVALID, "ms_relax_tilts: NULL argument");
+  if (iters_out) *iters_out = 0;
+  if (evals_out) *evals_out = 0;
+  const uint32_t mods = c->params.modules;
+  if (!(mods & MS_TILT_MODS) || !c->tf[0].tilts)
+    return fail(c, MS_ERR_STATE, "ms_relax_tilts: no tilt-reading module / no tilts set");
+  if (mods & MS_LEAFLET_MODS)
+    return fail(c, MS_ERR_STATE, "ms_relax_tilts: leaflet modules are active, use ms_relax_leaflet_tilts");
+  if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "tilt passes are single-shard only");
+  if (rp->step_size <= 0.0 || rp->max_iters <= 0) return MS_OK;
+  TiltField* fl[1] = {&c->tf[0]};
+  return relax_fields(c, rp, fl, 1, /*jacobi_smooth_by_param=*/false, iters_out, evals_out);
+}
+
+// ---- two-leaflet tilt fields ---------------------------------------------------------------
+int ms_set_leaflet_tilts(ms_ctx* c, int leaflet, const double* tilts, const uint8_t* tilt_fixed,
+                         const ms_leaflet_params* lp) {
+  if (!c || !tilts || !lp) return fail(c, MS_ERR_INVALID, "ms_set_leaflet_tilts: NULL argument");
+  if (leaflet != MS_LEAFLET_IN && leaflet != MS_LEAFLET_OUT)
+    return fail(c, MS_ERR_INVALID, "ms_set_leaflet_tilts: leaflet must be MS_LEAFLET_IN or MS_LEAFLET_OUT");
+  TiltField& f = c->tf[1 + leaflet];
+  const Tiling& t = c->til;
+  const size_t bytes = sizeof(double) * 3 * (size_t)t.nvp;
+  if (!f.tilts) {
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&f.tilts), bytes));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&f.grad), bytes));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&f.trial), bytes));
+    HIPCHK(c, hipMemset(f.tilts, 0, bytes));
+    HIPCHK(c, hipMemset(f.grad, 0, bytes));
+    HIPCHK(c, hipMemset(f.trial, 0, bytes));
+  }
+  f.k_tilt = lp->tilt_modulus;
+  f.consistent = lp->tilt_mass_consistent ? 1 : 0;
+  f.k_smooth = lp->smoothness;
+  f.k_smooth_precond = lp->precond_smoothness;
+  bool flags_changed = false;
+  for (int i = 0; i < t.nv; ++i) {
+    uint8_t fl = c->h_vflags[(size_t)i] & (uint8_t)~f.fixed_bit;
+    if (tilt_fixed && tilt_fixed[t.perm[i]]) fl |= f.fixed_bit;
+    flags_changed = flags_changed || fl != c->h_vflags[(size_t)i];
+    c->h_vflags[(size_t)i] = fl;
+  }
+  if (flags_changed) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(c->d_vflags, c->h_vflags.data(), c->h_vflags.size(), hipMemcpyHostToDevice));
+  }
+  c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
+  c->sh_carry_valid = c->sh_grad_valid = false;
+  return ext_to_patch(c, tilts, f.tilts, 3);
+}
+
+int ms_get_leaflet_tilts(ms_ctx* c, int leaflet, double* tilts) {
+  if (!c || !tilts || (leaflet != MS_LEAFLET_IN && leaflet != MS_LEAFLET_OUT) || !c->tf[1 + leaflet].tilts)
+    return fail(c, MS_ERR_INVALID, "ms_get_leaflet_tilts: bad leaflet / no tilts set");
+  return patch_to_ext(c, c->tf[1 + leaflet].tilts, tilts, 3);
+}
+
+namespace {
+int leaflet_ready(ms_ctx* c, const char* who, TiltField** fl, int* nf) {
+  const uint32_t mods = c->params.modules;
+  if (!(mods & MS_LEAFLET_MODS)) return fail(c, MS_ERR_STATE, std::string(who) + ": no leaflet module is active");
+  if (mods & MS_TILT_MODS)
+    return fail(c, MS_ERR_STATE, std::string(who) + ": single-field and leaflet tilt modules together are outside the device path");
+  if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "tilt passes are single-shard only");
+  *nf = 0;
+  for (int l = 1; l <= 2; ++l) {
+    TiltField& f = c->tf[l];
+    if (!(mods & (f.mod_tilt | f.mod_smooth))) continue;
+    if (!f.tilts) return fail(c, MS_ERR_STATE, std::string(who) + ": ms_set_leaflet_tilts was not called for an active leaflet");
+    fl[(*nf)++] = &f;
+  }
+  return MS_OK;
+}
+}  // namespace
+
+int ms_leaflet_tilt_energy_and_gradient(ms_ctx* c, double* energy, double* grad_in, double* grad_out) {
+  if (!c || !energy) return fail(c, MS_ERR_INVALID, "ms_leaflet_tilt_energy_and_gradient: NULL argument");
+  TiltField* fl[2];
+  int nf = 0;
+  int rc = leaflet_ready(c, "ms_leaflet_tilt_energy_and_gradient", fl, &nf);
+  if (rc) return rc;
+  rc = tilt_eval(c, false, true);
+  if (rc) return rc;
+  rc = fetch(c);
+  if (rc) return rc;
+  *energy = tilt_energy_from_mailbox(c);
+  double* outs[2] = {grad_in, grad_out};
+  for (int l = 0; l < 2; ++l) {
+    if (!outs[l]) continue;
+    TiltField& f = c->tf[1 + l];
+    if (f.tilts && (c->params.modules & (f.mod_tilt | f.mod_smooth))) {
+      rc = patch_to_ext(c, f.grad, outs[l], 3);
+      if (rc) return rc;
+    } else {
+      memset(outs[l], 0, sizeof(double) * 3 * (size_t)c->til.nv);
+    }
+  }
+  return MS_OK;
+}
+
+int ms_relax_leaflet_tilts(ms_ctx* c, const ms_tilt_relax_params* rp, int* iters_out, int* evals_out) {
+  if (!c || !rp) return fail(c, MS_ERR_INVALID, "ms_relax_leaflet_tilts: NULL argument");
+  if (iters_out) *iters_out = 0;
+  if (evals_out) *evals_out = 0;
+  TiltField* fl[2];
+  int nf = 0;
+  int rc = leaflet_ready(c, "ms_relax_leaflet_tilts", fl, &nf);
+  if (rc) return rc;
+  if (rp->step_size <= 0.0 || rp->max_iters <= 0) return MS_OK;
+  return relax_fields(c, rp, fl, nf, /*jacobi_smooth_by_param=*/true, iters_out, evals_out);
 }
 
 int ms_set_positions(ms_ctx* c, const double* positions) {
@@ -1086,12 +1336,14 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   const int restart = sp->restart_interval > 0 ? sp->restart_interval : 10;
   // conjugate_gradient.py:78-82: steepest descent on first call and every restart
   const bool use_history = cg && c->cg_have_history && (c->cg_iter_count % restart != 0);
-  const bool tilt = (c->params.modules & MS_TILT_MODS) != 0;
+  const bool tilt = (c->params.modules & MS_ANY_TILT_MODS) != 0;
+  TiltField* tfl[3];
+  const int n_tf = active_fields(c, c->params.modules, tfl);
   // reuse_energy0 == 2: an accepted trial doubles as the next step's energy/factor pass
   const bool carry_mode = sp->reuse_energy0 >= 2 && !tilt;
   const bool carried = carry_mode && c->carry_valid &&
                        (c->factors_valid || !(c->params.modules & (MS_MOD_BENDING | MS_MOD_BENDING_TILT)));
-  const bool constraint = (c->params.modules & (MS_CON_VOLUME | MS_MOD_TILT)) != 0;
+  const bool constraint = (c->params.modules & (MS_CON_VOLUME | MS_TILT_SHAPE_MODS)) != 0;
   int rc;
   bool restart_sd = false;
   if (carried && c->grad_valid && !constraint && c->til.T <= 256) {
@@ -1145,8 +1397,8 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   // ---- backtracking_line_search_array (line_search.py:267-426) -------------
   double energy0 = E_eval;
   double min_edge = std::sqrt(c->h_scal[MS_S_MINEDGE2]);
-  if (tilt) {  // energy_fn projects the stored tilts first (minimizer.py:581-588)
-    rc = tilt_pass(c, 2, false, 0.0);
+  for (int k = 0; k < n_tf; ++k) {  // energy_fn projects the stored tilts first (minimizer.py:581-588)
+    rc = tilt_pass_f(c, *tfl[k], 2, false, 0.0);
     if (rc) return rc;
   }
   if (!sp->reuse_energy0 || tilt) {
@@ -1191,7 +1443,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       c->grad_valid = false;
       // minimizer.py:1415 re-projects the stored tilts onto the accepted surface: that is
       // exactly the trial projection computed above
-      if (tilt) std::swap(c->d_tilts, c->d_tilts_trial);
+      for (int k = 0; k < n_tf; ++k) std::swap(tfl[k]->tilts, tfl[k]->trial);
       c->bt_valid = (c->params.modules & MS_MOD_BENDING_TILT) != 0;  // the trial's record is x's now
       if (cg) {  // conjugate_gradient.py:114-117 history on success only
         std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
@@ -1209,7 +1461,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     }
     // a rejected trial restores the positions, not the tilts: energy_fn stored their projection
     // onto the trial surface (line_search.py:456-487 without an enforcer)
-    if (tilt) std::swap(c->d_tilts, c->d_tilts_trial);
+    for (int k = 0; k < n_tf; ++k) std::swap(tfl[k]->tilts, tfl[k]->trial);
     alpha *= sp->beta;
     if (alpha < 1e-8) break;
   }
@@ -1258,7 +1510,8 @@ int ms_minimize(ms_ctx* c, const ms_minimize_params* mp, int n_steps, ms_minimiz
   for (int i = 0; i < n_steps; ++i) {
     int rc;
     if (mp->relax_tilts) {  // minimizer.py:1237-1307: before the convergence check
-      rc = ms_relax_tilts(c, &mp->relax, nullptr, nullptr);
+      rc = (c->params.modules & MS_LEAFLET_MODS) ? ms_relax_leaflet_tilts(c, &mp->relax, nullptr, nullptr)
+                                                  : ms_relax_tilts(c, &mp->relax, nullptr, nullptr);
       if (rc) return rc;
       out->moved = 1;
     }
@@ -1330,7 +1583,7 @@ int ms_minimize(ms_ctx* c, const ms_minimize_params* mp, int n_steps, ms_minimiz
 int ms_phase_energy(ms_ctx* c, int use_direction, double alpha, int write_trial, int guard,
                     int write_bending_factors) {
   if (!c) return MS_ERR_INVALID;
-  if ((c->params.modules & MS_MOD_TILT) && c->shard_count != 1)
+  if ((c->params.modules & MS_ANY_TILT_MODS) && c->shard_count != 1)
     return fail(c, MS_ERR_STATE, "the tilt module is not sharded yet (single GPU only)");
   return phase_energy(c, c->params.modules, use_direction != 0, alpha, write_trial != 0, guard != 0,
                       write_bending_factors != 0);
@@ -1387,7 +1640,7 @@ int ms_phase_commit_trial(ms_ctx* c, double alpha, int keep_history) {
 
 int ms_phase_gradient_direction(ms_ctx* c, int stepper, int use_history) {
   if (!c) return MS_ERR_INVALID;
-  if (c->params.modules & (MS_CON_VOLUME | MS_MOD_TILT))
+  if (c->params.modules & (MS_CON_VOLUME | MS_TILT_SHAPE_MODS))
     return fail(c, MS_ERR_STATE, "fused gradient+direction needs no constraint row and no tilt module");
   c->grad_valid = false;
   const int dir_mode = (stepper == MS_STEPPER_CG && use_history) ? 2 : 1;
@@ -1640,7 +1893,7 @@ int64_t ms_shard_exchange_count(const ms_ctx* c) { return c ? (int64_t)c->sh_exc
 int ms_shard_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol, ms_step_result* out) {
   if (!c || !sp || !out) return fail(c, MS_ERR_INVALID, "ms_shard_step: NULL argument");
   const uint32_t mods = c->params.modules;
-  if (mods & MS_TILT_MODS) return fail(c, MS_ERR_STATE, "the tilt modules are not sharded yet (single GPU only)");
+  if (mods & MS_ANY_TILT_MODS) return fail(c, MS_ERR_STATE, "the tilt modules are not sharded yet (single GPU only)");
   memset(out, 0, sizeof(*out));
   const bool cg = sp->stepper == MS_STEPPER_CG;
   const int restart = sp->restart_interval > 0 ? sp->restart_interval : 10;

@@ -27,6 +27,8 @@ constexpr uint16_t TF_BODY = 2;
 constexpr uint8_t VF_FIXED = 1;
 constexpr uint8_t VF_BOUNDARY = 2;
 constexpr uint8_t VF_TILT_FIXED = 4;  // vertex.tilt_fixed (runtime/minimizer_helpers.py:49-75)
+constexpr uint8_t VF_TILT_FIXED_IN = 8;    // vertex.tilt_fixed_in  (minimizer.py:460-472)
+constexpr uint8_t VF_TILT_FIXED_OUT = 16;  // vertex.tilt_fixed_out (minimizer.py:474-486)
 
 // Host-side result of the tiling pass.
 struct Tiling {
@@ -129,6 +131,8 @@ struct TiltArgs {
   double* tilt_grad;      // mode 1: k_t t_v A_v (written)
   double* minv;           // mode 3: Jacobi preconditioner 1/(k_t A_v) (normals go to tilts_out)
   double* partials;
+  int e_slot;             // reduction slot of the energy partial (MS_S_ETILT / _IN / _OUT)
+  int consistent;         // tilt_leaflet.py:101-114: consistent P1 mass coeff (energy / shape gradient)
 };
 
 struct BtArgs {
@@ -156,6 +160,7 @@ struct TsArgs {
   double* tilt_grad;       // mode 1: dE/dt ADDED here
   double* diag;            // mode 2: Jacobi diagonal 1/2 k_s sum (c_a + c_b) ADDED here
   double* partials;
+  int e_slot;              // reduction slot of the energy partial (MS_S_ETS / _IN / _OUT)
 };
 
 // kernel launchers (ms_kernels.hip).  cap = T + max halo (LDS patch slots),
@@ -165,7 +170,7 @@ size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow, b
 hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, hipStream_t s);
 hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStream_t s);
 // mode 0: energy partial (MS_S_ETILT); 1: energy + gradients; 2: project tilts to tangent
-size_t tilt_lds_bytes(int T, int cap, int max_ent);
+size_t tilt_lds_bytes(int T, int cap, int max_ent, bool consistent = false);
 hipError_t launch_tilt(const TiltArgs& a, int mode, int cap, int max_ent, hipStream_t s);
 // bending_tilt facet pass.  mode 0: energy (MS_S_EBT); 1: energy + back-prop factors;
 // 2: energy + tilt gradient
@@ -177,7 +182,8 @@ hipError_t launch_ts(const TsArgs& a, int mode, int cap, int max_ent, hipStream_
 hipError_t launch_tvec(int mode, int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* tg,
                        const double* minv, double* dir, const double* tilts, const double* src,
                        const double* normals, double* out, double coef, int flag, double* partials,
-                       int n_tiles, hipStream_t s);
+                       int n_tiles, hipStream_t s, uint8_t fixed_bit = VF_TILT_FIXED,
+                       int s_gn2 = MS_S_TGNORM2, int s_rz = MS_S_TRZ);
 hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
                          uint32_t slot_mask, double* scal, double* host_mirror,
                          unsigned long long* host_seq, unsigned long long ticket, hipStream_t s);

@@ -1143,7 +1143,9 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
   const int T = a.m.T;
   double* px = lds;
   double* tq = px + 3 * cap;
-  double* stg = tq + cap;
+  double* tl = tq + cap;  // consistent mass only: the tilt vectors themselves
+  const bool cons = (MODE == 0 || MODE == 1) && a.consistent;
+  double* stg = tl + (cons ? 3 * cap : 0);
   double* red = stg + 10 * T;
   uint16_t* voff = reinterpret_cast<uint16_t*>(red + 16);
   uint16_t* vent = voff + (T + 2);
@@ -1164,6 +1166,11 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
     }
     tv = mk(a.tilts[g], a.tilts[g + 1], a.tilts[g + 2]);
     tq[tid] = dot(tv, tv);
+    if (cons) {
+      tl[tid] = tv.x;
+      tl[cap + tid] = tv.y;
+      tl[2 * cap + tid] = tv.z;
+    }
   }
   for (int h = tid; h < t.nh; h += T) {
     const int v = a.m.halo_ids[t.h0 + h];
@@ -1177,6 +1184,11 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
     }
     const V3 th = mk(a.tilts[g], a.tilts[g + 1], a.tilts[g + 2]);
     tq[sl] = dot(th, th);
+    if (cons) {
+      tl[sl] = th.x;
+      tl[cap + sl] = th.y;
+      tl[2 * cap + sl] = th.z;
+    }
   }
   if (MODE != 0) {  // (modes 1-3 gather per vertex)
     const uint16_t* gv = a.m.tile_voff + (size_t)t.tile * (T + 1);
@@ -1213,7 +1225,12 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
         double a3 = 0.0;
         if (A2 >= 1.0e-12) {
           const double area = 0.5 * A2;
-          const double coeff = 0.5 * a.k_tilt * (((tq[tf.l0] + tq[tf.l1]) + tq[tf.l2]) / 3.0);
+          const double sq = (tq[tf.l0] + tq[tf.l1]) + tq[tf.l2];
+          double coeff = 0.5 * a.k_tilt * (sq / 3.0);
+          if (cons) {  // tilt_leaflet.py:91-114: (k/12)(sum |t|^2 + t0.t1 + t1.t2 + t2.t0)
+            const V3 t0 = lds_v3(tl, cap, tf.l0), t1 = lds_v3(tl, cap, tf.l1), t2 = lds_v3(tl, cap, tf.l2);
+            coeff = (a.k_tilt / 12.0) * (((sq + dot(t0, t1)) + dot(t1, t2)) + dot(t2, t0));
+          }
           if (tf.flags & TF_OWNER) e_tilt += coeff * area;
           if (MODE == 1) {
             const double hs = 0.5 * coeff / A2;
@@ -1290,19 +1307,20 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
   if (MODE != 2 && MODE != 3) {
     const double vals[1] = {e_tilt};
     const int ops[1] = {0};
-    const int slots[1] = {MS_S_ETILT};
+    const int slots[1] = {a.e_slot};
     block_reduce_store<1>(vals, ops, slots, red, a.partials + t.tile, (size_t)a.m.n_tiles);
   }
 }
 
-size_t tilt_lds_bytes(int T, int cap, int max_ent) {
-  return (4 * (size_t)cap + 10 * (size_t)T + 16) * sizeof(double) + 2 * ((size_t)T + 2 + max_ent + 8);
+size_t tilt_lds_bytes(int T, int cap, int max_ent, bool consistent) {
+  return ((consistent ? 7 : 4) * (size_t)cap + 10 * (size_t)T + 16) * sizeof(double) +
+         2 * ((size_t)T + 2 + max_ent + 8);
 }
 
 hipError_t launch_tilt(const TiltArgs& a, int mode, int cap, int max_ent, hipStream_t s) {
   const int nb = a.tile1 - a.tile0;
   if (nb <= 0) return hipSuccess;
-  const size_t lds = tilt_lds_bytes(a.m.T, cap, max_ent);
+  const size_t lds = tilt_lds_bytes(a.m.T, cap, max_ent, (mode == 0 || mode == 1) && a.consistent);
   hipError_t e;
 #define MS_LAUNCH_T(M)                                                                  \
   do {                                                                                  \
@@ -1687,7 +1705,7 @@ __global__ __launch_bounds__(512) void k_tsmooth(TsArgs a, int cap, int max_ent)
     if (MODE != 0) __syncthreads();  // red aliases the staging block
     const double vals[1] = {e_ts};
     const int ops[1] = {0};
-    const int slots[1] = {MS_S_ETS};
+    const int slots[1] = {a.e_slot};
     block_reduce_store<1>(vals, ops, slots, red, a.partials + t.tile, (size_t)a.m.n_tiles);
   }
 }
@@ -1725,7 +1743,8 @@ __global__ __launch_bounds__(BLOCK) void k_tvec(int mode, int tile0, int nv, int
                                                 double* tg, const double* minv, double* dir,
                                                 const double* tilts, const double* src,
                                                 const double* normals, double* out, double coef,
-                                                int flag, double* partials, int n_tiles) {
+                                                int flag, double* partials, int n_tiles,
+                                                uint8_t fixed_bit, int s_gn2, int s_rz) {
   __shared__ double red[16];
   const int tile = tile0 + blockIdx.x;
   double s0 = 0.0, s1 = 0.0;
@@ -1733,7 +1752,7 @@ __global__ __launch_bounds__(BLOCK) void k_tvec(int mode, int tile0, int nv, int
     const int v = tile * T + i;
     if (v >= nv) break;
     const size_t o = 3 * (size_t)v;
-    const bool tfix = vflags[v] & VF_TILT_FIXED;
+    const bool tfix = vflags[v] & fixed_bit;
     if (mode == 3) {
       // Jacobi preconditioner from the accumulated diagonal: 1 where <= 1e-12 and on tilt-fixed
       // rows (runtime/preconditioners.py:57-59)
@@ -1779,19 +1798,19 @@ __global__ __launch_bounds__(BLOCK) void k_tvec(int mode, int tile0, int nv, int
     double* po = partials + tile;
     const size_t ps = (size_t)n_tiles;
     double r = block_reduce(s0, 0, red);
-    if (threadIdx.x == 0) po[MS_S_TGNORM2 * ps] = r;
+    if (threadIdx.x == 0) po[s_gn2 * ps] = r;
     r = block_reduce(s1, 0, red);
-    if (threadIdx.x == 0) po[MS_S_TRZ * ps] = r;
+    if (threadIdx.x == 0) po[s_rz * ps] = r;
   }
 }
 
 hipError_t launch_tvec(int mode, int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* tg,
                        const double* minv, double* dir, const double* tilts, const double* src,
                        const double* normals, double* out, double coef, int flag, double* partials,
-                       int n_tiles, hipStream_t s) {
+                       int n_tiles, hipStream_t s, uint8_t fixed_bit, int s_gn2, int s_rz) {
   if (tile1 <= tile0) return hipSuccess;
   hipLaunchKernelGGL(k_tvec, dim3(tile1 - tile0), dim3(BLOCK), 0, s, mode, tile0, nv, T, vflags, tg, minv,
-                     dir, tilts, src, normals, out, coef, flag, partials, n_tiles);
+                     dir, tilts, src, normals, out, coef, flag, partials, n_tiles, fixed_bit, s_gn2, s_rz);
   return hipGetLastError();
 }
 

@@ -188,6 +188,53 @@ class DeviceMesh:
                   "ms_relax_tilts")
         return int(it.value), int(ev.value)
 
+    # -- two-leaflet tilt fields (tilts_in / tilts_out) ----------------------------
+    def set_leaflet_tilts(self, leaflet: str, tilts, *, tilt_fixed=None, tilt_modulus: float = 0.0,
+                          mass_mode: str = "lumped", smoothness: float = 0.0,
+                          precond_smoothness: float | None = None):
+        """Mesh.tilts_in_view()/tilts_out_view() + the leaflet's module parameters."""
+        lf = {"in": L.MS_LEAFLET_IN, "out": L.MS_LEAFLET_OUT}[leaflet]
+        arr = _f64(tilts, (self.nv, 3), f"tilts_{leaflet}")
+        if tilt_fixed is None:
+            ptr = None
+        else:
+            fx = np.ascontiguousarray(np.asarray(tilt_fixed, dtype=bool).astype(np.uint8))
+            if fx.shape != (self.nv,):
+                raise ValueError("tilt_fixed must have shape (nv,)")
+            ptr = fx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+        if mass_mode not in ("lumped", "consistent"):
+            raise ValueError(f"tilt_mass_mode_{leaflet} must be 'lumped' or 'consistent'.")
+        lp = L.ms_leaflet_params(float(tilt_modulus), 1 if mass_mode == "consistent" else 0, float(smoothness),
+                                 float(smoothness if precond_smoothness is None else precond_smoothness))
+        self._chk(L.lib().ms_set_leaflet_tilts(self._h, lf, _pd(arr), ptr, ctypes.byref(lp)), "ms_set_leaflet_tilts")
+
+    def get_leaflet_tilts(self, leaflet: str) -> np.ndarray:
+        out = np.empty((self.nv, 3), dtype=np.float64)
+        lf = {"in": L.MS_LEAFLET_IN, "out": L.MS_LEAFLET_OUT}[leaflet]
+        self._chk(L.lib().ms_get_leaflet_tilts(self._h, lf, _pd(out)), "ms_get_leaflet_tilts")
+        return out
+
+    def leaflet_tilt_energy_and_gradient(self, want_gradient: bool = True):
+        """-> (tilt-dependent energy, dE/dt_in, dE/dt_out) at frozen positions, magnitude modules
+        in their vertex-area form (evaluation_manager.py:630-742 with tilt_vertex_areas)."""
+        e = ctypes.c_double(0.0)
+        gi = np.empty((self.nv, 3), dtype=np.float64) if want_gradient else None
+        go = np.empty((self.nv, 3), dtype=np.float64) if want_gradient else None
+        self._chk(L.lib().ms_leaflet_tilt_energy_and_gradient(self._h, ctypes.byref(e), _pd(gi) if want_gradient else None,
+                                                              _pd(go) if want_gradient else None),
+                  "ms_leaflet_tilt_energy_and_gradient")
+        return float(e.value), gi, go
+
+    def relax_leaflet_tilts(self, *, solver: str = "cg", max_iters: int, step_size: float, tol: float = 0.0,
+                            jacobi: bool = True):
+        """TiltRelaxationManager.relax_leaflet_tilts on the device -> (iterations, energy evaluations)."""
+        rp = L.ms_tilt_relax_params(1 if solver == "cg" else 0, int(max_iters), float(step_size), float(tol),
+                                    1 if jacobi else 0)
+        it, ev = ctypes.c_int(0), ctypes.c_int(0)
+        self._chk(L.lib().ms_relax_leaflet_tilts(self._h, ctypes.byref(rp), ctypes.byref(it), ctypes.byref(ev)),
+                  "ms_relax_leaflet_tilts")
+        return int(it.value), int(ev.value)
+
     def project_tilts_to_tangent(self):
         self._chk(L.lib().ms_project_tilts_to_tangent(self._h), "ms_project_tilts_to_tangent")
 

@@ -38,7 +38,8 @@ class ArrayBody:
 class ArrayMesh:
     def __init__(self, positions, tri_rows, *, fixed=None, surface_tension=None,
                  bending_modulus=None, spontaneous_curvature=None, bodies=None, tilts=None,
-                 tilt_fixed=None, global_parameters=None, energy_modules=None, constraint_modules=None):
+                 tilt_fixed=None, global_parameters=None, energy_modules=None, constraint_modules=None,
+                 tilts_in=None, tilts_out=None, tilt_fixed_in=None, tilt_fixed_out=None):
         self._positions = np.array(positions, dtype=np.float64, order="C", copy=True)
         self._tri_rows = np.ascontiguousarray(tri_rows, dtype=np.int32)
         nv, nf = self._positions.shape[0], self._tri_rows.shape[0]
@@ -75,6 +76,15 @@ class ArrayMesh:
         self._tilts_version = 0
         self.tilt_fixed = (np.zeros(nv, dtype=bool) if tilt_fixed is None
                            else np.asarray(tilt_fixed, dtype=bool).copy())
+        # two-leaflet tilt fields (geometry/mesh.py:427-470 of the reference: zeros until set)
+        self._tilts_in = (np.zeros_like(self._positions) if tilts_in is None
+                          else np.array(tilts_in, dtype=np.float64, order="C", copy=True))
+        self._tilts_out = (np.zeros_like(self._positions) if tilts_out is None
+                           else np.array(tilts_out, dtype=np.float64, order="C", copy=True))
+        self.tilt_fixed_in = (np.zeros(nv, dtype=bool) if tilt_fixed_in is None
+                              else np.asarray(tilt_fixed_in, dtype=bool).copy())
+        self.tilt_fixed_out = (np.zeros(nv, dtype=bool) if tilt_fixed_out is None
+                               else np.asarray(tilt_fixed_out, dtype=bool).copy())
         self._version = 0
         self._facet_loops_version = 0
         self._vertex_ids_version = 0
@@ -145,6 +155,10 @@ class ArrayMesh:
         self._tilts = (np.zeros_like(self._positions) if tilts is None
                        else np.array(tilts, dtype=np.float64, order="C", copy=True))
         self.tilt_fixed = np.zeros(nv, dtype=bool)
+        self._tilts_in = np.zeros_like(self._positions)
+        self._tilts_out = np.zeros_like(self._positions)
+        self.tilt_fixed_in = np.zeros(nv, dtype=bool)
+        self.tilt_fixed_out = np.zeros(nv, dtype=bool)
         self._tilts_version += 1
         self._version += 1
         self._facet_loops_version += 1
@@ -157,6 +171,21 @@ class ArrayMesh:
 
     def set_tilts_from_array(self, tilts) -> None:
         self._tilts[...] = tilts
+        self._tilts_version += 1
+
+    # leaflet tilt fields (geometry/mesh.py:427-470, :534-577 of the reference)
+    def tilts_in_view(self) -> np.ndarray:
+        return self._tilts_in
+
+    def tilts_out_view(self) -> np.ndarray:
+        return self._tilts_out
+
+    def set_tilts_in_from_array(self, tilts) -> None:
+        self._tilts_in[...] = tilts
+        self._tilts_version += 1
+
+    def set_tilts_out_from_array(self, tilts) -> None:
+        self._tilts_out[...] = tilts
         self._tilts_version += 1
 
     def compute_total_surface_area(self) -> float:
@@ -257,6 +286,7 @@ class HipMirror:
         self._pos_version = None
         self._gamma_key = None
         self._bend_key = None
+        self._leaflet_keys = {}
         self.body = None
 
     def _topology_key(self):
@@ -315,6 +345,24 @@ class HipMirror:
             self.dm.set_tilts(tilts, k_t)
             self._tilt_key = key
 
+    def upload_leaflets(self, params: dict):
+        """Mesh.tilts_in_view()/tilts_out_view(), the tilt_fixed_in/out flags and the per-leaflet module
+        parameters (``params[leaflet]`` = kwargs of DeviceMesh.set_leaflet_tilts)."""
+        for lf in ("in", "out"):
+            view = getattr(self.mesh, f"tilts_{lf}_view", None)
+            tilts = (np.zeros((len(self.mesh.vertex_ids), 3)) if view is None
+                     else np.ascontiguousarray(view(), dtype=np.float64))
+            mask = tilt_fixed_mask(self.mesh, f"tilt_fixed_{lf}")
+            key = (self._topo_key, getattr(self.mesh, "_tilts_version", None), tuple(sorted(params[lf].items())),
+                   mask.tobytes(), None if hasattr(self.mesh, "_tilts_version") else float(np.sum(tilts)))
+            if key != self._leaflet_keys.get(lf):
+                self.dm.set_leaflet_tilts(lf, tilts, tilt_fixed=mask if mask.any() else None, **params[lf])
+                self._leaflet_keys[lf] = key
+
+    def mark_device_leaflets_current(self):
+        for lf, key in list(self._leaflet_keys.items()):
+            self._leaflet_keys[lf] = (key[0], getattr(self.mesh, "_tilts_version", None)) + key[2:4] + (None,)
+
     def upload_tilt_fixed(self):
         """vertex.tilt_fixed flags (runtime/minimizer_helpers.py:49-75)."""
         mask = tilt_fixed_mask(self.mesh)
@@ -335,15 +383,16 @@ class HipMirror:
             self._bend_key = key
 
 
-def tilt_fixed_mask(mesh) -> np.ndarray:
-    """(nv,) bool: ArrayMesh.tilt_fixed, or the reference Mesh's per-vertex ``tilt_fixed`` attribute."""
-    own = getattr(mesh, "tilt_fixed", None)
+def tilt_fixed_mask(mesh, attr: str = "tilt_fixed") -> np.ndarray:
+    """(nv,) bool: ArrayMesh.tilt_fixed[_in|_out], or the reference Mesh's per-vertex attribute of that
+    name (runtime/minimizer_helpers.py:49-75, minimizer.py:460-486)."""
+    own = getattr(mesh, attr, None)
     if own is not None and not callable(own):
         return np.asarray(own, dtype=bool)
     verts = getattr(mesh, "vertices", None)
     ids = getattr(mesh, "vertex_ids", None)
     if verts is not None and ids is not None and isinstance(verts, dict):
-        return np.array([bool(getattr(verts[int(v)], "tilt_fixed", False)) for v in ids], dtype=bool)
+        return np.array([bool(getattr(verts[int(v)], attr, False)) for v in ids], dtype=bool)
     return np.zeros(len(mesh.positions_view()), dtype=bool)
 
 

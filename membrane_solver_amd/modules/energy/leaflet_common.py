@@ -1,0 +1,133 @@
+"""Shared pieces of the two-leaflet tilt plugins (tilt_in, tilt_out, tilt_smoothness_in, tilt_smoothness_out).
+
+Parameter resolution follows the reference's helpers (modules/energy/tilt_params.py:6-23,
+modules/energy/tilt_smoothness_utils.py:95-100, runtime/preconditioners.py:111-120); the toggles the
+device path does not implement raise ``MembraneHipError`` instead of being ignored.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from ... import _lib as L
+from ...geometry.mesh import mirror_for
+
+LEAFLET_BITS = {("tilt", "in"): L.MS_MOD_TILT_IN, ("tilt", "out"): L.MS_MOD_TILT_OUT,
+                ("smooth", "in"): L.MS_MOD_TILT_SMOOTH_IN, ("smooth", "out"): L.MS_MOD_TILT_SMOOTH_OUT}
+
+# options of the reference's leaflet modules that change their result and are not on the device path
+_UNSUPPORTED_KEYS = (
+    "leaflet_out_absent_presets", "leaflet_in_absent_presets",  # leaflet_presence.py
+    "tilt_in_exclude_shared_rim_outer_rows", "tilt_out_exclude_shared_rim_outer_rows",
+    "tilt_exclude_shared_rim_outer_rows_in", "tilt_exclude_shared_rim_outer_rows_out",
+    "tilt_out_exclude_shared_rim_rows", "tilt_exclude_shared_rim_rows_out",
+    "tilt_in_shared_rim_outer_shell_mass_mode", "tilt_out_shared_rim_outer_shell_mass_mode",
+    "tilt_axisymmetric_about_thetaB_center", "inner_coupled_update_mode", "tilt_relax_energy_guard_factor",
+    "tilt_thetaB_optimize",
+)
+
+
+def _get(param_resolver, global_params, key):
+    val = param_resolver.get(None, key) if param_resolver is not None else None
+    if val is None and global_params is not None:
+        val = global_params.get(key)
+    return val
+
+
+def check_supported(global_params) -> None:
+    for key in _UNSUPPORTED_KEYS:
+        val = global_params.get(key) if global_params is not None else None
+        if val in (None, False, 0, 0.0, "", "off", "none", [], ()):
+            continue
+        raise L.MembraneHipError(f"leaflet tilt option {key}={val!r} is outside the HIP hot path")
+    model = str(global_params.get("tilt_transport_model", "ambient_v1") or "ambient_v1").strip().lower()
+    if model != "ambient_v1":
+        raise L.MembraneHipError("tilt_transport_model other than ambient_v1 is outside the HIP hot path")
+    cadence = str(global_params.get("tilt_projection_cadence", "per_step") or "per_step").strip().lower()
+    if cadence not in {"per_step", "per_pass"}:
+        raise ValueError("tilt_projection_cadence must be 'per_step' or 'per_pass'.")
+    fb = str(global_params.get("tilt_cg_rejection_fallback", "off") or "off").strip().lower()
+    if fb not in {"off", "gd"}:
+        raise ValueError("tilt_cg_rejection_fallback must be 'off' or 'gd'.")
+    if fb == "gd":
+        raise L.MembraneHipError("tilt_cg_rejection_fallback=gd is outside the HIP hot path")
+
+
+def tilt_modulus(param_resolver, global_params, leaflet: str) -> float:
+    k = _get(param_resolver, global_params, f"tilt_modulus_{leaflet}")
+    if k is None:
+        k = _get(param_resolver, global_params, f"tilt_modolus_{leaflet}")  # legacy typo fallback
+    return float(k or 0.0)
+
+
+def tilt_mass_mode(param_resolver, global_params, leaflet: str) -> str:
+    mode = _get(param_resolver, global_params, f"tilt_mass_mode_{leaflet}")
+    if mode is None:
+        mode = _get(param_resolver, global_params, "tilt_mass_mode")
+    txt = str(mode or "lumped").strip().lower()
+    if txt not in {"lumped", "consistent"}:
+        raise ValueError(f"tilt_mass_mode_{leaflet} must be 'lumped' or 'consistent'.")
+    return txt
+
+
+def smoothness_rigidity(param_resolver, global_params, leaflet: str) -> float:
+    k = _get(param_resolver, global_params, f"bending_modulus_{leaflet}")
+    if k is None:
+        k = _get(param_resolver, global_params, "bending_modulus")
+    return float(k or 0.0)
+
+
+def precond_smoothness(param_resolver, global_params, leaflet: str) -> float:
+    """Rigidity in the leaflet Jacobi diagonal: ``get(bending_modulus_<l>) or get(bending_modulus) or 0``."""
+    return float(_get(param_resolver, global_params, f"bending_modulus_{leaflet}")
+                 or _get(param_resolver, global_params, "bending_modulus") or 0.0)
+
+
+def relax_tilt_modulus(param_resolver, global_params, leaflet: str) -> float:
+    """The relaxation's fast path reads ``tilt_modulus_<l>`` only (evaluation_manager.py:566, 674)."""
+    return float(_get(param_resolver, global_params, f"tilt_modulus_{leaflet}") or 0.0)
+
+
+def device_params(param_resolver, global_params, leaflet: str) -> dict:
+    return {"tilt_modulus": tilt_modulus(param_resolver, global_params, leaflet),
+            "mass_mode": tilt_mass_mode(param_resolver, global_params, leaflet),
+            "smoothness": smoothness_rigidity(param_resolver, global_params, leaflet),
+            "precond_smoothness": precond_smoothness(param_resolver, global_params, leaflet)}
+
+
+def evaluate(mesh, global_params, param_resolver, *, kind: str, leaflet: str, positions, tilts, grad_arr,
+             tilt_grad_arr) -> float:
+    """One leaflet module on caller arrays (H2D/D2H per call: the parity seam, not the hot loop)."""
+    check_supported(global_params)
+    tri, _f = mesh.triangle_row_cache()
+    if tri is None or len(tri) == 0:
+        return 0.0
+    nv = len(mesh.vertex_ids)
+    if tilts is None:
+        tilts = mesh.tilts_in_view() if leaflet == "in" else mesh.tilts_out_view()
+    tilts = np.ascontiguousarray(tilts, dtype=np.float64)
+    if tilts.shape != (nv, 3):
+        raise ValueError(f"tilts for leaflet '{leaflet}' must have shape (N_vertices, 3)")
+    if tilt_grad_arr is not None and np.shape(tilt_grad_arr) != (nv, 3):
+        raise ValueError(f"tilt_grad_arr for leaflet '{leaflet}' must have shape (N_vertices, 3)")
+    params = device_params(param_resolver, global_params, leaflet)
+    if kind == "tilt" and tilt_grad_arr is not None and params["mass_mode"] == "consistent":
+        raise L.MembraneHipError("the consistent-mass tilt gradient of tilt_in/tilt_out is outside the HIP hot "
+                                 "path (the relaxation uses the vertex-area form; energy and shape gradient are on it)")
+    mir = mirror_for(mesh)
+    dm = mir.sync(positions=None if positions is mesh.positions_view() else positions)
+    other = "out" if leaflet == "in" else "in"
+    dm.set_leaflet_tilts(leaflet, tilts, **params)
+    dm.set_leaflet_tilts(other, np.zeros((nv, 3)), tilt_modulus=0.0, smoothness=0.0)
+    mir._leaflet_keys = {}  # foreign arrays were uploaded
+    dm.set_params(modules=LEAFLET_BITS[(kind, leaflet)])
+    if grad_arr is not None and kind == "tilt":
+        e, g = dm.energy_and_gradient(want_grad=True)
+        grad_arr += g
+        E = float(e[3])
+    else:
+        E = float(dm.energy()[3])
+    if tilt_grad_arr is not None:
+        _e, gi, go = dm.leaflet_tilt_energy_and_gradient(want_gradient=True)
+        tilt_grad_arr += gi if leaflet == "in" else go
+    return E

@@ -1,0 +1,61 @@
+"""Outer-leaflet tilt magnitude energy plugin on the HIP path.
+
+Drop-in for the reference's modules/energy/tilt_out.py (-> tilt_leaflet.py:26-169).
+    E = sum_f coeff_f A_f,  coeff_f = 1/2 k (sum |t_k|^2)/3 (lumped) or k/12 (sum |t_k|^2 + t0.t1 + t1.t2 + t2.t0)
+(consistent, ``tilt_mass_mode_out``), k = ``tilt_modulus_out``; shape gradient coeff_f dA/dx into ``grad_arr``;
+lumped tilt gradient k t_v A_v into ``tilt_out_grad_arr``.
+"""
+
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+
+from . import leaflet_common as _lc
+
+USES_TILT_LEAFLETS = True
+_LEAFLET = "out"
+_KIND = "tilt"
+
+
+def compute_energy_and_gradient_array(mesh, global_params, param_resolver, *, positions: np.ndarray,
+                                      index_map: Dict[int, int], grad_arr: np.ndarray | None, ctx=None,
+                                      tilts_in: np.ndarray | None = None, tilts_out: np.ndarray | None = None,
+                                      tilt_in_grad_arr: np.ndarray | None = None,
+                                      tilt_out_grad_arr: np.ndarray | None = None) -> float:
+    _ = (index_map, ctx)
+    if _rigidity(param_resolver, global_params) == 0.0:
+        return 0.0
+    return _lc.evaluate(mesh, global_params, param_resolver, kind=_KIND, leaflet=_LEAFLET, positions=positions,
+                        tilts=tilts_in if _LEAFLET == "in" else tilts_out, grad_arr=grad_arr,
+                        tilt_grad_arr=tilt_in_grad_arr if _LEAFLET == "in" else tilt_out_grad_arr)
+
+
+def compute_energy_array(mesh, global_params, param_resolver, *, positions: np.ndarray, index_map: Dict[int, int],
+                         tilts_in: np.ndarray | None = None, tilts_out: np.ndarray | None = None, ctx=None) -> float:
+    return compute_energy_and_gradient_array(mesh, global_params, param_resolver, positions=positions,
+                                             index_map=index_map, grad_arr=None, ctx=ctx, tilts_in=tilts_in,
+                                             tilts_out=tilts_out)
+
+
+def compute_energy_and_gradient(mesh, global_params, param_resolver, *, compute_gradient: bool = True):
+    """Dict API of the reference: (E, shape_grad, tilt_grad)."""
+    positions = mesh.positions_view()
+    g = np.zeros_like(positions)
+    tg = np.zeros_like(positions) if compute_gradient else None
+    kw = {"tilt_in_grad_arr": tg} if _LEAFLET == "in" else {"tilt_out_grad_arr": tg}
+    E = compute_energy_and_gradient_array(mesh, global_params, param_resolver, positions=positions,
+                                          index_map=mesh.vertex_index_to_row, grad_arr=g, **kw)
+    if not compute_gradient:
+        return float(E), {}
+    ids = mesh.vertex_ids
+    return (float(E), {int(v): g[r].copy() for r, v in enumerate(ids)},
+            {int(v): tg[r].copy() for r, v in enumerate(ids)})
+
+
+def _rigidity(param_resolver, global_params) -> float:
+    return _lc.tilt_modulus(param_resolver, global_params, _LEAFLET)
+
+
+__all__ = ["compute_energy_and_gradient", "compute_energy_and_gradient_array", "compute_energy_array"]

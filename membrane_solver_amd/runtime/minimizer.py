@@ -36,6 +36,7 @@ from .. import _lib as L
 from ..core.parameters import ParameterResolver
 from .steppers.base import BaseStepper
 from ..geometry.mesh import mirror_for
+from ..modules.energy import leaflet_common as _lc
 from ..modules.energy._common import bending_gradient_mode, bending_model
 from ..modules.energy.volume import body_penalty_params
 from .steppers.base import write_back_positions
@@ -44,9 +45,18 @@ logger = logging.getLogger("membrane_solver")
 
 _ENERGY_BITS = {"surface": L.MS_MOD_SURFACE, "bending": L.MS_MOD_BENDING, "volume": L.MS_MOD_VOLUME_PENALTY,
                 "tilt": L.MS_MOD_TILT, "bending_tilt": L.MS_MOD_BENDING_TILT,
-                "tilt_smoothness": L.MS_MOD_TILT_SMOOTH}
-_ENERGY_SLOT = {"surface": 0, "bending": 1, "volume": 2, "tilt": 3, "bending_tilt": 1, "tilt_smoothness": 3}
-_TILT_BITS = L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT | L.MS_MOD_TILT_SMOOTH
+                "tilt_smoothness": L.MS_MOD_TILT_SMOOTH,
+                "tilt_in": L.MS_MOD_TILT_IN, "tilt_out": L.MS_MOD_TILT_OUT,
+                "tilt_smoothness_in": L.MS_MOD_TILT_SMOOTH_IN, "tilt_smoothness_out": L.MS_MOD_TILT_SMOOTH_OUT}
+_ENERGY_SLOT = {"surface": 0, "bending": 1, "volume": 2, "tilt": 3, "bending_tilt": 1, "tilt_smoothness": 3,
+                "tilt_in": 3, "tilt_out": 3, "tilt_smoothness_in": 3, "tilt_smoothness_out": 3}
+_SINGLE_TILT_BITS = L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT | L.MS_MOD_TILT_SMOOTH
+_LEAFLET_BITS = L.MS_MOD_TILT_IN | L.MS_MOD_TILT_OUT | L.MS_MOD_TILT_SMOOTH_IN | L.MS_MOD_TILT_SMOOTH_OUT
+_TILT_BITS = _SINGLE_TILT_BITS | _LEAFLET_BITS
+# scalar slot of every module that shares energies[3]
+_TILT_SCALAR = {"tilt": L.MS_S_ETILT, "tilt_smoothness": L.MS_S_ETS, "tilt_in": L.MS_S_ETILT_IN,
+                "tilt_out": L.MS_S_ETILT_OUT, "tilt_smoothness_in": L.MS_S_ETS_IN,
+                "tilt_smoothness_out": L.MS_S_ETS_OUT}
 
 
 class GradientRows:
@@ -137,7 +147,7 @@ class Minimizer:
             if name not in _ENERGY_BITS:
                 raise L.MembraneHipError(
                     f"energy module {name!r} is outside the HIP hot path (surface, bending, volume, tilt, "
-                    "bending_tilt, tilt_smoothness)")
+                    "bending_tilt, tilt_smoothness, tilt_in, tilt_out, tilt_smoothness_in, tilt_smoothness_out)")
         self.constraint_modules = [self.constraint_manager.get_constraint(c)
                                    for c in self.constraint_module_names]
         for name in self.constraint_module_names:
@@ -187,6 +197,12 @@ class Minimizer:
             elif name == "tilt_smoothness":
                 if float(gp.get("tilt_smoothness_rigidity", 0.0) or 0.0) != 0.0:  # tilt_smoothness.py:258-260
                     mods |= L.MS_MOD_TILT_SMOOTH
+            elif name in ("tilt_in", "tilt_out"):
+                if _lc.tilt_modulus(self.param_resolver, gp, name[5:]) != 0.0:  # tilt_leaflet.py:41-43
+                    mods |= _ENERGY_BITS[name]
+            elif name in ("tilt_smoothness_in", "tilt_smoothness_out"):
+                if _lc.smoothness_rigidity(self.param_resolver, gp, name[16:]) != 0.0:  # tilt_smoothness_leaflet.py:32-34
+                    mods |= _ENERGY_BITS[name]
             else:
                 mods |= _ENERGY_BITS[name]
         target = 0.0
@@ -229,7 +245,14 @@ class Minimizer:
             mir.upload_surface_tension()
         if any_bend:
             mir.upload_bending_params(gp, model)
-        if mods & (_TILT_BITS):
+        if (mods & _SINGLE_TILT_BITS) and (mods & _LEAFLET_BITS):
+            raise L.MembraneHipError("single-field and leaflet tilt modules together are outside the HIP hot path")
+        if mods & _LEAFLET_BITS:
+            _lc.check_supported(gp)
+            if gp.get("line_search_reduced_energy", False):
+                raise L.MembraneHipError("line_search_reduced_energy is outside the HIP hot path")
+            mir.upload_leaflets({lf: _lc.device_params(self.param_resolver, gp, lf) for lf in ("in", "out")})
+        if mods & (_SINGLE_TILT_BITS):
             if gp.get("line_search_reduced_energy", False):
                 raise L.MembraneHipError("line_search_reduced_energy (inner tilt relaxation inside every "
                                          "line-search trial, minimizer.py:568-608) is outside the HIP hot path")
@@ -280,10 +303,11 @@ class Minimizer:
         out = {}
         for name in self.energy_module_names:
             out[name] = float(e[_ENERGY_SLOT[name]])
-        if "tilt" in out and "tilt_smoothness" in out:  # the two share slot 3: split via the scalars
+        sharing = [n for n in out if n in _TILT_SCALAR]
+        if len(sharing) > 1:  # they share energies[3]: split via the scalars
             sc = dm.fetch_scalars()
-            out["tilt"] = float(sc[L.MS_S_ETILT]) if dm.modules & L.MS_MOD_TILT else 0.0
-            out["tilt_smoothness"] = float(sc[L.MS_S_ETS]) if dm.modules & L.MS_MOD_TILT_SMOOTH else 0.0
+            for n in sharing:
+                out[n] = float(sc[_TILT_SCALAR[n]]) if dm.modules & _ENERGY_BITS[n] else 0.0
         return out
 
     # -- constraint enforcement (minimizer.py:1103-1188) ---------------------------
@@ -336,8 +360,21 @@ class Minimizer:
         rp = self._tilt_relax_params()
         if rp is None:
             return False
-        dm.relax_tilts(**rp)
+        if dm.modules & _LEAFLET_BITS:
+            dm.relax_leaflet_tilts(**rp)  # minimizer.py:1240-1305 (no energy guard)
+        else:
+            dm.relax_tilts(**rp)
         return True
+
+    def _write_back_tilts(self, dm, mir):
+        """Device tilt fields -> mesh (the reference leaves relaxed / projected tilts on the mesh)."""
+        if dm.modules & _SINGLE_TILT_BITS:
+            self.mesh.set_tilts_from_array(dm.get_tilts())
+            mir.mark_device_tilts_current()
+        if dm.modules & _LEAFLET_BITS:
+            self.mesh.set_tilts_in_from_array(dm.get_leaflet_tilts("in"))
+            self.mesh.set_tilts_out_from_array(dm.get_leaflet_tilts("out"))
+            mir.mark_device_leaflets_current()
 
     def _fast_path_ok(self, callback) -> bool:
         """The whole loop can run inside the library (ms_minimize) when nothing on the Python side
@@ -426,8 +463,7 @@ class Minimizer:
                 if sync_mesh:
                     write_back_positions(self.mesh, dm, mir)
                     if dm.modules & (_TILT_BITS):
-                        self.mesh.set_tilts_from_array(dm.get_tilts())
-                        mir.mark_device_tilts_current()
+                        self._write_back_tilts(dm, mir)
                     self._device_ahead = False
                 else:
                     self._device_ahead = True
@@ -450,8 +486,7 @@ class Minimizer:
                 if sync_mesh:
                     write_back_positions(self.mesh, dm, mir)
                     if dm.modules & (_TILT_BITS):  # tilts changed on the device
-                        self.mesh.set_tilts_from_array(dm.get_tilts())
-                        mir.mark_device_tilts_current()
+                        self._write_back_tilts(dm, mir)
                     self._device_ahead = False
                 else:
                     self._device_ahead = True

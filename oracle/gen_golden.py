@@ -16,6 +16,7 @@ where the reference's tests compare both (tests/test_fortran_kernels.py).
 from __future__ import annotations
 
 import argparse
+import json
 import os
 import sys
 
@@ -31,6 +32,7 @@ ap.add_argument("--fortran-dir", default="/tmp/fprobe/f2py_try")
 ap.add_argument("--only-tilt", action="store_true")
 ap.add_argument("--only-bt", action="store_true", help="bending_tilt + tilt relaxation vectors only")
 ap.add_argument("--only-ts", action="store_true", help="tilt_smoothness vectors only")
+ap.add_argument("--only-leaflet", action="store_true", help="two-leaflet tilt vectors only")
 args = ap.parse_args()
 
 sys.dont_write_bytecode = True
@@ -643,10 +645,179 @@ def gen_tilt_smoothness():
                         ["surface", "tilt", "tilt_smoothness", "bending_tilt"], GradientDescent(), 5, 8e-2)
 
 
+# ---------------------------------------------------------------------------
+# two-leaflet tilt fields: tilt_in / tilt_out (lumped + consistent mass), tilt_smoothness_in / _out,
+# the leaflet Jacobi preconditioner and relax_leaflet_tilts inside Minimizer.minimize
+# ---------------------------------------------------------------------------
+def _set_leaflet_fields(m, seed, scale, fixed_in_every=0, fixed_out_every=0):
+    rng = np.random.default_rng(seed)
+    tin = _tangent_tilts(m, rng, scale)
+    tout = _tangent_tilts(m, rng, 0.8 * scale)
+    m.set_tilts_in_from_array(tin)
+    m.set_tilts_out_from_array(tout)
+    nv = len(m.vertex_ids)
+    fin, fout = np.zeros(nv, bool), np.zeros(nv, bool)
+    if fixed_in_every:
+        fin[::fixed_in_every] = True
+        for i in np.flatnonzero(fin):
+            m.vertices[int(i)].tilt_fixed_in = True
+    if fixed_out_every:
+        fout[1::fixed_out_every] = True
+        for i in np.flatnonzero(fout):
+            m.vertices[int(i)].tilt_fixed_out = True
+    return tin, tout, fin, fout
+
+
+def run_leaflet_trajectory(fname, P, T, gp, mods, stepper, n_steps, step_size, tilt_scale=0.3, seed=33,
+                           fixed_in_every=0, fixed_out_every=0):
+    mm = build_mesh(P, T, gp)
+    tin, tout, fin, fout = _set_leaflet_fields(mm, seed, tilt_scale, fixed_in_every, fixed_out_every)
+    mm.energy_modules = list(mods)
+    mm.constraint_modules = []
+    em = EnergyModuleManager(mm.energy_modules)
+    cm = ConstraintModuleManager(mm.constraint_modules)
+    mz = Minimizer(mm, mm.global_parameters, stepper, em, cm, quiet=True, step_size=step_size)
+    pos0, tri, isb, fixed = mesh_arrays(mm)
+    log = []
+    orig_step = stepper.step
+
+    # without ``trial_energy_fn``: the mesh-mutating line search, as for the single field
+    # (run_tilt_trajectory) -- one protocol for every tilt family on the device
+    def logged_step(mesh, grad, step_size, energy_fn, constraint_enforcer=None):
+        r = orig_step(mesh, grad, step_size, energy_fn, constraint_enforcer=constraint_enforcer)
+        log.append((float(bool(r[0])), float(r[1]), float(r[2])))
+        return r
+
+    stepper.step = logged_step
+    snaps, tin_snaps, tout_snaps = [], [], []
+
+    def cb(mesh, i):
+        snaps.append(mesh.positions_view().copy())
+        tin_snaps.append(np.ascontiguousarray(mesh.tilts_in_view()).copy())
+        tout_snaps.append(np.ascontiguousarray(mesh.tilts_out_view()).copy())
+
+    E0, g0 = mz.compute_energy_and_gradient_array()
+    res = mz.minimize(n_steps, callback=cb)
+    out = {"meta_fortran": META, "positions0": pos0, "tri": tri, "is_boundary": isb, "fixed": fixed,
+           "tilt_fixed_in": fin, "tilt_fixed_out": fout,
+           "gamma": mm.get_facet_parameter_array("surface_tension").copy(),
+           "E0": np.array(E0), "grad0": np.array(g0), "tilts_in0": tin, "tilts_out0": tout,
+           "positions_iter": np.array(snaps), "tilts_in_iter": np.array(tin_snaps),
+           "tilts_out_iter": np.array(tout_snaps), "positions_final": mm.positions_view().copy(),
+           "tilts_in_final": np.ascontiguousarray(mm.tilts_in_view()).copy(),
+           "tilts_out_final": np.ascontiguousarray(mm.tilts_out_view()).copy(),
+           "step_log": np.array(log), "E_final": np.array(res["energy"]),
+           "n_steps": np.array(n_steps), "step_size0": np.array(step_size),
+           "gp_json": np.array(json.dumps(gp, sort_keys=True)), "modules": np.array(list(mods))}
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, "E_final=%.16g" % out["E_final"], out["step_log"][:, 0])
+
+
+def gen_leaflet():
+    import importlib
+
+    from runtime.preconditioners import build_leaflet_tilt_cg_preconditioner
+
+    out = {"meta_fortran": META}
+    rng = np.random.default_rng(43)
+    P, T = meshgen.icosphere(5)
+    P = meshgen.smooth_displace(P, 0.08) + 4e-3 * rng.normal(size=P.shape)
+    Pd, Td, _isb = meshgen.disk_patch(5, bulge=0.35, jitter=0.03, seed=5)
+    for name, (P_, T_) in {"ico5": (P, T), "disk5": (Pd, Td)}.items():
+        for mass in ("lumped", "consistent"):
+            gp = {"surface_tension": 1.0, "tilt_modulus_in": 1.7, "tilt_modulus_out": 2.3,
+                  "tilt_mass_mode_in": mass, "tilt_mass_mode": "lumped" if mass == "consistent" else "consistent",
+                  "bending_modulus": 0.8, "bending_modulus_out": 0.5}
+            m = build_mesh(P_, T_, gp)
+            tin, tout, _fi, _fo = _set_leaflet_fields(m, 12, 0.25)
+            pos, tri, isb, fixed = mesh_arrays(m)
+            res = ParameterResolver(m.global_parameters)
+            key = f"{name}_{mass}"
+            if mass == "lumped":
+                out[name + "_positions"], out[name + "_tri"], out[name + "_is_boundary"] = pos, tri, isb
+                out[name + "_tilts_in"], out[name + "_tilts_out"] = tin, tout
+            out[key + "_gp_json"] = np.array(json.dumps(gp, sort_keys=True))
+            for mod in ("tilt_in", "tilt_out", "tilt_smoothness_in", "tilt_smoothness_out"):
+                module = importlib.import_module(f"modules.energy.{mod}")
+                g = np.zeros_like(pos)
+                tgi, tgo = np.zeros_like(pos), np.zeros_like(pos)
+                E = module.compute_energy_and_gradient_array(
+                    m, m.global_parameters, res, positions=pos, index_map=m.vertex_index_to_row, grad_arr=g,
+                    tilts_in=tin, tilts_out=tout, tilt_in_grad_arr=tgi, tilt_out_grad_arr=tgo)
+                out[f"{key}_{mod}_E"], out[f"{key}_{mod}_grad"] = np.array(E), g
+                out[f"{key}_{mod}_tilt_grad"] = tgi if mod.endswith("_in") else tgo
+                assert not np.any(tgo if mod.endswith("_in") else tgi)
+                print("leaflet", key, mod, "E=%.16g" % E, "shape grad max", np.abs(g).max())
+            mods = ["tilt_in", "tilt_out", "tilt_smoothness_in", "tilt_smoothness_out"]
+            m.energy_modules = list(mods)
+            m.constraint_modules = []
+            mz = Minimizer(m, m.global_parameters, GradientDescent(), EnergyModuleManager(mods),
+                           ConstraintModuleManager([]), quiet=True)
+            va = m.barycentric_vertex_areas(positions=pos)
+            fin = np.zeros(len(pos), bool)
+            fout = np.zeros(len(pos), bool)
+            fin[::7] = True
+            Mi, Mo = build_leaflet_tilt_cg_preconditioner(
+                m, mz.param_resolver, mz.energy_context(), positions=pos, index_map=m.vertex_index_to_row,
+                fixed_mask_in=fin, fixed_mask_out=fout, tilt_vertex_areas_in=va, tilt_vertex_areas_out=va)
+            out[key + "_jacobi_Minv_in"], out[key + "_jacobi_Minv_out"], out[key + "_jacobi_fixed_in"] = Mi, Mo, fin
+            # the relaxation's evaluation (vertex-area fast path for the magnitude modules)
+            tgi, tgo = np.zeros_like(pos), np.zeros_like(pos)
+            E_rel = mz._compute_energy_and_leaflet_tilt_gradients_array(
+                positions=pos, tilts_in=tin, tilts_out=tout, tilt_in_grad_arr=tgi, tilt_out_grad_arr=tgo,
+                tilt_vertex_areas_in=va, tilt_vertex_areas_out=va, tilt_only=True)
+            out[key + "_relax_E"], out[key + "_relax_grad_in"], out[key + "_relax_grad_out"] = np.array(E_rel), tgi, tgo
+    np.savez_compressed(os.path.join(OUT, "tilt_leaflet_cases.npz"), **out)
+
+    base = {"surface_tension": 1.0, "tilt_modulus_in": 2.0, "tilt_modulus_out": 1.4, "bending_modulus": 0.6,
+            "bending_modulus_in": 0.9, "volume_constraint_mode": "lagrange",
+            "volume_projection_during_minimization": False, "mesh_quality_auto_repair_enabled": False}
+    allm = ["surface", "tilt_in", "tilt_out", "tilt_smoothness_in", "tilt_smoothness_out"]
+    P4, T4 = meshgen.icosphere(4)
+    P4 = meshgen.smooth_displace(P4, 0.08)
+    run_leaflet_trajectory("traj_ico4_gd_leaflet_nested_cg.npz", P4, T4,
+                           dict(base, tilt_solve_mode="nested", tilt_solver="cg", tilt_step_size=0.1,
+                                tilt_inner_steps=6), allm, GradientDescent(), 5, 1e-3, fixed_in_every=9)
+    run_leaflet_trajectory("traj_ico4_cg_leaflet_coupled_gd.npz", P4, T4,
+                           dict(base, tilt_solve_mode="coupled", tilt_solver="gd", tilt_step_size=0.05,
+                                tilt_coupled_steps=4, tilt_tol=1e-9), allm, ConjugateGradient(), 6, 2e-3,
+                           fixed_out_every=11)
+    run_leaflet_trajectory("traj_ico4_cg_leaflet_plaincg.npz", P4, T4,
+                           dict(base, tilt_solve_mode="nested", tilt_solver="cg", tilt_cg_preconditioner="none",
+                                tilt_step_size=0.08, tilt_inner_steps=5, tilt_cg_max_iters=4), allm,
+                           ConjugateGradient(), 5, 2e-3)
+    # consistent mass in the outer energy / shape gradient, tilts fixed, over-long first step (rejections)
+    Pd5, Td5, _ = meshgen.disk_patch(5, bulge=0.35, jitter=0.02, seed=7)
+    m0 = build_mesh(Pd5, Td5, base)
+    fixed = mesh_arrays(m0)[2].copy()  # boundary rows clamped
+    run_leaflet_trajectory_fixed("traj_disk5_gd_leaflet_consistent_backtrack.npz", Pd5, Td5,
+                                 dict(base, tilt_solve_mode="fixed", tilt_mass_mode="consistent"),
+                                 ["surface", "tilt_in", "tilt_out", "tilt_smoothness_out"], GradientDescent(), 5, 8e-2,
+                                 fixed)
+
+
+def run_leaflet_trajectory_fixed(fname, P, T, gp, mods, stepper, n_steps, step_size, fixed):
+    global build_mesh
+    orig = build_mesh
+
+    def bm(P_, T_, gp_, fixed=None, tilts=None):
+        return orig(P_, T_, gp_, fixed=fixed_rows, tilts=tilts)
+
+    fixed_rows = fixed
+    build_mesh = bm
+    try:
+        run_leaflet_trajectory(fname, P, T, gp, mods, stepper, n_steps, step_size)
+    finally:
+        build_mesh = orig
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if "--only-tilt" in sys.argv:
         gen_tilt_trajectory()
+        sys.exit(0)
+    if "--only-leaflet" in sys.argv:
+        gen_leaflet()
         sys.exit(0)
     if "--only-ts" in sys.argv:
         gen_tilt_smoothness()
@@ -662,3 +833,4 @@ if __name__ == "__main__":
     gen_bending_tilt_cases()
     gen_bending_tilt_trajectories()
     gen_tilt_smoothness()
+    gen_leaflet()

@@ -30,6 +30,10 @@ class Problem:
     fixed: np.ndarray | None = None  # (nv,) bool, mesh.fixed_mask
     tilts: np.ndarray | None = None  # (nv,3) mesh.tilts_view() (tilt / bending_tilt modules)
     tilt_fixed: np.ndarray | None = None  # (nv,) bool, vertex.tilt_fixed (minimizer_helpers.py:49-75)
+    tilts_in: np.ndarray | None = None  # (nv,3) mesh.tilts_in_view() / tilts_out_view() (leaflet modules)
+    tilts_out: np.ndarray | None = None
+    tilt_fixed_in: np.ndarray | None = None  # vertex.tilt_fixed_in / tilt_fixed_out (minimizer.py:460-486)
+    tilt_fixed_out: np.ndarray | None = None
     energy_modules: list = field(default_factory=lambda: ["surface"])
     constraint_modules: list = field(default_factory=list)
     body_rows: np.ndarray | None = None  # None = all facets in one body
@@ -60,6 +64,13 @@ class Problem:
         if self.tilt_fixed is None:
             self.tilt_fixed = np.zeros(nv, dtype=bool)
         self.tilt_fixed = np.asarray(self.tilt_fixed, dtype=bool)
+        for name in ("tilts_in", "tilts_out"):
+            arr = getattr(self, name)
+            if arr is not None:
+                setattr(self, name, np.ascontiguousarray(arr, dtype=np.float64).copy())
+        for name in ("tilt_fixed_in", "tilt_fixed_out"):
+            arr = getattr(self, name)
+            setattr(self, name, np.zeros(nv, dtype=bool) if arr is None else np.asarray(arr, dtype=bool))
 
     # -- parameter helpers (modules/energy/bending_params.py:19-33) ----------
     @property
@@ -110,6 +121,13 @@ def energy_and_gradient(p: Problem, pos: np.ndarray):
                                                       mode=p.grad_mode, grad=grad)
         elif name == "tilt_smoothness":
             E += _smoothness(p, pos, p.tilts)
+        elif name in ("tilt_in", "tilt_out"):
+            lf = name[5:]
+            E += orc.tilt_leaflet_energy_and_gradient(pos, leaflet_tilts(p, lf), p.tri, tilt_modulus(p, lf),
+                                                      tilt_mass_mode(p, lf), grad, None)
+        elif name in ("tilt_smoothness_in", "tilt_smoothness_out"):
+            lf = name[16:]
+            E += _smoothness_leaflet(p, pos, leaflet_tilts(p, lf), lf)
         else:
             raise ValueError(f"module {name!r} is outside the hot-path scope")
     # constraint_manager.apply_gradient_modifications_array (k == 1 dense branch :293-301)
@@ -126,10 +144,11 @@ def energy_and_gradient(p: Problem, pos: np.ndarray):
 
 
 # runtime/evaluation_manager.py:184-225 compute_energy_array_total
-def energy_total(p: Problem, pos: np.ndarray, tilts=None) -> float:
+def energy_total(p: Problem, pos: np.ndarray, tilts=None, tilts_in=None, tilts_out=None) -> float:
     E = 0.0
     if tilts is None:
         tilts = p.tilts
+    lt = {"in": p.tilts_in if tilts_in is None else tilts_in, "out": p.tilts_out if tilts_out is None else tilts_out}
     for name in p.energy_modules:
         if name == "surface":
             # no compute_energy_array -> gradient API into a scratch (:201-210)
@@ -149,6 +168,12 @@ def energy_total(p: Problem, pos: np.ndarray, tilts=None) -> float:
             E += orc.bending_tilt_energy_and_gradient(pos, tilts, p.tri, p.kappa, p.c0, p.is_boundary)
         elif name == "tilt_smoothness":
             E += _smoothness(p, pos, tilts)
+        elif name in ("tilt_in", "tilt_out"):
+            lf = name[5:]
+            E += orc.tilt_leaflet_energy_and_gradient(pos, lt[lf], p.tri, tilt_modulus(p, lf), tilt_mass_mode(p, lf))
+        elif name in ("tilt_smoothness_in", "tilt_smoothness_out"):
+            lf = name[16:]
+            E += _smoothness_leaflet(p, pos, lt[lf], lf)
         else:
             raise ValueError(name)
     return float(E)
@@ -163,6 +188,231 @@ def _smoothness(p: Problem, pos, tilts, tilt_grad=None) -> float:
 
 
 TILT_MODULES = ("tilt", "bending_tilt", "tilt_smoothness")  # modules with USES_TILT = True in scope
+LEAFLET_MODULES = ("tilt_in", "tilt_out", "tilt_smoothness_in", "tilt_smoothness_out")  # USES_TILT_LEAFLETS
+
+
+def leaflet_tilts(p: Problem, leaflet: str) -> np.ndarray:
+    t = p.tilts_in if leaflet == "in" else p.tilts_out
+    return np.zeros_like(p.positions) if t is None else t  # Mesh.tilts_in_view() is zeros until set
+
+
+def tilt_modulus(p: Problem, leaflet: str) -> float:
+    """modules/energy/tilt_params.py:6-12."""
+    k = p.gp.get(f"tilt_modulus_{leaflet}")
+    if k is None:
+        k = p.gp.get(f"tilt_modolus_{leaflet}")
+    return float(k or 0.0)
+
+
+def tilt_mass_mode(p: Problem, leaflet: str) -> str:
+    """modules/energy/tilt_params.py:15-23."""
+    mode = p.gp.get(f"tilt_mass_mode_{leaflet}")
+    if mode is None:
+        mode = p.gp.get("tilt_mass_mode")
+    txt = str(mode or "lumped").strip().lower()
+    if txt not in {"lumped", "consistent"}:
+        raise ValueError(f"tilt_mass_mode_{leaflet} must be 'lumped' or 'consistent'.")
+    return txt
+
+
+def smoothness_rigidity(p: Problem, leaflet: str) -> float:
+    """modules/energy/tilt_smoothness_utils.py:95-100."""
+    k = p.gp.get(f"bending_modulus_{leaflet}")
+    if k is None:
+        k = p.gp.get("bending_modulus")
+    return float(k or 0.0)
+
+
+def _smoothness_leaflet(p: Problem, pos, tilts, leaflet: str, tilt_grad=None) -> float:
+    """modules/energy/tilt_smoothness_leaflet.py:17-79 (no absent-leaflet mask): the base smoothness
+    energy with the leaflet's rigidity."""
+    k_s = smoothness_rigidity(p, leaflet)
+    if k_s == 0.0:
+        return 0.0
+    return orc.tilt_smoothness_energy_and_gradient(pos, tilts, p.tri, k_s, tilt_grad)
+
+
+# runtime/evaluation_manager.py:630-742 with tilt_vertex_areas given (the relaxation's call): the
+# magnitude modules take the vertex-area form, whatever their mass mode (:663-695)
+def energy_and_leaflet_tilt_gradients(p: Problem, pos, tilts_in, tilts_out, vertex_areas):
+    tg = {"in": np.zeros_like(pos), "out": np.zeros_like(pos)}
+    lt = {"in": tilts_in, "out": tilts_out}
+    E = 0.0
+    for name in p.energy_modules:
+        if name in ("tilt_in", "tilt_out"):
+            lf = name[5:]
+            k = float(p.gp.get(f"tilt_modulus_{lf}") or 0.0)
+            if k != 0.0:
+                sq = np.einsum("ij,ij->i", lt[lf], lt[lf])
+                E += float(0.5 * k * np.sum(sq * vertex_areas))
+                tg[lf] += k * lt[lf] * vertex_areas[:, None]
+        elif name in ("tilt_smoothness_in", "tilt_smoothness_out"):
+            lf = name[16:]
+            E += _smoothness_leaflet(p, pos, lt[lf], lf, tg[lf])
+    return float(E), tg["in"], tg["out"]
+
+
+# runtime/evaluation_manager.py:537-628 (same fast path for the magnitude modules, :558-581)
+def tilt_dependent_energy_leaflets(p: Problem, pos, tilts_in, tilts_out, vertex_areas) -> float:
+    lt = {"in": tilts_in, "out": tilts_out}
+    E = 0.0
+    for name in p.energy_modules:
+        if name in ("tilt_in", "tilt_out"):
+            lf = name[5:]
+            k = float(p.gp.get(f"tilt_modulus_{lf}") or 0.0)
+            if k != 0.0:
+                sq = np.einsum("ij,ij->i", lt[lf], lt[lf])
+                E += float(0.5 * k * np.sum(sq * vertex_areas))
+        elif name in ("tilt_smoothness_in", "tilt_smoothness_out"):
+            lf = name[16:]
+            E += _smoothness_leaflet(p, pos, lt[lf], lf)
+    return float(E)
+
+
+# runtime/preconditioners.py:62-146
+def leaflet_tilt_cg_preconditioner(p: Problem, pos, fixed_in, fixed_out, vertex_areas):
+    nv = pos.shape[0]
+    diag = {"in": np.zeros(nv), "out": np.zeros(nv)}
+    for lf in ("in", "out"):
+        k = float(p.gp.get(f"tilt_modulus_{lf}") or 0.0)
+        if k != 0.0:
+            diag[lf] += k * vertex_areas
+    ks = {lf: float(p.gp.get(f"bending_modulus_{lf}") or p.gp.get("bending_modulus") or 0.0) for lf in ("in", "out")}
+    if (ks["in"] != 0.0 or ks["out"] != 0.0) and p.tri.shape[0]:
+        _k, _a, w = orc.compute_curvature_data(pos, p.tri)
+        for lf in ("in", "out"):
+            if ks[lf] != 0.0:
+                f = 0.5 * ks[lf]
+                np.add.at(diag[lf], p.tri[:, 0], f * (w[:, 1] + w[:, 2]))
+                np.add.at(diag[lf], p.tri[:, 1], f * (w[:, 2] + w[:, 0]))
+                np.add.at(diag[lf], p.tri[:, 2], f * (w[:, 0] + w[:, 1]))
+    out = []
+    for lf, fx in (("in", fixed_in), ("out", fixed_out)):
+        d = np.where(diag[lf] > 1e-12, diag[lf], 1.0)
+        d[fx] = 1.0
+        out.append(1.0 / d)
+    return out[0], out[1]
+
+
+# runtime/steppers/tilt_relaxation.py:426-1478 relax_leaflet_tilts, default options (per-step projection
+# refresh without tilt constraints = projecting already projected fields; no update modes, no fallback)
+def relax_leaflet_tilts(p: Problem, pos: np.ndarray) -> dict:
+    stats = {"iters": 0, "evals": 0}
+    mode = str(p.gp.get("tilt_solve_mode", "fixed") or "").strip().lower()
+    if mode in ("", "none", "off", "false", "fixed") or mode not in ("nested", "coupled"):
+        return stats
+    step_size = float(p.gp.get("tilt_step_size", 0.0) or 0.0)
+    if step_size <= 0.0:
+        return stats
+    tol = float(p.gp.get("tilt_tol", 0.0) or 0.0)
+    if tol <= 0.0:
+        tol = 0.0
+    if mode == "nested":
+        n_inner = int(p.gp.get("tilt_inner_steps", 0) or 0)
+    else:
+        n_inner = int(p.gp.get("tilt_coupled_steps", p.gp.get("tilt_inner_steps", 0)) or 0)
+    if n_inner <= 0:
+        return stats
+    solver = str(p.gp.get("tilt_solver", "cg") or "cg").strip().lower()
+    if solver not in ("gd", "cg"):
+        solver = "gd"
+    if solver == "cg":
+        max_iters = int(p.gp.get("tilt_cg_max_iters", n_inner) or 0)
+        if max_iters <= 0:
+            return stats
+    else:
+        max_iters = n_inner
+    fx_in, fx_out = p.tilt_fixed_in, p.tilt_fixed_out
+    if not (np.any(~fx_in) or np.any(~fx_out)):
+        return stats
+    normals = unit_vertex_normals(pos, p.tri)
+
+    def project(t):
+        return t - np.einsum("ij,ij->i", t, normals)[:, None] * normals
+
+    t_in = project(leaflet_tilts(p, "in").copy())
+    t_out = project(leaflet_tilts(p, "out").copy())
+    fv_in = t_in[fx_in].copy() if np.any(fx_in) else None
+    fv_out = t_out[fx_out].copy() if np.any(fx_out) else None
+    va = orc.barycentric_vertex_areas(pos, p.tri)
+
+    def trial_of(step, d_in, d_out):  # projections/tilt.py:99-138
+        a = project(t_in + step * d_in)
+        b = project(t_out + step * d_out)
+        if fv_in is not None:
+            a[fx_in] = fv_in
+        if fv_out is not None:
+            b[fx_out] = fv_out
+        return a, b
+
+    def grad_at():
+        E, gi, go = energy_and_leaflet_tilt_gradients(p, pos, t_in, t_out, va)
+        stats["evals"] += 1
+        gi[fx_in] = 0.0
+        go[fx_out] = 0.0
+        gnorm = float(np.sqrt(np.sum(gi[~fx_in] ** 2) + np.sum(go[~fx_out] ** 2)))
+        return E, gi, go, gnorm
+
+    def search(E0, sign, d_in, d_out):
+        step = step_size
+        for _bt in range(12):
+            a, b = trial_of(sign * step, d_in, d_out)
+            E1 = tilt_dependent_energy_leaflets(p, pos, a, b, va)
+            stats["evals"] += 1
+            if E1 <= E0:
+                return True, a, b, E1
+            step *= 0.5
+            if step < 1e-16:
+                break
+        return False, None, None, E0
+
+    if solver == "gd":
+        for _ in range(max_iters):
+            E0, gi, go, gnorm = grad_at()
+            if gnorm == 0.0 or (tol > 0.0 and gnorm < tol):
+                break
+            ok, a, b, _E1 = search(E0, -1.0, gi, go)
+            stats["iters"] += 1
+            if not ok:
+                break
+            t_in, t_out = a, b
+    else:
+        pre = str(p.gp.get("tilt_cg_preconditioner", "jacobi") or "jacobi").strip().lower()
+        if pre in ("none", "off", "false"):
+            pre = None
+        E0, gi, go, gnorm = grad_at()
+        if not (gnorm == 0.0 or (tol > 0.0 and gnorm < tol)):
+            Mi = Mo = None
+            if pre == "jacobi":
+                Mi, Mo = leaflet_tilt_cg_preconditioner(p, pos, fx_in, fx_out, va)
+            r_in, r_out = -gi, -go
+            z_in = r_in * Mi[:, None] if Mi is not None else r_in
+            z_out = r_out * Mo[:, None] if Mo is not None else r_out
+            d_in, d_out = z_in.copy(), z_out.copy()
+            rz_old = float(np.sum(r_in * z_in) + np.sum(r_out * z_out))
+            for _ in range(max_iters):
+                if gnorm == 0.0 or (tol > 0.0 and gnorm < tol):
+                    break
+                ok, a, b, E1 = search(E0, 1.0, d_in, d_out)
+                stats["iters"] += 1
+                if not ok:
+                    break
+                t_in, t_out, E0 = a, b, E1
+                E0, gi, go, gnorm = grad_at()
+                if gnorm == 0.0 or (tol > 0.0 and gnorm < tol):
+                    break
+                r_in, r_out = -gi, -go
+                z_in = r_in * Mi[:, None] if Mi is not None else r_in
+                z_out = r_out * Mo[:, None] if Mo is not None else r_out
+                rz_new = float(np.sum(r_in * z_in) + np.sum(r_out * z_out))
+                if rz_old == 0.0:
+                    break
+                beta = rz_new / rz_old
+                d_in = z_in + beta * d_in
+                d_out = z_out + beta * d_out
+                rz_old = rz_new
+    p.tilts_in, p.tilts_out = t_in, t_out
+    return stats
 
 
 # runtime/evaluation_manager.py:386-462 (energy of the USES_TILT modules + dense tilt gradient)
@@ -368,6 +618,12 @@ def projected_tilts(p: Problem, pos: np.ndarray):
 
 def project_tilts_to_tangent(p: Problem, pos: np.ndarray) -> None:
     p.tilts = projected_tilts(p, pos)
+    if (p.tilts_in is not None or p.tilts_out is not None) and p.tri.shape[0]:
+        normals = unit_vertex_normals(pos, p.tri)
+        for name in ("tilts_in", "tilts_out"):
+            t = getattr(p, name)
+            if t is not None:
+                setattr(p, name, t - np.einsum("ij,ij->i", t, normals)[:, None] * normals)
 
 
 # runtime/topology.py:174-199 (min over mesh edges == min over facet edges)
@@ -440,7 +696,7 @@ def line_search(p: Problem, direction, gradient, step_size, *, max_iter=10, beta
     gives the same numbers for the shape-only modules; for bending_tilt it reads a P1-gradient
     cache keyed to the mesh, i.e. stale for a trial array, so the consistent path is the one
     restated and pinned (oracle/gen_golden.py: run_tilt_trajectory)."""
-    has_tilt = any(m in p.energy_modules for m in TILT_MODULES)
+    has_tilt = any(m in p.energy_modules for m in TILT_MODULES + LEAFLET_MODULES)
     array_trials = array_trials and enforcer is None and not has_tilt
     movable = ~p.fixed
     baseline = p.positions.copy()
@@ -476,6 +732,8 @@ def line_search(p: Problem, direction, gradient, step_size, *, max_iter=10, beta
             E_t = energy_total(p, trial, tilts=projected_tilts(p, trial) if has_tilt else None)
         else:
             tilts_before = None if p.tilts is None else p.tilts.copy()
+            leaf_before = (None if p.tilts_in is None else p.tilts_in.copy(),
+                           None if p.tilts_out is None else p.tilts_out.copy())
             p.positions = trial
             if has_tilt:
                 project_tilts_to_tangent(p, trial)
@@ -488,6 +746,8 @@ def line_search(p: Problem, direction, gradient, step_size, *, max_iter=10, beta
             p.positions = baseline
             if enforcer is not None and tilts_before is not None:
                 p.tilts = tilts_before  # needs_tilt_restore (line_search.py:300-312)
+            if enforcer is not None:
+                p.tilts_in, p.tilts_out = leaf_before
         alpha *= beta
         if alpha < 1e-8:
             break
@@ -582,7 +842,9 @@ def minimize(p: Problem, stepper, n_steps: int, step_size: float = 1e-3, tol: fl
     step_success = True
     grad = None
     for i in range(n_steps):
-        if p.tilts is not None:
+        if any(m in p.energy_modules for m in LEAFLET_MODULES):
+            relax_leaflet_tilts(p, p.positions)  # minimizer.py:1240-1305 (guard factor 0)
+        elif p.tilts is not None:
             relax_tilts(p, p.positions)  # minimizer.py:1237-1307 (single tilt field)
         E, grad = energy_and_gradient(p, p.positions)
         grad_norm = float(np.linalg.norm(grad))

@@ -336,3 +336,66 @@ def tilt_smoothness_energy_and_gradient(pos, tilts, tri, k_smooth, tilt_grad=Non
         np.add.at(tilt_grad, tri[:, 1], f * (c2[:, None] * (t1 - t0) + c0[:, None] * (t1 - t2)))
         np.add.at(tilt_grad, tri[:, 2], f * (c0[:, None] * (t2 - t1) + c1[:, None] * (t2 - t0)))
     return E
+
+
+def tilt_leaflet_energy_and_gradient(pos, tilts, tri, k_tilt, mass_mode="lumped", grad=None, tilt_grad=None) -> float:
+    """modules/energy/tilt_leaflet.py:26-169 (tilt_in / tilt_out), default options: no absent-leaflet
+    presets, no active-row weights, no shared-rim shell mode.  NumPy restatement.
+    lumped: coeff_f = 1/2 k (sum |t_k|^2)/3 ; consistent: coeff_f = k/12 (sum |t_k|^2 + t0.t1 + t1.t2 + t2.t0);
+    E = sum coeff_f A_f over facets with |n| >= 1e-12; shape gradient coeff_f dA/dx; tilt gradient
+    k A/3 t_k (lumped) or k A/12 (2 t_k + t_a + t_b) (consistent)."""
+    pos = _f64(pos)
+    tilts = _f64(tilts)
+    tri = _i32(tri)
+    if k_tilt == 0.0 or tri.shape[0] == 0:
+        return 0.0
+    v0, v1, v2 = pos[tri[:, 0]], pos[tri[:, 1]], pos[tri[:, 2]]
+    n = np.cross(v1 - v0, v2 - v0)
+    n_norm = np.linalg.norm(n, axis=1)
+    mask = n_norm >= 1e-12  # tilt_utils._triangle_geometry
+    if not np.any(mask):
+        return 0.0
+    rows = tri[mask]
+    areas = 0.5 * n_norm[mask]
+    t0, t1, t2 = tilts[rows[:, 0]], tilts[rows[:, 1]], tilts[rows[:, 2]]
+    sq = np.einsum("ij,ij->i", t0, t0) + np.einsum("ij,ij->i", t1, t1) + np.einsum("ij,ij->i", t2, t2)
+    if mass_mode == "consistent":
+        cs = sq + np.einsum("ij,ij->i", t0, t1) + np.einsum("ij,ij->i", t1, t2) + np.einsum("ij,ij->i", t2, t0)
+        coeff = (k_tilt / 12.0) * cs
+    else:
+        coeff = 0.5 * k_tilt * (sq / 3.0)
+    energy = float(np.dot(coeff, areas))
+    if tilt_grad is not None:
+        if mass_mode == "consistent":
+            f = (k_tilt * areas / 12.0)[:, None]
+            np.add.at(tilt_grad, rows[:, 0], f * (2.0 * t0 + t1 + t2))
+            np.add.at(tilt_grad, rows[:, 1], f * (2.0 * t1 + t2 + t0))
+            np.add.at(tilt_grad, rows[:, 2], f * (2.0 * t2 + t0 + t1))
+        else:
+            f = (k_tilt * areas / 3.0)[:, None]
+            np.add.at(tilt_grad, rows[:, 0], f * t0)
+            np.add.at(tilt_grad, rows[:, 1], f * t1)
+            np.add.at(tilt_grad, rows[:, 2], f * t2)
+    if grad is not None:
+        n_hat = n[mask] / n_norm[mask][:, None]
+        m0, m1, m2 = v0[mask], v1[mask], v2[mask]
+        c = coeff[:, None]
+        np.add.at(grad, rows[:, 0], c * (0.5 * np.cross(n_hat, m2 - m1)))
+        np.add.at(grad, rows[:, 1], c * (0.5 * np.cross(n_hat, m0 - m2)))
+        np.add.at(grad, rows[:, 2], c * (0.5 * np.cross(n_hat, m1 - m0)))
+    return energy
+
+
+def barycentric_vertex_areas(pos, tri):
+    """Mesh.barycentric_vertex_areas (geometry/mesh.py:671-730): A_v = sum_f A_f / 3 over |n| >= 1e-12."""
+    pos = _f64(pos)
+    tri = _i32(tri)
+    n = np.cross(pos[tri[:, 1]] - pos[tri[:, 0]], pos[tri[:, 2]] - pos[tri[:, 0]])
+    n_norm = np.linalg.norm(n, axis=1)
+    mask = n_norm >= 1e-12  # mesh.py:703-707
+    thirds = 0.5 * n_norm[mask] / 3.0
+    rows = tri[mask]
+    va = np.zeros(pos.shape[0])
+    for k in range(3):
+        np.add.at(va, rows[:, k], thirds)
+    return va

@@ -300,3 +300,80 @@ def test_port_reproduces_tilt_smoothness_trajectory(fname):
     assert np.allclose(got[:, 2], log[:, 2], rtol=1e-9, atol=0)
     assert relerr(p.positions, g["positions_final"]) < 1e-8
     assert relerr(p.tilts, g["tilts_final"]) < 1e-8
+
+
+# ---------------------------------------------------------------------------
+# two-leaflet tilt fields: tilt_in / tilt_out (lumped + consistent), tilt_smoothness_in / _out,
+# leaflet Jacobi preconditioner, relax_leaflet_tilts (oracle/gen_golden.py: gen_leaflet)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["ico5", "disk5"])
+@pytest.mark.parametrize("mass", ["lumped", "consistent"])
+def test_leaflet_modules_match_reference(name, mass):
+    import json
+
+    g = load_golden("tilt_leaflet_cases.npz")
+    key = f"{name}_{mass}"
+    gp = json.loads(str(g[key + "_gp_json"]))
+    pos, tri = g[name + "_positions"], g[name + "_tri"]
+    tin, tout = g[name + "_tilts_in"], g[name + "_tilts_out"]
+    p = mp.Problem(positions=pos, tri=tri, is_boundary=g[name + "_is_boundary"], tilts_in=tin, tilts_out=tout,
+                   energy_modules=[], gp=gp)
+    for lf, tl in (("in", tin), ("out", tout)):
+        grad, tg = np.zeros_like(pos), np.zeros_like(pos)
+        E = orc.tilt_leaflet_energy_and_gradient(pos, tl, tri, mp.tilt_modulus(p, lf), mp.tilt_mass_mode(p, lf), grad, tg)
+        assert abs(E - g[f"{key}_tilt_{lf}_E"]) <= 1e-13 * abs(g[f"{key}_tilt_{lf}_E"])
+        assert relerr(grad, g[f"{key}_tilt_{lf}_grad"]) < 1e-12
+        assert relerr(tg, g[f"{key}_tilt_{lf}_tilt_grad"]) < 1e-12
+        tg = np.zeros_like(pos)
+        E = mp._smoothness_leaflet(p, pos, tl, lf, tg)
+        assert abs(E - g[f"{key}_tilt_smoothness_{lf}_E"]) <= 1e-12 * abs(g[f"{key}_tilt_smoothness_{lf}_E"])
+        assert relerr(tg, g[f"{key}_tilt_smoothness_{lf}_tilt_grad"]) < 1e-11
+        assert not np.any(g[f"{key}_tilt_smoothness_{lf}_grad"])  # no shape gradient
+    # the mass mode really is per leaflet: "in" follows tilt_mass_mode_in, "out" the global key
+    assert mp.tilt_mass_mode(p, "in") == mass and mp.tilt_mass_mode(p, "out") != mass
+    va = orc.barycentric_vertex_areas(pos, tri)
+    fin = g[key + "_jacobi_fixed_in"]
+    Mi, Mo = mp.leaflet_tilt_cg_preconditioner(p, pos, fin, np.zeros(len(pos), bool), va)
+    assert relerr(Mi, g[key + "_jacobi_Minv_in"]) < 1e-11 and relerr(Mo, g[key + "_jacobi_Minv_out"]) < 1e-11
+    p.energy_modules = ["tilt_in", "tilt_out", "tilt_smoothness_in", "tilt_smoothness_out"]
+    E, gi, go = mp.energy_and_leaflet_tilt_gradients(p, pos, tin, tout, va)
+    assert abs(E - g[key + "_relax_E"]) <= 1e-12 * abs(g[key + "_relax_E"])
+    assert relerr(gi, g[key + "_relax_grad_in"]) < 1e-11 and relerr(go, g[key + "_relax_grad_out"]) < 1e-11
+
+
+LEAFLET_TRAJ = {
+    "traj_ico4_gd_leaflet_nested_cg.npz": "gd",
+    "traj_ico4_cg_leaflet_coupled_gd.npz": "cg",
+    "traj_ico4_cg_leaflet_plaincg.npz": "cg",
+    "traj_disk5_gd_leaflet_consistent_backtrack.npz": "gd",
+}
+
+
+def leaflet_problem(g):
+    import json
+
+    return mp.Problem(positions=g["positions0"], tri=g["tri"], gamma=g["gamma"], is_boundary=g["is_boundary"],
+                      fixed=g["fixed"], tilts_in=g["tilts_in0"], tilts_out=g["tilts_out0"],
+                      tilt_fixed_in=g["tilt_fixed_in"], tilt_fixed_out=g["tilt_fixed_out"],
+                      energy_modules=[str(m) for m in g["modules"]], constraint_modules=[],
+                      gp=json.loads(str(g["gp_json"])))
+
+
+@pytest.mark.parametrize("fname", sorted(LEAFLET_TRAJ))
+def test_port_reproduces_leaflet_trajectory(fname):
+    g = load_golden(fname)
+    p = leaflet_problem(g)
+    E0, grad0 = mp.energy_and_gradient(p, p.positions)
+    assert abs(E0 - g["E0"]) <= 1e-12 * abs(g["E0"])
+    assert relerr(grad0, g["grad0"]) < 1e-11
+    stepper = mp.GradientDescent() if LEAFLET_TRAJ[fname] == "gd" else mp.ConjugateGradient()
+    res = mp.minimize(p, stepper, int(g["n_steps"]), step_size=float(g["step_size0"]))
+    log = g["step_log"]
+    got = np.array([[float(t["success"]), t["next_step"], t["E_accepted"]] for t in res["trace"]])
+    assert got.shape == log.shape
+    assert np.array_equal(got[:, 0], log[:, 0])
+    assert np.allclose(got[:, 1], log[:, 1], rtol=1e-12, atol=0)
+    assert np.allclose(got[:, 2], log[:, 2], rtol=1e-9, atol=0)
+    assert relerr(p.positions, g["positions_final"]) < 1e-8
+    assert relerr(p.tilts_in, g["tilts_in_final"]) < 1e-8
+    assert relerr(p.tilts_out, g["tilts_out_final"]) < 1e-8
