@@ -33,6 +33,7 @@ ap.add_argument("--only-tilt", action="store_true")
 ap.add_argument("--only-bt", action="store_true", help="bending_tilt + tilt relaxation vectors only")
 ap.add_argument("--only-ts", action="store_true", help="tilt_smoothness vectors only")
 ap.add_argument("--only-leaflet", action="store_true", help="two-leaflet tilt vectors only")
+ap.add_argument("--only-btl", action="store_true", help="bending_tilt_in/out vectors only")
 args = ap.parse_args()
 
 sys.dont_write_bytecode = True
@@ -796,6 +797,65 @@ def gen_leaflet():
                                  fixed)
 
 
+
+def gen_bending_tilt_leaflet():
+    """bending_tilt_in / bending_tilt_out (bending_tilt_leaflet.py:231-758, default options)."""
+    import importlib
+
+    out = {"meta_fortran": META}
+    rng = np.random.default_rng(47)
+    P, T = meshgen.icosphere(5)
+    P = meshgen.smooth_displace(P, 0.08) + 4e-3 * rng.normal(size=P.shape)
+    Pd, Td, _isb = meshgen.disk_patch(5, bulge=0.35, jitter=0.03, seed=5)
+    gp = {"surface_tension": 1.0, "bending_modulus": 0.9, "bending_modulus_in": 1.3, "spontaneous_curvature": 0.1,
+          "spontaneous_curvature_out": -0.2, "bending_gradient_mode": "analytic"}
+    out["gp_json"] = np.array(json.dumps(gp, sort_keys=True))
+    for name, (P_, T_) in {"ico5": (P, T), "disk5": (Pd, Td)}.items():
+        m = build_mesh(P_, T_, gp)
+        tin, tout, _fi, _fo = _set_leaflet_fields(m, 12, 0.25)
+        pos, tri, isb, fixed = mesh_arrays(m)
+        res = ParameterResolver(m.global_parameters)
+        out[name + "_positions"], out[name + "_tri"], out[name + "_is_boundary"] = pos, tri, isb
+        out[name + "_tilts_in"], out[name + "_tilts_out"] = tin, tout
+        for mod in ("bending_tilt_in", "bending_tilt_out"):
+            module = importlib.import_module(f"modules.energy.{mod}")
+            g = np.zeros_like(pos)
+            tgi, tgo = np.zeros_like(pos), np.zeros_like(pos)
+            E = module.compute_energy_and_gradient_array(
+                m, m.global_parameters, res, positions=pos, index_map=m.vertex_index_to_row, grad_arr=g,
+                tilts_in=tin, tilts_out=tout, tilt_in_grad_arr=tgi, tilt_out_grad_arr=tgo)
+            E_only = module.compute_energy_and_gradient_array(
+                m, m.global_parameters, res, positions=pos, index_map=m.vertex_index_to_row, grad_arr=None,
+                tilts_in=tin, tilts_out=tout, tilt_in_grad_arr=None, tilt_out_grad_arr=None)
+            assert abs(E_only - E) <= 1e-13 * abs(E)
+            out[f"{name}_{mod}_E"], out[f"{name}_{mod}_grad"] = np.array(E), g
+            out[f"{name}_{mod}_tilt_grad"] = tgi if mod.endswith("_in") else tgo
+            print("bending_tilt leaflet", name, mod, "E=%.16g" % E, "shape grad max", np.abs(g).max())
+    np.savez_compressed(os.path.join(OUT, "bending_tilt_leaflet_cases.npz"), **out)
+
+    base = {"surface_tension": 1.0, "bending_modulus": 0.7, "bending_modulus_in": 1.1, "spontaneous_curvature": 0.1,
+            "spontaneous_curvature_out": -0.15, "bending_energy_model": "helfrich",
+            "bending_gradient_mode": "analytic", "tilt_modulus_in": 2.0, "tilt_modulus_out": 1.4,
+            "volume_constraint_mode": "lagrange", "volume_projection_during_minimization": False,
+            "mesh_quality_auto_repair_enabled": False}
+    allm = ["surface", "tilt_in", "tilt_out", "bending_tilt_in", "bending_tilt_out"]
+    P4, T4 = meshgen.icosphere(4)
+    P4 = meshgen.smooth_displace(P4, 0.08)
+    run_leaflet_trajectory("traj_ico4_gd_btl_nested_cg.npz", P4, T4,
+                           dict(base, tilt_solve_mode="nested", tilt_solver="cg", tilt_step_size=0.1,
+                                tilt_inner_steps=5), allm, GradientDescent(), 5, 1e-3, fixed_in_every=9)
+    run_leaflet_trajectory("traj_ico4_cg_btl_coupled_gd.npz", P4, T4,
+                           dict(base, tilt_solve_mode="coupled", tilt_solver="gd", tilt_step_size=0.05,
+                                tilt_coupled_steps=3), allm + ["tilt_smoothness_in"], ConjugateGradient(), 5, 1e-3,
+                           fixed_out_every=11)
+    Pd5, Td5, _ = meshgen.disk_patch(5, bulge=0.35, jitter=0.02, seed=7)
+    m0 = build_mesh(Pd5, Td5, base)
+    fixed = mesh_arrays(m0)[2].copy()
+    run_leaflet_trajectory_fixed("traj_disk5_gd_btl_backtrack.npz", Pd5, Td5, dict(base, tilt_solve_mode="fixed"),
+                                 ["surface", "bending_tilt_out", "tilt_out", "bending_tilt_in"], GradientDescent(), 5,
+                                 5e-2, fixed)
+
+
 def run_leaflet_trajectory_fixed(fname, P, T, gp, mods, stepper, n_steps, step_size, fixed):
     global build_mesh
     orig = build_mesh
@@ -819,6 +879,9 @@ if __name__ == "__main__":
     if "--only-leaflet" in sys.argv:
         gen_leaflet()
         sys.exit(0)
+    if "--only-btl" in sys.argv:
+        gen_bending_tilt_leaflet()
+        sys.exit(0)
     if "--only-ts" in sys.argv:
         gen_tilt_smoothness()
         sys.exit(0)
@@ -834,3 +897,4 @@ if __name__ == "__main__":
     gen_bending_tilt_trajectories()
     gen_tilt_smoothness()
     gen_leaflet()
+    gen_bending_tilt_leaflet()

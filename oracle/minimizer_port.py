@@ -128,6 +128,9 @@ def energy_and_gradient(p: Problem, pos: np.ndarray):
         elif name in ("tilt_smoothness_in", "tilt_smoothness_out"):
             lf = name[16:]
             E += _smoothness_leaflet(p, pos, leaflet_tilts(p, lf), lf)
+        elif name in ("bending_tilt_in", "bending_tilt_out"):
+            lf = name[13:]
+            E += _bending_tilt_leaflet(p, pos, leaflet_tilts(p, lf), lf, grad=grad)
         else:
             raise ValueError(f"module {name!r} is outside the hot-path scope")
     # constraint_manager.apply_gradient_modifications_array (k == 1 dense branch :293-301)
@@ -174,6 +177,9 @@ def energy_total(p: Problem, pos: np.ndarray, tilts=None, tilts_in=None, tilts_o
         elif name in ("tilt_smoothness_in", "tilt_smoothness_out"):
             lf = name[16:]
             E += _smoothness_leaflet(p, pos, lt[lf], lf)
+        elif name in ("bending_tilt_in", "bending_tilt_out"):
+            lf = name[13:]
+            E += _bending_tilt_leaflet(p, pos, lt[lf], lf)
         else:
             raise ValueError(name)
     return float(E)
@@ -188,7 +194,30 @@ def _smoothness(p: Problem, pos, tilts, tilt_grad=None) -> float:
 
 
 TILT_MODULES = ("tilt", "bending_tilt", "tilt_smoothness")  # modules with USES_TILT = True in scope
-LEAFLET_MODULES = ("tilt_in", "tilt_out", "tilt_smoothness_in", "tilt_smoothness_out")  # USES_TILT_LEAFLETS
+LEAFLET_MODULES = ("tilt_in", "tilt_out", "tilt_smoothness_in", "tilt_smoothness_out",
+                   "bending_tilt_in", "bending_tilt_out")  # USES_TILT_LEAFLETS
+
+
+def leaflet_bending_params(p: Problem, leaflet: str):
+    """modules/energy/bt_params.py:225-318 without per-vertex option overrides: (kappa, c0) arrays."""
+    k = p.gp.get(f"bending_modulus_{leaflet}")
+    if k is None:
+        k = p.gp.get("bending_modulus", 0.0)
+    c0 = p.gp.get(f"spontaneous_curvature_{leaflet}")
+    if c0 is None:
+        c0 = p.gp.get("spontaneous_curvature")
+        if c0 is None:
+            c0 = p.gp.get("intrinsic_curvature", 0.0)
+    nv = p.positions.shape[0]
+    return np.full(nv, float(k or 0.0)), np.full(nv, float(c0 or 0.0))
+
+
+def _bending_tilt_leaflet(p: Problem, pos, tilts, leaflet: str, grad=None, tilt_grad=None) -> float:
+    """bending_tilt_in.py:46 (div_sign = -1) / bending_tilt_out.py (+1)."""
+    kappa, c0 = leaflet_bending_params(p, leaflet)
+    return orc.bending_tilt_leaflet_energy_and_gradient(pos, tilts, p.tri, kappa, c0, p.is_boundary,
+                                                        -1.0 if leaflet == "in" else 1.0, mode=p.grad_mode,
+                                                        grad=grad, tilt_grad=tilt_grad)
 
 
 def leaflet_tilts(p: Problem, leaflet: str) -> np.ndarray:
@@ -249,6 +278,9 @@ def energy_and_leaflet_tilt_gradients(p: Problem, pos, tilts_in, tilts_out, vert
         elif name in ("tilt_smoothness_in", "tilt_smoothness_out"):
             lf = name[16:]
             E += _smoothness_leaflet(p, pos, lt[lf], lf, tg[lf])
+        elif name in ("bending_tilt_in", "bending_tilt_out"):
+            lf = name[13:]
+            E += _bending_tilt_leaflet(p, pos, lt[lf], lf, tilt_grad=tg[lf])
     return float(E), tg["in"], tg["out"]
 
 
@@ -266,6 +298,9 @@ def tilt_dependent_energy_leaflets(p: Problem, pos, tilts_in, tilts_out, vertex_
         elif name in ("tilt_smoothness_in", "tilt_smoothness_out"):
             lf = name[16:]
             E += _smoothness_leaflet(p, pos, lt[lf], lf)
+        elif name in ("bending_tilt_in", "bending_tilt_out"):
+            lf = name[13:]
+            E += _bending_tilt_leaflet(p, pos, lt[lf], lf)
     return float(E)
 
 

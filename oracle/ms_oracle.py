@@ -399,3 +399,177 @@ def barycentric_vertex_areas(pos, tri):
     for k in range(3):
         np.add.at(va, rows[:, k], thirds)
     return va
+
+
+# --- leaflet bending + tilt-splay coupling (bending_tilt_in / bending_tilt_out) ----
+def unit_vertex_normals_tri(pos, tri):
+    """bending_utils._vertex_normals restated on arrays (same routine the C oracle exposes)."""
+    return vertex_normals(pos, tri)
+
+
+def _backprop_corner_areas(pos, tri, weights, is_boundary, corner_fA_eff, fA_vor, fK, grad):
+    """modules/energy/bt_gradient.py:139-387 with tri_rows == tri_rows_full (no absent-leaflet mask, no
+    transition operator): the bending back-propagation whose effective-area factor is PER CORNER."""
+    i0, i1, i2 = tri[:, 0], tri[:, 1], tri[:, 2]
+    v0, v1, v2 = pos[i0], pos[i1], pos[i2]
+    e0, e1, e2 = v2 - v1, v0 - v2, v1 - v0
+    c0, c1, c2 = weights[:, 0], weights[:, 1], weights[:, 2]
+    grad_linear = -apply_beltrami_laplacian(weights, tri, fK)
+    dE_dc0 = -0.5 * np.einsum("ij,ij->i", fK[i1] - fK[i2], v1 - v2)
+    dE_dc1 = -0.5 * np.einsum("ij,ij->i", fK[i2] - fK[i0], v2 - v0)
+    dE_dc2 = -0.5 * np.einsum("ij,ij->i", fK[i0] - fK[i1], v0 - v1)
+    g0u, g0v = grad_cotan_batch(v1 - v0, v2 - v0)
+    g1u, g1v = grad_cotan_batch(v2 - v1, v0 - v1)
+    g2u, g2v = grad_cotan_batch(v0 - v2, v1 - v2)
+    grad_cot = np.zeros_like(pos)
+    a0, a1, a2 = dE_dc0[:, None], dE_dc1[:, None], dE_dc2[:, None]
+    np.add.at(grad_cot, i1, a0 * g0u)
+    np.add.at(grad_cot, i2, a0 * g0v)
+    np.add.at(grad_cot, i0, a0 * -(g0u + g0v))
+    np.add.at(grad_cot, i2, a1 * g1u)
+    np.add.at(grad_cot, i0, a1 * g1v)
+    np.add.at(grad_cot, i1, a1 * -(g1u + g1v))
+    np.add.at(grad_cot, i0, a2 * g2u)
+    np.add.at(grad_cot, i1, a2 * g2v)
+    np.add.at(grad_cot, i2, a2 * -(g2u + g2v))
+    tri_is_int = (~np.asarray(is_boundary, dtype=bool))[tri]
+    counts = np.sum(tri_is_int, axis=1)
+    sum_int = np.sum(corner_fA_eff * tri_is_int, axis=1)
+    avg = np.zeros(tri.shape[0])
+    m = counts > 0
+    avg[m] = sum_int[m] / counts[m]
+    C = np.where(tri_is_int, corner_fA_eff, avg[:, None]) + fA_vor[tri]
+    grad_area = np.zeros_like(pos)
+    obt = (c0 < 0) | (c1 < 0) | (c2 < 0)
+    ms = ~obt
+    if np.any(ms):
+        c0s, c1s, c2s = c0[ms], c1[ms], c2[ms]
+        C0, C1, C2 = C[ms, 0], C[ms, 1], C[ms, 2]
+        E0, E1, E2 = e0[ms], e1[ms], e2[ms]
+        j0, j1, j2 = i0[ms], i1[ms], i2[ms]
+        for coeff, ev, plus, minus in ((0.25 * c1s * C0, E1, j0, j2), (0.25 * c2s * C0, E2, j1, j0),
+                                       (0.25 * c2s * C1, E2, j1, j0), (0.25 * c0s * C1, E0, j2, j1),
+                                       (0.25 * c0s * C2, E0, j2, j1), (0.25 * c1s * C2, E1, j0, j2)):
+            np.add.at(grad_area, plus, coeff[:, None] * ev)
+            np.add.at(grad_area, minus, -coeff[:, None] * ev)
+        l0 = np.einsum("ij,ij->i", E0, E0)
+        l1 = np.einsum("ij,ij->i", E1, E1)
+        l2 = np.einsum("ij,ij->i", E2, E2)
+        k0 = (0.125 * l0 * (C1 + C2))[:, None]
+        k1 = (0.125 * l1 * (C0 + C2))[:, None]
+        k2 = (0.125 * l2 * (C0 + C1))[:, None]
+        h0u, h0v = grad_cotan_batch(E2, -E1)
+        h1u, h1v = grad_cotan_batch(E0, -E2)
+        h2u, h2v = grad_cotan_batch(E1, -E0)
+        np.add.at(grad_area, j1, k0 * h0u)
+        np.add.at(grad_area, j2, k0 * h0v)
+        np.add.at(grad_area, j0, k0 * -(h0u + h0v))
+        np.add.at(grad_area, j2, k1 * h1u)
+        np.add.at(grad_area, j0, k1 * h1v)
+        np.add.at(grad_area, j1, k1 * -(h1u + h1v))
+        np.add.at(grad_area, j0, k2 * h2u)
+        np.add.at(grad_area, j1, k2 * h2v)
+        np.add.at(grad_area, j2, k2 * -(h2u + h2v))
+    if np.any(obt):
+        for i, sub in enumerate(((c0 < 0), (c1 < 0), (c2 < 0))):
+            md = sub & obt
+            if not np.any(md):
+                continue
+            u, v = pos[i1[md]] - pos[i0[md]], pos[i2[md]] - pos[i0[md]]
+            w = np.cross(u, v)
+            S = np.linalg.norm(w, axis=1)
+            ok = S > 1e-15
+            gu, gv = np.zeros_like(u), np.zeros_like(v)
+            gu[ok] = 0.5 * np.cross(v[ok], w[ok]) / S[ok][:, None]
+            gv[ok] = 0.5 * np.cross(w[ok], u[ok]) / S[ok][:, None]
+            Co = C[md]
+            other = [k for k in range(3) if k != i]
+            factor = (0.5 * Co[:, i] + 0.25 * Co[:, other[0]] + 0.25 * Co[:, other[1]])[:, None]
+            np.add.at(grad_area, i1[md], factor * gu)
+            np.add.at(grad_area, i2[md], factor * gv)
+            np.add.at(grad_area, i0[md], factor * -(gu + gv))
+    grad += grad_linear
+    grad += grad_cot
+    grad += grad_area
+
+
+def _ambient_p1_divergence_shape_gradient(pos, tilts, tri, coefficient, grad):
+    """modules/energy/bt_gradient.py:20-64: coefficient_f * d(div_P1 t)/dx for ambient tilts."""
+    v0, v1, v2 = pos[tri[:, 0]], pos[tri[:, 1]], pos[tri[:, 2]]
+    a, b = v1 - v0, v2 - v0
+    n = np.cross(a, b)
+    n2 = np.maximum(np.einsum("ij,ij->i", n, n), 1.0e-20)
+    t0, t1, t2 = tilts[tri[:, 0]], tilts[tri[:, 1]], tilts[tri[:, 2]]
+    e0, e1, e2 = b - a, -b, a
+    w = np.cross(e0, t0) + np.cross(e1, t1) + np.cross(e2, t2)
+    ndw = np.einsum("ij,ij->i", n, w)
+    ddn = w / n2[:, None] - 2.0 * ndw[:, None] * n / (n2**2)[:, None]
+    d0 = np.cross(t0, n) / n2[:, None]
+    d1 = np.cross(t1, n) / n2[:, None]
+    d2 = np.cross(t2, n) / n2[:, None]
+    da = np.cross(b, ddn) - d0 + d2
+    db = np.cross(ddn, a) + d0 - d1
+    f = np.asarray(coefficient, dtype=float)[:, None]
+    ga, gb = f * da, f * db
+    np.add.at(grad, tri[:, 1], ga)
+    np.add.at(grad, tri[:, 2], gb)
+    np.add.at(grad, tri[:, 0], -(ga + gb))
+
+
+def bending_tilt_leaflet_energy_and_gradient(pos, tilts, tri, kappa, c0, is_boundary, div_sign, *, mode="analytic",
+                                             grad=None, tilt_grad=None) -> float:
+    """modules/energy/bending_tilt_leaflet.py:231-758 (bending_tilt_in: div_sign = -1, bending_tilt_out: +1),
+    default options (ambient_v1 transport; no absent-leaflet presets, recovered / reconstructed divergence,
+    update modes, assume-J0 presets, base-term groups, stage-A lanes or scaffold stencils):
+        E = 1/2 sum_f sum_k kappa_k (base_k + s div_f t)^2 va_eff[f,k],  base = 2 H - c0 with the SIGNED
+        H = (K . n)/(2 max(A_vor, 1e-12)) (:457-459), 0 on boundary rows;
+    shape gradient = back-propagation with K_dir = n, per-corner fA_eff = 1/2 kappa_k term_tri^2 (:608-610) plus the
+    exact s dE/ddiv d(div)/dx (:692-699); tilt gradient s (sum_k kappa_k term_tri_k va_eff_k) g_k."""
+    pos, tilts, tri = _f64(pos), _f64(tilts), _i32(tri)
+    nv = pos.shape[0]
+    kappa, c0 = _f64(kappa, (nv,)), _f64(c0, (nv,))
+    isb = np.asarray(is_boundary, dtype=bool)
+    if tri.shape[0] == 0:
+        return 0.0
+    k_vecs, A_vor, weights = compute_curvature_data(pos, tri)
+    div_tri, _area, g0, g1, g2 = p1_triangle_divergence(pos, tilts, tri)
+    div_term = float(div_sign) * div_tri
+    A_eff, va_eff = effective_areas(pos, tri, weights, isb)
+    safe = np.maximum(A_vor, 1e-12)
+    normals = vertex_normals(pos, tri)
+    H = np.einsum("ij,ij->i", k_vecs, normals) / (2.0 * safe)
+    base = (2.0 * H) - c0
+    base[isb] = 0.0
+    base_tri = base[tri]
+    term_tri = base_tri + div_term[:, None]
+    kappa_tri = kappa[tri]
+    E = float(0.5 * np.sum(kappa_tri * term_tri**2 * va_eff))
+    dE_ddiv = float(div_sign) * np.sum(kappa_tri * term_tri * va_eff, axis=1)
+    if tilt_grad is not None:
+        f = dE_ddiv[:, None]
+        np.add.at(tilt_grad, tri[:, 0], f * g0)
+        np.add.at(tilt_grad, tri[:, 1], f * g1)
+        np.add.at(tilt_grad, tri[:, 2], f * g2)
+    if grad is None:
+        return E
+    ratio = np.zeros_like(A_eff)
+    m = safe > 1e-15
+    ratio[m] = A_eff[m] / safe[m]
+    num = np.zeros(nv)
+    for kcol in range(3):
+        np.add.at(num, tri[:, kcol], va_eff[:, kcol] * div_term)
+    div_eff = np.zeros(nv)
+    me = A_eff > 1e-20
+    div_eff[me] = num[me] / A_eff[me]
+    term = base + div_eff
+    term[isb] = 0.0
+    fK = np.ascontiguousarray(normals * (kappa * term * ratio)[:, None])
+    corner_fA_eff = 0.5 * kappa_tri * term_tri**2
+    fA_vor = -2.0 * kappa * term * ratio * H
+    if mode != "analytic":
+        # approx mode (bt_gradient.py:112-137) zeroes boundary rows of what other modules accumulated and adds
+        # the d(div)/dx term only when the caller also asked for a tilt gradient (:631-633): not restated
+        raise NotImplementedError("bending_tilt_in/out: only bending_gradient_mode=analytic is restated")
+    _backprop_corner_areas(pos, tri, weights, isb, corner_fA_eff, fA_vor, fK, grad)
+    _ambient_p1_divergence_shape_gradient(pos, tilts, tri, dE_ddiv, grad)
+    return E

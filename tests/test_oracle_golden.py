@@ -377,3 +377,49 @@ def test_port_reproduces_leaflet_trajectory(fname):
     assert relerr(p.positions, g["positions_final"]) < 1e-8
     assert relerr(p.tilts_in, g["tilts_in_final"]) < 1e-8
     assert relerr(p.tilts_out, g["tilts_out_final"]) < 1e-8
+
+
+# ---------------------------------------------------------------------------
+# bending_tilt_in / bending_tilt_out (oracle/gen_golden.py: gen_bending_tilt_leaflet)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["ico5", "disk5"])
+def test_bending_tilt_leaflet_matches_reference(name):
+    import json
+
+    g = load_golden("bending_tilt_leaflet_cases.npz")
+    gp = json.loads(str(g["gp_json"]))
+    pos, tri = g[name + "_positions"], g[name + "_tri"]
+    p = mp.Problem(positions=pos, tri=tri, is_boundary=g[name + "_is_boundary"], tilts_in=g[name + "_tilts_in"],
+                   tilts_out=g[name + "_tilts_out"], energy_modules=[], gp=gp)
+    for lf in ("in", "out"):
+        grad, tg = np.zeros_like(pos), np.zeros_like(pos)
+        E = mp._bending_tilt_leaflet(p, pos, mp.leaflet_tilts(p, lf), lf, grad=grad, tilt_grad=tg)
+        ref = g[f"{name}_bending_tilt_{lf}_E"]
+        assert abs(E - ref) <= 1e-12 * abs(ref)
+        assert relerr(grad, g[f"{name}_bending_tilt_{lf}_grad"]) < 1e-11
+        assert relerr(tg, g[f"{name}_bending_tilt_{lf}_tilt_grad"]) < 1e-11
+        assert abs(mp._bending_tilt_leaflet(p, pos, mp.leaflet_tilts(p, lf), lf) - ref) <= 1e-12 * abs(ref)
+
+
+BTL_TRAJ = {"traj_ico4_gd_btl_nested_cg.npz": "gd", "traj_ico4_cg_btl_coupled_gd.npz": "cg",
+            "traj_disk5_gd_btl_backtrack.npz": "gd"}
+
+
+@pytest.mark.parametrize("fname", sorted(BTL_TRAJ))
+def test_port_reproduces_bending_tilt_leaflet_trajectory(fname):
+    g = load_golden(fname)
+    p = leaflet_problem(g)
+    E0, grad0 = mp.energy_and_gradient(p, p.positions)
+    assert abs(E0 - g["E0"]) <= 1e-12 * abs(g["E0"])
+    assert relerr(grad0, g["grad0"]) < 1e-11
+    stepper = mp.GradientDescent() if BTL_TRAJ[fname] == "gd" else mp.ConjugateGradient()
+    res = mp.minimize(p, stepper, int(g["n_steps"]), step_size=float(g["step_size0"]))
+    log = g["step_log"]
+    got = np.array([[float(t["success"]), t["next_step"], t["E_accepted"]] for t in res["trace"]])
+    assert got.shape == log.shape
+    assert np.array_equal(got[:, 0], log[:, 0])
+    assert np.allclose(got[:, 1], log[:, 1], rtol=1e-12, atol=0)
+    assert np.allclose(got[:, 2], log[:, 2], rtol=1e-9, atol=0)
+    assert relerr(p.positions, g["positions_final"]) < 1e-8
+    assert relerr(p.tilts_in, g["tilts_in_final"]) < 1e-8
+    assert relerr(p.tilts_out, g["tilts_out_final"]) < 1e-8
