@@ -61,6 +61,10 @@ extern "C" {
 #define MS_MOD_TILT_OUT 512u
 #define MS_MOD_TILT_SMOOTH_IN 1024u
 #define MS_MOD_TILT_SMOOTH_OUT 2048u
+/* leaflet bending + tilt-splay coupling (modules/energy/bending_tilt_in.py, bending_tilt_out.py ->
+ * bending_tilt_leaflet.py:231-758, default options, analytic gradient mode) */
+#define MS_MOD_BENDING_TILT_IN 4096u
+#define MS_MOD_BENDING_TILT_OUT 8192u
 #define MS_LEAFLET_IN 0
 #define MS_LEAFLET_OUT 1
 
@@ -116,7 +120,9 @@ enum ms_scalar {
   MS_S_TGNORM2_OUT = 21, /* adds the two (tilt_relaxation.py:862-868, 1139-1141)               */
   MS_S_TRZ_IN = 22,
   MS_S_TRZ_OUT = 23,
-  MS_NSCAL = 24
+  MS_S_EBT_IN = 24,  /* bending_tilt_in / bending_tilt_out energies */
+  MS_S_EBT_OUT = 25,
+  MS_NSCAL = 26
 };
 
 typedef struct ms_params {
@@ -250,6 +256,9 @@ typedef struct ms_leaflet_params {
 int ms_set_leaflet_tilts(ms_ctx *ctx, int leaflet, const double *tilts /* nv*3 */,
                          const uint8_t *tilt_fixed /* nv or NULL */, const ms_leaflet_params *params);
 int ms_get_leaflet_tilts(ms_ctx *ctx, int leaflet, double *tilts /* nv*3 */);
+/* per-vertex (kappa, c0) of bending_tilt_in / bending_tilt_out (modules/energy/bt_params.py:225-318:
+ * bending_modulus_in|out else bending_modulus; spontaneous_curvature_in|out else the global one) */
+int ms_set_leaflet_bending(ms_ctx *ctx, int leaflet, const double *kappa /* nv */, const double *c0 /* nv */);
 int ms_leaflet_tilt_energy_and_gradient(ms_ctx *ctx, double *energy, double *grad_in /* nv*3 or NULL */,
                                         double *grad_out /* nv*3 or NULL */);
 int ms_relax_leaflet_tilts(ms_ctx *ctx, const ms_tilt_relax_params *params,

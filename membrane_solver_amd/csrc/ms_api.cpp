@@ -54,9 +54,16 @@ struct ms_ctx {
     double k_smooth = 0.0;     // smoothness rigidity of the energy
     double k_smooth_precond = 0.0;  // rigidity entering the Jacobi diagonal
     uint8_t fixed_bit = 0;     // vertex flag bit that clamps a row of this field
-    uint32_t mod_tilt = 0, mod_smooth = 0;  // module bits that read this field
-    int s_etilt = 0, s_ets = 0, s_gn2 = 0, s_rz = 0;  // reduction slots
+    uint32_t mod_tilt = 0, mod_smooth = 0, mod_bt = 0;  // module bits that read this field
+    int s_etilt = 0, s_ets = 0, s_gn2 = 0, s_rz = 0, s_ebt = 0;  // reduction slots
+    // leaflet bending_tilt: per-vertex (kappa, c0), the per-vertex record of the last energy pass
+    // {base, A_eff, kappa*ratio*H, 0} and the sign of the divergence term
+    double* kappa = nullptr;
+    double* c0 = nullptr;
+    double* bt_vert = nullptr;
+    double div_sign = 1.0;
   } tf[3];
+  int factors_leaflet = 0;  // which leaflet's back-prop factors fK/fA hold (1 in, 2 out; 0: not a leaflet's)
   double* d_bt_vert = nullptr;    // (nvp,4) bending_tilt per-vertex record of the last energy pass
   bool bt_valid = false;          // d_bt_vert describes the current x
   // tilt relaxation work space (positions frozen): unit vertex normals, CG direction, Jacobi M^-1
@@ -195,12 +202,14 @@ struct ProfScope {
 constexpr uint32_t MASK_ENERGY = (1u << MS_S_ESURF) | (1u << MS_S_VOL) | (1u << MS_S_EBEND) |
                                  (1u << MS_S_MINEDGE2) | (1u << MS_S_GUARD) | (1u << MS_S_ETILT) |
                                  (1u << MS_S_EBT) | (1u << MS_S_ETS) | (1u << MS_S_ETILT_IN) |
-                                 (1u << MS_S_ETILT_OUT) | (1u << MS_S_ETS_IN) | (1u << MS_S_ETS_OUT);
+                                 (1u << MS_S_ETILT_OUT) | (1u << MS_S_ETS_IN) | (1u << MS_S_ETS_OUT) |
+                                 (1u << MS_S_EBT_IN) | (1u << MS_S_EBT_OUT);
 constexpr uint32_t MS_TILT_MODS = MS_MOD_TILT | MS_MOD_BENDING_TILT | MS_MOD_TILT_SMOOTH;  // modules reading the single tilt field
-constexpr uint32_t MS_LEAFLET_MODS = MS_MOD_TILT_IN | MS_MOD_TILT_OUT | MS_MOD_TILT_SMOOTH_IN | MS_MOD_TILT_SMOOTH_OUT;
+constexpr uint32_t MS_LEAFLET_BT = MS_MOD_BENDING_TILT_IN | MS_MOD_BENDING_TILT_OUT;
+constexpr uint32_t MS_LEAFLET_MODS = MS_MOD_TILT_IN | MS_MOD_TILT_OUT | MS_MOD_TILT_SMOOTH_IN | MS_MOD_TILT_SMOOTH_OUT | MS_LEAFLET_BT;
 constexpr uint32_t MS_ANY_TILT_MODS = MS_TILT_MODS | MS_LEAFLET_MODS;
 // modules whose shape gradient is added into g by a pass after K_C (so the direction cannot be fused)
-constexpr uint32_t MS_TILT_SHAPE_MODS = MS_MOD_TILT | MS_MOD_TILT_IN | MS_MOD_TILT_OUT;
+constexpr uint32_t MS_TILT_SHAPE_MODS = MS_MOD_TILT | MS_MOD_TILT_IN | MS_MOD_TILT_OUT | MS_LEAFLET_BT;
 using TiltField = ms_ctx::TiltField;
 
 // the tilt fields the module set reads: [0] single field, [1] inner, [2] outer leaflet
@@ -208,7 +217,7 @@ int active_fields(ms_ctx* c, uint32_t mods, TiltField* out[3]) {
   int n = 0;
   for (int k = 0; k < 3; ++k) {
     TiltField& f = c->tf[k];
-    const uint32_t reads = k == 0 ? MS_TILT_MODS : (f.mod_tilt | f.mod_smooth);
+    const uint32_t reads = k == 0 ? MS_TILT_MODS : (f.mod_tilt | f.mod_smooth | f.mod_bt);
     if (mods & reads) out[n++] = &f;
   }
   return n;
@@ -247,21 +256,35 @@ int tilt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* src
 }
 // bending_tilt facet pass (mode 0 energy / 1 + factors / 2 + tilt gradient) on the positions of
 // the preceding energy pass; `tilts` = the tangent tilts belonging to those positions
+int bt_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, const double* tilts);
 int bt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* tilts) {
-  if (!c->tf[0].tilts) return fail(c, MS_ERR_STATE, "bending_tilt module active but ms_set_tilts was never called");
+  return bt_pass_f(c, c->tf[0], mode, use_dir, alpha, tilts);
+}
+int bt_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, const double* tilts) {
+  if (!f.tilts) return fail(c, MS_ERR_STATE, "bending_tilt module active but its tilt field was never set");
+  const bool leaflet = &f != &c->tf[0];
+  if (leaflet && (!f.kappa || !f.bt_vert))
+    return fail(c, MS_ERR_STATE, "bending_tilt_in/out active but ms_set_leaflet_bending was never called");
   BtArgs a;
   a.m = device_mesh(c);
+  if (leaflet) {
+    a.m.kappa = f.kappa;
+    a.m.c0 = f.c0;
+  }
   a.tile0 = c->tile0;
   a.tile1 = c->tile1;
   a.x = c->buf[MS_BUF_X];
   a.d = use_dir ? c->buf[MS_BUF_D] : nullptr;
   a.alpha = alpha;
   a.tilts = tilts;
-  a.bt_vert = c->d_bt_vert;
+  a.bt_vert = leaflet ? f.bt_vert : c->d_bt_vert;
   a.fK = c->buf[MS_BUF_FK];
   a.fA = c->buf[MS_BUF_FA];
-  a.tilt_grad = c->tf[0].grad;
+  a.tilt_grad = f.grad;
   a.partials = c->d_partials;
+  a.g = c->buf[MS_BUF_G];
+  a.div_sign = f.div_sign;
+  a.e_slot = f.s_ebt;
   {
     ProfScope ps(c, 5);
     HIPCHK(c, launch_bt(a, mode, c->cap, c->til.max_ent, c->stream));
@@ -320,18 +343,76 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   a.alpha = alpha;
   a.xt = write_trial ? c->buf[MS_BUF_XT] : nullptr;
   const bool bt = (modules & MS_MOD_BENDING_TILT) != 0;
-  const bool bend = (modules & MS_MOD_BENDING) != 0 || bt;
+  const bool lbt = (modules & MS_LEAFLET_BT) != 0;
+  const bool bend = (modules & MS_MOD_BENDING) != 0 || bt || lbt;
   a.fK = (bend && write_factors) ? c->buf[MS_BUF_FK] : nullptr;
   a.fA = (bend && write_factors) ? c->buf[MS_BUF_FA] : nullptr;
   a.bt_vert = bt ? c->d_bt_vert : nullptr;
+  a.bt_normals = nullptr;
   a.atomic = c->deterministic ? 0 : 1;
   if (bt && !c->d_bt_vert) return fail(c, MS_ERR_STATE, "bending_tilt: ms_set_params did not allocate its buffers");
   a.partials = c->d_partials;
   a.bending_model = c->params.bending_model;
   a.modules = modules;
-  {
+  if (!lbt) {
     ProfScope ps(c, 0);
     HIPCHK(c, launch_energy(a, guard && use_dir, c->cap, c->til.max_ent, c->stream));
+  } else {
+    // leaflet bending_tilt: the tilt projections and the unit vertex normals of the evaluated positions come
+    // first, then per leaflet an energy pass with that leaflet's (kappa, c0) (signed curvature, K_dir = n)
+    // directly followed by its facet pass, because the factor buffers serve one leaflet at a time
+    for (int l = 1; l <= 2 && use_dir; ++l) {
+      TiltField& f = c->tf[l];
+      if (!(modules & (f.mod_tilt | f.mod_smooth | f.mod_bt))) continue;
+      int rc = tilt_pass_f(c, f, 2, true, alpha, f.tilts, f.trial);
+      if (rc) return rc;
+    }
+    if (!c->d_tn) {
+      const size_t b3 = sizeof(double) * 3 * (size_t)c->til.nvp;
+      HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_tn), b3));
+      HIPCHK(c, hipMemset(c->d_tn, 0, b3));
+    }
+    {
+      TiltArgs ta;
+      ta.m = device_mesh(c);
+      ta.tile0 = c->tile0;
+      ta.tile1 = c->tile1;
+      ta.x = c->buf[MS_BUF_X];
+      ta.d = use_dir ? c->buf[MS_BUF_D] : nullptr;
+      ta.alpha = alpha;
+      ta.tilts = c->tf[1].tilts ? c->tf[1].tilts : c->tf[2].tilts;
+      ta.tilts_out = c->d_tn;
+      ta.k_tilt = 0.0;
+      ta.g = nullptr;
+      ta.tilt_grad = nullptr;
+      ta.minv = nullptr;
+      ta.partials = c->d_partials;
+      ta.e_slot = MS_S_ETILT;
+      ta.consistent = 0;
+      if (!ta.tilts) return fail(c, MS_ERR_STATE, "bending_tilt_in/out active but ms_set_leaflet_tilts was never called");
+      ProfScope ps(c, 4);
+      HIPCHK(c, launch_tilt(ta, 3, c->cap, c->til.max_ent, c->stream));
+    }
+    for (int l = 1; l <= 2; ++l) {
+      TiltField& f = c->tf[l];
+      if (!(modules & f.mod_bt)) continue;
+      if (!f.kappa || !f.bt_vert || !f.tilts)
+        return fail(c, MS_ERR_STATE, "bending_tilt_in/out active but ms_set_leaflet_tilts / ms_set_leaflet_bending were not called");
+      EnergyArgs al = a;
+      al.m.kappa = f.kappa;
+      al.m.c0 = f.c0;
+      al.bt_vert = f.bt_vert;
+      al.bt_normals = c->d_tn;
+      al.bending_model = MS_BEND_HELFRICH;  // bending_tilt_leaflet.py:448-450
+      al.modules = (modules & ~MS_LEAFLET_MODS & ~MS_TILT_MODS) | MS_MOD_BENDING_TILT;
+      {
+        ProfScope ps(c, 0);
+        HIPCHK(c, launch_energy(al, guard && use_dir, c->cap, c->til.max_ent, c->stream));
+      }
+      int rc = bt_pass_f(c, f, write_factors ? 1 : 0, use_dir, alpha, use_dir ? f.trial : f.tilts);
+      if (rc) return rc;
+      if (write_factors) c->factors_leaflet = l;
+    }
   }
   if (modules & MS_TILT_MODS) {
     int rc = MS_OK;
@@ -357,7 +438,7 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
     int rc = MS_OK;
     const double* tilts = f.tilts;
     if (use_dir) {
-      rc = tilt_pass_f(c, f, 2, true, alpha, f.tilts, f.trial);
+      if (!lbt) rc = tilt_pass_f(c, f, 2, true, alpha, f.tilts, f.trial);  // (done above otherwise)
       if (rc) return rc;
       tilts = f.trial;
     }
@@ -371,7 +452,8 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
     if (rc) return rc;
   }
   if (bend && write_factors) c->factors_valid = !use_dir;
-  c->bt_valid = bt && !use_dir;
+  if (!lbt) c->factors_leaflet = 0;
+  c->bt_valid = (bt || lbt) && !use_dir;
   return MS_OK;
 }
 
@@ -379,10 +461,23 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
 int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulate, int dir_mode = 0,
                    bool reduce_now = true) {
   uint32_t modules = modules_in;
-  if ((modules & (MS_MOD_BENDING | MS_MOD_BENDING_TILT)) && !c->factors_valid)
+  if ((modules & (MS_MOD_BENDING | MS_MOD_BENDING_TILT | MS_LEAFLET_BT)) && !c->factors_valid)
     return fail(c, MS_ERR_STATE, "gradient pass needs the bending factors of an energy pass at x");
   if (modules & MS_MOD_BENDING_TILT)  // k_bt finished the factors: K_C is the plain bending back-prop
     modules = (modules & ~MS_MOD_BENDING_TILT) | MS_MOD_BENDING;
+  // leaflet bending_tilt: one back-propagation per leaflet (per-corner area factors), starting with the
+  // leaflet whose factors the energy pass left in fK/fA; the other leaflet's energy + facet pass is redone
+  int lbt_order[2] = {0, 0}, n_lbt = 0;
+  if (modules & MS_LEAFLET_BT) {
+    if (dir_mode) return fail(c, MS_ERR_STATE, "bending_tilt_in/out cannot use the fused direction pass");
+    if (modules & MS_MOD_BENDING) return fail(c, MS_ERR_STATE, "bending together with bending_tilt_in/out is outside the device path");
+    if (c->params.bending_grad_mode != MS_GRAD_ANALYTIC)
+      return fail(c, MS_ERR_STATE, "bending_tilt_in/out: only bending_gradient_mode=analytic is on the device path");
+    for (int l = 2; l >= 1; --l)
+      if (modules & c->tf[l].mod_bt) lbt_order[n_lbt++] = l;
+    if (n_lbt == 2 && c->factors_leaflet == lbt_order[1]) std::swap(lbt_order[0], lbt_order[1]);
+    modules |= MS_MOD_BENDING;
+  }
   GradientArgs a;
   a.m = device_mesh(c);
   a.tile0 = c->tile0;
@@ -404,9 +499,36 @@ int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulat
   a.pg = c->buf[MS_BUF_PG];
   a.pd = c->buf[MS_BUF_PD];
   a.atomic = c->deterministic ? 0 : 1;
-  {
+  a.bt_vert = nullptr;
+  a.tilts = nullptr;
+  a.div_sign = 1.0;
+  if (n_lbt == 0) {
     ProfScope ps(c, 1);
     HIPCHK(c, launch_gradient(a, c->cap, c->til.max_ent, c->stream));
+  }
+  for (int k = 0; k < n_lbt; ++k) {
+    TiltField& f = c->tf[lbt_order[k]];
+    if (c->factors_leaflet != lbt_order[k]) {  // redo this leaflet's energy + facet pass at x (factors on)
+      int rc = phase_energy(c, (modules_in & ~MS_LEAFLET_BT) | f.mod_bt, false, 0.0, false, false, true, false);
+      if (rc) return rc;
+    }
+    GradientArgs al = a;
+    al.m.kappa = f.kappa;
+    al.m.c0 = f.c0;
+    al.bt_vert = f.bt_vert;
+    al.tilts = f.tilts;
+    al.div_sign = f.div_sign;
+    if (k > 0) {  // the other modules' gradient went in with the first leaflet
+      al.modules = MS_MOD_BENDING;
+      al.gC = nullptr;
+      al.accumulate = 1;
+    }
+    {
+      ProfScope ps(c, 1);
+      HIPCHK(c, launch_gradient(al, c->cap, c->til.max_ent, c->stream));
+    }
+    int rc = bt_pass_f(c, f, 3, false, 0.0, f.tilts);  // + s dE/ddiv d(div)/dx
+    if (rc) return rc;
   }
   if (dir_mode) c->last_g = g_out;
   for (int k = 0; k < 3 && g_out; ++k) {  // module loop: the tilt magnitude modules add their shape gradient into g
@@ -471,6 +593,7 @@ void energies_from_mailbox(const ms_ctx* c, double e[4]) {
     const TiltField& f = c->tf[l];
     if (c->params.modules & f.mod_tilt) e[3] += c->h_scal[f.s_etilt];
     if (c->params.modules & f.mod_smooth) e[3] += c->h_scal[f.s_ets];
+    if (c->params.modules & f.mod_bt) e[1] += c->h_scal[f.s_ebt];
   }
 }
 
@@ -714,9 +837,12 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
     TiltField& f1 = c->tf[1];
     f1.fixed_bit = VF_TILT_FIXED_IN; f1.mod_tilt = MS_MOD_TILT_IN; f1.mod_smooth = MS_MOD_TILT_SMOOTH_IN;
     f1.s_etilt = MS_S_ETILT_IN; f1.s_ets = MS_S_ETS_IN; f1.s_gn2 = MS_S_TGNORM2_IN; f1.s_rz = MS_S_TRZ_IN;
+    f1.mod_bt = MS_MOD_BENDING_TILT_IN; f1.s_ebt = MS_S_EBT_IN; f1.div_sign = -1.0;  // bending_tilt_in.py:46
+    f0.mod_bt = MS_MOD_BENDING_TILT; f0.s_ebt = MS_S_EBT;
     TiltField& f2 = c->tf[2];
     f2.fixed_bit = VF_TILT_FIXED_OUT; f2.mod_tilt = MS_MOD_TILT_OUT; f2.mod_smooth = MS_MOD_TILT_SMOOTH_OUT;
     f2.s_etilt = MS_S_ETILT_OUT; f2.s_ets = MS_S_ETS_OUT; f2.s_gn2 = MS_S_TGNORM2_OUT; f2.s_rz = MS_S_TRZ_OUT;
+    f2.mod_bt = MS_MOD_BENDING_TILT_OUT; f2.s_ebt = MS_S_EBT_OUT; f2.div_sign = 1.0;
   }
   c->deterministic = getenv("MS_DETERMINISTIC") != nullptr && atoi(getenv("MS_DETERMINISTIC")) != 0;
   c->params.modules = MS_MOD_SURFACE;
@@ -742,6 +868,7 @@ void ms_destroy(ms_ctx* c) {
                   c->d_vflags, c->d_kappa, c->d_c0, c->tf[0].tilts, c->tf[0].grad, c->tf[0].trial, c->d_bt_vert, c->d_tn, c->tf[0].dir, c->tf[0].minv,
                   c->tf[1].tilts, c->tf[1].grad, c->tf[1].trial, c->tf[1].dir, c->tf[1].minv,
                   c->tf[2].tilts, c->tf[2].grad, c->tf[2].trial, c->tf[2].dir, c->tf[2].minv,
+                  c->tf[1].kappa, c->tf[1].c0, c->tf[1].bt_vert, c->tf[2].kappa, c->tf[2].c0, c->tf[2].bt_vert,
                   c->state, c->d_partials, c->d_scal, c->d_stage, c->d_bnd_rows, c->d_bnd_off,
                   c->d_halo_rows, c->d_scal_all};
   for (void* p : ptrs)
@@ -816,6 +943,8 @@ int ms_set_params(ms_ctx* c, const ms_params* p) {
     return fail(c, MS_ERR_INVALID, "ms_set_params: bad bending_grad_mode");
   if ((p->modules & MS_MOD_BENDING) && (p->modules & MS_MOD_BENDING_TILT))
     return fail(c, MS_ERR_INVALID, "ms_set_params: bending and bending_tilt are mutually exclusive");
+  if ((p->modules & MS_LEAFLET_BT) && (p->modules & (MS_MOD_BENDING | MS_MOD_BENDING_TILT)))
+    return fail(c, MS_ERR_INVALID, "ms_set_params: bending / bending_tilt together with bending_tilt_in/out is outside the device path");
   if ((p->modules & MS_MOD_BENDING_TILT) && c->shard_count != 1)
     return fail(c, MS_ERR_STATE, "the bending_tilt module is not sharded yet (single GPU only)");
   if ((p->modules & MS_MOD_BENDING_TILT) && !c->d_bt_vert) {
@@ -935,7 +1064,7 @@ int tilt_eval(ms_ctx* c, bool trial, bool gradient) {
   }
   for (int l = 1; l <= 2; ++l) {
     TiltField& f = c->tf[l];
-    if (!(mods & (f.mod_tilt | f.mod_smooth))) continue;
+    if (!(mods & (f.mod_tilt | f.mod_smooth | f.mod_bt))) continue;
     const double* tilts = trial ? f.trial : f.tilts;
     if (mods & f.mod_tilt) {
       rc = tilt_pass_f(c, f, gradient ? 1 : 0, false, 0.0, tilts, nullptr, /*shape_gradient=*/false, /*lumped=*/true);
@@ -943,6 +1072,11 @@ int tilt_eval(ms_ctx* c, bool trial, bool gradient) {
       mask |= 1u << f.s_etilt;
     } else if (gradient) {
       HIPCHK(c, hipMemsetAsync(f.grad, 0, b3, c->stream));
+    }
+    if (mods & f.mod_bt) {
+      rc = bt_pass_f(c, f, gradient ? 2 : 0, false, 0.0, tilts);
+      if (rc) return rc;
+      mask |= 1u << f.s_ebt;
     }
     if (mods & f.mod_smooth) {
       rc = ts_pass_f(c, f, gradient ? 1 : 0, false, 0.0, tilts);
@@ -961,11 +1095,12 @@ double tilt_energy_from_mailbox(const ms_ctx* c) {
     const TiltField& f = c->tf[l];
     if (c->params.modules & f.mod_tilt) e += c->h_scal[f.s_etilt];
     if (c->params.modules & f.mod_smooth) e += c->h_scal[f.s_ets];
+    if (c->params.modules & f.mod_bt) e += c->h_scal[f.s_ebt];
   }
   return e;
 }
 int ensure_bt_record(ms_ctx* c) {
-  if (!(c->params.modules & MS_MOD_BENDING_TILT) || c->bt_valid) return MS_OK;
+  if (!(c->params.modules & (MS_MOD_BENDING_TILT | MS_LEAFLET_BT)) || c->bt_valid) return MS_OK;
   return phase_energy(c, c->params.modules, false, 0.0, false, false, false, /*reduce_now=*/false);
 }
 
@@ -1138,7 +1273,7 @@ int relax_fields(ms_ctx* c, const ms_tilt_relax_params* rp, TiltField** fl, int 
   if (evals_out) *evals_out = evals;
   // the tilt-dependent energies in the mailbox belong to whatever was evaluated last
   c->carry_valid = c->grad_valid = false;
-  c->factors_valid = c->factors_valid && !(mods & MS_MOD_BENDING_TILT);
+  c->factors_valid = c->factors_valid && !(mods & (MS_MOD_BENDING_TILT | MS_LEAFLET_BT));
   return MS_OK;
 }
 }  // namespace
@@ -1211,6 +1346,31 @@ int ms_set_leaflet_tilts(ms_ctx* c, int leaflet, const double* tilts, const uint
   return ext_to_patch(c, tilts, f.tilts, 3);
 }
 
+int ms_set_leaflet_bending(ms_ctx* c, int leaflet, const double* kappa, const double* c0) {
+  if (!c || !kappa || !c0) return fail(c, MS_ERR_INVALID, "ms_set_leaflet_bending: NULL argument");
+  if (leaflet != MS_LEAFLET_IN && leaflet != MS_LEAFLET_OUT)
+    return fail(c, MS_ERR_INVALID, "ms_set_leaflet_bending: leaflet must be MS_LEAFLET_IN or MS_LEAFLET_OUT");
+  TiltField& f = c->tf[1 + leaflet];
+  const Tiling& t = c->til;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!f.kappa) {
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&f.kappa), sizeof(double) * (size_t)t.nvp));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&f.c0), sizeof(double) * (size_t)t.nvp));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&f.bt_vert), sizeof(double) * 4 * (size_t)t.nvp));
+    HIPCHK(c, hipMemset(f.bt_vert, 0, sizeof(double) * 4 * (size_t)t.nvp));
+  }
+  std::vector<double> k((size_t)t.nvp, 0.0), z((size_t)t.nvp, 0.0);
+  for (int i = 0; i < t.nv; ++i) {
+    k[i] = kappa[t.perm[i]];
+    z[i] = c0[t.perm[i]];
+  }
+  HIPCHK(c, hipMemcpy(f.kappa, k.data(), k.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(f.c0, z.data(), z.size() * sizeof(double), hipMemcpyHostToDevice));
+  c->factors_valid = false;
+  c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
+  return MS_OK;
+}
+
 int ms_get_leaflet_tilts(ms_ctx* c, int leaflet, double* tilts) {
   if (!c || !tilts || (leaflet != MS_LEAFLET_IN && leaflet != MS_LEAFLET_OUT) || !c->tf[1 + leaflet].tilts)
     return fail(c, MS_ERR_INVALID, "ms_get_leaflet_tilts: bad leaflet / no tilts set");
@@ -1227,7 +1387,7 @@ int leaflet_ready(ms_ctx* c, const char* who, TiltField** fl, int* nf) {
   *nf = 0;
   for (int l = 1; l <= 2; ++l) {
     TiltField& f = c->tf[l];
-    if (!(mods & (f.mod_tilt | f.mod_smooth))) continue;
+    if (!(mods & (f.mod_tilt | f.mod_smooth | f.mod_bt))) continue;
     if (!f.tilts) return fail(c, MS_ERR_STATE, std::string(who) + ": ms_set_leaflet_tilts was not called for an active leaflet");
     fl[(*nf)++] = &f;
   }
@@ -1250,7 +1410,7 @@ int ms_leaflet_tilt_energy_and_gradient(ms_ctx* c, double* energy, double* grad_
   for (int l = 0; l < 2; ++l) {
     if (!outs[l]) continue;
     TiltField& f = c->tf[1 + l];
-    if (f.tilts && (c->params.modules & (f.mod_tilt | f.mod_smooth))) {
+    if (f.tilts && (c->params.modules & (f.mod_tilt | f.mod_smooth | f.mod_bt))) {
       rc = patch_to_ext(c, f.grad, outs[l], 3);
       if (rc) return rc;
     } else {

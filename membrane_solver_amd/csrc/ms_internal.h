@@ -93,6 +93,7 @@ struct EnergyArgs {
   // bending_tilt: per-vertex record {base = 2H - c0 (0 on boundary), A_eff, kappa*ratio*H, 0}
   // written instead of the final factors; fK then holds K_dir * kappa * ratio (k_bt finishes)
   double* bt_vert;
+  const double* bt_normals;  // leaflet bending_tilt: unit vertex normals of the evaluated positions (signed H, K_dir = n)
   int atomic;             // accumulate per-vertex sums with LDS atomics (not bitwise reproducible)
 };
 
@@ -116,6 +117,10 @@ struct GradientArgs {
   const double* pg;
   const double* pd;
   int atomic;
+  // leaflet bending_tilt (BENDMODE 3): per-corner fA_eff = 1/2 kappa_k (base_k + s div_f t)^2
+  const double* bt_vert;   // (nvp,4): [0] = base
+  const double* tilts;     // (nvp,3) the leaflet's tangent tilts
+  double div_sign;
 };
 
 struct TiltArgs {
@@ -147,6 +152,9 @@ struct BtArgs {
   double* fA;              // mode 1: out {fA_eff, fA_vor}
   double* tilt_grad;       // mode 2: dE/dt ADDED here
   double* partials;
+  double* g;               // mode 3: shape gradient of the divergence term ADDED here
+  double div_sign;         // -1 inner leaflet, +1 outer leaflet / single field
+  int e_slot;              // reduction slot of the energy partial (MS_S_EBT / _IN / _OUT)
 };
 
 struct TsArgs {
@@ -166,7 +174,7 @@ struct TsArgs {
 // kernel launchers (ms_kernels.hip).  cap = T + max halo (LDS patch slots),
 // max_ent = largest per-tile vertex->corner entry count.
 size_t energy_lds_bytes(int T, int cap, int max_ent, bool bend, bool guard, bool flags, bool atomic = false);
-size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow, bool atomic = false);
+size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow, bool atomic = false, bool leaf = false);
 hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, hipStream_t s);
 hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStream_t s);
 // mode 0: energy partial (MS_S_ETILT); 1: energy + gradients; 2: project tilts to tangent

@@ -547,7 +547,15 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
     const bool interior = !(own_fl & VF_BOUNDARY);
     const double safe = fmax(aAv, 1.0e-12);
     const double k_mag = norm(K);
-    const double H = k_mag / (2.0 * safe);
+    double H = k_mag / (2.0 * safe);
+    // leaflet bending_tilt (bending_tilt_leaflet.py:455-459): oriented curvature H = (K . n)/(2 A) with
+    // the unit vertex normal, and K_dir = n (:574-575)
+    const bool signed_h = a.bt_normals != nullptr;
+    V3 nh = mk(0, 0, 0);
+    if (signed_h) {
+      nh = mk(a.bt_normals[3 * (size_t)v], a.bt_normals[3 * (size_t)v + 1], a.bt_normals[3 * (size_t)v + 2]);
+      H = dot(K, nh) / (2.0 * safe);
+    }
     const double ratio = safe > 1.0e-15 ? aAe / safe : 0.0;
     double scale_K, fe, fv;
     if (a.bt_vert) {
@@ -578,7 +586,9 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
     }
     if (a.fK) {
       V3 Kd;
-      if (k_mag > 1.0e-15) {
+      if (signed_h) {
+        Kd = nh;
+      } else if (k_mag > 1.0e-15) {
         Kd = mk(K.x / k_mag, K.y / k_mag, K.z / k_mag);
       } else {
         // bending.py:154-158 falls back to the vertex normal (bending_utils.py:13-34)
@@ -701,13 +711,19 @@ template <int BENDMODE, bool VOLROW, int TT, int CAPC, bool ATOMIC>
 __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
   extern __shared__ double lds[];
   constexpr bool BEND = BENDMODE != 0;
+  // BENDMODE 3: leaflet bending_tilt (bt_gradient.py:89-389): analytic back-propagation whose effective-area
+  // factor is per corner, 1/2 kappa_k (base_k + s div_f t)^2; `fae` then holds base_k
+  constexpr bool LEAF = BENDMODE == 3;
+  constexpr bool ANALYTIC = BENDMODE == 1 || BENDMODE == 3;
   const int T = TT ? TT : a.m.T;
   const int cap = CAPC ? CAPC : cap_rt;
   double* px = lds;
   double* fk = px + 3 * cap;
   double* fae = fk + (BEND ? 3 * cap : 0);
   double* fav = fae + (BEND ? cap : 0);
-  double* stg = fav + (BEND ? cap : 0);
+  double* kp = fav + (BEND ? cap : 0);        // LEAF: kappa
+  double* tl = kp + (LEAF ? cap : 0);         // LEAF: tilts
+  double* stg = tl + (LEAF ? 3 * cap : 0);
   // ATOMIC: stg holds the per-vertex accumulators (ds_add_f64) instead of per-corner columns
   constexpr int NACC = VOLROW ? 6 : 3;  // ATOMIC: gradient (and constraint-row) accumulator columns
   double* red = stg + (ATOMIC ? NACC : (VOLROW ? 18 : 9)) * T;
@@ -733,6 +749,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
     int hv = 0;
     if (has_h) hv = a.m.halo_ids[t.h0 + tid];
     double x0 = 0, x1 = 0, x2 = 0, k0 = 0, k1 = 0, k2 = 0, ae = 0, av = 0;
+    double okp = 0, ot0 = 0, ot1 = 0, ot2 = 0, hkp = 0, ht0 = 0, ht1 = 0, ht2 = 0;
     uint8_t fl = 0;
     if (own) {
       const size_t g = 3 * (size_t)v_own;
@@ -744,8 +761,14 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
         k0 = a.fK[g];
         k1 = a.fK[g + 1];
         k2 = a.fK[g + 2];
-        ae = a.fA[2 * (size_t)v_own];
+        ae = LEAF ? a.bt_vert[4 * (size_t)v_own] : a.fA[2 * (size_t)v_own];
         av = a.fA[2 * (size_t)v_own + 1];
+      }
+      if (LEAF) {
+        okp = a.m.kappa[v_own];
+        ot0 = a.tilts[g];
+        ot1 = a.tilts[g + 1];
+        ot2 = a.tilts[g + 2];
       }
     }
     CsrStage cs;
@@ -765,8 +788,14 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
         hk0 = a.fK[g];
         hk1 = a.fK[g + 1];
         hk2 = a.fK[g + 2];
-        hae = a.fA[2 * (size_t)hv];
+        hae = LEAF ? a.bt_vert[4 * (size_t)hv] : a.fA[2 * (size_t)hv];
         hav = a.fA[2 * (size_t)hv + 1];
+      }
+      if (LEAF) {
+        hkp = a.m.kappa[hv];
+        ht0 = a.tilts[g];
+        ht1 = a.tilts[g + 1];
+        ht2 = a.tilts[g + 2];
       }
     }
     if (own) {
@@ -780,6 +809,12 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
         fk[2 * cap + tid] = k2;
         fae[tid] = ae;
         fav[tid] = av;
+      }
+      if (LEAF) {
+        kp[tid] = okp;
+        tl[tid] = ot0;
+        tl[cap + tid] = ot1;
+        tl[2 * cap + tid] = ot2;
       }
     }
     if (!ATOMIC) {
@@ -800,6 +835,12 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
         fae[s] = hae;
         fav[s] = hav;
       }
+      if (LEAF) {
+        kp[s] = hkp;
+        tl[s] = ht0;
+        tl[cap + s] = ht1;
+        tl[2 * cap + s] = ht2;
+      }
     }
     for (int h = tid + T; h < t.nh; h += T) {  // halo longer than the workgroup (small tiles)
       const int v = a.m.halo_ids[t.h0 + h];
@@ -809,11 +850,13 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
       for (int c = 0; c < 3; ++c) {
         px[c * cap + s] = a.x[3 * (size_t)v + c];
         if (BEND) fk[c * cap + s] = a.fK[3 * (size_t)v + c];
+        if (LEAF) tl[c * cap + s] = a.tilts[3 * (size_t)v + c];
       }
       if (BEND) {
-        fae[s] = a.fA[2 * (size_t)v];
+        fae[s] = LEAF ? a.bt_vert[4 * (size_t)v] : a.fA[2 * (size_t)v];
         fav[s] = a.fA[2 * (size_t)v + 1];
       }
+      if (LEAF) kp[s] = a.m.kappa[v];
     }
   }
   __syncthreads();
@@ -895,7 +938,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
           G1 = G1 - 0.5 * (c0 * f12 - c2 * f01);
           G2 = G2 + 0.5 * (c0 * f12 + c1 * f02);
         }
-        if (BENDMODE == 1) {
+        if (ANALYTIC) {
           // term 2 weights (bending_gradient.py:37-42); (v1-v2) == -e0 etc.
           double w0 = 0.5 * dot(k1 - k2, e0);
           double w1 = 0.5 * dot(k2 - k0, e1);
@@ -908,7 +951,23 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
             t2 = (lfl[tf.l2] & VF_BOUNDARY) ? 0 : 1;
           }
           const int cnt = t0 + t1 + t2;
-          const double fe0 = fae[tf.l0], fe1 = fae[tf.l1], fe2 = fae[tf.l2];
+          double fe0 = fae[tf.l0], fe1 = fae[tf.l1], fe2 = fae[tf.l2];
+          if (LEAF) {
+            // per-corner factor 1/2 kappa_k (base_k + s div_f t)^2 (bending_tilt_leaflet.py:608-610);
+            // div_f t = sum_k t_k . (n x e_k) / max(|n|^2, 1e-20) (tilt_operators.py:191-330)
+            const double n2 = dot(n, n);
+            const double den = n2 > 1.0e-20 ? n2 : 1.0e-20;
+            const V3 q0 = cross(n, e0), q1 = cross(n, e1), q2 = cross(n, e2);
+            const V3 g0 = mk(q0.x / den, q0.y / den, q0.z / den);
+            const V3 g1 = mk(q1.x / den, q1.y / den, q1.z / den);
+            const V3 g2 = mk(q2.x / den, q2.y / den, q2.z / den);
+            const double dv = a.div_sign * (dot(lds_v3(tl, cap, tf.l0), g0) + dot(lds_v3(tl, cap, tf.l1), g1) +
+                                            dot(lds_v3(tl, cap, tf.l2), g2));
+            const double u0 = fe0 + dv, u1 = fe1 + dv, u2 = fe2 + dv;
+            fe0 = 0.5 * kp[tf.l0] * (u0 * u0);
+            fe1 = 0.5 * kp[tf.l1] * (u1 * u1);
+            fe2 = 0.5 * kp[tf.l2] * (u2 * u2);
+          }
           const double avg = cnt > 0 ? (fe0 * t0 + fe1 * t1 + fe2 * t2) / (double)cnt : 0.0;
           const double C0 = (t0 ? fe0 : avg) + fav[tf.l0];
           const double C1 = (t1 ? fe1 : avg) + fav[tf.l1];
@@ -1087,9 +1146,9 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
   }
 }
 
-size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow, bool atomic) {
+size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow, bool atomic, bool leaf) {
   const size_t cols = atomic ? (volrow ? 6 : 3) : (volrow ? 18 : 9);
-  size_t d = 3 * (size_t)cap + (bend ? 5 * (size_t)cap : 0) + cols * (size_t)T + 4 * 16;
+  size_t d = 3 * (size_t)cap + (bend ? 5 * (size_t)cap : 0) + (leaf ? 4 * (size_t)cap : 0) + cols * (size_t)T + 4 * 16;
   return d * sizeof(double) + (atomic ? 0 : u16_bytes(T, max_ent)) + (((size_t)cap + 15) / 16) * 16;
 }
 
@@ -1100,7 +1159,8 @@ hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStrea
   const bool volrow = a.gC != nullptr && (a.modules & MS_CON_VOLUME);
   const bool fast = a.m.T == FAST_T;
   const bool atomic = a.atomic != 0;
-  const size_t lds = gradient_lds_bytes(a.m.T, cap, max_ent, bend, volrow, atomic);
+  const bool leaf = bend && a.bt_vert != nullptr;
+  const size_t lds = gradient_lds_bytes(a.m.T, cap, max_ent, bend, volrow, atomic, leaf);
   hipError_t e;
 #define MS_LAUNCH_G(M, V, TT, CC, AT)                                                                \
   do {                                                                                               \
@@ -1115,8 +1175,14 @@ hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStrea
     else if (atomic) MS_LAUNCH_G(M, V, 0, 0, true);               \
     else MS_LAUNCH_G(M, V, 0, 0, false);                          \
   } while (0)
-  const int mode = !bend ? 0 : (a.bending_grad_mode == MS_GRAD_APPROX ? 2 : 1);
-  if (volrow) {
+  const int mode = !bend ? 0 : (leaf ? 3 : (a.bending_grad_mode == MS_GRAD_APPROX ? 2 : 1));
+  if (mode == 3) {  // leaflet bending_tilt: generic-size instances only (not a headline path)
+    if (volrow) {
+      if (atomic) MS_LAUNCH_G(3, true, 0, 0, true); else MS_LAUNCH_G(3, true, 0, 0, false);
+    } else {
+      if (atomic) MS_LAUNCH_G(3, false, 0, 0, true); else MS_LAUNCH_G(3, false, 0, 0, false);
+    }
+  } else if (volrow) {
     if (mode == 0) MS_PICK_G(0, true); else if (mode == 1) MS_PICK_G(1, true); else MS_PICK_G(2, true);
   } else {
     if (mode == 0) MS_PICK_G(0, false); else if (mode == 1) MS_PICK_G(1, false); else MS_PICK_G(2, false);
@@ -1301,7 +1367,7 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
       a.tilts_out[o] = nrm.x;
       a.tilts_out[o + 1] = nrm.y;
       a.tilts_out[o + 2] = nrm.z;
-      a.minv[t.v_lo + tid] = a.k_tilt * aw;  // raw diagonal; k_tvec mode 3 clamps and inverts
+      if (a.minv) a.minv[t.v_lo + tid] = a.k_tilt * aw;  // raw diagonal; k_tvec mode 3 clamps and inverts
     }
   }
   if (MODE != 2 && MODE != 3) {
@@ -1344,7 +1410,10 @@ hipError_t launch_tilt(const TiltArgs& a, int mode, int cap, int max_ent, hipStr
 //   MODE 1: div_eff_v = sum va_eff div / A_eff (:243-253), term = base + div_eff (0 on the
 //           boundary), then fK = K_dir kappa ratio term, fA_eff = kappa term^2/2,
 //           fA_vor = -2 kappa term ratio H (:279-283) for the unchanged gradient pass
-//   MODE 2: tilt gradient dE/dt_k = (sum_j kappa_j term_j va_eff_j) g_k ADDED to tilt_grad
+//   MODE 2: tilt gradient dE/dt_k = s (sum_j kappa_j term_j va_eff_j) g_k ADDED to tilt_grad
+//   MODE 3: (leaflet form) shape gradient of the divergence, s (sum_j ...) d(div_f t)/dx ADDED to g
+//           (modules/energy/bt_gradient.py:20-64, bending_tilt_leaflet.py:692-699)
+//   div_sign s: -1 for bending_tilt_in (bending_tilt_in.py:46), +1 otherwise.
 // LDS: px[3][cap] | tl[3][cap] | bs[cap] | kp[cap] | stg[9][T] (red aliases it) | vent | fl
 // ---------------------------------------------------------------------------
 template <int MODE>
@@ -1449,8 +1518,9 @@ __global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
       const V3 g0 = mk(c0v.x / denom, c0v.y / denom, c0v.z / denom);
       const V3 g1 = mk(c1v.x / denom, c1v.y / denom, c1v.z / denom);
       const V3 g2 = mk(c2v.x / denom, c2v.y / denom, c2v.z / denom);
-      const double dv = dot(lds_v3(tl, cap, tf.l0), g0) + dot(lds_v3(tl, cap, tf.l1), g1) +
-                        dot(lds_v3(tl, cap, tf.l2), g2);
+      const V3 tt0 = lds_v3(tl, cap, tf.l0), tt1 = lds_v3(tl, cap, tf.l1), tt2 = lds_v3(tl, cap, tf.l2);
+      // div_term = s * div_f t (bending_tilt_in.py:46: s = -1; out and the single field: +1)
+      const double dv = a.div_sign * (dot(tt0, g0) + dot(tt1, g1) + dot(tt2, g2));
       // cotans and effective corner areas, as in the energy pass
       const double ad = A2 < 1.0e-12 ? 1.0e-12 : A2;
       const double inv_ad = 1.0 / ad;
@@ -1481,10 +1551,25 @@ __global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
         s[1 * T] = ve1 * dv;
         s[2 * T] = ve2 * dv;
       } else if (MODE == 2) {
-        const double dE = (k0 * t0 * ve0 + k1 * t1 * ve1) + k2 * t2 * ve2;
+        const double dE = a.div_sign * ((k0 * t0 * ve0 + k1 * t1 * ve1) + k2 * t2 * ve2);
         s[0 * T] = dE * g0.x; s[1 * T] = dE * g0.y; s[2 * T] = dE * g0.z;
         s[3 * T] = dE * g1.x; s[4 * T] = dE * g1.y; s[5 * T] = dE * g1.z;
         s[6 * T] = dE * g2.x; s[7 * T] = dE * g2.y; s[8 * T] = dE * g2.z;
+      } else if (MODE == 3) {
+        // dE/ddiv * d(div_P1 t)/dx for ambient tilts (bt_gradient.py:20-64): a = e2, b = -e1,
+        // w = sum e_k x t_k, div = n.w/|n|^2
+        const double dE = a.div_sign * ((k0 * t0 * ve0 + k1 * t1 * ve1) + k2 * t2 * ve2);
+        const V3 w = (cross(e0, tt0) + cross(e1, tt1)) + cross(e2, tt2);
+        const double ndw = dot(n, w);
+        const double i2 = 1.0 / denom;
+        const V3 ddn = i2 * w - ((2.0 * ndw) * (i2 * i2)) * n;
+        const V3 d0 = i2 * cross(tt0, n), d1 = i2 * cross(tt1, n), d2 = i2 * cross(tt2, n);
+        const V3 ga = dE * ((cross(-e1, ddn) - d0) + d2);
+        const V3 gb = dE * ((cross(ddn, e2) + d0) - d1);
+        const V3 gc = -(ga + gb);
+        s[0 * T] = gc.x; s[1 * T] = gc.y; s[2 * T] = gc.z;
+        s[3 * T] = ga.x; s[4 * T] = ga.y; s[5 * T] = ga.z;
+        s[6 * T] = gb.x; s[7 * T] = gb.y; s[8 * T] = gb.z;
       }
     }
     if (MODE != 0) {
@@ -1524,16 +1609,17 @@ __global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
       a.fA[2 * (size_t)v] = 0.5 * kappa * (term * term);
       a.fA[2 * (size_t)v + 1] = -2.0 * term * krH;
     } else {
-      a.tilt_grad[o] += ax;
-      a.tilt_grad[o + 1] += ay;
-      a.tilt_grad[o + 2] += az;
+      double* dst = MODE == 3 ? a.g : a.tilt_grad;  // MODE 3: shape gradient, MODE 2: tilt gradient
+      dst[o] += ax;
+      dst[o + 1] += ay;
+      dst[o + 2] += az;
     }
   }
   if (MODE != 0) __syncthreads();  // red aliases the staging block
   {
     const double vals[1] = {e_bt};
     const int ops[1] = {0};
-    const int slots[1] = {MS_S_EBT};
+    const int slots[1] = {a.e_slot};
     block_reduce_store<1>(vals, ops, slots, red, a.partials + t.tile, (size_t)a.m.n_tiles);
   }
 }
@@ -1554,7 +1640,7 @@ hipError_t launch_bt(const BtArgs& a, int mode, int cap, int max_ent, hipStream_
     if (e != hipSuccess) return e;                                                          \
     hipLaunchKernelGGL((k_bt<M>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);          \
   } while (0)
-  if (mode == 0) MS_LAUNCH_B(0); else if (mode == 1) MS_LAUNCH_B(1); else MS_LAUNCH_B(2);
+  if (mode == 0) MS_LAUNCH_B(0); else if (mode == 1) MS_LAUNCH_B(1); else if (mode == 2) MS_LAUNCH_B(2); else MS_LAUNCH_B(3);
 #undef MS_LAUNCH_B
   return hipGetLastError();
 }

@@ -208,6 +208,13 @@ class DeviceMesh:
                                  float(smoothness if precond_smoothness is None else precond_smoothness))
         self._chk(L.lib().ms_set_leaflet_tilts(self._h, lf, _pd(arr), ptr, ctypes.byref(lp)), "ms_set_leaflet_tilts")
 
+    def set_leaflet_bending(self, leaflet: str, kappa, c0):
+        """Per-vertex (kappa, c0) of bending_tilt_in / bending_tilt_out."""
+        lf = {"in": L.MS_LEAFLET_IN, "out": L.MS_LEAFLET_OUT}[leaflet]
+        k = _f64(np.broadcast_to(np.asarray(kappa, dtype=np.float64), (self.nv,)), (self.nv,), "kappa")
+        c = _f64(np.broadcast_to(np.asarray(c0, dtype=np.float64), (self.nv,)), (self.nv,), "c0")
+        self._chk(L.lib().ms_set_leaflet_bending(self._h, lf, _pd(k), _pd(c)), "ms_set_leaflet_bending")
+
     def get_leaflet_tilts(self, leaflet: str) -> np.ndarray:
         out = np.empty((self.nv, 3), dtype=np.float64)
         lf = {"in": L.MS_LEAFLET_IN, "out": L.MS_LEAFLET_OUT}[leaflet]

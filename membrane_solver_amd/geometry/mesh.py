@@ -361,6 +361,8 @@ class HipMirror:
 
     def mark_device_leaflets_current(self):
         for lf, key in list(self._leaflet_keys.items()):
+            if lf.startswith("bend_"):
+                continue
             self._leaflet_keys[lf] = (key[0], getattr(self.mesh, "_tilts_version", None)) + key[2:4] + (None,)
 
     def upload_tilt_fixed(self):

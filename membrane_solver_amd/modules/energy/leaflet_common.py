@@ -13,7 +13,8 @@ from ... import _lib as L
 from ...geometry.mesh import mirror_for
 
 LEAFLET_BITS = {("tilt", "in"): L.MS_MOD_TILT_IN, ("tilt", "out"): L.MS_MOD_TILT_OUT,
-                ("smooth", "in"): L.MS_MOD_TILT_SMOOTH_IN, ("smooth", "out"): L.MS_MOD_TILT_SMOOTH_OUT}
+                ("smooth", "in"): L.MS_MOD_TILT_SMOOTH_IN, ("smooth", "out"): L.MS_MOD_TILT_SMOOTH_OUT,
+                ("bt", "in"): L.MS_MOD_BENDING_TILT_IN, ("bt", "out"): L.MS_MOD_BENDING_TILT_OUT}
 
 # options of the reference's leaflet modules that change their result and are not on the device path
 _UNSUPPORTED_KEYS = (
@@ -24,6 +25,14 @@ _UNSUPPORTED_KEYS = (
     "tilt_in_shared_rim_outer_shell_mass_mode", "tilt_out_shared_rim_outer_shell_mass_mode",
     "tilt_axisymmetric_about_thetaB_center", "inner_coupled_update_mode", "tilt_relax_energy_guard_factor",
     "tilt_thetaB_optimize",
+    # bending_tilt_leaflet.py toggles (bt_params.py:13-222, bt_selection.py, bt_divergence.py)
+    "theory_parity_lane", "bending_tilt_assume_J0_presets", "bending_tilt_assume_J0_presets_in",
+    "bending_tilt_assume_J0_presets_out", "bending_tilt_base_term_reference_mode",
+    "bending_tilt_base_term_reference_mode_in", "bending_tilt_base_term_reference_mode_out",
+    "bending_tilt_base_term_boundary_group_in", "bending_tilt_base_term_boundary_group_out",
+    "bending_tilt_base_term_region_mode", "bending_tilt_in_update_mode",
+    "bending_tilt_in_scaffold_shape_stencil_mode", "bending_tilt_interface_divergence_mode",
+    "bending_tilt_out_interface_divergence_mode",
 )
 
 
@@ -88,6 +97,62 @@ def relax_tilt_modulus(param_resolver, global_params, leaflet: str) -> float:
     return float(_get(param_resolver, global_params, f"tilt_modulus_{leaflet}") or 0.0)
 
 
+def bending_params(mesh, global_params, leaflet: str):
+    """(kappa, c0) arrays of bending_tilt_in/out (bt_params.py:225-318): leaflet modulus / spontaneous curvature with
+    the global fallbacks; per-vertex arrays of an ArrayMesh override like vertex options do."""
+    nv = len(mesh.vertex_ids)
+    k = global_params.get(f"bending_modulus_{leaflet}")
+    if k is None:
+        k = global_params.get("bending_modulus", 0.0)
+    c = global_params.get(f"spontaneous_curvature_{leaflet}")
+    if c is None:
+        c = global_params.get("spontaneous_curvature")
+        if c is None:
+            c = global_params.get("intrinsic_curvature", 0.0)
+    kappa = np.full(nv, float(k or 0.0))
+    c0 = np.full(nv, float(c or 0.0))
+    getter = getattr(mesh, "get_vertex_parameter_array", None)
+    if getter is not None:
+        for key in (f"bending_modulus_{leaflet}", "bending_modulus"):
+            arr = getter(key)
+            if arr is not None:
+                kappa = np.asarray(arr, dtype=np.float64)
+                break
+        for key in (f"spontaneous_curvature_{leaflet}", "spontaneous_curvature"):
+            arr = getter(key)
+            if arr is not None:
+                c0 = np.asarray(arr, dtype=np.float64)
+                break
+    elif isinstance(getattr(mesh, "vertices", None), dict):
+        rows = mesh.vertex_index_to_row
+        for vid, vertex in mesh.vertices.items():
+            row = rows.get(int(vid))
+            opts = getattr(vertex, "options", None) or {}
+            if row is None:
+                continue
+            for key in (f"bending_modulus_{leaflet}", "bending_modulus"):
+                if key in opts:
+                    try:
+                        kappa[row] = float(opts[key])
+                    except (TypeError, ValueError):
+                        pass
+                    break
+            for key in (f"spontaneous_curvature_{leaflet}", "spontaneous_curvature", "intrinsic_curvature"):
+                if opts.get(key) is not None:
+                    try:
+                        c0[row] = float(opts[key])
+                    except (TypeError, ValueError):
+                        pass
+                    break
+    return kappa, c0
+
+
+def check_bt_supported(global_params) -> None:
+    mode = str(global_params.get("bending_gradient_mode", "analytic") or "analytic").strip().lower()
+    if mode != "analytic":
+        raise L.MembraneHipError("bending_tilt_in/out: only bending_gradient_mode=analytic is on the HIP hot path")
+
+
 def device_params(param_resolver, global_params, leaflet: str) -> dict:
     return {"tilt_modulus": tilt_modulus(param_resolver, global_params, leaflet),
             "mass_mode": tilt_mass_mode(param_resolver, global_params, leaflet),
@@ -120,8 +185,18 @@ def evaluate(mesh, global_params, param_resolver, *, kind: str, leaflet: str, po
     dm.set_leaflet_tilts(leaflet, tilts, **params)
     dm.set_leaflet_tilts(other, np.zeros((nv, 3)), tilt_modulus=0.0, smoothness=0.0)
     mir._leaflet_keys = {}  # foreign arrays were uploaded
+    if kind == "bt":
+        check_bt_supported(global_params)
+        dm.set_leaflet_bending(leaflet, *bending_params(mesh, global_params, leaflet))
     dm.set_params(modules=LEAFLET_BITS[(kind, leaflet)])
-    if grad_arr is not None and kind == "tilt":
+    if kind == "bt":
+        if grad_arr is not None:
+            e, g = dm.energy_and_gradient(want_grad=True)
+            grad_arr += g
+            E = float(e[1])
+        else:
+            E = float(dm.energy()[1])
+    elif grad_arr is not None and kind == "tilt":
         e, g = dm.energy_and_gradient(want_grad=True)
         grad_arr += g
         E = float(e[3])

@@ -47,16 +47,22 @@ _ENERGY_BITS = {"surface": L.MS_MOD_SURFACE, "bending": L.MS_MOD_BENDING, "volum
                 "tilt": L.MS_MOD_TILT, "bending_tilt": L.MS_MOD_BENDING_TILT,
                 "tilt_smoothness": L.MS_MOD_TILT_SMOOTH,
                 "tilt_in": L.MS_MOD_TILT_IN, "tilt_out": L.MS_MOD_TILT_OUT,
-                "tilt_smoothness_in": L.MS_MOD_TILT_SMOOTH_IN, "tilt_smoothness_out": L.MS_MOD_TILT_SMOOTH_OUT}
+                "tilt_smoothness_in": L.MS_MOD_TILT_SMOOTH_IN, "tilt_smoothness_out": L.MS_MOD_TILT_SMOOTH_OUT,
+                "bending_tilt_in": L.MS_MOD_BENDING_TILT_IN, "bending_tilt_out": L.MS_MOD_BENDING_TILT_OUT}
 _ENERGY_SLOT = {"surface": 0, "bending": 1, "volume": 2, "tilt": 3, "bending_tilt": 1, "tilt_smoothness": 3,
-                "tilt_in": 3, "tilt_out": 3, "tilt_smoothness_in": 3, "tilt_smoothness_out": 3}
+                "tilt_in": 3, "tilt_out": 3, "tilt_smoothness_in": 3, "tilt_smoothness_out": 3,
+                "bending_tilt_in": 1, "bending_tilt_out": 1}
 _SINGLE_TILT_BITS = L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT | L.MS_MOD_TILT_SMOOTH
-_LEAFLET_BITS = L.MS_MOD_TILT_IN | L.MS_MOD_TILT_OUT | L.MS_MOD_TILT_SMOOTH_IN | L.MS_MOD_TILT_SMOOTH_OUT
+_LEAFLET_BT_BITS = L.MS_MOD_BENDING_TILT_IN | L.MS_MOD_BENDING_TILT_OUT
+_LEAFLET_BITS = (L.MS_MOD_TILT_IN | L.MS_MOD_TILT_OUT | L.MS_MOD_TILT_SMOOTH_IN | L.MS_MOD_TILT_SMOOTH_OUT
+                 | _LEAFLET_BT_BITS)
 _TILT_BITS = _SINGLE_TILT_BITS | _LEAFLET_BITS
 # scalar slot of every module that shares energies[3]
 _TILT_SCALAR = {"tilt": L.MS_S_ETILT, "tilt_smoothness": L.MS_S_ETS, "tilt_in": L.MS_S_ETILT_IN,
                 "tilt_out": L.MS_S_ETILT_OUT, "tilt_smoothness_in": L.MS_S_ETS_IN,
                 "tilt_smoothness_out": L.MS_S_ETS_OUT}
+_BEND_SCALAR = {"bending": L.MS_S_EBEND, "bending_tilt": L.MS_S_EBT, "bending_tilt_in": L.MS_S_EBT_IN,
+                "bending_tilt_out": L.MS_S_EBT_OUT}
 
 
 class GradientRows:
@@ -147,7 +153,8 @@ class Minimizer:
             if name not in _ENERGY_BITS:
                 raise L.MembraneHipError(
                     f"energy module {name!r} is outside the HIP hot path (surface, bending, volume, tilt, "
-                    "bending_tilt, tilt_smoothness, tilt_in, tilt_out, tilt_smoothness_in, tilt_smoothness_out)")
+                    "bending_tilt, tilt_smoothness, tilt_in, tilt_out, tilt_smoothness_in, tilt_smoothness_out, "
+                    "bending_tilt_in, bending_tilt_out)")
         self.constraint_modules = [self.constraint_manager.get_constraint(c)
                                    for c in self.constraint_module_names]
         for name in self.constraint_module_names:
@@ -252,6 +259,18 @@ class Minimizer:
             if gp.get("line_search_reduced_energy", False):
                 raise L.MembraneHipError("line_search_reduced_energy is outside the HIP hot path")
             mir.upload_leaflets({lf: _lc.device_params(self.param_resolver, gp, lf) for lf in ("in", "out")})
+            if mods & _LEAFLET_BT_BITS:
+                _lc.check_bt_supported(gp)
+                if mods & (L.MS_MOD_BENDING | L.MS_MOD_BENDING_TILT):
+                    raise L.MembraneHipError("bending / bending_tilt together with bending_tilt_in/out is outside "
+                                             "the HIP hot path")
+                for lf, bit in (("in", L.MS_MOD_BENDING_TILT_IN), ("out", L.MS_MOD_BENDING_TILT_OUT)):
+                    if mods & bit:
+                        kappa, c0 = _lc.bending_params(self.mesh, gp, lf)
+                        key = (mir._topo_key, kappa.tobytes(), c0.tobytes())
+                        if mir._leaflet_keys.get("bend_" + lf) != key:
+                            dm.set_leaflet_bending(lf, kappa, c0)
+                            mir._leaflet_keys["bend_" + lf] = key
         if mods & (_SINGLE_TILT_BITS):
             if gp.get("line_search_reduced_energy", False):
                 raise L.MembraneHipError("line_search_reduced_energy (inner tilt relaxation inside every "
@@ -303,11 +322,12 @@ class Minimizer:
         out = {}
         for name in self.energy_module_names:
             out[name] = float(e[_ENERGY_SLOT[name]])
-        sharing = [n for n in out if n in _TILT_SCALAR]
-        if len(sharing) > 1:  # they share energies[3]: split via the scalars
-            sc = dm.fetch_scalars()
-            for n in sharing:
-                out[n] = float(sc[_TILT_SCALAR[n]]) if dm.modules & _ENERGY_BITS[n] else 0.0
+        for table in (_TILT_SCALAR, _BEND_SCALAR):
+            sharing = [n for n in out if n in table]
+            if len(sharing) > 1:  # they share one entry of the energy vector: split via the scalars
+                sc = dm.fetch_scalars()
+                for n in sharing:
+                    out[n] = float(sc[table[n]]) if dm.modules & _ENERGY_BITS[n] else 0.0
         return out
 
     # -- constraint enforcement (minimizer.py:1103-1188) ---------------------------

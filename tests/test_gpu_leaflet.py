@@ -243,3 +243,108 @@ def test_leaflet_guards():
                    ConstraintModuleManager([]), quiet=True)
     with pytest.raises(L.MembraneHipError, match="together"):
         mz.compute_energy()
+
+
+# ---------------------------------------------------------------------------
+# bending_tilt_in / bending_tilt_out (bending_tilt_leaflet.py, default options, analytic gradient)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["ico5", "disk5"])
+def test_bending_tilt_leaflet_plugins_match_reference(name):
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd.core.parameters import GlobalParameters, ParameterResolver
+    from membrane_solver_amd.geometry.mesh import ArrayMesh
+    from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
+
+    g = load_golden("bending_tilt_leaflet_cases.npz")
+    gp = GlobalParameters(_gp(g, "gp_json"))
+    pos, tri = g[name + "_positions"], g[name + "_tri"]
+    tin, tout = g[name + "_tilts_in"], g[name + "_tilts_out"]
+    mesh = ArrayMesh(pos, tri, global_parameters=gp, tilts_in=tin, tilts_out=tout)
+    res = ParameterResolver(gp)
+    em = EnergyModuleManager(["bending_tilt_in", "bending_tilt_out"])
+    for lf in ("in", "out"):
+        module = em.get_module(f"bending_tilt_{lf}")
+        grad, tg = np.zeros_like(pos), np.zeros_like(pos)
+        kw = {"tilt_in_grad_arr": tg} if lf == "in" else {"tilt_out_grad_arr": tg}
+        E = module.compute_energy_and_gradient_array(mesh, gp, res, positions=pos, index_map=mesh.vertex_index_to_row,
+                                                     grad_arr=grad, tilts_in=tin, tilts_out=tout, **kw)
+        ref = g[f"{name}_bending_tilt_{lf}_E"]
+        assert abs(E - ref) <= 1e-12 * abs(ref)
+        assert relerr(grad, g[f"{name}_bending_tilt_{lf}_grad"]) < 1e-10
+        assert relerr(tg, g[f"{name}_bending_tilt_{lf}_tilt_grad"]) < 1e-10
+        E2 = module.compute_energy_and_gradient_array(mesh, gp, res, positions=pos, index_map=mesh.vertex_index_to_row,
+                                                      grad_arr=None, tilts_in=tin, tilts_out=tout)
+        assert abs(E2 - ref) <= 1e-12 * abs(ref)
+    gp.set("bending_gradient_mode", "approx")
+    with pytest.raises(L.MembraneHipError, match="analytic"):
+        em.get_module("bending_tilt_in").compute_energy_and_gradient_array(
+            mesh, gp, res, positions=pos, index_map=mesh.vertex_index_to_row, grad_arr=np.zeros_like(pos),
+            tilts_in=tin, tilts_out=tout)
+
+
+BTL_TRAJ = {"traj_ico4_gd_btl_nested_cg.npz": "gd", "traj_ico4_cg_btl_coupled_gd.npz": "cg",
+            "traj_disk5_gd_btl_backtrack.npz": "gd"}
+
+
+@pytest.mark.parametrize("fname", sorted(BTL_TRAJ))
+def test_minimizer_reproduces_bending_tilt_leaflet_trajectory(fname):
+    g = load_golden(fname)
+    mesh, mz, log = _leaflet_minimizer(g, BTL_TRAJ[fname], observe=True)
+    E0, grad0 = mz.compute_energy_and_gradient_array()
+    assert abs(E0 - g["E0"]) <= 1e-12 * abs(g["E0"])
+    assert relerr(grad0, g["grad0"]) < 1e-10
+    res = mz.minimize(int(g["n_steps"]))
+    got, ref = np.array(log), g["step_log"]
+    assert got.shape == ref.shape
+    assert np.array_equal(got[:, 0], ref[:, 0]), "accept/reject sequence differs from the reference"
+    assert np.allclose(got[:, 1], ref[:, 1], rtol=1e-12, atol=0)
+    assert np.allclose(got[:, 2], ref[:, 2], rtol=1e-9, atol=0)
+    assert relerr(mesh.positions_view(), g["positions_final"]) < 1e-8
+    assert relerr(mesh.tilts_in_view(), g["tilts_in_final"]) < 1e-8
+    assert relerr(mesh.tilts_out_view(), g["tilts_out_final"]) < 1e-8
+    assert abs(res["energy"] - g["E_final"]) <= 1e-9 * abs(g["E_final"])
+    bd = mz.compute_energy_breakdown()
+    assert abs(sum(bd.values()) - res["energy"]) <= 1e-12 * abs(res["energy"])
+    mesh2, mz2, _ = _leaflet_minimizer(g, BTL_TRAJ[fname], observe=False)
+    res2 = mz2.minimize(int(g["n_steps"]))
+    assert relerr(mesh2.positions_view(), g["positions_final"]) < 1e-8
+    assert relerr(mesh2.tilts_in_view(), g["tilts_in_final"]) < 1e-8
+    assert abs(res2["energy"] - g["E_final"]) <= 1e-9 * abs(g["E_final"])
+
+
+def test_bending_tilt_leaflet_midsize_matches_oracle():
+    """131 220 facets (many tiles, default tile size): both leaflets at once against the CPU oracle."""
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+    from oracle import minimizer_port as mp
+
+    P, T = meshgen.icosphere(81)
+    P = meshgen.smooth_displace(P, 0.05)
+    rng = np.random.default_rng(4)
+    nrm = mp.unit_vertex_normals(P, T)
+    tin = 0.2 * rng.normal(size=P.shape)
+    tin -= np.einsum("ij,ij->i", tin, nrm)[:, None] * nrm
+    tout = 0.15 * rng.normal(size=P.shape)
+    tout -= np.einsum("ij,ij->i", tout, nrm)[:, None] * nrm
+    gp = {"bending_modulus": 0.8, "bending_modulus_in": 1.2, "spontaneous_curvature": 0.05,
+          "spontaneous_curvature_out": -0.1, "tilt_modulus_in": 1.3, "surface_tension": 1.0}
+    mods = ["surface", "tilt_in", "bending_tilt_in", "bending_tilt_out"]
+    p = mp.Problem(positions=P, tri=T, tilts_in=tin, tilts_out=tout, energy_modules=mods, gp=gp)
+    dm = DeviceMesh(P, T)
+    dm.set_leaflet_tilts("in", tin, tilt_modulus=1.3)
+    dm.set_leaflet_tilts("out", tout)
+    dm.set_leaflet_bending("in", 1.2, 0.05)
+    dm.set_leaflet_bending("out", 0.8, -0.1)
+    dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_TILT_IN | L.MS_MOD_BENDING_TILT_IN | L.MS_MOD_BENDING_TILT_OUT)
+    E_ref, g_ref = mp.energy_and_gradient(p, P)
+    e, grad = dm.energy_and_gradient()
+    assert abs(e.sum() - E_ref) <= 1e-11 * abs(E_ref)
+    assert relerr(grad, g_ref) < 1e-10
+    from oracle import ms_oracle as orc
+    va = orc.barycentric_vertex_areas(P, T)
+    Er, gi_ref, go_ref = mp.energy_and_leaflet_tilt_gradients(p, P, tin, tout, va)
+    E, gi, go = dm.leaflet_tilt_energy_and_gradient()
+    assert abs(E - Er) <= 1e-11 * abs(Er)
+    assert relerr(gi, gi_ref) < 1e-10 and relerr(go, go_ref) < 1e-10
+    dm.close()
