@@ -260,7 +260,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
   // barrier); the vertex offsets stay in registers; the flag bytes are staged only when
   // some vertex carries VF_BOUNDARY
   double* red = stg;
-  // ATOMIC: stg holds the five per-vertex accumulators K(3), A_vor, A_eff (ds_add_f64), no CSR
+  // ATOMIC: stg holds the five per-vertex accumulators K(3), A_vor, A_eff - A_vor (ds_add_f64), no CSR
   uint16_t* vent = reinterpret_cast<uint16_t*>(stg + (BEND ? (ATOMIC ? 5 : 9) * T : 5 * 16));
   uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + ((BEND && !ATOMIC) ? ((max_ent + 3) & ~3) : 0));
   const bool stage_flags = a.m.has_boundary || GUARD;
@@ -476,15 +476,18 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
             const int no = t.n_owned;
             if (tf.l0 < no) {
               atomicAdd(&stg[tf.l0], K0.x); atomicAdd(&stg[T + tf.l0], K0.y); atomicAdd(&stg[2 * T + tf.l0], K0.z);
-              atomicAdd(&stg[3 * T + tf.l0], va0); atomicAdd(&stg[4 * T + tf.l0], ve0);
+              atomicAdd(&stg[3 * T + tf.l0], va0);
+              if (ve0 != va0) atomicAdd(&stg[4 * T + tf.l0], ve0 - va0);
             }
             if (tf.l1 < no) {
               atomicAdd(&stg[tf.l1], K1.x); atomicAdd(&stg[T + tf.l1], K1.y); atomicAdd(&stg[2 * T + tf.l1], K1.z);
-              atomicAdd(&stg[3 * T + tf.l1], va1); atomicAdd(&stg[4 * T + tf.l1], ve1);
+              atomicAdd(&stg[3 * T + tf.l1], va1);
+              if (ve1 != va1) atomicAdd(&stg[4 * T + tf.l1], ve1 - va1);
             }
             if (tf.l2 < no) {
               atomicAdd(&stg[tf.l2], K2.x); atomicAdd(&stg[T + tf.l2], K2.y); atomicAdd(&stg[2 * T + tf.l2], K2.z);
-              atomicAdd(&stg[3 * T + tf.l2], va2); atomicAdd(&stg[4 * T + tf.l2], ve2);
+              atomicAdd(&stg[3 * T + tf.l2], va2);
+              if (ve2 != va2) atomicAdd(&stg[4 * T + tf.l2], ve2 - va2);
             }
           } else {
             double* s = stg + tid;
@@ -534,7 +537,9 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
       aKy = stg[T + tid];
       aKz = stg[2 * T + tid];
       aAv = stg[3 * T + tid];
-      aAe = stg[4 * T + tid];
+      // A_eff differs from A_vor only through the boundary redistribution and the degenerate-area clamp:
+      // the fifth column holds that (mostly empty) difference, saving one LDS atomic per corner
+      aAe = aAv + stg[4 * T + tid];
     }
     __syncthreads();  // red aliases stg
   }
@@ -890,14 +895,18 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
       V3 G0 = mk(0, 0, 0), G1 = mk(0, 0, 0), G2 = mk(0, 0, 0);
       const V3 n = cross(e2, -e1);
       const double S = norm(n);
-
-      if (surf && S >= 1.0e-12) {
-        // g0 = gamma * 0.5 * (v1 - v2) x nhat ; (v1-v2) == -e0 exactly
-        const double hs = 0.5 * gam / S;
-        G0 = G0 + hs * cross(-e0, n);
-        G1 = G1 + hs * cross(-e1, n);
-        G2 = G2 + hs * cross(-e2, n);
-      }
+      // Every geometric contribution of this facet has the form
+      //     G_k = (a_k1 e1 + a_k2 e2) + R (e_k x n) [+ the -L fK difference vectors]:
+      // surface: -(gamma/2S) (e_k x n); grad-cot corner k with weight w_k: +-(w_k/S) e_j and
+      // +-(w_k cot_k/S^2) (e_j x n) -- collected over the three corners the (e_j x n) coefficients are the SAME
+      // scalar R for all three vertices (sum_k e_k = 0); obtuse area term: -(factor/2S) (e_k x n); the six edge
+      // terms q_k e_k.  Collecting scalars first leaves 2 cross products and ~10 vector FMAs per facet instead
+      // of 9 cross products; sum_k G_k = 0 (translation invariance) gives the third vertex for free.
+      const double invS = S > 1.0e-15 ? 1.0 / S : 0.0;
+      double R = 0.0;                       // coefficient of (e_k x n)
+      double a01 = 0, a02 = 0, a11 = 0, a12 = 0;  // e-part of G0, G1 in the basis (e1, e2)
+      V3 T0 = mk(0, 0, 0), T1 = mk(0, 0, 0);     // -L fK part of G0, G1
+      if (surf && S >= 1.0e-12) R = -(0.5 * gam) * invS;  // g_k = gamma/2 (v_{k+1}-v_{k+2}) x nhat
       if ((VOLROW || volpen) && (tf.flags & TF_BODY)) {
         const V3 w0 = cross(v1, v2), w1 = cross(v2, v0), w2 = cross(v0, v1);
         if (volpen) {
@@ -927,22 +936,21 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
       if (BEND) {
         const V3 k0 = lds_v3(fk, cap, tf.l0), k1 = lds_v3(fk, cap, tf.l1), k2 = lds_v3(fk, cap, tf.l2);
         // cotans exactly as compute_curvature_data produces `weights`
-        const double ad = S < 1.0e-12 ? 1.0e-12 : S;
-        const double inv_ad = 1.0 / ad;
+        const double inv_ad = S < 1.0e-12 ? 1.0e12 : invS;  // 1 / max(S, 1e-12)
         const double d12 = dot(e1, e2), d20 = dot(e2, e0), d01 = dot(e0, e1);
         const double c0 = -d12 * inv_ad, c1 = -d20 * inv_ad, c2 = -d01 * inv_ad;
-        // term 1: -L fK  (bending_kernels.f90:118-129)
+        // term 1: -L fK  (bending_kernels.f90:118-129): G0 -= b + c, G1 -= a - c, G2 += a + b
+        const V3 f02 = k0 - k2, f01 = k0 - k1, f12 = k1 - k2;
         {
-          const V3 f02 = k0 - k2, f01 = k0 - k1, f12 = k1 - k2;
-          G0 = G0 - 0.5 * (c1 * f02 + c2 * f01);
-          G1 = G1 - 0.5 * (c0 * f12 - c2 * f01);
-          G2 = G2 + 0.5 * (c0 * f12 + c1 * f02);
+          const V3 ta = (0.5 * c0) * f12, tb = (0.5 * c1) * f02, tc = (0.5 * c2) * f01;
+          T0 = -(tb + tc);
+          T1 = tc - ta;
         }
         if (ANALYTIC) {
           // term 2 weights (bending_gradient.py:37-42); (v1-v2) == -e0 etc.
-          double w0 = 0.5 * dot(k1 - k2, e0);
-          double w1 = 0.5 * dot(k2 - k0, e1);
-          double w2 = 0.5 * dot(k0 - k1, e2);
+          double w0 = 0.5 * dot(f12, e0);
+          double w1 = -0.5 * dot(f02, e1);
+          double w2 = 0.5 * dot(f01, e2);
           // term 3 coefficients (bending_gradient.py:80-95)
           int t0 = 1, t1 = 1, t2 = 1;
           if (a.m.has_boundary) {
@@ -973,57 +981,45 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
           const double C1 = (t1 ? fe1 : avg) + fav[tf.l1];
           const double C2 = (t2 ? fe2 : avg) + fav[tf.l2];
           const bool obtuse = (c0 < 0.0) || (c1 < 0.0) || (c2 < 0.0);
+          double q0 = 0.0, q1 = 0.0, q2 = 0.0;
           if (!obtuse) {
-            // six edge terms (:107-124); the second grad_cotan family
-            // (bending_math.py:244-249) has the same arguments as the first, so
-            // its weights (:126-152) fold into w_k.
-            const double q0 = 0.25 * c0 * (C1 + C2), q1 = 0.25 * c1 * (C0 + C2), q2 = 0.25 * c2 * (C0 + C1);
-            G0 = G0 + q1 * e1 - q2 * e2;
-            G1 = G1 + q2 * e2 - q0 * e0;
-            G2 = G2 + q0 * e0 - q1 * e1;
+            // six edge terms (:107-124): G0 += q1 e1 - q2 e2, G1 += q2 e2 - q0 e0, G2 += q0 e0 - q1 e1;
+            // the second grad_cotan family (bending_math.py:244-249) has the same arguments as the
+            // first, so its weights (:126-152) fold into w_k.
+            q0 = 0.25 * c0 * (C1 + C2);
+            q1 = 0.25 * c1 * (C0 + C2);
+            q2 = 0.25 * c2 * (C0 + C1);
             w0 += 0.125 * dot(e0, e0) * (C1 + C2);
             w1 += 0.125 * dot(e1, e1) * (C0 + C2);
             w2 += 0.125 * dot(e2, e2) * (C0 + C1);
-          } else if (S > 1.0e-15) {
-            // (:154-173) grad T with u = v1-v0, v = v2-v0: gT_u = 0.5 (v x n)/S, gT_v = 0.5 (n x u)/S
+          } else {
+            // (:154-173) grad T with u = v1-v0, v = v2-v0: +factor/(2S) (n x e_k) at vertex k
             double factor = 0.0;
             if (c0 < 0.0) factor += 0.5 * C0 + 0.25 * C1 + 0.25 * C2;
             if (c1 < 0.0) factor += 0.5 * C1 + 0.25 * C0 + 0.25 * C2;
             if (c2 < 0.0) factor += 0.5 * C2 + 0.25 * C0 + 0.25 * C1;
-            const double fs = 0.5 * factor / S;
-            const V3 gTu = fs * cross(-e1, n), gTv = fs * cross(n, e2);
-            G1 = G1 + gTu;
-            G2 = G2 + gTv;
-            G0 = G0 - (gTu + gTv);
+            R -= (0.5 * factor) * invS;
           }
-          if (S > 1.0e-15) {
-            // grad cot at corner k (u,v) = (e2,-e1), (e0,-e2), (e1,-e0); w = u x v = n:
-            //   gu = v/S - (C/S^3) v x n ,  gv = u/S - (C/S^3) n x u ,  C = u.v
-            const double invS = 1.0 / S;
-            const double invS3 = invS * invS * invS;
-            {  // corner 0: +gu -> v1, +gv -> v2, -(gu+gv) -> v0
-              const double kk = -d12 * invS3;
-              const V3 gu = invS * (-e1) - kk * cross(-e1, n), gv = invS * e2 - kk * cross(n, e2);
-              G1 = G1 + w0 * gu;
-              G2 = G2 + w0 * gv;
-              G0 = G0 - w0 * (gu + gv);
-            }
-            {  // corner 1: +gu -> v2, +gv -> v0, -(gu+gv) -> v1
-              const double kk = -d20 * invS3;
-              const V3 gu = invS * (-e2) - kk * cross(-e2, n), gv = invS * e0 - kk * cross(n, e0);
-              G2 = G2 + w1 * gu;
-              G0 = G0 + w1 * gv;
-              G1 = G1 - w1 * (gu + gv);
-            }
-            {  // corner 2: +gu -> v0, +gv -> v1, -(gu+gv) -> v2
-              const double kk = -d01 * invS3;
-              const V3 gu = invS * (-e0) - kk * cross(-e0, n), gv = invS * e1 - kk * cross(n, e1);
-              G0 = G0 + w2 * gu;
-              G1 = G1 + w2 * gv;
-              G2 = G2 - w2 * (gu + gv);
-            }
-          }
+          // grad cot at corner k (bending_kernels.f90:32-74 with w = n for every corner):
+          //   corner 0 -> G1 += w0 gu, G2 += w0 gv, G0 -= w0 (gu + gv), gu = -e1/S + kk0 (e1 x n), gv = e2/S + kk0 (e2 x n)
+          //   (cyclic); kk_k = cot_k / S^2
+          const double invS2 = invS * invS;
+          const double p0 = w0 * invS, p1 = w1 * invS, p2 = w2 * invS;
+          R += ((w0 * (-d12) + w1 * (-d20)) + w2 * (-d01)) * (invS2 * invS);
+          a01 = ((p0 + q1) - p1) + p2;
+          a02 = ((-p0 - q2) - p1) + p2;
+          a11 = ((p2 - p0) + p1) + q0;
+          a12 = (2.0 * p1 + q2) + q0;
         }
+      }
+      {
+        const V3 Rn = R * n;
+        const V3 X1 = cross(e1, Rn), X2 = cross(e2, Rn);
+        const V3 H0 = (T0 + (a01 * e1 + a02 * e2)) - (X1 + X2);  // e0 x n = -(e1 + e2) x n
+        const V3 H1 = (T1 + (a11 * e1 + a12 * e2)) + X1;
+        G0 = G0 + H0;
+        G1 = G1 + H1;
+        G2 = G2 - (H0 + H1);
       }
       if (ATOMIC) {
         const int no = t.n_owned;

@@ -8,6 +8,7 @@
 // so a workgroup can accumulate its owned vertices' sums in LDS and write them
 // with plain coalesced stores -- no global atomics, no second pass.
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -167,6 +168,36 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
       if (!body_facets || body_facets[f]) fl |= TF_BODY;
       out.tile_facets[p].flags = fl;
       out.tile_facet_ext[p] = f;
+    }
+  }
+
+  // ---- 2b. spread neighbouring facets over different waves -------------------
+  // In walk order consecutive facets share their first corner (and mostly a second one), so the 64
+  // lanes of a wave would send their per-corner LDS atomics (or staged gathers) to a handful of
+  // vertices: same-address atomics serialise.  A stride permutation inside each tile puts facets
+  // that were adjacent ~n/64 lanes apart, i.e. into different waves.
+  {
+    const char* env = getenv("MS_FACET_STRIDE");
+    const int mode = env ? atoi(env) : 1;  // 0: keep the walk order
+    std::vector<TileFacet> tf_tmp;
+    std::vector<int32_t> ext_tmp, v_tmp;
+    for (int t = 0; t < out.n_tiles && mode != 0; ++t) {
+      const size_t b = (size_t)out.tile_facet_off[t], e = (size_t)out.tile_facet_off[t + 1];
+      const size_t n = e - b;
+      if (n < 128) continue;
+      size_t S = std::max<size_t>(mode > 1 ? (size_t)mode : 7, (n + 63) / 64);
+      while (std::gcd(S, n) != 1) ++S;
+      tf_tmp.assign(out.tile_facets.begin() + b, out.tile_facets.begin() + e);
+      ext_tmp.assign(out.tile_facet_ext.begin() + b, out.tile_facet_ext.begin() + e);
+      v_tmp.assign(inst_v.begin() + 3 * b, inst_v.begin() + 3 * e);
+      for (size_t i = 0; i < n; ++i) {
+        const size_t o = (i * S) % n;  // new slot i takes old instance o
+        out.tile_facets[b + i] = tf_tmp[o];
+        out.tile_facet_ext[b + i] = ext_tmp[o];
+        inst_v[3 * (b + i)] = v_tmp[3 * o];
+        inst_v[3 * (b + i) + 1] = v_tmp[3 * o + 1];
+        inst_v[3 * (b + i) + 2] = v_tmp[3 * o + 2];
+      }
     }
   }
 
