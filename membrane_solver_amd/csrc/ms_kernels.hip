@@ -552,16 +552,18 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
     const bool interior = !(own_fl & VF_BOUNDARY);
     const double safe = fmax(aAv, 1.0e-12);
     const double k_mag = norm(K);
-    double H = k_mag / (2.0 * safe);
+    // one reciprocal serves H and the area ratio (each fp64 division is ~14 VALU instructions)
+    const double inv_safe = 1.0 / safe;
+    double H = k_mag * (0.5 * inv_safe);
     // leaflet bending_tilt (bending_tilt_leaflet.py:455-459): oriented curvature H = (K . n)/(2 A) with
     // the unit vertex normal, and K_dir = n (:574-575)
     const bool signed_h = a.bt_normals != nullptr;
     V3 nh = mk(0, 0, 0);
     if (signed_h) {
       nh = mk(a.bt_normals[3 * (size_t)v], a.bt_normals[3 * (size_t)v + 1], a.bt_normals[3 * (size_t)v + 2]);
-      H = dot(K, nh) / (2.0 * safe);
+      H = dot(K, nh) * (0.5 * inv_safe);
     }
-    const double ratio = safe > 1.0e-15 ? aAe / safe : 0.0;
+    const double ratio = safe > 1.0e-15 ? aAe * inv_safe : 0.0;
     double scale_K, fe, fv;
     if (a.bt_vert) {
       // bending_tilt.py:217-233: the energy and the factors need div t, which k_bt adds;
@@ -594,7 +596,8 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
       if (signed_h) {
         Kd = nh;
       } else if (k_mag > 1.0e-15) {
-        Kd = mk(K.x / k_mag, K.y / k_mag, K.z / k_mag);
+        const double inv_k = 1.0 / k_mag;
+        Kd = mk(K.x * inv_k, K.y * inv_k, K.z * inv_k);
       } else {
         // bending.py:154-158 falls back to the vertex normal (bending_utils.py:13-34)
         // where K vanishes (flat patches): sum the incident facet normals now.
