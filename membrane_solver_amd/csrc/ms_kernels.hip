@@ -1904,7 +1904,8 @@ hipError_t launch_tvec(int mode, int tile0, int tile1, int nv, int T, const uint
 // requested slots in a fixed order.  Volume gets its 1/6 here
 // (geometry/body.py:121: vol_contrib.sum() / 6.0).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_reduce(const double* partials, int n_tiles, int tile0,
+constexpr int RBLOCK = 512;  // 512 threads x 8 loads in flight cover 4096 tiles in one round trip
+__global__ __launch_bounds__(RBLOCK) void k_reduce(const double* partials, int n_tiles, int tile0,
                                                   int tile1, uint32_t slot_mask, double* scal,
                                                   double* host_mirror,
                                                   unsigned long long* host_seq,
@@ -1931,14 +1932,14 @@ __global__ __launch_bounds__(BLOCK) void k_reduce(const double* partials, int n_
   // RU loads in flight per thread (the order of the additions is unchanged)
   constexpr int RU = 8;
   const double neutral = op == 1 ? 1.0e300 : 0.0;
-  for (int t = tile0 + threadIdx.x; t < tile1; t += RU * BLOCK) {
+  for (int t = tile0 + threadIdx.x; t < tile1; t += RU * RBLOCK) {
     double q[RU];
 #pragma unroll
-    for (int k = 0; k < RU; ++k) q[k] = t + k * BLOCK < tile1 ? p[t + k * BLOCK] : neutral;
+    for (int k = 0; k < RU; ++k) q[k] = t + k * RBLOCK < tile1 ? p[t + k * RBLOCK] : neutral;
 #pragma unroll
     for (int k = 0; k < RU; ++k) {
       if (op == 0) {
-        if (t + k * BLOCK < tile1) v = v + q[k];
+        if (t + k * RBLOCK < tile1) v = v + q[k];
       } else if (op == 1) {
         v = fmin(v, q[k]);
       } else {
@@ -1965,7 +1966,7 @@ hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int til
                          unsigned long long* host_seq, unsigned long long ticket, hipStream_t s) {
   const int nslots = __builtin_popcount(slot_mask);
   if (nslots == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_reduce, dim3(nslots), dim3(BLOCK), 0, s, partials, n_tiles, tile0, tile1,
+  hipLaunchKernelGGL(k_reduce, dim3(nslots), dim3(RBLOCK), 0, s, partials, n_tiles, tile0, tile1,
                      slot_mask, scal, host_mirror, host_seq, ticket);
   return hipGetLastError();
 }
