@@ -34,6 +34,7 @@ ap.add_argument("--only-bt", action="store_true", help="bending_tilt + tilt rela
 ap.add_argument("--only-ts", action="store_true", help="tilt_smoothness vectors only")
 ap.add_argument("--only-leaflet", action="store_true", help="two-leaflet tilt vectors only")
 ap.add_argument("--only-btl", action="store_true", help="bending_tilt_in/out vectors only")
+ap.add_argument("--only-disk", action="store_true", help="tilt_disk_target_in/out vectors only")
 args = ap.parse_args()
 
 sys.dont_write_bytecode = True
@@ -672,6 +673,7 @@ def _set_leaflet_fields(m, seed, scale, fixed_in_every=0, fixed_out_every=0):
 def run_leaflet_trajectory(fname, P, T, gp, mods, stepper, n_steps, step_size, tilt_scale=0.3, seed=33,
                            fixed_in_every=0, fixed_out_every=0):
     mm = build_mesh(P, T, gp)
+    disk_rows = _tag_disk(mm) if _DISK_TAG else np.zeros(0, dtype=int)
     tin, tout, fin, fout = _set_leaflet_fields(mm, seed, tilt_scale, fixed_in_every, fixed_out_every)
     mm.energy_modules = list(mods)
     mm.constraint_modules = []
@@ -709,7 +711,8 @@ def run_leaflet_trajectory(fname, P, T, gp, mods, stepper, n_steps, step_size, t
            "tilts_out_final": np.ascontiguousarray(mm.tilts_out_view()).copy(),
            "step_log": np.array(log), "E_final": np.array(res["energy"]),
            "n_steps": np.array(n_steps), "step_size0": np.array(step_size),
-           "gp_json": np.array(json.dumps(gp, sort_keys=True)), "modules": np.array(list(mods))}
+           "gp_json": np.array(json.dumps(gp, sort_keys=True)), "modules": np.array(list(mods)),
+           "disk_rows": disk_rows}
     np.savez_compressed(os.path.join(OUT, fname), **out)
     print(fname, "E_final=%.16g" % out["E_final"], out["step_log"][:, 0])
 
@@ -856,6 +859,91 @@ def gen_bending_tilt_leaflet():
                                  5e-2, fixed)
 
 
+
+def _tag_disk(m, frac=0.45):
+    """Tag the vertices with the smallest in-plane radius as group "disk" for both leaflets."""
+    pos = m.positions_view()
+    r = np.linalg.norm(pos[:, :2], axis=1)
+    rows = np.flatnonzero((r <= np.quantile(r, frac)) & (pos[:, 2] >= np.median(pos[:, 2]) - 1e-9))
+    ids = m.vertex_ids
+    for row in rows:
+        v = m.vertices[int(ids[row])]
+        v.options = dict(getattr(v, "options", None) or {})
+        v.options["tilt_disk_target_group_in"] = "disk"
+        v.options["tilt_disk_target_group_out"] = "disk"
+    return rows
+
+
+def gen_disk_target():
+    """tilt_disk_target_in / _out (tilt_disk_target_in.py:160-286)."""
+    import importlib
+
+    out = {"meta_fortran": META}
+    Pd, Td, _isb = meshgen.disk_patch(6, bulge=0.3, jitter=0.02, seed=11)
+    P, T = meshgen.icosphere(5)
+    P = meshgen.smooth_displace(P, 0.06)
+    gps = {"bessel": {"surface_tension": 1.0, "tilt_disk_target_group_in": "disk", "tilt_disk_target_strength_in": 20.0,
+                      "tilt_disk_target_group_out": "disk", "tilt_disk_target_strength_out": 12.0,
+                      "tilt_disk_target_theta_B": 0.6, "tilt_disk_target_theta_B_out": -0.4,
+                      "tilt_disk_target_lambda": 1.3, "tilt_disk_target_center": [0.02, -0.01, 0.1],
+                      "tilt_disk_target_normal": [0.0, 0.1, 1.0]},
+           "linear": {"surface_tension": 1.0, "tilt_disk_target_group_in": "disk", "tilt_disk_target_strength_in": 20.0,
+                      "tilt_disk_target_group_out": "disk", "tilt_disk_target_strength_out": 12.0,
+                      "tilt_disk_target_theta_B": 0.6, "tilt_disk_target_lambda": 0.0, "tilt_disk_target_radius": 0.9,
+                      "tilt_disk_target_normal": [0.0, 0.0, 2.0]},
+           "moduli": {"surface_tension": 1.0, "tilt_disk_target_group_in": "disk", "tilt_disk_target_strength_in": 20.0,
+                      "tilt_disk_target_group_out": "disk", "tilt_disk_target_strength_out": 12.0,
+                      "tilt_disk_target_theta_B": 0.6, "tilt_modulus_in": 2.0, "tilt_modulus_out": 1.0,
+                      "bending_modulus": 0.5, "tilt_disk_target_normal": [0.0, 0.0, 1.0]}}
+    for name, (P_, T_) in {"disk6": (Pd, Td), "ico5": (P, T)}.items():
+        for tag, gp in gps.items():
+            m = build_mesh(P_, T_, gp)
+            rows = _tag_disk(m)
+            tin, tout, _fi, _fo = _set_leaflet_fields(m, 14, 0.25)
+            pos, tri, isb, fixed = mesh_arrays(m)
+            res = ParameterResolver(m.global_parameters)
+            key = f"{name}_{tag}"
+            out[name + "_positions"], out[name + "_tri"], out[name + "_is_boundary"] = pos, tri, isb
+            out[name + "_tilts_in"], out[name + "_tilts_out"], out[name + "_disk_rows"] = tin, tout, rows
+            out[key + "_gp_json"] = np.array(json.dumps(gp, sort_keys=True))
+            for mod in ("tilt_disk_target_in", "tilt_disk_target_out"):
+                module = importlib.import_module(f"modules.energy.{mod}")
+                g = np.zeros_like(pos)
+                tgi, tgo = np.zeros_like(pos), np.zeros_like(pos)
+                E = module.compute_energy_and_gradient_array(
+                    m, m.global_parameters, res, positions=pos, index_map=m.vertex_index_to_row, grad_arr=g,
+                    tilts_in=tin, tilts_out=tout, tilt_in_grad_arr=tgi, tilt_out_grad_arr=tgo)
+                out[f"{key}_{mod}_E"], out[f"{key}_{mod}_grad"] = np.array(E), g
+                out[f"{key}_{mod}_tilt_grad"] = tgi if mod.endswith("_in") else tgo
+                print("disk target", key, mod, "E=%.16g" % E, len(rows))
+    np.savez_compressed(os.path.join(OUT, "tilt_disk_target_cases.npz"), **out)
+
+    base = {"surface_tension": 1.0, "tilt_modulus_in": 2.0, "tilt_modulus_out": 1.4, "bending_modulus": 0.6,
+            "tilt_disk_target_group_in": "disk", "tilt_disk_target_strength_in": 15.0,
+            "tilt_disk_target_group_out": "disk", "tilt_disk_target_strength_out": 10.0,
+            "tilt_disk_target_theta_B": 0.5, "tilt_disk_target_lambda": 1.0, "tilt_disk_target_normal": [0.0, 0.0, 1.0],
+            "volume_constraint_mode": "lagrange", "volume_projection_during_minimization": False,
+            "mesh_quality_auto_repair_enabled": False}
+    allm = ["surface", "tilt_in", "tilt_out", "tilt_smoothness_in", "tilt_disk_target_in", "tilt_disk_target_out"]
+    Pd5, Td5, _ = meshgen.disk_patch(6, bulge=0.3, jitter=0.02, seed=11)
+    m0 = build_mesh(Pd5, Td5, base)
+    fixed = mesh_arrays(m0)[2].copy()
+    global _DISK_TAG
+    _DISK_TAG = True
+    try:
+        run_leaflet_trajectory_fixed("traj_disk6_gd_disktarget_nested_cg.npz", Pd5, Td5,
+                                     dict(base, tilt_solve_mode="nested", tilt_solver="cg", tilt_step_size=0.05,
+                                          tilt_inner_steps=5), allm, GradientDescent(), 5, 2e-3, fixed)
+        run_leaflet_trajectory_fixed("traj_disk6_cg_disktarget_coupled_gd.npz", Pd5, Td5,
+                                     dict(base, tilt_solve_mode="coupled", tilt_solver="gd", tilt_step_size=0.03,
+                                          tilt_coupled_steps=3), allm, ConjugateGradient(), 5, 2e-3, fixed)
+    finally:
+        _DISK_TAG = False
+
+
+_DISK_TAG = False
+
+
 def run_leaflet_trajectory_fixed(fname, P, T, gp, mods, stepper, n_steps, step_size, fixed):
     global build_mesh
     orig = build_mesh
@@ -879,6 +967,9 @@ if __name__ == "__main__":
     if "--only-leaflet" in sys.argv:
         gen_leaflet()
         sys.exit(0)
+    if "--only-disk" in sys.argv:
+        gen_disk_target()
+        sys.exit(0)
     if "--only-btl" in sys.argv:
         gen_bending_tilt_leaflet()
         sys.exit(0)
@@ -898,3 +989,4 @@ if __name__ == "__main__":
     gen_tilt_smoothness()
     gen_leaflet()
     gen_bending_tilt_leaflet()
+    gen_disk_target()

@@ -34,6 +34,8 @@ class Problem:
     tilts_out: np.ndarray | None = None
     tilt_fixed_in: np.ndarray | None = None  # vertex.tilt_fixed_in / tilt_fixed_out (minimizer.py:460-486)
     tilt_fixed_out: np.ndarray | None = None
+    disk_rows_in: np.ndarray | None = None  # rows tagged tilt_disk_target_group_in == gp group (tilt_disk_target_in.py:137-145)
+    disk_rows_out: np.ndarray | None = None
     energy_modules: list = field(default_factory=lambda: ["surface"])
     constraint_modules: list = field(default_factory=list)
     body_rows: np.ndarray | None = None  # None = all facets in one body
@@ -131,6 +133,9 @@ def energy_and_gradient(p: Problem, pos: np.ndarray):
         elif name in ("bending_tilt_in", "bending_tilt_out"):
             lf = name[13:]
             E += _bending_tilt_leaflet(p, pos, leaflet_tilts(p, lf), lf, grad=grad)
+        elif name in ("tilt_disk_target_in", "tilt_disk_target_out"):
+            lf = name[17:]
+            E += _disk_target(p, pos, leaflet_tilts(p, lf), lf, grad=grad)
         else:
             raise ValueError(f"module {name!r} is outside the hot-path scope")
     # constraint_manager.apply_gradient_modifications_array (k == 1 dense branch :293-301)
@@ -180,6 +185,9 @@ def energy_total(p: Problem, pos: np.ndarray, tilts=None, tilts_in=None, tilts_o
         elif name in ("bending_tilt_in", "bending_tilt_out"):
             lf = name[13:]
             E += _bending_tilt_leaflet(p, pos, lt[lf], lf)
+        elif name in ("tilt_disk_target_in", "tilt_disk_target_out"):
+            lf = name[17:]
+            E += _disk_target(p, pos, lt[lf], lf)
         else:
             raise ValueError(name)
     return float(E)
@@ -195,7 +203,59 @@ def _smoothness(p: Problem, pos, tilts, tilt_grad=None) -> float:
 
 TILT_MODULES = ("tilt", "bending_tilt", "tilt_smoothness")  # modules with USES_TILT = True in scope
 LEAFLET_MODULES = ("tilt_in", "tilt_out", "tilt_smoothness_in", "tilt_smoothness_out",
-                   "bending_tilt_in", "bending_tilt_out")  # USES_TILT_LEAFLETS
+                   "bending_tilt_in", "bending_tilt_out", "tilt_disk_target_in", "tilt_disk_target_out")  # USES_TILT_LEAFLETS
+
+
+def disk_target_params(p: Problem, leaflet: str):
+    """modules/energy/tilt_disk_target_in.py:38-134 -> dict or None when the module contributes nothing."""
+    gp = p.gp
+
+    def pick(name):
+        v = gp.get(f"tilt_disk_target_{name}_{leaflet}")
+        return gp.get(f"tilt_disk_target_{name}") if v is None else v
+
+    group = gp.get(f"tilt_disk_target_group_{leaflet}")
+    if group is None or not str(group).strip():
+        return None
+    k = float(gp.get(f"tilt_disk_target_strength_{leaflet}") or 0.0)
+    theta_b = float(pick("theta_B") or 0.0)
+    rows = p.disk_rows_in if leaflet == "in" else p.disk_rows_out
+    if k == 0.0 or theta_b == 0.0 or rows is None or len(rows) == 0:
+        return None
+    center = pick("center")
+    normal = pick("normal")
+    if normal is None:
+        raise NotImplementedError("tilt_disk_target: the SVD plane fit (no tilt_disk_target_normal) is not restated")
+    radius = pick("radius")
+    try:
+        radius = float(radius) if radius is not None and float(radius) > 0.0 else None
+    except (TypeError, ValueError):
+        radius = None
+    lam = pick("lambda")
+    if lam is not None:
+        try:
+            lam = float(lam)
+        except (TypeError, ValueError):
+            lam = 0.0
+    else:
+        kt = gp.get(f"tilt_modulus_{leaflet}")
+        if kt is None and leaflet == "in":
+            kt = gp.get("tilt_modolus_in")
+        kap = gp.get(f"bending_modulus_{leaflet}")
+        if kap is None:
+            kap = gp.get("bending_modulus")
+        lam = 0.0
+        if kt is not None and kap is not None and float(kt) > 0.0 and float(kap) > 0.0:
+            lam = float(np.sqrt(float(kt) / float(kap)))
+    return {"disk_rows": np.asarray(rows, dtype=int), "k_target": k, "theta_b": theta_b, "lam": lam,
+            "center": [0.0, 0.0, 0.0] if center is None else center, "normal": normal, "radius": radius}
+
+
+def _disk_target(p: Problem, pos, tilts, leaflet: str, grad=None, tilt_grad=None) -> float:
+    prm = disk_target_params(p, leaflet)
+    if prm is None:
+        return 0.0
+    return orc.tilt_disk_target_energy_and_gradient(pos, tilts, p.tri, grad=grad, tilt_grad=tilt_grad, **prm)
 
 
 def leaflet_bending_params(p: Problem, leaflet: str):
@@ -281,6 +341,9 @@ def energy_and_leaflet_tilt_gradients(p: Problem, pos, tilts_in, tilts_out, vert
         elif name in ("bending_tilt_in", "bending_tilt_out"):
             lf = name[13:]
             E += _bending_tilt_leaflet(p, pos, lt[lf], lf, tilt_grad=tg[lf])
+        elif name in ("tilt_disk_target_in", "tilt_disk_target_out"):
+            lf = name[17:]
+            E += _disk_target(p, pos, lt[lf], lf, tilt_grad=tg[lf])
     return float(E), tg["in"], tg["out"]
 
 
@@ -301,6 +364,9 @@ def tilt_dependent_energy_leaflets(p: Problem, pos, tilts_in, tilts_out, vertex_
         elif name in ("bending_tilt_in", "bending_tilt_out"):
             lf = name[13:]
             E += _bending_tilt_leaflet(p, pos, lt[lf], lf)
+        elif name in ("tilt_disk_target_in", "tilt_disk_target_out"):
+            lf = name[17:]
+            E += _disk_target(p, pos, lt[lf], lf)
     return float(E)
 
 

@@ -573,3 +573,77 @@ def bending_tilt_leaflet_energy_and_gradient(pos, tilts, tri, kappa, c0, is_boun
     _backprop_corner_areas(pos, tri, weights, isb, corner_fA_eff, fA_vor, fK, grad)
     _ambient_p1_divergence_shape_gradient(pos, tilts, tri, dE_ddiv, grad)
     return E
+
+
+# --- disk tilt target (soft profile enforcement) -----------------------------------
+def bessel_i1_series(x, n_terms: int = 30):
+    """modules/energy/tilt_disk_target_in.py:148-157."""
+    t = 0.5 * np.asarray(x, dtype=float)
+    t2 = t * t
+    term = t.copy()
+    out = term.copy()
+    for k in range(1, int(n_terms)):
+        term = term * (t2 / (k * (k + 1)))
+        out = out + term
+    return out
+
+
+def tilt_disk_target_energy_and_gradient(pos, tilts, tri, disk_rows, k_target, theta_b, lam, center, normal,
+                                         radius=None, grad=None, tilt_grad=None) -> float:
+    """modules/energy/tilt_disk_target_in.py:160-286 (and _out): E = sum_f 1/2 k (sum_k |t_k - target_k|^2)/3 A_f
+    with target = theta(r) r_hat on the disk rows and the difference zeroed elsewhere; theta(r) =
+    theta_B I1(lam r)/I1(lam R) (30-term series) or theta_B r/R when |lam| < 1e-12; R = ``radius`` or the largest
+    in-plane distance of a disk row.  Shape gradient coeff_f dA/dx (the target is not differentiated);
+    tilt gradient k diff_v A_v with the barycentric areas.  ``normal`` must be given (unit length is enforced
+    as :67-77 does); the SVD plane fit of :80-93 is not restated."""
+    pos, tilts, tri = _f64(pos), _f64(tilts), _i32(tri)
+    disk_rows = np.asarray(disk_rows, dtype=int)
+    if k_target == 0.0 or theta_b == 0.0 or disk_rows.size == 0 or tri.shape[0] == 0:
+        return 0.0
+    center = np.asarray(center, dtype=float).reshape(3)
+    normal = np.asarray(normal, dtype=float).reshape(3)
+    normal = normal / np.linalg.norm(normal)
+    r_vec = pos[disk_rows] - center[None, :]
+    r_vec = r_vec - np.einsum("ij,j->i", r_vec, normal)[:, None] * normal[None, :]
+    r_len = np.linalg.norm(r_vec, axis=1)
+    good = r_len > 1e-12
+    if not np.any(good):
+        return 0.0
+    r_hat = np.zeros_like(r_vec)
+    r_hat[good] = r_vec[good] / r_len[good][:, None]
+    if radius is None:
+        radius = float(np.max(r_len))
+    if radius <= 0.0:
+        return 0.0
+    if abs(lam) < 1e-12:
+        theta = theta_b * r_len / radius
+    else:
+        den = bessel_i1_series(np.array([lam * radius]))[0]
+        if abs(den) < 1e-15:
+            return 0.0
+        theta = theta_b * bessel_i1_series(lam * r_len) / den
+    diff = np.zeros_like(tilts)
+    diff[disk_rows] = tilts[disk_rows] - theta[:, None] * r_hat
+    diff_sq = np.einsum("ij,ij->i", diff, diff)
+    v0, v1, v2 = pos[tri[:, 0]], pos[tri[:, 1]], pos[tri[:, 2]]
+    n = np.cross(v1 - v0, v2 - v0)
+    n_norm = np.linalg.norm(n, axis=1)
+    mask = n_norm >= 1e-12
+    if not np.any(mask):
+        return 0.0
+    areas = 0.5 * n_norm[mask]
+    rows = tri[mask]
+    coeff = 0.5 * k_target * (diff_sq[rows].sum(axis=1) / 3.0)
+    energy = float(np.dot(coeff, areas))
+    if grad is not None:
+        n_hat = n[mask] / n_norm[mask][:, None]
+        c = coeff[:, None]
+        np.add.at(grad, rows[:, 0], c * (0.5 * np.cross(n_hat, v2[mask] - v1[mask])))
+        np.add.at(grad, rows[:, 1], c * (0.5 * np.cross(n_hat, v0[mask] - v2[mask])))
+        np.add.at(grad, rows[:, 2], c * (0.5 * np.cross(n_hat, v1[mask] - v0[mask])))
+    if tilt_grad is not None:
+        va = np.zeros(pos.shape[0])
+        for kcol in range(3):
+            np.add.at(va, rows[:, kcol], areas / 3.0)
+        tilt_grad += k_target * diff * va[:, None]
+    return energy

@@ -423,3 +423,50 @@ def test_port_reproduces_bending_tilt_leaflet_trajectory(fname):
     assert relerr(p.positions, g["positions_final"]) < 1e-8
     assert relerr(p.tilts_in, g["tilts_in_final"]) < 1e-8
     assert relerr(p.tilts_out, g["tilts_out_final"]) < 1e-8
+
+
+# ---------------------------------------------------------------------------
+# tilt_disk_target_in / _out (oracle/gen_golden.py: gen_disk_target)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["disk6", "ico5"])
+@pytest.mark.parametrize("tag", ["bessel", "linear", "moduli"])
+def test_disk_target_matches_reference(name, tag):
+    import json
+
+    g = load_golden("tilt_disk_target_cases.npz")
+    key = f"{name}_{tag}"
+    gp = json.loads(str(g[key + "_gp_json"]))
+    pos, tri, rows = g[name + "_positions"], g[name + "_tri"], g[name + "_disk_rows"]
+    p = mp.Problem(positions=pos, tri=tri, is_boundary=g[name + "_is_boundary"], tilts_in=g[name + "_tilts_in"],
+                   tilts_out=g[name + "_tilts_out"], disk_rows_in=rows, disk_rows_out=rows, energy_modules=[], gp=gp)
+    for lf in ("in", "out"):
+        grad, tg = np.zeros_like(pos), np.zeros_like(pos)
+        E = mp._disk_target(p, pos, mp.leaflet_tilts(p, lf), lf, grad=grad, tilt_grad=tg)
+        ref = g[f"{key}_tilt_disk_target_{lf}_E"]
+        assert abs(E - ref) <= 1e-12 * abs(ref)
+        assert relerr(grad, g[f"{key}_tilt_disk_target_{lf}_grad"]) < 1e-11
+        assert relerr(tg, g[f"{key}_tilt_disk_target_{lf}_tilt_grad"]) < 1e-11
+
+
+DISK_TRAJ = {"traj_disk6_gd_disktarget_nested_cg.npz": "gd", "traj_disk6_cg_disktarget_coupled_gd.npz": "cg"}
+
+
+@pytest.mark.parametrize("fname", sorted(DISK_TRAJ))
+def test_port_reproduces_disk_target_trajectory(fname):
+    g = load_golden(fname)
+    p = leaflet_problem(g)
+    p.disk_rows_in = p.disk_rows_out = g["disk_rows"]
+    E0, grad0 = mp.energy_and_gradient(p, p.positions)
+    assert abs(E0 - g["E0"]) <= 1e-12 * abs(g["E0"])
+    assert relerr(grad0, g["grad0"]) < 1e-11
+    stepper = mp.GradientDescent() if DISK_TRAJ[fname] == "gd" else mp.ConjugateGradient()
+    res = mp.minimize(p, stepper, int(g["n_steps"]), step_size=float(g["step_size0"]))
+    log = g["step_log"]
+    got = np.array([[float(t["success"]), t["next_step"], t["E_accepted"]] for t in res["trace"]])
+    assert got.shape == log.shape
+    assert np.array_equal(got[:, 0], log[:, 0])
+    assert np.allclose(got[:, 1], log[:, 1], rtol=1e-12, atol=0)
+    assert np.allclose(got[:, 2], log[:, 2], rtol=1e-9, atol=0)
+    assert relerr(p.positions, g["positions_final"]) < 1e-8
+    assert relerr(p.tilts_in, g["tilts_in_final"]) < 1e-8
+    assert relerr(p.tilts_out, g["tilts_out_final"]) < 1e-8
