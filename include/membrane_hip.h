@@ -65,6 +65,9 @@ extern "C" {
  * bending_tilt_leaflet.py:231-758, default options, analytic gradient mode) */
 #define MS_MOD_BENDING_TILT_IN 4096u
 #define MS_MOD_BENDING_TILT_OUT 8192u
+/* soft disk tilt-profile target (modules/energy/tilt_disk_target_in.py:160-286, tilt_disk_target_out.py) */
+#define MS_MOD_TILT_DISK_TARGET_IN 16384u
+#define MS_MOD_TILT_DISK_TARGET_OUT 32768u
 #define MS_LEAFLET_IN 0
 #define MS_LEAFLET_OUT 1
 
@@ -122,7 +125,11 @@ enum ms_scalar {
   MS_S_TRZ_OUT = 23,
   MS_S_EBT_IN = 24,  /* bending_tilt_in / bending_tilt_out energies */
   MS_S_EBT_OUT = 25,
-  MS_NSCAL = 26
+  MS_S_EDT_IN = 26,  /* tilt_disk_target_in / _out energies */
+  MS_S_EDT_OUT = 27,
+  MS_S_DTR_IN = 28,  /* largest in-plane distance of a disk row (the default disk radius), max-reduced */
+  MS_S_DTR_OUT = 29,
+  MS_NSCAL = 30
 };
 
 typedef struct ms_params {
@@ -256,6 +263,20 @@ typedef struct ms_leaflet_params {
 int ms_set_leaflet_tilts(ms_ctx *ctx, int leaflet, const double *tilts /* nv*3 */,
                          const uint8_t *tilt_fixed /* nv or NULL */, const ms_leaflet_params *params);
 int ms_get_leaflet_tilts(ms_ctx *ctx, int leaflet, double *tilts /* nv*3 */);
+/* tilt_disk_target_in / _out: E = 1/2 k int |t - theta(r) r_hat|^2 dA over the tagged disk rows, theta(r) =
+ * theta_B I1(lambda r)/I1(lambda R) (30-term series, tilt_disk_target_in.py:148-157) or theta_B r/R when
+ * |lambda| < 1e-12; r, r_hat in the plane through `center` with unit `normal`; R = radius, or the largest
+ * in-plane distance of a disk row when radius <= 0 (:216-220).  disk_rows: nv flags (NULL switches it off). */
+typedef struct ms_disk_target_params {
+  double strength;   /* tilt_disk_target_strength_in|out */
+  double theta_b;    /* tilt_disk_target_theta_B[_in|_out] */
+  double lambda;     /* tilt_disk_target_lambda[_in|_out], else sqrt(tilt_modulus / bending_modulus) */
+  double center[3];
+  double normal[3];  /* required (the SVD plane fit of :80-93 is host work) */
+  double radius;     /* <= 0: from the disk rows */
+} ms_disk_target_params;
+int ms_set_leaflet_disk_target(ms_ctx *ctx, int leaflet, const uint8_t *disk_rows /* nv or NULL */,
+                               const ms_disk_target_params *params);
 /* per-vertex (kappa, c0) of bending_tilt_in / bending_tilt_out (modules/energy/bt_params.py:225-318:
  * bending_modulus_in|out else bending_modulus; spontaneous_curvature_in|out else the global one) */
 int ms_set_leaflet_bending(ms_ctx *ctx, int leaflet, const double *kappa /* nv */, const double *c0 /* nv */);

@@ -29,6 +29,7 @@ MS_MOD_BENDING_TILT = 64
 MS_MOD_TILT_SMOOTH = 128
 MS_MOD_TILT_IN, MS_MOD_TILT_OUT, MS_MOD_TILT_SMOOTH_IN, MS_MOD_TILT_SMOOTH_OUT = 256, 512, 1024, 2048
 MS_MOD_BENDING_TILT_IN, MS_MOD_BENDING_TILT_OUT = 4096, 8192
+MS_MOD_TILT_DISK_TARGET_IN, MS_MOD_TILT_DISK_TARGET_OUT = 16384, 32768
 MS_LEAFLET_IN, MS_LEAFLET_OUT = 0, 1
 MS_BEND_HELFRICH, MS_BEND_WILLMORE = 0, 1
 MS_GRAD_ANALYTIC, MS_GRAD_APPROX = 0, 1
@@ -39,8 +40,9 @@ MS_STEPPER_GD, MS_STEPPER_CG = 0, 1
 (MS_S_ESURF, MS_S_VOL, MS_S_EBEND, MS_S_MINEDGE2, MS_S_GUARD, MS_S_GGC, MS_S_GCGC,
  MS_S_GNORM2, MS_S_GDOTD, MS_S_MAXD2, MS_S_ETILT, MS_S_EBT, MS_S_TGNORM2, MS_S_TRZ, MS_S_MAXG2,
  MS_S_ETS, MS_S_ETILT_IN, MS_S_ETILT_OUT, MS_S_ETS_IN, MS_S_ETS_OUT, MS_S_TGNORM2_IN, MS_S_TGNORM2_OUT,
- MS_S_TRZ_IN, MS_S_TRZ_OUT, MS_S_EBT_IN, MS_S_EBT_OUT) = range(26)
-MS_NSCAL = 26
+ MS_S_TRZ_IN, MS_S_TRZ_OUT, MS_S_EBT_IN, MS_S_EBT_OUT, MS_S_EDT_IN, MS_S_EDT_OUT, MS_S_DTR_IN,
+ MS_S_DTR_OUT) = range(30)
+MS_NSCAL = 30
 
 
 class MembraneHipError(RuntimeError):
@@ -68,6 +70,11 @@ class ms_tilt_relax_params(ctypes.Structure):
 class ms_leaflet_params(ctypes.Structure):
     _fields_ = [("tilt_modulus", ctypes.c_double), ("tilt_mass_consistent", ctypes.c_int),
                 ("smoothness", ctypes.c_double), ("precond_smoothness", ctypes.c_double)]
+
+
+class ms_disk_target_params(ctypes.Structure):
+    _fields_ = [("strength", ctypes.c_double), ("theta_b", ctypes.c_double), ("lam", ctypes.c_double),
+                ("center", ctypes.c_double * 3), ("normal", ctypes.c_double * 3), ("radius", ctypes.c_double)]
 
 
 class ms_minimize_params(ctypes.Structure):
@@ -129,6 +136,8 @@ SIGNATURES = {
                                             ctypes.POINTER(ms_leaflet_params)]),
     "ms_get_leaflet_tilts": (ctypes.c_int, [_P, ctypes.c_int, _D]),
     "ms_set_leaflet_bending": (ctypes.c_int, [_P, ctypes.c_int, _D, _D]),
+    "ms_set_leaflet_disk_target": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ctypes.c_uint8),
+                                                  ctypes.POINTER(ms_disk_target_params)]),
     "ms_leaflet_tilt_energy_and_gradient": (ctypes.c_int, [_P, _D, _D, _D]),
     "ms_relax_leaflet_tilts": (ctypes.c_int, [_P, ctypes.POINTER(ms_tilt_relax_params),
                                               ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),

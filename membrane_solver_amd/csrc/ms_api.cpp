@@ -62,6 +62,12 @@ struct ms_ctx {
     double* c0 = nullptr;
     double* bt_vert = nullptr;
     double div_sign = 1.0;
+    // disk tilt target (tilt_disk_target_in/out): tagged rows, parameters, the difference field
+    uint8_t* disk = nullptr;
+    double* diff = nullptr;
+    ms_disk_target_params dt = {};
+    uint32_t mod_dt = 0;
+    int s_edt = 0, s_dtr = 0;
   } tf[3];
   int factors_leaflet = 0;  // which leaflet's back-prop factors fK/fA hold (1 in, 2 out; 0: not a leaflet's)
   double* d_bt_vert = nullptr;    // (nvp,4) bending_tilt per-vertex record of the last energy pass
@@ -203,13 +209,14 @@ constexpr uint32_t MASK_ENERGY = (1u << MS_S_ESURF) | (1u << MS_S_VOL) | (1u << 
                                  (1u << MS_S_MINEDGE2) | (1u << MS_S_GUARD) | (1u << MS_S_ETILT) |
                                  (1u << MS_S_EBT) | (1u << MS_S_ETS) | (1u << MS_S_ETILT_IN) |
                                  (1u << MS_S_ETILT_OUT) | (1u << MS_S_ETS_IN) | (1u << MS_S_ETS_OUT) |
-                                 (1u << MS_S_EBT_IN) | (1u << MS_S_EBT_OUT);
+                                 (1u << MS_S_EBT_IN) | (1u << MS_S_EBT_OUT) | (1u << MS_S_EDT_IN) | (1u << MS_S_EDT_OUT);
 constexpr uint32_t MS_TILT_MODS = MS_MOD_TILT | MS_MOD_BENDING_TILT | MS_MOD_TILT_SMOOTH;  // modules reading the single tilt field
 constexpr uint32_t MS_LEAFLET_BT = MS_MOD_BENDING_TILT_IN | MS_MOD_BENDING_TILT_OUT;
-constexpr uint32_t MS_LEAFLET_MODS = MS_MOD_TILT_IN | MS_MOD_TILT_OUT | MS_MOD_TILT_SMOOTH_IN | MS_MOD_TILT_SMOOTH_OUT | MS_LEAFLET_BT;
+constexpr uint32_t MS_LEAFLET_DT = MS_MOD_TILT_DISK_TARGET_IN | MS_MOD_TILT_DISK_TARGET_OUT;
+constexpr uint32_t MS_LEAFLET_MODS = MS_MOD_TILT_IN | MS_MOD_TILT_OUT | MS_MOD_TILT_SMOOTH_IN | MS_MOD_TILT_SMOOTH_OUT | MS_LEAFLET_BT | MS_LEAFLET_DT;
 constexpr uint32_t MS_ANY_TILT_MODS = MS_TILT_MODS | MS_LEAFLET_MODS;
 // modules whose shape gradient is added into g by a pass after K_C (so the direction cannot be fused)
-constexpr uint32_t MS_TILT_SHAPE_MODS = MS_MOD_TILT | MS_MOD_TILT_IN | MS_MOD_TILT_OUT | MS_LEAFLET_BT;
+constexpr uint32_t MS_TILT_SHAPE_MODS = MS_MOD_TILT | MS_MOD_TILT_IN | MS_MOD_TILT_OUT | MS_LEAFLET_BT | MS_LEAFLET_DT;
 using TiltField = ms_ctx::TiltField;
 
 // the tilt fields the module set reads: [0] single field, [1] inner, [2] outer leaflet
@@ -217,7 +224,7 @@ int active_fields(ms_ctx* c, uint32_t mods, TiltField* out[3]) {
   int n = 0;
   for (int k = 0; k < 3; ++k) {
     TiltField& f = c->tf[k];
-    const uint32_t reads = k == 0 ? MS_TILT_MODS : (f.mod_tilt | f.mod_smooth | f.mod_bt);
+    const uint32_t reads = k == 0 ? MS_TILT_MODS : (f.mod_tilt | f.mod_smooth | f.mod_bt | f.mod_dt);
     if (mods & reads) out[n++] = &f;
   }
   return n;
@@ -226,7 +233,8 @@ int active_fields(ms_ctx* c, uint32_t mods, TiltField* out[3]) {
 // mode 0 energy / 1 energy+gradients read `src`; mode 2 projects `src` onto the tangent
 // planes of x (+ alpha d) and writes `dst`.
 int tilt_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, const double* src = nullptr,
-                double* dst = nullptr, bool shape_gradient = true, bool lumped = false) {
+                double* dst = nullptr, bool shape_gradient = true, bool lumped = false, double k_override = -1.0,
+                int slot_override = -1, bool tg_accumulate = false) {
   if (!f.tilts) return fail(c, MS_ERR_STATE, "tilt module active but its tilt field was never set (ms_set_tilts / ms_set_leaflet_tilts)");
   TiltArgs a;
   a.m = device_mesh(c);
@@ -237,13 +245,14 @@ int tilt_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, c
   a.alpha = alpha;
   a.tilts = src ? src : f.tilts;
   a.tilts_out = dst ? dst : f.tilts;
-  a.k_tilt = f.k_tilt;
+  a.k_tilt = k_override >= 0.0 ? k_override : f.k_tilt;
   a.g = shape_gradient ? c->buf[MS_BUF_G] : nullptr;
   a.tilt_grad = f.grad;
   a.minv = nullptr;
   a.partials = c->d_partials;
-  a.e_slot = f.s_etilt;
+  a.e_slot = slot_override >= 0 ? slot_override : f.s_etilt;
   a.consistent = (f.consistent && !lumped) ? 1 : 0;
+  a.tg_accumulate = tg_accumulate ? 1 : 0;
   {
     ProfScope ps(c, 4);
     HIPCHK(c, launch_tilt(a, mode, c->cap, c->til.max_ent, c->stream));
@@ -317,6 +326,48 @@ int ts_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, con
 int ts_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* tilts, double* diag = nullptr) {
   return ts_pass_f(c, c->tf[0], mode, use_dir, alpha, tilts, diag);
 }
+// tilt_disk_target_in/out on the positions x (+ alpha d) and `tilts`: (radius reduction ->) difference field ->
+// tilt magnitude kernel on it with k = strength.  mode 0 energy / 1 energy + shape gradient (+ tilt gradient
+// ADDED to f.grad when tilt_gradient).
+int reduce_slots(ms_ctx* c, uint32_t mask);
+int disk_target_pass(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, const double* tilts,
+                     bool shape_gradient, bool tilt_gradient) {
+  if (!f.disk || !f.diff) return fail(c, MS_ERR_STATE, "tilt_disk_target active but ms_set_leaflet_disk_target was never called");
+  DiskTargetArgs a;
+  a.tile0 = c->tile0;
+  a.tile1 = c->tile1;
+  a.nv = c->til.nv;
+  a.T = c->til.T;
+  a.n_tiles = c->til.n_tiles;
+  a.vflags = c->d_vflags;
+  a.disk = f.disk;
+  a.x = c->buf[MS_BUF_X];
+  a.d = use_dir ? c->buf[MS_BUF_D] : nullptr;
+  a.alpha = alpha;
+  a.tilts = tilts;
+  a.diff = f.diff;
+  a.theta_b = f.dt.theta_b;
+  a.lambda = f.dt.lambda;
+  a.radius = f.dt.radius;
+  for (int k = 0; k < 3; ++k) {
+    a.center[k] = f.dt.center[k];
+    a.normal[k] = f.dt.normal[k];
+  }
+  a.scal = c->d_scal;
+  a.partials = c->d_partials;
+  a.r_slot = f.s_dtr;
+  {
+    ProfScope ps(c, 6);
+    if (!(f.dt.radius > 0.0)) {
+      HIPCHK(c, launch_disk_target(a, 0, c->stream));
+      int rc = reduce_slots(c, 1u << f.s_dtr);
+      if (rc) return rc;
+    }
+    HIPCHK(c, launch_disk_target(a, 1, c->stream));
+  }
+  return tilt_pass_f(c, f, mode, use_dir, alpha, f.diff, nullptr, shape_gradient, /*lumped=*/true, f.dt.strength,
+                     f.s_edt, tilt_gradient);
+}
 constexpr uint32_t MASK_GRAD = (1u << MS_S_GGC) | (1u << MS_S_GCGC);
 constexpr uint32_t MASK_DIR = (1u << MS_S_GNORM2) | (1u << MS_S_GDOTD) | (1u << MS_S_MAXD2) | (1u << MS_S_MAXG2);
 
@@ -363,7 +414,7 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
     // directly followed by its facet pass, because the factor buffers serve one leaflet at a time
     for (int l = 1; l <= 2 && use_dir; ++l) {
       TiltField& f = c->tf[l];
-      if (!(modules & (f.mod_tilt | f.mod_smooth | f.mod_bt))) continue;
+      if (!(modules & (f.mod_tilt | f.mod_smooth | f.mod_bt | f.mod_dt))) continue;
       int rc = tilt_pass_f(c, f, 2, true, alpha, f.tilts, f.trial);
       if (rc) return rc;
     }
@@ -389,6 +440,7 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
       ta.partials = c->d_partials;
       ta.e_slot = MS_S_ETILT;
       ta.consistent = 0;
+      ta.tg_accumulate = 0;
       if (!ta.tilts) return fail(c, MS_ERR_STATE, "bending_tilt_in/out active but ms_set_leaflet_tilts was never called");
       ProfScope ps(c, 4);
       HIPCHK(c, launch_tilt(ta, 3, c->cap, c->til.max_ent, c->stream));
@@ -434,7 +486,7 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   }
   for (int l = 1; l <= 2 && (modules & MS_LEAFLET_MODS); ++l) {  // leaflet fields, same protocol
     TiltField& f = c->tf[l];
-    if (!(modules & (f.mod_tilt | f.mod_smooth))) continue;
+    if (!(modules & (f.mod_tilt | f.mod_smooth | f.mod_dt))) continue;
     int rc = MS_OK;
     const double* tilts = f.tilts;
     if (use_dir) {
@@ -442,6 +494,8 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
       if (rc) return rc;
       tilts = f.trial;
     }
+    if (modules & f.mod_dt) rc = disk_target_pass(c, f, 0, use_dir, alpha, tilts, false, false);
+    if (rc) return rc;
     if (modules & f.mod_tilt) rc = tilt_pass_f(c, f, 0, use_dir, alpha, tilts);
     if (rc) return rc;
     if (modules & f.mod_smooth) rc = ts_pass_f(c, f, 0, use_dir, alpha, tilts);
@@ -533,9 +587,14 @@ int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulat
   if (dir_mode) c->last_g = g_out;
   for (int k = 0; k < 3 && g_out; ++k) {  // module loop: the tilt magnitude modules add their shape gradient into g
     TiltField& f = c->tf[k];
-    if (!(modules & f.mod_tilt)) continue;
-    int rc = tilt_pass_f(c, f, 1, false, 0.0);
-    if (rc) return rc;
+    if (modules & f.mod_tilt) {
+      int rc = tilt_pass_f(c, f, 1, false, 0.0);
+      if (rc) return rc;
+    }
+    if (k > 0 && (modules & f.mod_dt)) {
+      int rc = disk_target_pass(c, f, 1, false, 0.0, f.tilts, true, false);
+      if (rc) return rc;
+    }
   }
   if (reduce_now) return reduce_slots(c, dir_mode ? MASK_DIR : MASK_GRAD);
   return MS_OK;
@@ -594,6 +653,7 @@ void energies_from_mailbox(const ms_ctx* c, double e[4]) {
     if (c->params.modules & f.mod_tilt) e[3] += c->h_scal[f.s_etilt];
     if (c->params.modules & f.mod_smooth) e[3] += c->h_scal[f.s_ets];
     if (c->params.modules & f.mod_bt) e[1] += c->h_scal[f.s_ebt];
+    if (c->params.modules & f.mod_dt) e[3] += c->h_scal[f.s_edt];
   }
 }
 
@@ -839,10 +899,12 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
     f1.s_etilt = MS_S_ETILT_IN; f1.s_ets = MS_S_ETS_IN; f1.s_gn2 = MS_S_TGNORM2_IN; f1.s_rz = MS_S_TRZ_IN;
     f1.mod_bt = MS_MOD_BENDING_TILT_IN; f1.s_ebt = MS_S_EBT_IN; f1.div_sign = -1.0;  // bending_tilt_in.py:46
     f0.mod_bt = MS_MOD_BENDING_TILT; f0.s_ebt = MS_S_EBT;
+    f1.mod_dt = MS_MOD_TILT_DISK_TARGET_IN; f1.s_edt = MS_S_EDT_IN; f1.s_dtr = MS_S_DTR_IN;
     TiltField& f2 = c->tf[2];
     f2.fixed_bit = VF_TILT_FIXED_OUT; f2.mod_tilt = MS_MOD_TILT_OUT; f2.mod_smooth = MS_MOD_TILT_SMOOTH_OUT;
     f2.s_etilt = MS_S_ETILT_OUT; f2.s_ets = MS_S_ETS_OUT; f2.s_gn2 = MS_S_TGNORM2_OUT; f2.s_rz = MS_S_TRZ_OUT;
     f2.mod_bt = MS_MOD_BENDING_TILT_OUT; f2.s_ebt = MS_S_EBT_OUT; f2.div_sign = 1.0;
+    f2.mod_dt = MS_MOD_TILT_DISK_TARGET_OUT; f2.s_edt = MS_S_EDT_OUT; f2.s_dtr = MS_S_DTR_OUT;
   }
   c->deterministic = getenv("MS_DETERMINISTIC") != nullptr && atoi(getenv("MS_DETERMINISTIC")) != 0;
   c->params.modules = MS_MOD_SURFACE;
@@ -869,6 +931,7 @@ void ms_destroy(ms_ctx* c) {
                   c->tf[1].tilts, c->tf[1].grad, c->tf[1].trial, c->tf[1].dir, c->tf[1].minv,
                   c->tf[2].tilts, c->tf[2].grad, c->tf[2].trial, c->tf[2].dir, c->tf[2].minv,
                   c->tf[1].kappa, c->tf[1].c0, c->tf[1].bt_vert, c->tf[2].kappa, c->tf[2].c0, c->tf[2].bt_vert,
+                  c->tf[1].disk, c->tf[1].diff, c->tf[2].disk, c->tf[2].diff,
                   c->state, c->d_partials, c->d_scal, c->d_stage, c->d_bnd_rows, c->d_bnd_off,
                   c->d_halo_rows, c->d_scal_all};
   for (void* p : ptrs)
@@ -1064,7 +1127,7 @@ int tilt_eval(ms_ctx* c, bool trial, bool gradient) {
   }
   for (int l = 1; l <= 2; ++l) {
     TiltField& f = c->tf[l];
-    if (!(mods & (f.mod_tilt | f.mod_smooth | f.mod_bt))) continue;
+    if (!(mods & (f.mod_tilt | f.mod_smooth | f.mod_bt | f.mod_dt))) continue;
     const double* tilts = trial ? f.trial : f.tilts;
     if (mods & f.mod_tilt) {
       rc = tilt_pass_f(c, f, gradient ? 1 : 0, false, 0.0, tilts, nullptr, /*shape_gradient=*/false, /*lumped=*/true);
@@ -1077,6 +1140,11 @@ int tilt_eval(ms_ctx* c, bool trial, bool gradient) {
       rc = bt_pass_f(c, f, gradient ? 2 : 0, false, 0.0, tilts);
       if (rc) return rc;
       mask |= 1u << f.s_ebt;
+    }
+    if (mods & f.mod_dt) {
+      rc = disk_target_pass(c, f, gradient ? 1 : 0, false, 0.0, tilts, false, gradient);
+      if (rc) return rc;
+      mask |= 1u << f.s_edt;
     }
     if (mods & f.mod_smooth) {
       rc = ts_pass_f(c, f, gradient ? 1 : 0, false, 0.0, tilts);
@@ -1096,6 +1164,7 @@ double tilt_energy_from_mailbox(const ms_ctx* c) {
     if (c->params.modules & f.mod_tilt) e += c->h_scal[f.s_etilt];
     if (c->params.modules & f.mod_smooth) e += c->h_scal[f.s_ets];
     if (c->params.modules & f.mod_bt) e += c->h_scal[f.s_ebt];
+    if (c->params.modules & f.mod_dt) e += c->h_scal[f.s_edt];
   }
   return e;
 }
@@ -1160,6 +1229,7 @@ int relax_fields(ms_ctx* c, const ms_tilt_relax_params* rp, TiltField** fl, int 
       a.partials = c->d_partials;
       a.e_slot = f.s_etilt;
       a.consistent = 0;
+      a.tg_accumulate = 0;
       HIPCHK(c, launch_tilt(a, 3, c->cap, t.max_ent, c->stream));
     }
     // + 1/2 k_s sum (c_a + c_b): the parameter alone decides, loaded module or not
@@ -1371,6 +1441,29 @@ int ms_set_leaflet_bending(ms_ctx* c, int leaflet, const double* kappa, const do
   return MS_OK;
 }
 
+int ms_set_leaflet_disk_target(ms_ctx* c, int leaflet, const uint8_t* disk_rows, const ms_disk_target_params* p) {
+  if (!c || !p) return fail(c, MS_ERR_INVALID, "ms_set_leaflet_disk_target: NULL argument");
+  if (leaflet != MS_LEAFLET_IN && leaflet != MS_LEAFLET_OUT)
+    return fail(c, MS_ERR_INVALID, "ms_set_leaflet_disk_target: leaflet must be MS_LEAFLET_IN or MS_LEAFLET_OUT");
+  TiltField& f = c->tf[1 + leaflet];
+  const Tiling& t = c->til;
+  const double nn = std::sqrt(p->normal[0] * p->normal[0] + p->normal[1] * p->normal[1] + p->normal[2] * p->normal[2]);
+  if (!(nn >= 1e-15)) return fail(c, MS_ERR_INVALID, "ms_set_leaflet_disk_target: a plane normal is required");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!f.disk) {
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&f.disk), (size_t)t.nvp));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&f.diff), sizeof(double) * 3 * (size_t)t.nvp));
+    HIPCHK(c, hipMemset(f.diff, 0, sizeof(double) * 3 * (size_t)t.nvp));
+  }
+  std::vector<uint8_t> m((size_t)t.nvp, 0);
+  for (int i = 0; i < t.nv && disk_rows; ++i) m[(size_t)i] = disk_rows[t.perm[i]] ? 1 : 0;
+  HIPCHK(c, hipMemcpy(f.disk, m.data(), m.size(), hipMemcpyHostToDevice));
+  f.dt = *p;
+  for (int k = 0; k < 3; ++k) f.dt.normal[k] = p->normal[k] / nn;  // tilt_disk_target_in.py:73-77
+  c->carry_valid = c->grad_valid = c->maxg2_valid = false;
+  return MS_OK;
+}
+
 int ms_get_leaflet_tilts(ms_ctx* c, int leaflet, double* tilts) {
   if (!c || !tilts || (leaflet != MS_LEAFLET_IN && leaflet != MS_LEAFLET_OUT) || !c->tf[1 + leaflet].tilts)
     return fail(c, MS_ERR_INVALID, "ms_get_leaflet_tilts: bad leaflet / no tilts set");
@@ -1387,7 +1480,7 @@ int leaflet_ready(ms_ctx* c, const char* who, TiltField** fl, int* nf) {
   *nf = 0;
   for (int l = 1; l <= 2; ++l) {
     TiltField& f = c->tf[l];
-    if (!(mods & (f.mod_tilt | f.mod_smooth | f.mod_bt))) continue;
+    if (!(mods & (f.mod_tilt | f.mod_smooth | f.mod_bt | f.mod_dt))) continue;
     if (!f.tilts) return fail(c, MS_ERR_STATE, std::string(who) + ": ms_set_leaflet_tilts was not called for an active leaflet");
     fl[(*nf)++] = &f;
   }
@@ -1410,7 +1503,7 @@ int ms_leaflet_tilt_energy_and_gradient(ms_ctx* c, double* energy, double* grad_
   for (int l = 0; l < 2; ++l) {
     if (!outs[l]) continue;
     TiltField& f = c->tf[1 + l];
-    if (f.tilts && (c->params.modules & (f.mod_tilt | f.mod_smooth | f.mod_bt))) {
+    if (f.tilts && (c->params.modules & (f.mod_tilt | f.mod_smooth | f.mod_bt | f.mod_dt))) {
       rc = patch_to_ext(c, f.grad, outs[l], 3);
       if (rc) return rc;
     } else {

@@ -138,7 +138,25 @@ struct TiltArgs {
   double* partials;
   int e_slot;             // reduction slot of the energy partial (MS_S_ETILT / _IN / _OUT)
   int consistent;         // tilt_leaflet.py:101-114: consistent P1 mass coeff (energy / shape gradient)
+  int tg_accumulate;      // mode 1: ADD the tilt gradient instead of writing it
 };
+
+struct DiskTargetArgs {   // tilt_disk_target_in.py:160-286
+  int tile0, tile1, nv, T, n_tiles;
+  const uint8_t* vflags;
+  const uint8_t* disk;    // (nvp) 1 on the tagged rows
+  const double* x;
+  const double* d;        // direction or nullptr (positions x + alpha d)
+  double alpha;
+  const double* tilts;
+  double* diff;           // mode 1 out: t - theta(r) r_hat on the disk rows, 0 elsewhere
+  double theta_b, lambda, radius;  // radius <= 0: read scal[r_slot]
+  double center[3], normal[3];
+  const double* scal;
+  double* partials;
+  int r_slot;
+};
+hipError_t launch_disk_target(const DiskTargetArgs& a, int mode, hipStream_t s);
 
 struct BtArgs {
   DeviceMesh m;

@@ -1346,9 +1346,15 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
         a.g[o + 1] += ay;
         a.g[o + 2] += az;
       }
-      a.tilt_grad[o] = a.k_tilt * tv.x * aw;
-      a.tilt_grad[o + 1] = a.k_tilt * tv.y * aw;
-      a.tilt_grad[o + 2] = a.k_tilt * tv.z * aw;
+      if (a.tg_accumulate) {
+        a.tilt_grad[o] += a.k_tilt * tv.x * aw;
+        a.tilt_grad[o + 1] += a.k_tilt * tv.y * aw;
+        a.tilt_grad[o + 2] += a.k_tilt * tv.z * aw;
+      } else {
+        a.tilt_grad[o] = a.k_tilt * tv.x * aw;
+        a.tilt_grad[o + 1] = a.k_tilt * tv.y * aw;
+        a.tilt_grad[o + 2] = a.k_tilt * tv.z * aw;
+      }
     } else if (MODE == 2) {
       V3 nrm = mk(ax, ay, az);
       const double len = norm(nrm);
@@ -1904,6 +1910,80 @@ hipError_t launch_tvec(int mode, int tile0, int tile1, int nv, int T, const uint
 // requested slots in a fixed order.  Volume gets its 1/6 here
 // (geometry/body.py:121: vol_contrib.sum() / 6.0).
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// k_disk_target: the soft disk tilt-profile target (modules/energy/tilt_disk_target_in.py:160-286).
+//   mode 0: largest in-plane distance |r_vec| of a tagged row (the default disk radius, :216-218), per-tile max
+//   mode 1: diff = t - theta(r) r_hat on the tagged rows, 0 elsewhere (:237-243); the energy / gradients are the
+//           tilt magnitude kernel applied to diff with k = strength (:256-284)
+// One workgroup per tile so the partial lines up with k_reduce.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double bessel_i1_series30(double x) {  // :148-157, same operation order
+  const double t = 0.5 * x, t2 = t * t;
+  double term = t, out = t;
+  for (int k = 1; k < 30; ++k) {
+    term = term * (t2 / (double)(k * (k + 1)));
+    out = out + term;
+  }
+  return out;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_disk_target(DiskTargetArgs a, int mode) {
+  __shared__ double red[16];
+  const int tile = a.tile0 + blockIdx.x;
+  double rmax = 0.0;
+  double R = a.radius, den = 1.0;
+  bool off = false;
+  if (mode == 1) {
+    if (!(R > 0.0)) R = a.scal[a.r_slot];
+    off = !(R > 0.0);                         // :219-220
+    if (!off && !(fabs(a.lambda) < 1.0e-12)) {
+      den = bessel_i1_series30(a.lambda * R);
+      off = fabs(den) < 1.0e-15;              // :227-228
+    }
+  }
+  for (int i = threadIdx.x; i < a.T; i += BLOCK) {
+    const int v = tile * a.T + i;
+    if (v >= a.nv) break;
+    const size_t o = 3 * (size_t)v;
+    V3 df = mk(0, 0, 0);
+    if (a.disk[v]) {
+      V3 x = mk(a.x[o], a.x[o + 1], a.x[o + 2]);
+      if (a.d && !(a.vflags[v] & VF_FIXED))
+        x = mk(x.x + a.alpha * a.d[o], x.y + a.alpha * a.d[o + 1], x.z + a.alpha * a.d[o + 2]);
+      const V3 c = mk(a.center[0], a.center[1], a.center[2]), n = mk(a.normal[0], a.normal[1], a.normal[2]);
+      V3 r = x - c;
+      const double rn = dot(r, n);
+      r = mk(r.x - rn * n.x, r.y - rn * n.y, r.z - rn * n.z);
+      const double rl = norm(r);
+      if (mode == 0) {
+        rmax = fmax(rmax, rl);
+      } else if (!off) {
+        V3 rh = mk(0, 0, 0);
+        if (rl > 1.0e-12) rh = mk(r.x / rl, r.y / rl, r.z / rl);
+        double theta;
+        if (fabs(a.lambda) < 1.0e-12) theta = (a.theta_b * rl) / R;
+        else theta = (a.theta_b * bessel_i1_series30(a.lambda * rl)) / den;
+        df = mk(a.tilts[o] - theta * rh.x, a.tilts[o + 1] - theta * rh.y, a.tilts[o + 2] - theta * rh.z);
+      }
+    }
+    if (mode == 1) {
+      a.diff[o] = df.x;
+      a.diff[o + 1] = df.y;
+      a.diff[o + 2] = df.z;
+    }
+  }
+  if (mode == 0) {
+    const double r = block_reduce(rmax, 2, red);
+    if (threadIdx.x == 0) a.partials[(size_t)a.r_slot * a.n_tiles + tile] = r;
+  }
+}
+
+hipError_t launch_disk_target(const DiskTargetArgs& a, int mode, hipStream_t s) {
+  if (a.tile1 <= a.tile0) return hipSuccess;
+  hipLaunchKernelGGL(k_disk_target, dim3(a.tile1 - a.tile0), dim3(BLOCK), 0, s, a, mode);
+  return hipGetLastError();
+}
+
 constexpr int RBLOCK = 512;  // 512 threads x 8 loads in flight cover 4096 tiles in one round trip
 __global__ __launch_bounds__(RBLOCK) void k_reduce(const double* partials, int n_tiles, int tile0,
                                                   int tile1, uint32_t slot_mask, double* scal,
@@ -1926,7 +2006,8 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(const double* partials, int n
       }
   }
   if (slot < 0) return;
-  const int op = (slot == MS_S_MINEDGE2) ? 1 : ((slot == MS_S_GUARD || slot == MS_S_MAXD2 || slot == MS_S_MAXG2) ? 2 : 0);
+  const int op = (slot == MS_S_MINEDGE2) ? 1 : ((slot == MS_S_GUARD || slot == MS_S_MAXD2 || slot == MS_S_MAXG2 ||
+                                                 slot == MS_S_DTR_IN || slot == MS_S_DTR_OUT) ? 2 : 0);
   const double* p = partials + (size_t)slot * n_tiles;
   double v = op == 1 ? 1.0e300 : 0.0;
   // RU loads in flight per thread (the order of the additions is unchanged)

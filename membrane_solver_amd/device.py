@@ -215,6 +215,24 @@ class DeviceMesh:
         c = _f64(np.broadcast_to(np.asarray(c0, dtype=np.float64), (self.nv,)), (self.nv,), "c0")
         self._chk(L.lib().ms_set_leaflet_bending(self._h, lf, _pd(k), _pd(c)), "ms_set_leaflet_bending")
 
+    def set_leaflet_disk_target(self, leaflet: str, disk_rows, *, strength: float, theta_b: float, lam: float,
+                                center=(0.0, 0.0, 0.0), normal=(0.0, 0.0, 1.0), radius: float | None = None):
+        """tilt_disk_target_in/out: tagged rows (bool mask or row indices) and the profile parameters."""
+        lf = {"in": L.MS_LEAFLET_IN, "out": L.MS_LEAFLET_OUT}[leaflet]
+        rows = np.asarray(disk_rows)
+        if rows.dtype == bool:
+            mask = rows.astype(np.uint8)
+        else:
+            mask = np.zeros(self.nv, dtype=np.uint8)
+            mask[rows.astype(np.int64)] = 1
+        if mask.shape != (self.nv,):
+            raise ValueError("disk_rows must be a (nv,) mask or a list of rows")
+        mask = np.ascontiguousarray(mask)
+        p = L.ms_disk_target_params(float(strength), float(theta_b), float(lam), (ctypes.c_double * 3)(*map(float, center)),
+                                    (ctypes.c_double * 3)(*map(float, normal)), float(radius or 0.0))
+        self._chk(L.lib().ms_set_leaflet_disk_target(self._h, lf, mask.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                                     ctypes.byref(p)), "ms_set_leaflet_disk_target")
+
     def get_leaflet_tilts(self, leaflet: str) -> np.ndarray:
         out = np.empty((self.nv, 3), dtype=np.float64)
         lf = {"in": L.MS_LEAFLET_IN, "out": L.MS_LEAFLET_OUT}[leaflet]

@@ -39,7 +39,8 @@ class ArrayMesh:
     def __init__(self, positions, tri_rows, *, fixed=None, surface_tension=None,
                  bending_modulus=None, spontaneous_curvature=None, bodies=None, tilts=None,
                  tilt_fixed=None, global_parameters=None, energy_modules=None, constraint_modules=None,
-                 tilts_in=None, tilts_out=None, tilt_fixed_in=None, tilt_fixed_out=None):
+                 tilts_in=None, tilts_out=None, tilt_fixed_in=None, tilt_fixed_out=None,
+                 disk_rows_in=None, disk_rows_out=None):
         self._positions = np.array(positions, dtype=np.float64, order="C", copy=True)
         self._tri_rows = np.ascontiguousarray(tri_rows, dtype=np.int32)
         nv, nf = self._positions.shape[0], self._tri_rows.shape[0]
@@ -85,6 +86,9 @@ class ArrayMesh:
                               else np.asarray(tilt_fixed_in, dtype=bool).copy())
         self.tilt_fixed_out = (np.zeros(nv, dtype=bool) if tilt_fixed_out is None
                                else np.asarray(tilt_fixed_out, dtype=bool).copy())
+        # rows tagged for tilt_disk_target_in/out (the reference reads vertex.options["tilt_disk_target_group_*"])
+        self.disk_rows_in = None if disk_rows_in is None else np.asarray(disk_rows_in).copy()
+        self.disk_rows_out = None if disk_rows_out is None else np.asarray(disk_rows_out).copy()
         self._version = 0
         self._facet_loops_version = 0
         self._vertex_ids_version = 0

@@ -14,7 +14,8 @@ from ...geometry.mesh import mirror_for
 
 LEAFLET_BITS = {("tilt", "in"): L.MS_MOD_TILT_IN, ("tilt", "out"): L.MS_MOD_TILT_OUT,
                 ("smooth", "in"): L.MS_MOD_TILT_SMOOTH_IN, ("smooth", "out"): L.MS_MOD_TILT_SMOOTH_OUT,
-                ("bt", "in"): L.MS_MOD_BENDING_TILT_IN, ("bt", "out"): L.MS_MOD_BENDING_TILT_OUT}
+                ("bt", "in"): L.MS_MOD_BENDING_TILT_IN, ("bt", "out"): L.MS_MOD_BENDING_TILT_OUT,
+                ("disk", "in"): L.MS_MOD_TILT_DISK_TARGET_IN, ("disk", "out"): L.MS_MOD_TILT_DISK_TARGET_OUT}
 
 # options of the reference's leaflet modules that change their result and are not on the device path
 _UNSUPPORTED_KEYS = (
@@ -147,6 +148,81 @@ def bending_params(mesh, global_params, leaflet: str):
     return kappa, c0
 
 
+def disk_target_rows(mesh, leaflet: str, group: str) -> np.ndarray:
+    """Rows tagged ``tilt_disk_target_group_<leaflet> == group`` (tilt_disk_target_in.py:137-145): vertex options of
+    a reference Mesh, or the ``disk_rows_<leaflet>`` attribute (mask / row list) of an array mesh."""
+    nv = len(mesh.vertex_ids)
+    own = getattr(mesh, f"disk_rows_{leaflet}", None)
+    if own is not None:
+        own = np.asarray(own)
+        return np.flatnonzero(own) if own.dtype == bool else own.astype(np.int64)
+    verts = getattr(mesh, "vertices", None)
+    if isinstance(verts, dict):
+        rows = []
+        key = f"tilt_disk_target_group_{leaflet}"
+        for vid in mesh.vertex_ids:
+            opts = getattr(verts[int(vid)], "options", None) or {}
+            if opts.get(key) == group:
+                row = mesh.vertex_index_to_row.get(int(vid))
+                if row is not None:
+                    rows.append(int(row))
+        return np.asarray(rows, dtype=np.int64)
+    return np.zeros(0, dtype=np.int64) if nv >= 0 else None
+
+
+def disk_target_params(mesh, param_resolver, global_params, leaflet: str):
+    """Resolved parameters of tilt_disk_target_<leaflet> (tilt_disk_target_in.py:38-134) as kwargs of
+    DeviceMesh.set_leaflet_disk_target, or None when the module contributes nothing (:175-191)."""
+
+    def pick(name):
+        v = _get(param_resolver, global_params, f"tilt_disk_target_{name}_{leaflet}")
+        return _get(param_resolver, global_params, f"tilt_disk_target_{name}") if v is None else v
+
+    raw = _get(param_resolver, global_params, f"tilt_disk_target_group_{leaflet}")
+    group = None if raw is None else str(raw).strip()
+    if not group:
+        return None
+    k = float(_get(param_resolver, global_params, f"tilt_disk_target_strength_{leaflet}") or 0.0)
+    theta_b = float(pick("theta_B") or 0.0)
+    if k == 0.0 or theta_b == 0.0:
+        return None
+    rows = disk_target_rows(mesh, leaflet, group)
+    if rows.size == 0:
+        return None
+    normal = pick("normal")
+    if normal is None or float(np.linalg.norm(np.asarray(normal, dtype=float))) < 1e-15:
+        raise L.MembraneHipError("tilt_disk_target without tilt_disk_target_normal (SVD plane fit of the disk rows) "
+                                 "is outside the HIP hot path")
+    center = pick("center")
+    radius = pick("radius")
+    try:
+        radius = float(radius) if radius is not None and float(radius) > 0.0 else None
+    except (TypeError, ValueError):
+        radius = None
+    lam = pick("lambda")
+    if lam is not None:
+        try:
+            lam = float(lam)
+        except (TypeError, ValueError):
+            lam = 0.0
+    else:
+        kt = _get(param_resolver, global_params, f"tilt_modulus_{leaflet}")
+        if kt is None and leaflet == "in":
+            kt = _get(param_resolver, global_params, "tilt_modolus_in")
+        kap = _get(param_resolver, global_params, f"bending_modulus_{leaflet}")
+        if kap is None:
+            kap = _get(param_resolver, global_params, "bending_modulus")
+        lam = 0.0
+        try:
+            if kt is not None and kap is not None and float(kt) > 0.0 and float(kap) > 0.0:
+                lam = float(np.sqrt(float(kt) / float(kap)))
+        except (TypeError, ValueError):
+            lam = 0.0
+    return {"disk_rows": rows, "strength": k, "theta_b": theta_b, "lam": lam,
+            "center": tuple(np.asarray([0.0, 0.0, 0.0] if center is None else center, dtype=float).reshape(3)),
+            "normal": tuple(np.asarray(normal, dtype=float).reshape(3)), "radius": radius}
+
+
 def check_bt_supported(global_params) -> None:
     mode = str(global_params.get("bending_gradient_mode", "analytic") or "analytic").strip().lower()
     if mode != "analytic":
@@ -188,8 +264,20 @@ def evaluate(mesh, global_params, param_resolver, *, kind: str, leaflet: str, po
     if kind == "bt":
         check_bt_supported(global_params)
         dm.set_leaflet_bending(leaflet, *bending_params(mesh, global_params, leaflet))
+    if kind == "disk":
+        prm = disk_target_params(mesh, param_resolver, global_params, leaflet)
+        if prm is None:
+            return 0.0
+        dm.set_leaflet_disk_target(leaflet, **prm)
     dm.set_params(modules=LEAFLET_BITS[(kind, leaflet)])
-    if kind == "bt":
+    if kind == "disk":
+        if grad_arr is not None:
+            e, g = dm.energy_and_gradient(want_grad=True)
+            grad_arr += g
+            E = float(e[3])
+        else:
+            E = float(dm.energy()[3])
+    elif kind == "bt":
         if grad_arr is not None:
             e, g = dm.energy_and_gradient(want_grad=True)
             grad_arr += g

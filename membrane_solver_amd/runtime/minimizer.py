@@ -48,19 +48,22 @@ _ENERGY_BITS = {"surface": L.MS_MOD_SURFACE, "bending": L.MS_MOD_BENDING, "volum
                 "tilt_smoothness": L.MS_MOD_TILT_SMOOTH,
                 "tilt_in": L.MS_MOD_TILT_IN, "tilt_out": L.MS_MOD_TILT_OUT,
                 "tilt_smoothness_in": L.MS_MOD_TILT_SMOOTH_IN, "tilt_smoothness_out": L.MS_MOD_TILT_SMOOTH_OUT,
-                "bending_tilt_in": L.MS_MOD_BENDING_TILT_IN, "bending_tilt_out": L.MS_MOD_BENDING_TILT_OUT}
+                "bending_tilt_in": L.MS_MOD_BENDING_TILT_IN, "bending_tilt_out": L.MS_MOD_BENDING_TILT_OUT,
+                "tilt_disk_target_in": L.MS_MOD_TILT_DISK_TARGET_IN,
+                "tilt_disk_target_out": L.MS_MOD_TILT_DISK_TARGET_OUT}
 _ENERGY_SLOT = {"surface": 0, "bending": 1, "volume": 2, "tilt": 3, "bending_tilt": 1, "tilt_smoothness": 3,
                 "tilt_in": 3, "tilt_out": 3, "tilt_smoothness_in": 3, "tilt_smoothness_out": 3,
-                "bending_tilt_in": 1, "bending_tilt_out": 1}
+                "bending_tilt_in": 1, "bending_tilt_out": 1, "tilt_disk_target_in": 3, "tilt_disk_target_out": 3}
 _SINGLE_TILT_BITS = L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT | L.MS_MOD_TILT_SMOOTH
 _LEAFLET_BT_BITS = L.MS_MOD_BENDING_TILT_IN | L.MS_MOD_BENDING_TILT_OUT
 _LEAFLET_BITS = (L.MS_MOD_TILT_IN | L.MS_MOD_TILT_OUT | L.MS_MOD_TILT_SMOOTH_IN | L.MS_MOD_TILT_SMOOTH_OUT
-                 | _LEAFLET_BT_BITS)
+                 | _LEAFLET_BT_BITS | L.MS_MOD_TILT_DISK_TARGET_IN | L.MS_MOD_TILT_DISK_TARGET_OUT)
 _TILT_BITS = _SINGLE_TILT_BITS | _LEAFLET_BITS
 # scalar slot of every module that shares energies[3]
 _TILT_SCALAR = {"tilt": L.MS_S_ETILT, "tilt_smoothness": L.MS_S_ETS, "tilt_in": L.MS_S_ETILT_IN,
                 "tilt_out": L.MS_S_ETILT_OUT, "tilt_smoothness_in": L.MS_S_ETS_IN,
-                "tilt_smoothness_out": L.MS_S_ETS_OUT}
+                "tilt_smoothness_out": L.MS_S_ETS_OUT, "tilt_disk_target_in": L.MS_S_EDT_IN,
+                "tilt_disk_target_out": L.MS_S_EDT_OUT}
 _BEND_SCALAR = {"bending": L.MS_S_EBEND, "bending_tilt": L.MS_S_EBT, "bending_tilt_in": L.MS_S_EBT_IN,
                 "bending_tilt_out": L.MS_S_EBT_OUT}
 
@@ -154,7 +157,7 @@ class Minimizer:
                 raise L.MembraneHipError(
                     f"energy module {name!r} is outside the HIP hot path (surface, bending, volume, tilt, "
                     "bending_tilt, tilt_smoothness, tilt_in, tilt_out, tilt_smoothness_in, tilt_smoothness_out, "
-                    "bending_tilt_in, bending_tilt_out)")
+                    "bending_tilt_in, bending_tilt_out, tilt_disk_target_in, tilt_disk_target_out)")
         self.constraint_modules = [self.constraint_manager.get_constraint(c)
                                    for c in self.constraint_module_names]
         for name in self.constraint_module_names:
@@ -193,6 +196,7 @@ class Minimizer:
         if self.deterministic is not None:
             dm.set_deterministic(self.deterministic)
         mods = 0
+        disk_params = {}
         vol_mode = gp.get("volume_constraint_mode", "lagrange")
         for name in self.energy_module_names:
             if name == "volume":
@@ -210,6 +214,11 @@ class Minimizer:
             elif name in ("tilt_smoothness_in", "tilt_smoothness_out"):
                 if _lc.smoothness_rigidity(self.param_resolver, gp, name[16:]) != 0.0:  # tilt_smoothness_leaflet.py:32-34
                     mods |= _ENERGY_BITS[name]
+            elif name in ("tilt_disk_target_in", "tilt_disk_target_out"):
+                prm = _lc.disk_target_params(self.mesh, self.param_resolver, gp, name[17:])
+                if prm is not None:  # tilt_disk_target_in.py:175-191
+                    mods |= _ENERGY_BITS[name]
+                    disk_params[name[17:]] = prm
             else:
                 mods |= _ENERGY_BITS[name]
         target = 0.0
@@ -259,6 +268,11 @@ class Minimizer:
             if gp.get("line_search_reduced_energy", False):
                 raise L.MembraneHipError("line_search_reduced_energy is outside the HIP hot path")
             mir.upload_leaflets({lf: _lc.device_params(self.param_resolver, gp, lf) for lf in ("in", "out")})
+            for lf, prm in disk_params.items():
+                key = (mir._topo_key, prm["disk_rows"].tobytes(), tuple((k, v) for k, v in prm.items() if k != "disk_rows"))
+                if mir._leaflet_keys.get("bend_disk_" + lf) != key:
+                    dm.set_leaflet_disk_target(lf, **prm)
+                    mir._leaflet_keys["bend_disk_" + lf] = key
             if mods & _LEAFLET_BT_BITS:
                 _lc.check_bt_supported(gp)
                 if mods & (L.MS_MOD_BENDING | L.MS_MOD_BENDING_TILT):

@@ -348,3 +348,80 @@ def test_bending_tilt_leaflet_midsize_matches_oracle():
     assert abs(E - Er) <= 1e-11 * abs(Er)
     assert relerr(gi, gi_ref) < 1e-10 and relerr(go, go_ref) < 1e-10
     dm.close()
+
+
+# ---------------------------------------------------------------------------
+# tilt_disk_target_in / tilt_disk_target_out (tilt_disk_target_in.py:160-286)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["disk6", "ico5"])
+@pytest.mark.parametrize("tag", ["bessel", "linear", "moduli"])
+def test_disk_target_plugins_match_reference(name, tag):
+    from membrane_solver_amd.core.parameters import GlobalParameters, ParameterResolver
+    from membrane_solver_amd.geometry.mesh import ArrayMesh
+    from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
+
+    g = load_golden("tilt_disk_target_cases.npz")
+    key = f"{name}_{tag}"
+    gp = GlobalParameters(_gp(g, key + "_gp_json"))
+    pos, tri, rows = g[name + "_positions"], g[name + "_tri"], g[name + "_disk_rows"]
+    tin, tout = g[name + "_tilts_in"], g[name + "_tilts_out"]
+    mesh = ArrayMesh(pos, tri, global_parameters=gp, tilts_in=tin, tilts_out=tout, disk_rows_in=rows, disk_rows_out=rows)
+    res = ParameterResolver(gp)
+    em = EnergyModuleManager(["tilt_disk_target_in", "tilt_disk_target_out"])
+    for lf in ("in", "out"):
+        module = em.get_module(f"tilt_disk_target_{lf}")
+        grad, tg = np.zeros_like(pos), np.zeros_like(pos)
+        kw = {"tilt_in_grad_arr": tg} if lf == "in" else {"tilt_out_grad_arr": tg}
+        E = module.compute_energy_and_gradient_array(mesh, gp, res, positions=pos, index_map=mesh.vertex_index_to_row,
+                                                     grad_arr=grad, tilts_in=tin, tilts_out=tout, **kw)
+        ref = g[f"{key}_tilt_disk_target_{lf}_E"]
+        assert abs(E - ref) <= 1e-12 * abs(ref)
+        assert relerr(grad, g[f"{key}_tilt_disk_target_{lf}_grad"]) < 1e-10
+        assert relerr(tg, g[f"{key}_tilt_disk_target_{lf}_tilt_grad"]) < 1e-10
+
+
+DISK_TRAJ = {"traj_disk6_gd_disktarget_nested_cg.npz": "gd", "traj_disk6_cg_disktarget_coupled_gd.npz": "cg"}
+
+
+@pytest.mark.parametrize("fname", sorted(DISK_TRAJ))
+def test_minimizer_reproduces_disk_target_trajectory(fname):
+    g = load_golden(fname)
+    for observe in (True, False):
+        mesh, mz, log = _leaflet_minimizer(g, DISK_TRAJ[fname], observe=observe)
+        mesh.disk_rows_in = mesh.disk_rows_out = g["disk_rows"]
+        if observe:
+            E0, grad0 = mz.compute_energy_and_gradient_array()
+            assert abs(E0 - g["E0"]) <= 1e-12 * abs(g["E0"])
+            assert relerr(grad0, g["grad0"]) < 1e-10
+        res = mz.minimize(int(g["n_steps"]))
+        if observe:
+            got, ref = np.array(log), g["step_log"]
+            assert got.shape == ref.shape
+            assert np.array_equal(got[:, 0], ref[:, 0]), "accept/reject sequence differs from the reference"
+            assert np.allclose(got[:, 1], ref[:, 1], rtol=1e-12, atol=0)
+            assert np.allclose(got[:, 2], ref[:, 2], rtol=1e-9, atol=0)
+            bd = mz.compute_energy_breakdown()
+            assert abs(sum(bd.values()) - res["energy"]) <= 1e-12 * abs(res["energy"])
+        assert relerr(mesh.positions_view(), g["positions_final"]) < 1e-8
+        assert relerr(mesh.tilts_in_view(), g["tilts_in_final"]) < 1e-8
+        assert relerr(mesh.tilts_out_view(), g["tilts_out_final"]) < 1e-8
+        assert abs(res["energy"] - g["E_final"]) <= 1e-9 * abs(g["E_final"])
+
+
+def test_disk_target_needs_a_normal():
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.geometry.mesh import ArrayMesh
+    from membrane_solver_amd.runtime.constraint_manager import ConstraintModuleManager
+    from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
+    from membrane_solver_amd.runtime.minimizer import Minimizer
+    from membrane_solver_amd.runtime.steppers import GradientDescent
+
+    P, T = meshgen.icosphere(3)
+    gp = {"tilt_disk_target_group_in": "disk", "tilt_disk_target_strength_in": 5.0, "tilt_disk_target_theta_B": 0.3}
+    mods = ["surface", "tilt_disk_target_in"]
+    mesh = ArrayMesh(P, T, global_parameters=gp, energy_modules=mods, disk_rows_in=np.arange(10))
+    mz = Minimizer(mesh, mesh.global_parameters, GradientDescent(), EnergyModuleManager(mods), ConstraintModuleManager([]),
+                   quiet=True)
+    with pytest.raises(L.MembraneHipError, match="tilt_disk_target_normal"):
+        mz.compute_energy()
