@@ -469,9 +469,11 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
             ve1 = ve1 * m1 + m1 * extra;
             ve2 = ve2 * m2 + m2 * extra;
           }
-          const V3 K0 = 0.5 * (c1 * (-e1) + c2 * e2);
-          const V3 K1 = 0.5 * (c2 * (-e2) + c0 * e0);
-          const V3 K2 = 0.5 * (c0 * (-e0) + c1 * e1);
+          // K0 + K1 + K2 = 0 for every facet (each edge term enters two corners with opposite sign)
+          const double hc0 = 0.5 * c0, hc1 = 0.5 * c1, hc2 = 0.5 * c2;
+          const V3 K0 = hc2 * e2 - hc1 * e1;
+          const V3 K1 = hc0 * e0 - hc2 * e2;
+          const V3 K2 = -(K0 + K1);
           if (ATOMIC) {
             const int no = t.n_owned;
             if (tf.l0 < no) {
