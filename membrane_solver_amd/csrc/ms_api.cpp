@@ -68,6 +68,7 @@ struct ms_ctx {
     ms_disk_target_params dt = {};
     uint32_t mod_dt = 0;
     int s_edt = 0, s_dtr = 0;
+    bool any_free = true;      // some row of this field is not clamped (kept current by the flag setters)
   } tf[3];
   int factors_leaflet = 0;  // which leaflet's back-prop factors fK/fA hold (1 in, 2 out; 0: not a leaflet's)
   double* d_bt_vert = nullptr;    // (nvp,4) bending_tilt per-vertex record of the last energy pass
@@ -1089,6 +1090,8 @@ int ms_set_tilt_fixed(ms_ctx* c, const uint8_t* tilt_fixed) {
     if (tilt_fixed && tilt_fixed[t.perm[i]]) f |= VF_TILT_FIXED;
     c->h_vflags[(size_t)i] = f;
   }
+  c->tf[0].any_free = t.nv == 0;
+  for (int i = 0; i < t.nv && !c->tf[0].any_free; ++i) c->tf[0].any_free = !(c->h_vflags[(size_t)i] & VF_TILT_FIXED);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(c->d_vflags, c->h_vflags.data(), c->h_vflags.size(), hipMemcpyHostToDevice));
   return MS_OK;
@@ -1182,8 +1185,7 @@ int relax_fields(ms_ctx* c, const ms_tilt_relax_params* rp, TiltField** fl, int 
   const uint32_t mods = c->params.modules;
   const Tiling& t = c->til;
   bool any_free = false;
-  for (int k = 0; k < nf && !any_free; ++k)
-    for (int i = 0; i < t.nv && !any_free; ++i) any_free = !(c->h_vflags[(size_t)i] & fl[k]->fixed_bit);
+  for (int k = 0; k < nf; ++k) any_free = any_free || fl[k]->any_free;
   if (!any_free) return MS_OK;
   const size_t b3 = sizeof(double) * 3 * (size_t)t.nvp;
   if (!c->d_tn) {
@@ -1406,6 +1408,10 @@ int ms_set_leaflet_tilts(ms_ctx* c, int leaflet, const double* tilts, const uint
     if (tilt_fixed && tilt_fixed[t.perm[i]]) fl |= f.fixed_bit;
     flags_changed = flags_changed || fl != c->h_vflags[(size_t)i];
     c->h_vflags[(size_t)i] = fl;
+  }
+  if (flags_changed || !tilt_fixed) {
+    f.any_free = t.nv == 0 || !tilt_fixed;
+    for (int i = 0; i < t.nv && !f.any_free; ++i) f.any_free = !(c->h_vflags[(size_t)i] & f.fixed_bit);
   }
   if (flags_changed) {
     HIPCHK(c, hipStreamSynchronize(c->stream));

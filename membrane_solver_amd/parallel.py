@@ -491,7 +491,7 @@ def bench_main(args, rank: int, world: int, local_rank: int):
                                    "bending (analytic cotan gradient), CG stepper, Armijo line search, "
                                    f"evaluation reuse level {drv.reuse_energy0}",
                        "parallelism": f"tiles (facet blocks) sharded over {world} GPUs; per exchange one RCCL "
-                                      f"all-gather of [16 scalars | <= {be.boundary['max_rows']} boundary rows] "
+                                      f"all-gather of [{L.MS_NSCAL} scalars | <= {be.boundary['max_rows']} boundary rows] "
                                       f"per rank ({drv.exchanges - ex0} exchanges in the timed steps); driver: {driver}",
                        "tile_vertices": args.tile or 256, "initial_step_size": args.step_size,
                        "deterministic": bool(getattr(args, "deterministic", False))},

@@ -19,6 +19,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--freq", type=int, default=320)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--inner", type=int, default=5)
+ap.add_argument("--leaflet", action="store_true",
+                help="two-leaflet family instead: surface + tilt_in/out + bending_tilt_in/out + tilt_smoothness_in/out")
 args = ap.parse_args()
 
 P, T = meshgen.icosphere(args.freq)
@@ -31,7 +33,14 @@ gp = {"surface_tension": 1.0, "bending_modulus": 1.0, "spontaneous_curvature": 0
       "volume_projection_during_minimization": False, "tilt_solve_mode": "nested", "tilt_solver": "cg",
       "tilt_step_size": 0.2, "tilt_inner_steps": args.inner}
 mods = ["surface", "tilt", "bending_tilt"]
-mesh = ArrayMesh(P, T, tilts=tl, global_parameters=gp, energy_modules=mods, constraint_modules=[])
+if args.leaflet:
+    gp.update({"tilt_modulus_in": 2.0, "tilt_modulus_out": 1.5, "bending_modulus_in": 1.0, "bending_modulus_out": 0.8})
+    mods = ["surface", "tilt_in", "tilt_out", "bending_tilt_in", "bending_tilt_out", "tilt_smoothness_in",
+            "tilt_smoothness_out"]
+    mesh = ArrayMesh(P, T, tilts_in=tl, tilts_out=0.8 * tl[::-1].copy(), global_parameters=gp, energy_modules=mods,
+                     constraint_modules=[])
+else:
+    mesh = ArrayMesh(P, T, tilts=tl, global_parameters=gp, energy_modules=mods, constraint_modules=[])
 mz = Minimizer(mesh, mesh.global_parameters, GradientDescent(), EnergyModuleManager(mods),
                ConstraintModuleManager([]), quiet=True, step_size=1e-6)
 E0 = mz.compute_energy()
@@ -46,9 +55,10 @@ prof = dm.profile_read()
 dm.profile_enable(False)
 # relaxation alone
 t1 = time.perf_counter()
-it, ev = dm.relax_tilts(solver="cg", max_iters=args.inner, step_size=0.2)
+relax = dm.relax_leaflet_tilts if args.leaflet else dm.relax_tilts
+it, ev = relax(solver="cg", max_iters=args.inner, step_size=0.2)
 dtr = time.perf_counter() - t1
-out = {"workload": f"icosphere f={args.freq} (nv={nv}, nf={nf}), surface + tilt + bending_tilt, GD shape stepper, "
+out = {"workload": f"icosphere f={args.freq} (nv={nv}, nf={nf}), {' + '.join(mods)}, GD shape stepper, "
                    f"nested Jacobi-CG tilt relaxation ({args.inner} inner steps)",
        "steps_per_s": args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
        "relax_ms": 1e3 * dtr, "relax_iters": it, "relax_evals": ev,
