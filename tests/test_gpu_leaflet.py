@@ -106,7 +106,7 @@ LEAFLET_TRAJ = {
 }
 
 
-def _leaflet_minimizer(g, kind, observe):
+def _leaflet_minimizer(g, kind, observe, tile=0):
     from membrane_solver_amd.geometry.mesh import ArrayMesh
     from membrane_solver_amd.runtime.constraint_manager import ConstraintModuleManager
     from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
@@ -130,7 +130,7 @@ def _leaflet_minimizer(g, kind, observe):
 
         stepper.device_step = logged
     mz = Minimizer(mesh, mesh.global_parameters, stepper, EnergyModuleManager(mods), ConstraintModuleManager([]),
-                   quiet=True, step_size=float(g["step_size0"]))
+                   quiet=True, step_size=float(g["step_size0"]), tile_vertices=tile)
     return mesh, mz, log
 
 
@@ -425,3 +425,24 @@ def test_disk_target_needs_a_normal():
                    quiet=True)
     with pytest.raises(L.MembraneHipError, match="tilt_disk_target_normal"):
         mz.compute_energy()
+
+
+@pytest.mark.parametrize("fname", ["traj_ico4_gd_leaflet_nested_cg.npz", "traj_ico4_cg_btl_coupled_gd.npz",
+                                   "traj_disk5_gd_btl_backtrack.npz", "traj_disk6_cg_disktarget_coupled_gd.npz"])
+def test_leaflet_trajectories_with_small_tiles(fname):
+    """The same reference trajectories with 64-vertex tiles: several tiles, halos and the generic-size kernel
+    instances on the small golden meshes (the default 256-vertex tiling covers them with one tile)."""
+    g = load_golden(fname)
+    kind = "cg" if "_cg_" in fname else "gd"
+    mesh, mz, _ = _leaflet_minimizer(g, kind, observe=False, tile=64)
+    if "disk_rows" in g and len(g["disk_rows"]):
+        mesh.disk_rows_in = mesh.disk_rows_out = g["disk_rows"]
+    E0, grad0 = mz.compute_energy_and_gradient_array()
+    assert mesh._hip_mirror.dm.tile_stats()["n_tiles"] > 1
+    assert abs(E0 - g["E0"]) <= 1e-12 * abs(g["E0"])
+    assert relerr(grad0, g["grad0"]) < 1e-10
+    res = mz.minimize(int(g["n_steps"]))
+    assert relerr(mesh.positions_view(), g["positions_final"]) < 1e-8
+    assert relerr(mesh.tilts_in_view(), g["tilts_in_final"]) < 1e-8
+    assert relerr(mesh.tilts_out_view(), g["tilts_out_final"]) < 1e-8
+    assert abs(res["energy"] - g["E_final"]) <= 1e-9 * abs(g["E_final"])
