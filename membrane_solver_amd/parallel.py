@@ -481,6 +481,31 @@ def bench_main(args, rank: int, world: int, local_rank: int):
     tmax = torch.tensor([dt], dtype=torch.float64, device=be.device)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    n_exchanges = drv.exchanges - ex0
+    # roofline of the dominant kernel on THIS rank's shard: HIP events inside the library over a few more steps
+    roofline = None
+    try:
+        n_prof = min(args.steps, 30)
+        be.dm.profile_enable(True)
+        be.dm.profile_read()
+        run(n_prof)
+        prof = be.dm.profile_read()
+        be.dm.profile_enable(False)
+        ms_e, n_e = prof.get("energy", (0.0, 0))
+        if n_e:
+            info = be.dm.shard_info()
+            nv_l = int(info["row1"] - info["row0"])
+            nf_l = nf * nv_l / max(nv, 1)
+            # a trial pass that also writes the factors (reuse level 2), as in the single-GPU accounting
+            e_bytes = 20 * nf_l + (48 + 16 + 1) * nv_l + 24 * nv_l + 40 * nv_l
+            us = 1e3 * ms_e / n_e
+            ach = e_bytes / (us * 1e-6) / 1e9
+            roofline = {"bound": "hbm", "kernel": "ms::k_energy* (energy pass), rank 0's shard", "achieved": ach,
+                        "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                        "avg_launch_us": us, "algorithmic_bytes_per_launch": e_bytes, "per_gpu": True,
+                        "measured": f"HIP events around every launch over {n_prof} steps after the timed region"}
+    except Exception as exc:  # the measurement is an extra: never lose the bench line over it
+        print(f"[bench] roofline measurement skipped: {exc}", file=sys.stderr)
     if rank == 0:
         print(json.dumps({
             "metric": "minimizer steps/sec (energy+grad+CG) on 2M-facet icosphere",
@@ -492,10 +517,11 @@ def bench_main(args, rank: int, world: int, local_rank: int):
                                    f"evaluation reuse level {drv.reuse_energy0}",
                        "parallelism": f"tiles (facet blocks) sharded over {world} GPUs; per exchange one RCCL "
                                       f"all-gather of [{L.MS_NSCAL} scalars | <= {be.boundary['max_rows']} boundary rows] "
-                                      f"per rank ({drv.exchanges - ex0} exchanges in the timed steps); driver: {driver}",
+                                      f"per rank ({n_exchanges} exchanges in the timed steps); driver: {driver}",
                        "tile_vertices": args.tile or 256, "initial_step_size": args.step_size,
                        "deterministic": bool(getattr(args, "deterministic", False))},
             "steps_accepted": acc, "line_search_trials": trials,
             "energy_end": float(getattr(r, "energy", getattr(r, "energy_eval", float("nan")))),
+            "roofline": roofline,
         }))
     dist.destroy_process_group()
