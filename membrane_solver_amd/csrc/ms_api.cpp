@@ -69,7 +69,9 @@ struct ms_ctx {
     uint32_t mod_dt = 0;
     int s_edt = 0, s_dtr = 0;
     bool any_free = true;      // some row of this field is not clamped (kept current by the flag setters)
+    double* va = nullptr;      // relaxation: barycentric vertex areas of the frozen positions
   } tf[3];
+  bool relax_va_valid = false;  // a leaflet relaxation is running: tf[l].va describes the current x
   int factors_leaflet = 0;  // which leaflet's back-prop factors fK/fA hold (1 in, 2 out; 0: not a leaflet's)
   double* d_bt_vert = nullptr;    // (nvp,4) bending_tilt per-vertex record of the last energy pass
   bool bt_valid = false;          // d_bt_vert describes the current x
@@ -254,6 +256,7 @@ int tilt_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, c
   a.e_slot = slot_override >= 0 ? slot_override : f.s_etilt;
   a.consistent = (f.consistent && !lumped) ? 1 : 0;
   a.tg_accumulate = tg_accumulate ? 1 : 0;
+  a.va_out = nullptr;
   {
     ProfScope ps(c, 4);
     HIPCHK(c, launch_tilt(a, mode, c->cap, c->til.max_ent, c->stream));
@@ -442,6 +445,7 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
       ta.e_slot = MS_S_ETILT;
       ta.consistent = 0;
       ta.tg_accumulate = 0;
+      ta.va_out = nullptr;
       if (!ta.tilts) return fail(c, MS_ERR_STATE, "bending_tilt_in/out active but ms_set_leaflet_tilts was never called");
       ProfScope ps(c, 4);
       HIPCHK(c, launch_tilt(ta, 3, c->cap, c->til.max_ent, c->stream));
@@ -932,7 +936,7 @@ void ms_destroy(ms_ctx* c) {
                   c->tf[1].tilts, c->tf[1].grad, c->tf[1].trial, c->tf[1].dir, c->tf[1].minv,
                   c->tf[2].tilts, c->tf[2].grad, c->tf[2].trial, c->tf[2].dir, c->tf[2].minv,
                   c->tf[1].kappa, c->tf[1].c0, c->tf[1].bt_vert, c->tf[2].kappa, c->tf[2].c0, c->tf[2].bt_vert,
-                  c->tf[1].disk, c->tf[1].diff, c->tf[2].disk, c->tf[2].diff,
+                  c->tf[1].disk, c->tf[1].diff, c->tf[2].disk, c->tf[2].diff, c->tf[0].va, c->tf[1].va, c->tf[2].va,
                   c->state, c->d_partials, c->d_scal, c->d_stage, c->d_bnd_rows, c->d_bnd_off,
                   c->d_halo_rows, c->d_scal_all};
   for (void* p : ptrs)
@@ -1132,7 +1136,14 @@ int tilt_eval(ms_ctx* c, bool trial, bool gradient) {
     TiltField& f = c->tf[l];
     if (!(mods & (f.mod_tilt | f.mod_smooth | f.mod_bt | f.mod_dt))) continue;
     const double* tilts = trial ? f.trial : f.tilts;
-    if (mods & f.mod_tilt) {
+    if ((mods & f.mod_tilt) && c->relax_va_valid && f.va) {
+      // positions frozen, vertex areas at hand: the reference's own form of this evaluation, one streaming pass
+      ProfScope ps(c, 6);
+      HIPCHK(c, launch_tvec(4, c->tile0, c->tile1, c->til.nv, c->til.T, c->d_vflags, f.grad, f.va, f.dir, tilts,
+                            nullptr, nullptr, nullptr, f.k_tilt, gradient ? 1 : 0, c->d_partials, c->til.n_tiles,
+                            c->stream, f.fixed_bit, f.s_etilt, f.s_rz));
+      mask |= 1u << f.s_etilt;
+    } else if (mods & f.mod_tilt) {
       rc = tilt_pass_f(c, f, gradient ? 1 : 0, false, 0.0, tilts, nullptr, /*shape_gradient=*/false, /*lumped=*/true);
       if (rc) return rc;
       mask |= 1u << f.s_etilt;
@@ -1197,8 +1208,10 @@ int relax_fields(ms_ctx* c, const ms_tilt_relax_params* rp, TiltField** fl, int 
     if (f.dir) continue;
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&f.dir), b3));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&f.minv), sizeof(double) * (size_t)t.nvp));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&f.va), sizeof(double) * (size_t)t.nvp));
     HIPCHK(c, hipMemset(f.dir, 0, b3));
     HIPCHK(c, hipMemset(f.minv, 0, sizeof(double) * (size_t)t.nvp));
+    HIPCHK(c, hipMemset(f.va, 0, sizeof(double) * (size_t)t.nvp));
   }
   int iters = 0, evals = 0;
   int rc = ensure_bt_record(c);
@@ -1232,6 +1245,7 @@ int relax_fields(ms_ctx* c, const ms_tilt_relax_params* rp, TiltField** fl, int 
       a.e_slot = f.s_etilt;
       a.consistent = 0;
       a.tg_accumulate = 0;
+      a.va_out = f.va;
       HIPCHK(c, launch_tilt(a, 3, c->cap, t.max_ent, c->stream));
     }
     // + 1/2 k_s sum (c_a + c_b): the parameter alone decides, loaded module or not
@@ -1248,6 +1262,11 @@ int relax_fields(ms_ctx* c, const ms_tilt_relax_params* rp, TiltField** fl, int 
     if (rc) return rc;
     std::swap(f.tilts, f.trial);
   }
+  struct VaScope {  // the cached vertex areas are valid only while this relaxation runs (x frozen)
+    ms_ctx* c;
+    ~VaScope() { c->relax_va_valid = false; }
+  } va_scope{c};
+  c->relax_va_valid = jacobi_smooth_by_param;  // leaflet driver only (the single field has no such form)
   auto grad_at = [&](double* E, double* gnorm, double* rz) -> int {
     int r = tilt_eval(c, false, true);
     if (r) return r;

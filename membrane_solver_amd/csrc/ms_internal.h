@@ -139,6 +139,7 @@ struct TiltArgs {
   int e_slot;             // reduction slot of the energy partial (MS_S_ETILT / _IN / _OUT)
   int consistent;         // tilt_leaflet.py:101-114: consistent P1 mass coeff (energy / shape gradient)
   int tg_accumulate;      // mode 1: ADD the tilt gradient instead of writing it
+  double* va_out;         // mode 3: barycentric vertex areas (nvp) or nullptr
 };
 
 struct DiskTargetArgs {   // tilt_disk_target_in.py:160-286

@@ -1375,6 +1375,7 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
       a.tilts_out[o + 1] = nrm.y;
       a.tilts_out[o + 2] = nrm.z;
       if (a.minv) a.minv[t.v_lo + tid] = a.k_tilt * aw;  // raw diagonal; k_tvec mode 3 clamps and inverts
+      if (a.va_out) a.va_out[t.v_lo + tid] = aw;         // barycentric vertex area (mesh.py:671-730)
     }
   }
   if (MODE != 2 && MODE != 3) {
@@ -1861,6 +1862,17 @@ __global__ __launch_bounds__(BLOCK) void k_tvec(int mode, int tile0, int nv, int
       const double gg = dot_pinned(g, g);
       s0 += gg;
       s1 += gg * minv[v];
+    } else if (mode == 4) {
+      // leaflet magnitude modules with positions frozen: E = 1/2 k sum |t_v|^2 A_v, dE/dt = k t_v A_v
+      // (runtime/evaluation_manager.py:565-581, 663-695); `minv` carries the vertex areas, `coef` = k
+      const V3 tv = mk(tilts[o], tilts[o + 1], tilts[o + 2]);
+      const double av = minv[v];
+      s0 += (dot(tv, tv)) * av;
+      if (flag) {
+        tg[o] = coef * tv.x * av;
+        tg[o + 1] = coef * tv.y * av;
+        tg[o + 2] = coef * tv.z * av;
+      }
     } else if (mode == 1) {
       const double m = minv[v];
       const V3 z = mk(-tg[o] * m, -tg[o + 1] * m, -tg[o + 2] * m);
@@ -1886,6 +1898,10 @@ __global__ __launch_bounds__(BLOCK) void k_tvec(int mode, int tile0, int nv, int
       out[o + 1] = r.y;
       out[o + 2] = r.z;
     }
+  }
+  if (mode == 4) {
+    const double r = block_reduce(s0, 0, red);
+    if (threadIdx.x == 0) partials[(size_t)s_gn2 * n_tiles + tile] = (0.5 * coef) * r;
   }
   if (mode == 0) {
     double* po = partials + tile;
