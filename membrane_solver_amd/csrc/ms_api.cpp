@@ -71,6 +71,11 @@ struct ms_ctx {
     bool any_free = true;      // some row of this field is not clamped (kept current by the flag setters)
     double* va = nullptr;      // relaxation: barycentric vertex areas of the frozen positions
   } tf[3];
+  // steepest-descent restart on an unchanged gradient (ms_step): the direction is -G and is not written out;
+  // trial passes then read G with -alpha (bitwise the same x + alpha d).  After such a step is accepted the
+  // CG history's previous direction is -PG, which the next fused direction pass derives instead of loading.
+  bool dir_implicit = false;
+  bool pd_neg_pg = false;
   bool relax_va_valid = false;  // a leaflet relaxation is running: tf[l].va describes the current x
   int factors_leaflet = 0;  // which leaflet's back-prop factors fK/fA hold (1 in, 2 out; 0: not a leaflet's)
   double* d_bt_vert = nullptr;    // (nvp,4) bending_tilt per-vertex record of the last energy pass
@@ -143,6 +148,9 @@ struct ms_ctx {
 };
 
 namespace {
+
+inline const double* trial_dir(const ms_ctx* c) { return c->dir_implicit ? c->buf[MS_BUF_G] : c->buf[MS_BUF_D]; }
+inline double trial_alpha(const ms_ctx* c, double alpha) { return c->dir_implicit ? -alpha : alpha; }
 
 int fail(ms_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
@@ -244,8 +252,8 @@ int tilt_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, c
   a.tile0 = c->tile0;
   a.tile1 = c->tile1;
   a.x = c->buf[MS_BUF_X];
-  a.d = use_dir ? c->buf[MS_BUF_D] : nullptr;
-  a.alpha = alpha;
+  a.d = use_dir ? trial_dir(c) : nullptr;
+  a.alpha = trial_alpha(c, alpha);
   a.tilts = src ? src : f.tilts;
   a.tilts_out = dst ? dst : f.tilts;
   a.k_tilt = k_override >= 0.0 ? k_override : f.k_tilt;
@@ -287,8 +295,8 @@ int bt_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, con
   a.tile0 = c->tile0;
   a.tile1 = c->tile1;
   a.x = c->buf[MS_BUF_X];
-  a.d = use_dir ? c->buf[MS_BUF_D] : nullptr;
-  a.alpha = alpha;
+  a.d = use_dir ? trial_dir(c) : nullptr;
+  a.alpha = trial_alpha(c, alpha);
   a.tilts = tilts;
   a.bt_vert = leaflet ? f.bt_vert : c->d_bt_vert;
   a.fK = c->buf[MS_BUF_FK];
@@ -313,8 +321,8 @@ int ts_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, con
   a.tile0 = c->tile0;
   a.tile1 = c->tile1;
   a.x = c->buf[MS_BUF_X];
-  a.d = use_dir ? c->buf[MS_BUF_D] : nullptr;
-  a.alpha = alpha;
+  a.d = use_dir ? trial_dir(c) : nullptr;
+  a.alpha = trial_alpha(c, alpha);
   a.tilts = tilts;
   a.k_smooth = k_override >= 0.0 ? k_override : f.k_smooth;
   a.tilt_grad = f.grad;
@@ -346,8 +354,8 @@ int disk_target_pass(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alp
   a.vflags = c->d_vflags;
   a.disk = f.disk;
   a.x = c->buf[MS_BUF_X];
-  a.d = use_dir ? c->buf[MS_BUF_D] : nullptr;
-  a.alpha = alpha;
+  a.d = use_dir ? trial_dir(c) : nullptr;
+  a.alpha = trial_alpha(c, alpha);
   a.tilts = tilts;
   a.diff = f.diff;
   a.theta_b = f.dt.theta_b;
@@ -394,8 +402,8 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   a.tile0 = c->tile0;
   a.tile1 = c->tile1;
   a.x = c->buf[MS_BUF_X];
-  a.d = use_dir ? c->buf[MS_BUF_D] : nullptr;
-  a.alpha = alpha;
+  a.d = use_dir ? trial_dir(c) : nullptr;
+  a.alpha = trial_alpha(c, alpha);
   a.xt = write_trial ? c->buf[MS_BUF_XT] : nullptr;
   const bool bt = (modules & MS_MOD_BENDING_TILT) != 0;
   const bool lbt = (modules & MS_LEAFLET_BT) != 0;
@@ -433,8 +441,8 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
       ta.tile0 = c->tile0;
       ta.tile1 = c->tile1;
       ta.x = c->buf[MS_BUF_X];
-      ta.d = use_dir ? c->buf[MS_BUF_D] : nullptr;
-      ta.alpha = alpha;
+      ta.d = use_dir ? trial_dir(c) : nullptr;
+      ta.alpha = trial_alpha(c, alpha);
       ta.tilts = c->tf[1].tilts ? c->tf[1].tilts : c->tf[2].tilts;
       ta.tilts_out = c->d_tn;
       ta.k_tilt = 0.0;
@@ -557,6 +565,7 @@ int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulat
   a.d = c->buf[MS_BUF_D];
   a.pg = c->buf[MS_BUF_PG];
   a.pd = c->buf[MS_BUF_PD];
+  a.pd_neg_pg = (dir_mode == 2 && c->pd_neg_pg) ? 1 : 0;
   a.atomic = c->deterministic ? 0 : 1;
   a.bt_vert = nullptr;
   a.tilts = nullptr;
@@ -589,7 +598,10 @@ int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulat
     int rc = bt_pass_f(c, f, 3, false, 0.0, f.tilts);  // + s dE/ddiv d(div)/dx
     if (rc) return rc;
   }
-  if (dir_mode) c->last_g = g_out;
+  if (dir_mode) {
+    c->last_g = g_out;
+    c->dir_implicit = false;  // D was written
+  }
   for (int k = 0; k < 3 && g_out; ++k) {  // module loop: the tilt magnitude modules add their shape gradient into g
     TiltField& f = c->tf[k];
     if (modules & f.mod_tilt) {
@@ -607,6 +619,14 @@ int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulat
 
 int phase_direction(ms_ctx* c, int stepper, bool use_history, bool g_finalized = false) {
   const bool use_con = (c->params.modules & MS_CON_VOLUME) != 0;
+  c->dir_implicit = false;
+  if (stepper == MS_STEPPER_CG && use_history && c->pd_neg_pg) {
+    // the previous direction was an implicit -PG: write it out for the unfused direction kernel
+    HIPCHK(c, launch_direction(c->tile0, c->tile1, c->til.nv, c->til.T, c->d_vflags, c->buf[MS_BUF_PG],
+                               c->buf[MS_BUF_GC], c->buf[MS_BUF_PD], c->buf[MS_BUF_PG], c->buf[MS_BUF_PD], c->d_scal,
+                               0, 0, c->d_partials, c->til.n_tiles, 0, c->stream));
+    c->pd_neg_pg = false;
+  }
   {
   ProfScope ps(c, 2);
   HIPCHK(c, launch_direction(c->tile0, c->tile1, c->til.nv, c->til.T, c->d_vflags, c->buf[MS_BUF_G],
@@ -1571,6 +1591,14 @@ int ms_get_gradient(ms_ctx* c, double* grad) {
 int ms_get_vertex_buffer(ms_ctx* c, int buffer, double* out) {
   if (!c || !out || buffer < 0 || buffer > MS_BUF_FA)
     return fail(c, MS_ERR_INVALID, "ms_get_vertex_buffer: bad argument");
+  if ((buffer == MS_BUF_D && c->dir_implicit) || (buffer == MS_BUF_PD && c->pd_neg_pg)) {
+    // the direction asked for exists only as -G / -PG: write it out
+    const int src = buffer == MS_BUF_D ? MS_BUF_G : MS_BUF_PG;
+    HIPCHK(c, launch_direction(c->tile0, c->tile1, c->til.nv, c->til.T, c->d_vflags, c->buf[src], c->buf[MS_BUF_GC],
+                               c->buf[buffer], c->buf[MS_BUF_PG], c->buf[MS_BUF_PD], c->d_scal, 0, 0, c->d_partials,
+                               c->til.n_tiles, 0, c->stream));
+    if (buffer == MS_BUF_D) c->dir_implicit = false; else c->pd_neg_pg = false;
+  }
   return patch_to_ext(c, c->buf[buffer], out, buffer == MS_BUF_FA ? 2 : 3);
 }
 
@@ -1602,6 +1630,7 @@ int ms_reset_stepper(ms_ctx* c) {
   if (!c) return MS_ERR_INVALID;
   c->cg_have_history = false;
   c->cg_iter_count = 0;
+  c->pd_neg_pg = false;
   return MS_OK;
 }
 
@@ -1632,10 +1661,8 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     if (restart_sd) {
       // steepest-descent restart: d = -g, whose scalars the gradient pass already reduced
       // (|g|^2; <g,d> = -|g|^2 and max|d_i|^2 = max|g_i|^2 exactly) -- no fold, no host round trip
-      ProfScope ps(c, 2);
-      HIPCHK(c, launch_direction(c->tile0, c->tile1, c->til.nv, c->til.T, c->d_vflags, c->buf[MS_BUF_G],
-                                 c->buf[MS_BUF_GC], c->buf[MS_BUF_D], c->buf[MS_BUF_PG], c->buf[MS_BUF_PD],
-                                 c->d_scal, 0, 0, c->d_partials, c->til.n_tiles, 0, c->stream));
+      // -- and no kernel either: the trial passes read G with -alpha (dir_implicit)
+      c->dir_implicit = true;
       c->last_g = c->buf[MS_BUF_G];
       c->h_scal[MS_S_GDOTD] = -c->h_scal[MS_S_GNORM2];
       c->h_scal[MS_S_MAXD2] = c->h_scal[MS_S_MAXG2];
@@ -1726,6 +1753,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       if (cg) {  // conjugate_gradient.py:114-117 history on success only
         std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
         std::swap(c->buf[MS_BUF_D], c->buf[MS_BUF_PD]);
+        c->pd_neg_pg = c->dir_implicit;  // the accepted direction was -G = -PG from now on
         c->last_g = c->buf[MS_BUF_PG];
         c->cg_have_history = true;
         ++c->cg_iter_count;

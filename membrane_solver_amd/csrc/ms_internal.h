@@ -116,6 +116,7 @@ struct GradientArgs {
   double* d;
   const double* pg;
   const double* pd;
+  int pd_neg_pg;           // the previous direction is -pg (an implicit steepest-descent step): derive, do not load
   int atomic;
   // leaflet bending_tilt (BENDMODE 3): per-corner fA_eff = 1/2 kappa_k (base_k + s div_f t)^2
   const double* bt_vert;   // (nvp,4): [0] = base

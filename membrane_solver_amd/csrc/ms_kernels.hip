@@ -883,7 +883,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
   if (a.dir_mode == 2 && tid < t.n_owned) {
     const size_t o = 3 * (size_t)(t.v_lo + tid);
     h_pg = mk(a.pg[o], a.pg[o + 1], a.pg[o + 2]);
-    h_pd = mk(a.pd[o], a.pd[o + 1], a.pd[o + 2]);
+    h_pd = a.pd_neg_pg ? -h_pg : mk(a.pd[o], a.pd[o + 1], a.pd[o + 2]);
   }
 
   for (int c0f = t.f0; c0f < t.f1; c0f += T) {
