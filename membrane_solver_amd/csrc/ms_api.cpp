@@ -76,6 +76,22 @@ struct ms_ctx {
   // CG history's previous direction is -PG, which the next fused direction pass derives instead of loading.
   bool dir_implicit = false;
   bool pd_neg_pg = false;
+  // speculative line-search ladder (ms_step): when the last accepted step needed n > 1 Armijo trials, the next
+  // n trials are queued at once; stage k > 0 runs only if the device-side Armijo test of stage k-1 failed
+  // (k_armijo_gate).  Each stage posts its scalars to its own mailbox; the host takes the same decisions from the
+  // same doubles, so the trajectory does not change -- only the host round trips between trials disappear.
+  static constexpr int SPEC_STAGES = 3;  // extra mailboxes (stage 0 uses the main one)
+  struct Mailbox {
+    double* h_scal = nullptr;
+    double* d_h_scal = nullptr;
+    unsigned long long* h_seq = nullptr;
+    unsigned long long* d_h_seq = nullptr;
+    unsigned long long expected[MS_NSCAL] = {0};
+  } spec[SPEC_STAGES];
+  int* d_gate = nullptr;         // SPEC_STAGES + 1 gate words
+  const int* cur_gate = nullptr; // gate of the launches being queued (nullptr: unconditional)
+  int pred_trials = 1;           // trials the last successful search needed
+  bool speculate = true;         // MS_SPECULATE=0 switches the ladder off
   bool relax_va_valid = false;  // a leaflet relaxation is running: tf[l].va describes the current x
   int factors_leaflet = 0;  // which leaflet's back-prop factors fK/fA hold (1 in, 2 out; 0: not a leaflet's)
   double* d_bt_vert = nullptr;    // (nvp,4) bending_tilt per-vertex record of the last energy pass
@@ -194,7 +210,7 @@ struct ProfScope {
   hipEvent_t a = nullptr, b = nullptr;
   int kind;
   ProfScope(ms_ctx* ctx, int k) : c(ctx), kind(k) {
-    if (!c->profiling) return;
+    if (!c->profiling || k < 0) return;
     auto get = [&]() {
       hipEvent_t e = nullptr;
       if (!c->prof_pool.empty()) {
@@ -210,7 +226,7 @@ struct ProfScope {
     if (a && b) (void)hipEventRecord(a, c->stream);
   }
   ~ProfScope() {
-    if (!c->profiling || !a || !b) return;
+    if (!c->profiling || kind < 0 || !a || !b) return;
     (void)hipEventRecord(b, c->stream);
     c->prof_pending.push_back({a, b, kind});
   }
@@ -384,12 +400,12 @@ constexpr uint32_t MASK_GRAD = (1u << MS_S_GGC) | (1u << MS_S_GCGC);
 constexpr uint32_t MASK_DIR = (1u << MS_S_GNORM2) | (1u << MS_S_GDOTD) | (1u << MS_S_MAXD2) | (1u << MS_S_MAXG2);
 
 int reduce_slots(ms_ctx* c, uint32_t mask) {
-  ProfScope ps(c, 3);
+  ProfScope ps(c, c->cur_gate ? -1 : 3);
   ++c->ticket;
   for (int sl = 0; sl < MS_NSCAL; ++sl)
     if (mask & (1u << sl)) c->expected[sl] = c->ticket;
   HIPCHK(c, launch_reduce(c->d_partials, c->til.n_tiles, c->tile0, c->tile1, mask, c->d_scal,
-                          c->d_h_scal, c->d_h_seq, c->ticket, c->stream));
+                          c->d_h_scal, c->d_h_seq, c->ticket, c->stream, c->cur_gate));
   return MS_OK;
 }
 
@@ -412,13 +428,14 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   a.fA = (bend && write_factors) ? c->buf[MS_BUF_FA] : nullptr;
   a.bt_vert = bt ? c->d_bt_vert : nullptr;
   a.bt_normals = nullptr;
+  a.gate = c->cur_gate;
   a.atomic = c->deterministic ? 0 : 1;
   if (bt && !c->d_bt_vert) return fail(c, MS_ERR_STATE, "bending_tilt: ms_set_params did not allocate its buffers");
   a.partials = c->d_partials;
   a.bending_model = c->params.bending_model;
   a.modules = modules;
   if (!lbt) {
-    ProfScope ps(c, 0);
+    ProfScope ps(c, c->cur_gate ? -1 : 0);  // gated launches may be empty: keep them out of the kernel averages
     HIPCHK(c, launch_energy(a, guard && use_dir, c->cap, c->til.max_ent, c->stream));
   } else {
     // leaflet bending_tilt: the tilt projections and the unit vertex normals of the evaluated positions come
@@ -931,6 +948,7 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
     f2.mod_bt = MS_MOD_BENDING_TILT_OUT; f2.s_ebt = MS_S_EBT_OUT; f2.div_sign = 1.0;
     f2.mod_dt = MS_MOD_TILT_DISK_TARGET_OUT; f2.s_edt = MS_S_EDT_OUT; f2.s_dtr = MS_S_DTR_OUT;
   }
+  c->speculate = !(getenv("MS_SPECULATE") != nullptr && atoi(getenv("MS_SPECULATE")) == 0);
   c->deterministic = getenv("MS_DETERMINISTIC") != nullptr && atoi(getenv("MS_DETERMINISTIC")) != 0;
   c->params.modules = MS_MOD_SURFACE;
   c->params.bending_model = MS_BEND_HELFRICH;
@@ -966,6 +984,11 @@ void ms_destroy(ms_ctx* c) {
   if (c->d_xrecv) (void)hipFree(c->d_xrecv);
   if (c->h_scal_all) (void)hipHostFree(c->h_scal_all);
   if (c->h_xseq) (void)hipHostFree(c->h_xseq);
+  for (auto& m : c->spec) {
+    if (m.h_scal) (void)hipHostFree(m.h_scal);
+    if (m.h_seq) (void)hipHostFree(m.h_seq);
+  }
+  if (c->d_gate) (void)hipFree(c->d_gate);
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->h_seq) (void)hipHostFree(c->h_seq);
   for (auto& r : c->prof_pending) {
@@ -1634,6 +1657,32 @@ int ms_reset_stepper(ms_ctx* c) {
   return MS_OK;
 }
 
+namespace {
+int spec_prepare(ms_ctx* c) {
+  if (c->d_gate) return MS_OK;
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_gate), sizeof(int) * (ms_ctx::SPEC_STAGES + 2)));
+  HIPCHK(c, hipMemset(c->d_gate, 0, sizeof(int) * (ms_ctx::SPEC_STAGES + 2)));
+  for (auto& m : c->spec) {
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&m.h_scal), sizeof(double) * MS_NSCAL, hipHostMallocMapped));
+    memset(m.h_scal, 0, sizeof(double) * MS_NSCAL);
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&m.d_h_scal), m.h_scal, 0));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&m.h_seq), sizeof(unsigned long long) * MS_NSCAL,
+                            hipHostMallocMapped));
+    memset(m.h_seq, 0, sizeof(unsigned long long) * MS_NSCAL);
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&m.d_h_seq), m.h_seq, 0));
+  }
+  return MS_OK;
+}
+// make stage mailbox `m` the context's mailbox (and back: the swap is its own inverse)
+void swap_mailbox(ms_ctx* c, ms_ctx::Mailbox& m) {
+  std::swap(c->h_scal, m.h_scal);
+  std::swap(c->d_h_scal, m.d_h_scal);
+  std::swap(c->h_seq, m.h_seq);
+  std::swap(c->d_h_seq, m.d_h_seq);
+  for (int sl = 0; sl < MS_NSCAL; ++sl) std::swap(c->expected[sl], m.expected[sl]);
+}
+}  // namespace
+
 int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol,
             ms_step_result* out) {
   if (!c || !sp || !out) return fail(c, MS_ERR_INVALID, "ms_step: NULL argument");
@@ -1724,51 +1773,121 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     alpha = std::min(alpha, sp->edge_fraction * min_edge / max_dir);
   const double alpha_max = sp->alpha_max_factor * step_size;
   const int max_iter = sp->max_iter > 0 ? sp->max_iter : 10;
-  for (int it = 0; it < max_iter; ++it) {
+  // what an accepted trial at `alpha` does (positions, carry flags, CG history, result fields)
+  auto accept = [&](double alpha_acc, double E_t) {
+    std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
+    // carry mode: the trial pass evaluated exactly the accepted x (it wrote those very
+    // doubles to xt) with the factor outputs on -> it IS the next step's energy pass
+    c->factors_valid = carry_mode;
+    c->carry_valid = carry_mode;
+    c->grad_valid = false;
+    // minimizer.py:1415 re-projects the stored tilts onto the accepted surface: that is
+    // exactly the trial projection computed above
+    for (int k = 0; k < n_tf; ++k) std::swap(tfl[k]->tilts, tfl[k]->trial);
+    c->bt_valid = (c->params.modules & MS_MOD_BENDING_TILT) != 0;  // the trial's record is x's now
+    if (cg) {  // conjugate_gradient.py:114-117 history on success only
+      std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
+      std::swap(c->buf[MS_BUF_D], c->buf[MS_BUF_PD]);
+      c->pd_neg_pg = c->dir_implicit;  // the accepted direction was -G = -PG from now on
+      c->last_g = c->buf[MS_BUF_PG];
+      c->cg_have_history = true;
+      ++c->cg_iter_count;
+    }
+    out->success = 1;
+    out->alpha = alpha_acc;
+    out->energy = E_t;
+    out->volume = c->h_scal[MS_S_VOL];
+    out->next_step = std::min(alpha_acc * sp->gamma, alpha_max);
+    c->pred_trials = std::max(1, out->trials);
+  };
+  // the ladder needs: carry mode (a trial is a complete energy pass), energies the device can add up the way the
+  // host does (surface + bending only), no tilt projections between trials
+  const bool can_spec = c->speculate && carry_mode && !tilt && !(c->params.modules & MS_MOD_VOLUME_PENALTY) &&
+                        c->pred_trials > 1;
+  int it = 0;
+  while (it < max_iter) {
     const bool safe_small = alpha * max_dir < safe_step_limit;
-    rc = phase_energy(c, c->params.modules, true, alpha, true, !safe_small, carry_mode);
-    if (rc) return rc;
-    rc = fetch(c);
-    if (rc) return rc;
-    if (!safe_small && c->h_scal[MS_S_GUARD] > 0.0) {
-      ++out->guard_rejects;
+    int depth = 1;
+    double alphas[1 + ms_ctx::SPEC_STAGES];
+    alphas[0] = alpha;
+    if (can_spec && safe_small) {
+      // queue the trials the last search needed; each further stage must be an ordinary (unguarded) trial
+      const int want = std::min({c->pred_trials - out->trials, 1 + ms_ctx::SPEC_STAGES, max_iter - it});
+      while (depth < want) {
+        const double a_next = alphas[depth - 1] * sp->beta;
+        if (a_next < 1e-8) break;
+        alphas[depth++] = a_next;
+      }
+      if (depth > 1) {
+        rc = spec_prepare(c);
+        if (rc) return rc;
+      }
+    }
+    if (depth == 1) {
+      rc = phase_energy(c, c->params.modules, true, alpha, true, !safe_small, carry_mode);
+      if (rc) return rc;
+      rc = fetch(c);
+      if (rc) return rc;
+      if (!safe_small && c->h_scal[MS_S_GUARD] > 0.0) {
+        ++out->guard_rejects;
+        alpha *= sp->beta;
+        ++it;
+        if (alpha < 1e-8) break;
+        continue;
+      }
+      ++out->trials;
+      energies_from_mailbox(c, e);
+      const double E_t = e[0] + e[1] + e[2] + e[3];
+      if (E_t <= energy0 + sp->c * alpha * g_dot_d) {
+        accept(alpha, E_t);
+        return MS_OK;
+      }
+      // a rejected trial restores the positions, not the tilts: energy_fn stored their projection
+      // onto the trial surface (line_search.py:456-487 without an enforcer)
+      for (int k = 0; k < n_tf; ++k) std::swap(tfl[k]->tilts, tfl[k]->trial);
       alpha *= sp->beta;
+      ++it;
       if (alpha < 1e-8) break;
       continue;
     }
-    ++out->trials;
-    energies_from_mailbox(c, e);
-    const double E_t = e[0] + e[1] + e[2] + e[3];
-    if (E_t <= energy0 + sp->c * alpha * g_dot_d) {
-      std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
-      // carry mode: the trial pass evaluated exactly the accepted x (it wrote those very
-      // doubles to xt) with the factor outputs on -> it IS the next step's energy pass
-      c->factors_valid = carry_mode;
-      c->carry_valid = carry_mode;
-      c->grad_valid = false;
-      // minimizer.py:1415 re-projects the stored tilts onto the accepted surface: that is
-      // exactly the trial projection computed above
-      for (int k = 0; k < n_tf; ++k) std::swap(tfl[k]->tilts, tfl[k]->trial);
-      c->bt_valid = (c->params.modules & MS_MOD_BENDING_TILT) != 0;  // the trial's record is x's now
-      if (cg) {  // conjugate_gradient.py:114-117 history on success only
-        std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
-        std::swap(c->buf[MS_BUF_D], c->buf[MS_BUF_PD]);
-        c->pd_neg_pg = c->dir_implicit;  // the accepted direction was -G = -PG from now on
-        c->last_g = c->buf[MS_BUF_PG];
-        c->cg_have_history = true;
-        ++c->cg_iter_count;
-      }
-      out->success = 1;
-      out->alpha = alpha;
-      out->energy = E_t;
-      out->volume = c->h_scal[MS_S_VOL];
-      out->next_step = std::min(alpha * sp->gamma, alpha_max);
-      return MS_OK;
+    // ---- speculative ladder: queue `depth` trials, stage j > 0 gated on the rejection of stage j-1 ----
+    double rhs[1 + ms_ctx::SPEC_STAGES];
+    const int use_surf = (c->params.modules & MS_MOD_SURFACE) ? 1 : 0;
+    const int use_bend = (c->params.modules & MS_MOD_BENDING) ? 1 : 0;
+    for (int j = 0; j < depth; ++j) {
+      rhs[j] = energy0 + sp->c * alphas[j] * g_dot_d;
+      if (j > 0) swap_mailbox(c, c->spec[j - 1]);
+      c->cur_gate = j > 0 ? c->d_gate + j : nullptr;
+      rc = phase_energy(c, c->params.modules, true, alphas[j], true, false, carry_mode);
+      const int* gate_in = c->cur_gate;
+      c->cur_gate = nullptr;
+      if (j > 0) swap_mailbox(c, c->spec[j - 1]);
+      if (rc) return rc;
+      if (j + 1 < depth)
+        HIPCHK(c, launch_armijo_gate(c->d_scal, use_surf, use_bend, rhs[j], gate_in, c->d_gate + j + 1, c->stream));
     }
-    // a rejected trial restores the positions, not the tilts: energy_fn stored their projection
-    // onto the trial surface (line_search.py:456-487 without an enforcer)
-    for (int k = 0; k < n_tf; ++k) std::swap(tfl[k]->tilts, tfl[k]->trial);
-    alpha *= sp->beta;
+    bool accepted = false;
+    for (int j = 0; j < depth; ++j) {
+      if (j > 0) swap_mailbox(c, c->spec[j - 1]);
+      rc = fetch(c);
+      double vals[MS_NSCAL];
+      for (int sl = 0; sl < MS_NSCAL; ++sl) vals[sl] = c->h_scal[sl];
+      if (j > 0) swap_mailbox(c, c->spec[j - 1]);
+      if (rc) return rc;
+      for (int sl = 0; sl < MS_NSCAL; ++sl)
+        if (MASK_ENERGY & (1u << sl)) c->h_scal[sl] = vals[sl];
+      ++out->trials;
+      energies_from_mailbox(c, e);
+      const double E_t = e[0] + e[1] + e[2] + e[3];
+      if (E_t <= rhs[j]) {  // the device took the same decision from the same doubles: later stages skip
+        accept(alphas[j], E_t);
+        accepted = true;
+        break;
+      }
+    }
+    if (accepted) return MS_OK;
+    alpha = alphas[depth - 1] * sp->beta;
+    it += depth;
     if (alpha < 1e-8) break;
   }
   const double reduced = std::max(alpha * sp->beta, 0.0);  // :425-426

@@ -93,6 +93,7 @@ struct EnergyArgs {
   // bending_tilt: per-vertex record {base = 2H - c0 (0 on boundary), A_eff, kappa*ratio*H, 0}
   // written instead of the final factors; fK then holds K_dir * kappa * ratio (k_bt finishes)
   double* bt_vert;
+  const int* gate;           // speculative stage: run only if *gate != 0 (nullptr: always)
   const double* bt_normals;  // leaflet bending_tilt: unit vertex normals of the evaluated positions (signed H, K_dir = n)
   int atomic;             // accumulate per-vertex sums with LDS atomics (not bitwise reproducible)
 };
@@ -214,7 +215,10 @@ hipError_t launch_tvec(int mode, int tile0, int tile1, int nv, int T, const uint
                        int s_gn2 = MS_S_TGNORM2, int s_rz = MS_S_TRZ);
 hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
                          uint32_t slot_mask, double* scal, double* host_mirror,
-                         unsigned long long* host_seq, unsigned long long ticket, hipStream_t s);
+                         unsigned long long* host_seq, unsigned long long ticket, hipStream_t s,
+                         const int* gate = nullptr);
+hipError_t launch_armijo_gate(const double* scal, int use_surf, int use_bend, double rhs, const int* gate_in,
+                              int* gate_out, hipStream_t s);
 hipError_t launch_pack_boundary(const int32_t* rows, int n_rows, const double* const* bufs,
                                 const int* ncomp, int n_bufs, const double* scal, double* send,
                                 hipStream_t s);

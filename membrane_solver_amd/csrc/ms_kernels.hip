@@ -264,6 +264,8 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
   uint16_t* vent = reinterpret_cast<uint16_t*>(stg + (BEND ? (ATOMIC ? 5 : 9) * T : 5 * 16));
   uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + ((BEND && !ATOMIC) ? ((max_ent + 3) & ~3) : 0));
   const bool stage_flags = a.m.has_boundary || GUARD;
+  // speculative line-search stage: runs only if the decision kernel of the previous stage said "rejected"
+  if (a.gate != nullptr && *a.gate == 0) return;
 
   const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
   const int tid = threadIdx.x;
@@ -2007,8 +2009,9 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(const double* partials, int n
                                                   int tile1, uint32_t slot_mask, double* scal,
                                                   double* host_mirror,
                                                   unsigned long long* host_seq,
-                                                  unsigned long long ticket) {
+                                                  unsigned long long ticket, const int* gate) {
   __shared__ double red[16];
+  if (gate != nullptr && *gate == 0) return;
   // one workgroup per requested slot; partials are slot-major so lanes read
   // consecutive doubles.
   int slot = -1;
@@ -2062,11 +2065,29 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(const double* partials, int n
 
 hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
                          uint32_t slot_mask, double* scal, double* host_mirror,
-                         unsigned long long* host_seq, unsigned long long ticket, hipStream_t s) {
+                         unsigned long long* host_seq, unsigned long long ticket, hipStream_t s, const int* gate) {
   const int nslots = __builtin_popcount(slot_mask);
   if (nslots == 0) return hipSuccess;
   hipLaunchKernelGGL(k_reduce, dim3(nslots), dim3(RBLOCK), 0, s, partials, n_tiles, tile0, tile1,
-                     slot_mask, scal, host_mirror, host_seq, ticket);
+                     slot_mask, scal, host_mirror, host_seq, ticket, gate);
+  return hipGetLastError();
+}
+
+// Armijo test of a speculative line-search stage on the device (line_search.py:386-392): the next stage (a
+// shorter trial, already in the queue) may run only if this one ran and was rejected.  E_t is the same sum of
+// the same reduced doubles the host forms (surface + bending; other energy modules do not speculate), `rhs`
+// the host's energy0 + c alpha <g,d>.
+__global__ void k_armijo_gate(const double* scal, int use_surf, int use_bend, double rhs, const int* gate_in,
+                              int* gate_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int ran = gate_in ? *gate_in : 1;
+  const double E_t = (use_surf ? scal[MS_S_ESURF] : 0.0) + (use_bend ? scal[MS_S_EBEND] : 0.0);
+  *gate_out = (ran && !(E_t <= rhs)) ? 1 : 0;
+}
+
+hipError_t launch_armijo_gate(const double* scal, int use_surf, int use_bend, double rhs, const int* gate_in,
+                              int* gate_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_armijo_gate, dim3(1), dim3(64), 0, s, scal, use_surf, use_bend, rhs, gate_in, gate_out);
   return hipGetLastError();
 }
 
