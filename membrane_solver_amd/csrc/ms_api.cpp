@@ -88,8 +88,13 @@ struct ms_ctx {
     unsigned long long* d_h_seq = nullptr;
     unsigned long long expected[MS_NSCAL] = {0};
   } spec[SPEC_STAGES];
-  int* d_gate = nullptr;         // SPEC_STAGES + 1 gate words
-  const int* cur_gate = nullptr; // gate of the launches being queued (nullptr: unconditional)
+  Mailbox grad_mb;               // mailbox of the gradient pass queued behind a ladder
+  bool kc_pending = false;       // that pass ran for the accepted x: the next ms_step takes its result
+  int kc_stepper = 0;
+  bool kc_use_history = false;
+  int* d_gate = nullptr;         // SPEC_STAGES + 1 gate words + the "accepted" word
+  const int* cur_gate = nullptr; // gate word of the k_reduce launches being queued (nullptr: unconditional)
+  double cur_gate_rhs = 0.0;     // Armijo right-hand side the gated tile kernel tests the device scalars against
   int pred_trials = 1;           // trials the last successful search needed
   bool speculate = true;         // MS_SPECULATE=0 switches the ladder off
   bool relax_va_valid = false;  // a leaflet relaxation is running: tf[l].va describes the current x
@@ -155,6 +160,7 @@ struct ms_ctx {
   struct ProfRec {
     hipEvent_t a, b;
     int kind;
+    bool gated;  // may have been an empty (skipped) launch
   };
   std::vector<ProfRec> prof_pending;
   std::vector<hipEvent_t> prof_pool;
@@ -209,7 +215,8 @@ struct ProfScope {
   ms_ctx* c;
   hipEvent_t a = nullptr, b = nullptr;
   int kind;
-  ProfScope(ms_ctx* ctx, int k) : c(ctx), kind(k) {
+  bool gated = false;
+  ProfScope(ms_ctx* ctx, int k, bool maybe_skipped = false) : c(ctx), kind(k), gated(maybe_skipped) {
     if (!c->profiling || k < 0) return;
     auto get = [&]() {
       hipEvent_t e = nullptr;
@@ -228,7 +235,7 @@ struct ProfScope {
   ~ProfScope() {
     if (!c->profiling || kind < 0 || !a || !b) return;
     (void)hipEventRecord(b, c->stream);
-    c->prof_pending.push_back({a, b, kind});
+    c->prof_pending.push_back({a, b, kind, gated});
   }
 };
 
@@ -400,7 +407,7 @@ constexpr uint32_t MASK_GRAD = (1u << MS_S_GGC) | (1u << MS_S_GCGC);
 constexpr uint32_t MASK_DIR = (1u << MS_S_GNORM2) | (1u << MS_S_GDOTD) | (1u << MS_S_MAXD2) | (1u << MS_S_MAXG2);
 
 int reduce_slots(ms_ctx* c, uint32_t mask) {
-  ProfScope ps(c, c->cur_gate ? -1 : 3);
+  ProfScope ps(c, 3, c->cur_gate != nullptr);
   ++c->ticket;
   for (int sl = 0; sl < MS_NSCAL; ++sl)
     if (mask & (1u << sl)) c->expected[sl] = c->ticket;
@@ -428,14 +435,17 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   a.fA = (bend && write_factors) ? c->buf[MS_BUF_FA] : nullptr;
   a.bt_vert = bt ? c->d_bt_vert : nullptr;
   a.bt_normals = nullptr;
-  a.gate = c->cur_gate;
+  a.gate_scal = c->cur_gate ? c->d_scal : nullptr;
+  a.gate_rhs = c->cur_gate_rhs;
+  a.gate_mods = c->params.modules;
+  a.gate_out = const_cast<int*>(c->cur_gate);
   a.atomic = c->deterministic ? 0 : 1;
   if (bt && !c->d_bt_vert) return fail(c, MS_ERR_STATE, "bending_tilt: ms_set_params did not allocate its buffers");
   a.partials = c->d_partials;
   a.bending_model = c->params.bending_model;
   a.modules = modules;
   if (!lbt) {
-    ProfScope ps(c, c->cur_gate ? -1 : 0);  // gated launches may be empty: keep them out of the kernel averages
+    ProfScope ps(c, 0, c->cur_gate != nullptr);
     HIPCHK(c, launch_energy(a, guard && use_dir, c->cap, c->til.max_ent, c->stream));
   } else {
     // leaflet bending_tilt: the tilt projections and the unit vertex normals of the evaluated positions come
@@ -583,12 +593,16 @@ int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulat
   a.pg = c->buf[MS_BUF_PG];
   a.pd = c->buf[MS_BUF_PD];
   a.pd_neg_pg = (dir_mode == 2 && c->pd_neg_pg) ? 1 : 0;
+  a.gate_scal = c->cur_gate ? c->d_scal : nullptr;
+  a.gate_rhs = c->cur_gate_rhs;
+  a.gate_mods = c->params.modules;
+  a.gate_out = const_cast<int*>(c->cur_gate);
   a.atomic = c->deterministic ? 0 : 1;
   a.bt_vert = nullptr;
   a.tilts = nullptr;
   a.div_sign = 1.0;
   if (n_lbt == 0) {
-    ProfScope ps(c, 1);
+    ProfScope ps(c, 1, c->cur_gate != nullptr);
     HIPCHK(c, launch_gradient(a, c->cap, c->til.max_ent, c->stream));
   }
   for (int k = 0; k < n_lbt; ++k) {
@@ -988,6 +1002,8 @@ void ms_destroy(ms_ctx* c) {
     if (m.h_scal) (void)hipHostFree(m.h_scal);
     if (m.h_seq) (void)hipHostFree(m.h_seq);
   }
+  if (c->grad_mb.h_scal) (void)hipHostFree(c->grad_mb.h_scal);
+  if (c->grad_mb.h_seq) (void)hipHostFree(c->grad_mb.h_seq);
   if (c->d_gate) (void)hipFree(c->d_gate);
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->h_seq) (void)hipHostFree(c->h_seq);
@@ -1660,9 +1676,13 @@ int ms_reset_stepper(ms_ctx* c) {
 namespace {
 int spec_prepare(ms_ctx* c) {
   if (c->d_gate) return MS_OK;
-  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_gate), sizeof(int) * (ms_ctx::SPEC_STAGES + 2)));
-  HIPCHK(c, hipMemset(c->d_gate, 0, sizeof(int) * (ms_ctx::SPEC_STAGES + 2)));
-  for (auto& m : c->spec) {
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_gate), sizeof(int) * (ms_ctx::SPEC_STAGES + 3)));
+  HIPCHK(c, hipMemset(c->d_gate, 0, sizeof(int) * (ms_ctx::SPEC_STAGES + 3)));
+  ms_ctx::Mailbox* boxes[ms_ctx::SPEC_STAGES + 1];
+  for (int k = 0; k < ms_ctx::SPEC_STAGES; ++k) boxes[k] = &c->spec[k];
+  boxes[ms_ctx::SPEC_STAGES] = &c->grad_mb;
+  for (ms_ctx::Mailbox* mp : boxes) {
+    ms_ctx::Mailbox& m = *mp;
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&m.h_scal), sizeof(double) * MS_NSCAL, hipHostMallocMapped));
     memset(m.h_scal, 0, sizeof(double) * MS_NSCAL);
     HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&m.d_h_scal), m.h_scal, 0));
@@ -1719,7 +1739,23 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     } else {
       rc = phase_direction(c, sp->stepper, use_history, /*g_finalized=*/true);
     }
+  } else if (c->kc_pending && carried && !constraint && c->kc_stepper == sp->stepper &&
+             c->kc_use_history == use_history) {
+    // the fused gradient + direction pass of this x was queued behind the line search that accepted it
+    // (gated on the acceptance) and has run: take its scalars from its mailbox
+    c->kc_pending = false;
+    swap_mailbox(c, c->grad_mb);
+    rc = fetch(c);
+    double vals[MS_NSCAL];
+    for (int sl = 0; sl < MS_NSCAL; ++sl) vals[sl] = c->h_scal[sl];
+    swap_mailbox(c, c->grad_mb);
+    for (int sl = 0; sl < MS_NSCAL; ++sl)
+      if (MASK_DIR & (1u << sl)) c->h_scal[sl] = vals[sl];
+    c->last_g = c->buf[MS_BUF_G];
+    c->dir_implicit = false;
+    c->maxg2_valid = true;
   } else {
+    c->kc_pending = false;
     rc = queue_energy_and_gradient(c, sp->stepper, use_history, carried);
     c->maxg2_valid = !constraint;  // the fused epilogue reduced max|g_i|^2 as well
   }
@@ -1773,6 +1809,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     alpha = std::min(alpha, sp->edge_fraction * min_edge / max_dir);
   const double alpha_max = sp->alpha_max_factor * step_size;
   const int max_iter = sp->max_iter > 0 ? sp->max_iter : 10;
+  bool kc_queued = false;  // the next step's gradient pass is in the queue, gated on an acceptance
   // what an accepted trial at `alpha` does (positions, carry flags, CG history, result fields)
   auto accept = [&](double alpha_acc, double E_t) {
     std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
@@ -1799,14 +1836,19 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     out->volume = c->h_scal[MS_S_VOL];
     out->next_step = std::min(alpha_acc * sp->gamma, alpha_max);
     c->pred_trials = std::max(1, out->trials);
+    c->kc_pending = kc_queued;
   };
   // the ladder needs: carry mode (a trial is a complete energy pass), energies the device can add up the way the
   // host does (surface + bending only), no tilt projections between trials
-  const bool can_spec = c->speculate && carry_mode && !tilt && !(c->params.modules & MS_MOD_VOLUME_PENALTY) &&
-                        c->pred_trials > 1;
+  const bool can_chain = c->speculate && carry_mode && !tilt && !(c->params.modules & MS_MOD_VOLUME_PENALTY);
+  const bool can_spec = can_chain && c->pred_trials > 1;
+  // ... and the fused gradient + direction pass of the accepted point can follow in the same queue (no
+  // constraint row to reduce first), gated on "some stage accepted"
+  const bool can_spec_kc = can_chain && !constraint;
   int it = 0;
   while (it < max_iter) {
     const bool safe_small = alpha * max_dir < safe_step_limit;
+    kc_queued = false;  // (a gradient pass queued behind an earlier, fully rejected round found its gate closed)
     int depth = 1;
     double alphas[1 + ms_ctx::SPEC_STAGES];
     alphas[0] = alpha;
@@ -1818,12 +1860,13 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
         if (a_next < 1e-8) break;
         alphas[depth++] = a_next;
       }
-      if (depth > 1) {
-        rc = spec_prepare(c);
-        if (rc) return rc;
-      }
     }
-    if (depth == 1) {
+    const bool chain = safe_small && (depth > 1 || can_spec_kc);
+    if (chain) {
+      rc = spec_prepare(c);
+      if (rc) return rc;
+    }
+    if (!chain) {
       rc = phase_energy(c, c->params.modules, true, alpha, true, !safe_small, carry_mode);
       if (rc) return rc;
       rc = fetch(c);
@@ -1852,19 +1895,49 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     }
     // ---- speculative ladder: queue `depth` trials, stage j > 0 gated on the rejection of stage j-1 ----
     double rhs[1 + ms_ctx::SPEC_STAGES];
-    const int use_surf = (c->params.modules & MS_MOD_SURFACE) ? 1 : 0;
-    const int use_bend = (c->params.modules & MS_MOD_BENDING) ? 1 : 0;
+    int* const d_acc = c->d_gate + ms_ctx::SPEC_STAGES + 2;
     for (int j = 0; j < depth; ++j) {
       rhs[j] = energy0 + sp->c * alphas[j] * g_dot_d;
       if (j > 0) swap_mailbox(c, c->spec[j - 1]);
-      c->cur_gate = j > 0 ? c->d_gate + j : nullptr;
+      c->cur_gate = j > 0 ? c->d_gate + j : nullptr;  // stage j > 0 runs iff stage j-1 failed its Armijo test
+      c->cur_gate_rhs = j > 0 ? rhs[j - 1] : 0.0;
       rc = phase_energy(c, c->params.modules, true, alphas[j], true, false, carry_mode);
-      const int* gate_in = c->cur_gate;
       c->cur_gate = nullptr;
       if (j > 0) swap_mailbox(c, c->spec[j - 1]);
       if (rc) return rc;
-      if (j + 1 < depth)
-        HIPCHK(c, launch_armijo_gate(c->d_scal, use_surf, use_bend, rhs[j], gate_in, c->d_gate + j + 1, c->stream));
+    }
+    if (can_spec_kc) {
+      // queue the next step's gradient pass in the state an acceptance produces (x <-> xt, CG history swapped,
+      // factors of the accepted trial), gated on d_acc; every change of the context is undone afterwards
+      const bool next_hist = cg && ((c->cg_iter_count + 1) % restart != 0);
+      const bool s_factors = c->factors_valid, s_implicit = c->dir_implicit, s_pdneg = c->pd_neg_pg;
+      double* const s_last_g = c->last_g;
+      std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
+      if (cg) {
+        std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
+        std::swap(c->buf[MS_BUF_D], c->buf[MS_BUF_PD]);
+        c->pd_neg_pg = c->dir_implicit;
+      }
+      c->factors_valid = true;
+      swap_mailbox(c, c->grad_mb);
+      c->cur_gate = d_acc;  // runs iff the energies left in device memory pass the last stage's test
+      c->cur_gate_rhs = rhs[depth - 1];
+      rc = phase_gradient(c, c->params.modules, c->buf[MS_BUF_G], false, next_hist ? 2 : 1, /*reduce_now=*/true);
+      c->cur_gate = nullptr;
+      swap_mailbox(c, c->grad_mb);
+      if (cg) {
+        std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
+        std::swap(c->buf[MS_BUF_D], c->buf[MS_BUF_PD]);
+      }
+      std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
+      c->factors_valid = s_factors;
+      c->dir_implicit = s_implicit;
+      c->pd_neg_pg = s_pdneg;
+      c->last_g = s_last_g;
+      if (rc) return rc;
+      kc_queued = true;
+      c->kc_stepper = sp->stepper;
+      c->kc_use_history = next_hist;
     }
     bool accepted = false;
     for (int j = 0; j < depth; ++j) {
@@ -2514,7 +2587,8 @@ int ms_profile_read(ms_ctx* c, double total_ms[MS_PROF_KINDS], int64_t launches[
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (auto& r : c->prof_pending) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+    // a gated launch that found its gate closed returns at once (a few us): not a sample of the kernel
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && !(r.gated && ms < 0.012f)) {
       c->prof_ms[r.kind] += ms;
       c->prof_n[r.kind] += 1;
     }

@@ -93,7 +93,12 @@ struct EnergyArgs {
   // bending_tilt: per-vertex record {base = 2H - c0 (0 on boundary), A_eff, kappa*ratio*H, 0}
   // written instead of the final factors; fK then holds K_dir * kappa * ratio (k_bt finishes)
   double* bt_vert;
-  const int* gate;           // speculative stage: run only if *gate != 0 (nullptr: always)
+  // speculative stage (nullptr: unconditional): run only if the reduced energies in gate_scal FAIL the Armijo
+  // test against gate_rhs; the decision is published in *gate_out for the stage's k_reduce
+  const double* gate_scal;
+  double gate_rhs;
+  uint32_t gate_mods;
+  int* gate_out;
   const double* bt_normals;  // leaflet bending_tilt: unit vertex normals of the evaluated positions (signed H, K_dir = n)
   int atomic;             // accumulate per-vertex sums with LDS atomics (not bitwise reproducible)
 };
@@ -117,6 +122,12 @@ struct GradientArgs {
   double* d;
   const double* pg;
   const double* pd;
+  // speculative launch (nullptr: unconditional): run only if the reduced energies in gate_scal PASS the Armijo
+  // test against gate_rhs
+  const double* gate_scal;
+  double gate_rhs;
+  uint32_t gate_mods;
+  int* gate_out;
   int pd_neg_pg;           // the previous direction is -pg (an implicit steepest-descent step): derive, do not load
   int atomic;
   // leaflet bending_tilt (BENDMODE 3): per-corner fA_eff = 1/2 kappa_k (base_k + s div_f t)^2
@@ -217,8 +228,7 @@ hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int til
                          uint32_t slot_mask, double* scal, double* host_mirror,
                          unsigned long long* host_seq, unsigned long long ticket, hipStream_t s,
                          const int* gate = nullptr);
-hipError_t launch_armijo_gate(const double* scal, int use_surf, int use_bend, double rhs, const int* gate_in,
-                              int* gate_out, hipStream_t s);
+
 hipError_t launch_pack_boundary(const int32_t* rows, int n_rows, const double* const* bufs,
                                 const int* ncomp, int n_bufs, const double* scal, double* send,
                                 hipStream_t s);

@@ -264,8 +264,17 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
   uint16_t* vent = reinterpret_cast<uint16_t*>(stg + (BEND ? (ATOMIC ? 5 : 9) * T : 5 * 16));
   uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + ((BEND && !ATOMIC) ? ((max_ent + 3) & ~3) : 0));
   const bool stage_flags = a.m.has_boundary || GUARD;
-  // speculative line-search stage: runs only if the decision kernel of the previous stage said "rejected"
-  if (a.gate != nullptr && *a.gate == 0) return;
+  // speculative line-search stage: runs only if the trial before it was rejected.  Every workgroup repeats the
+  // host's Armijo test on the reduced energies in device memory (line_search.py:386-392; `gate_rhs` is the host's
+  // energy0 + c alpha <g,d> of the PREVIOUS stage).  The right-hand sides grow along the ladder (alpha shrinks,
+  // <g,d> < 0), so after an acceptance every later stage sees "accepted" too and returns.
+  if (a.gate_scal != nullptr) {
+    const double E_prev = ((a.gate_mods & MS_MOD_SURFACE) ? a.gate_scal[MS_S_ESURF] : 0.0) +
+                          ((a.gate_mods & MS_MOD_BENDING) ? a.gate_scal[MS_S_EBEND] : 0.0);
+    const bool run = !(E_prev <= a.gate_rhs);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.gate_out) *a.gate_out = run ? 1 : 0;  // for this stage's k_reduce
+    if (!run) return;
+  }
 
   const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
   const int tid = threadIdx.x;
@@ -741,6 +750,15 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
   double* red = stg + (ATOMIC ? NACC : (VOLROW ? 18 : 9)) * T;
   uint16_t* vent = reinterpret_cast<uint16_t*>(red + 4 * 16);
   uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + (ATOMIC ? 0 : ((max_ent + 3) & ~3)));
+  // queued behind a line-search ladder: runs only if one of its stages was accepted, i.e. if the energies now in
+  // device memory pass the Armijo test of the LAST stage (the right-hand sides grow along the ladder)
+  if (a.gate_scal != nullptr) {
+    const double E_last = ((a.gate_mods & MS_MOD_SURFACE) ? a.gate_scal[MS_S_ESURF] : 0.0) +
+                          ((a.gate_mods & MS_MOD_BENDING) ? a.gate_scal[MS_S_EBEND] : 0.0);
+    const bool run = E_last <= a.gate_rhs;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.gate_out) *a.gate_out = run ? 1 : 0;
+    if (!run) return;
+  }
 
   const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
   const int tid = threadIdx.x;
@@ -2073,23 +2091,6 @@ hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int til
   return hipGetLastError();
 }
 
-// Armijo test of a speculative line-search stage on the device (line_search.py:386-392): the next stage (a
-// shorter trial, already in the queue) may run only if this one ran and was rejected.  E_t is the same sum of
-// the same reduced doubles the host forms (surface + bending; other energy modules do not speculate), `rhs`
-// the host's energy0 + c alpha <g,d>.
-__global__ void k_armijo_gate(const double* scal, int use_surf, int use_bend, double rhs, const int* gate_in,
-                              int* gate_out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int ran = gate_in ? *gate_in : 1;
-  const double E_t = (use_surf ? scal[MS_S_ESURF] : 0.0) + (use_bend ? scal[MS_S_EBEND] : 0.0);
-  *gate_out = (ran && !(E_t <= rhs)) ? 1 : 0;
-}
-
-hipError_t launch_armijo_gate(const double* scal, int use_surf, int use_bend, double rhs, const int* gate_in,
-                              int* gate_out, hipStream_t s) {
-  hipLaunchKernelGGL(k_armijo_gate, dim3(1), dim3(64), 0, s, scal, use_surf, use_bend, rhs, gate_in, gate_out);
-  return hipGetLastError();
-}
 
 // ---------------------------------------------------------------------------
 // Direction pass over this shard's vertex rows (one workgroup per tile so the
