@@ -289,6 +289,11 @@ int ms_relax_leaflet_tilts(ms_ctx *ctx, const ms_tilt_relax_params *params,
  * unit vertex normals of the current positions (triangle_ops.py:55-73) */
 int ms_project_tilts_to_tangent(ms_ctx *ctx);
 
+/* compute_angle_defects (geometry/curvature.py:335-403): per-vertex angle defect 2 pi - sum of the incident
+ * triangle angles (law of cosines, lengths clamped at 1e-15, cosines clipped), 0 on boundary vertices: the
+ * integrated Gaussian curvature.  Their sum is 2 pi chi on a closed manifold mesh (Gauss-Bonnet). */
+int ms_angle_defects(ms_ctx *ctx, double *defects /* nv */);
+
 int ms_set_positions(ms_ctx *ctx, const double *positions /* nv*3 */);
 int ms_get_positions(ms_ctx *ctx, double *positions /* nv*3 */);
 int ms_get_gradient(ms_ctx *ctx, double *grad /* nv*3 */);

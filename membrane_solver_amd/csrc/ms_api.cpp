@@ -1113,6 +1113,40 @@ int ms_get_tilt_gradient(ms_ctx* c, double* tilt_grad) {
   return patch_to_ext(c, c->tf[0].grad, tilt_grad, 3);
 }
 
+int ms_angle_defects(ms_ctx* c, double* defects) {
+  if (!c || !defects) return fail(c, MS_ERR_INVALID, "ms_angle_defects: NULL argument");
+  if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "ms_angle_defects: single shard only");
+  const Tiling& t = c->til;
+  double* d_out = nullptr;
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(double) * (size_t)std::max<int64_t>(1, t.nvp)));
+  HIPCHK(c, hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)std::max<int64_t>(1, t.nvp), c->stream));
+  TiltArgs a;
+  a.m = device_mesh(c);
+  a.tile0 = c->tile0;
+  a.tile1 = c->tile1;
+  a.x = c->buf[MS_BUF_X];
+  a.d = nullptr;
+  a.alpha = 0.0;
+  a.tilts = c->buf[MS_BUF_X];  // (read, not used)
+  a.tilts_out = nullptr;
+  a.k_tilt = 0.0;
+  a.g = nullptr;
+  a.tilt_grad = nullptr;
+  a.minv = d_out;
+  a.partials = c->d_partials;
+  a.e_slot = MS_S_ETILT;
+  a.consistent = 0;
+  a.tg_accumulate = 0;
+  a.va_out = nullptr;
+  hipError_t e = launch_tilt(a, 4, c->cap, t.max_ent, c->stream);
+  int rc = MS_OK;
+  if (e != hipSuccess) rc = fail(c, MS_ERR_HIP, std::string("ms_angle_defects: ") + hipGetErrorString(e));
+  if (rc == MS_OK) rc = patch_to_ext(c, d_out, defects, 1);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(d_out);
+  return rc;
+}
+
 int ms_project_tilts_to_tangent(ms_ctx* c) {
   if (!c) return MS_ERR_INVALID;
   if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "tilt passes are single-shard only");

@@ -1302,7 +1302,17 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
       const V3 n = cross(e2, -e1);
       const double A2 = norm(n);
       double* s = stg + tid;
-      if (MODE == 2 || MODE == 3) {
+      if (MODE == 4) {
+        // interior angles by the law of cosines, edge lengths clamped at 1e-15, cosines clipped to [-1, 1]
+        // (geometry/curvature.py:366-386)
+        const double la = fmax(norm(e0), 1.0e-15), lb = fmax(norm(e1), 1.0e-15), lc = fmax(norm(e2), 1.0e-15);
+        const double c0 = ((lb * lb + lc * lc) - la * la) / ((2.0 * lb) * lc);
+        const double c1 = ((lc * lc + la * la) - lb * lb) / ((2.0 * lc) * la);
+        const double c2 = ((la * la + lb * lb) - lc * lc) / ((2.0 * la) * lb);
+        s[0 * T] = acos(fmin(1.0, fmax(-1.0, c0)));
+        s[1 * T] = acos(fmin(1.0, fmax(-1.0, c1)));
+        s[2 * T] = acos(fmin(1.0, fmax(-1.0, c2)));
+      } else if (MODE == 2 || MODE == 3) {
         s[0 * T] = n.x;
         s[1 * T] = n.y;
         s[2 * T] = n.z;
@@ -1343,7 +1353,9 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
         const int fl = ent >> 2;
         if (fl >= hi) break;
         const double* s = stg + (fl - lo);
-        if (MODE == 2 || MODE == 3) {
+        if (MODE == 4) {
+          aw += s[(ent & 3) * T];  // this corner's angle
+        } else if (MODE == 2 || MODE == 3) {
           ax += s[0];
           ay += s[T];
           az += s[2 * T];
@@ -1385,6 +1397,10 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
       a.tilts_out[o] = tv.x - dt * nrm.x;
       a.tilts_out[o + 1] = tv.y - dt * nrm.y;
       a.tilts_out[o + 2] = tv.z - dt * nrm.z;
+    } else if (MODE == 4) {
+      // angle defect 2 pi - sum of incident angles, 0 on boundary rows (geometry/curvature.py:393-401)
+      const double two_pi = 2.0 * 3.14159265358979323846;
+      a.minv[t.v_lo + tid] = (a.m.vflags[t.v_lo + tid] & VF_BOUNDARY) ? 0.0 : two_pi - aw;
     } else if (MODE == 3) {
       // relaxation geometry: unit vertex normals (triangle_ops.py:55-73) and the tilt-rigidity
       // part k_t A_v of the Jacobi diagonal (runtime/preconditioners.py:27-40)
@@ -1398,7 +1414,7 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
       if (a.va_out) a.va_out[t.v_lo + tid] = aw;         // barycentric vertex area (mesh.py:671-730)
     }
   }
-  if (MODE != 2 && MODE != 3) {
+  if (MODE != 2 && MODE != 3 && MODE != 4) {
     const double vals[1] = {e_tilt};
     const int ops[1] = {0};
     const int slots[1] = {a.e_slot};
@@ -1422,7 +1438,8 @@ hipError_t launch_tilt(const TiltArgs& a, int mode, int cap, int max_ent, hipStr
     if (e != hipSuccess) return e;                                                      \
     hipLaunchKernelGGL((k_tilt<M>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);    \
   } while (0)
-  if (mode == 0) MS_LAUNCH_T(0); else if (mode == 1) MS_LAUNCH_T(1); else if (mode == 2) MS_LAUNCH_T(2); else MS_LAUNCH_T(3);
+  if (mode == 0) MS_LAUNCH_T(0); else if (mode == 1) MS_LAUNCH_T(1); else if (mode == 2) MS_LAUNCH_T(2);
+  else if (mode == 3) MS_LAUNCH_T(3); else MS_LAUNCH_T(4);
 #undef MS_LAUNCH_T
   return hipGetLastError();
 }

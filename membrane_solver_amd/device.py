@@ -260,6 +260,12 @@ class DeviceMesh:
                   "ms_relax_leaflet_tilts")
         return int(it.value), int(ev.value)
 
+    def angle_defects(self) -> np.ndarray:
+        """Per-vertex angle defects (integrated Gaussian curvature) at the current positions."""
+        out = np.empty(self.nv, dtype=np.float64)
+        self._chk(L.lib().ms_angle_defects(self._h, _pd(out)), "ms_angle_defects")
+        return out
+
     def project_tilts_to_tangent(self):
         self._chk(L.lib().ms_project_tilts_to_tangent(self._h), "ms_project_tilts_to_tangent")
 

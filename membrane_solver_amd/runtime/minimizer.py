@@ -50,10 +50,12 @@ _ENERGY_BITS = {"surface": L.MS_MOD_SURFACE, "bending": L.MS_MOD_BENDING, "volum
                 "tilt_smoothness_in": L.MS_MOD_TILT_SMOOTH_IN, "tilt_smoothness_out": L.MS_MOD_TILT_SMOOTH_OUT,
                 "bending_tilt_in": L.MS_MOD_BENDING_TILT_IN, "bending_tilt_out": L.MS_MOD_BENDING_TILT_OUT,
                 "tilt_disk_target_in": L.MS_MOD_TILT_DISK_TARGET_IN,
-                "tilt_disk_target_out": L.MS_MOD_TILT_DISK_TARGET_OUT}
+                "tilt_disk_target_out": L.MS_MOD_TILT_DISK_TARGET_OUT,
+                "gaussian_curvature": 0}  # a topological constant on closed surfaces: host-side offset, no kernel
 _ENERGY_SLOT = {"surface": 0, "bending": 1, "volume": 2, "tilt": 3, "bending_tilt": 1, "tilt_smoothness": 3,
                 "tilt_in": 3, "tilt_out": 3, "tilt_smoothness_in": 3, "tilt_smoothness_out": 3,
-                "bending_tilt_in": 1, "bending_tilt_out": 1, "tilt_disk_target_in": 3, "tilt_disk_target_out": 3}
+                "bending_tilt_in": 1, "bending_tilt_out": 1, "tilt_disk_target_in": 3, "tilt_disk_target_out": 3,
+                "gaussian_curvature": None}
 _SINGLE_TILT_BITS = L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT | L.MS_MOD_TILT_SMOOTH
 _LEAFLET_BT_BITS = L.MS_MOD_BENDING_TILT_IN | L.MS_MOD_BENDING_TILT_OUT
 _LEAFLET_BITS = (L.MS_MOD_TILT_IN | L.MS_MOD_TILT_OUT | L.MS_MOD_TILT_SMOOTH_IN | L.MS_MOD_TILT_SMOOTH_OUT
@@ -196,6 +198,7 @@ class Minimizer:
         if self.deterministic is not None:
             dm.set_deterministic(self.deterministic)
         mods = 0
+        self._energy_offset = 0.0
         disk_params = {}
         vol_mode = gp.get("volume_constraint_mode", "lagrange")
         for name in self.energy_module_names:
@@ -214,6 +217,10 @@ class Minimizer:
             elif name in ("tilt_smoothness_in", "tilt_smoothness_out"):
                 if _lc.smoothness_rigidity(self.param_resolver, gp, name[16:]) != 0.0:  # tilt_smoothness_leaflet.py:32-34
                     mods |= _ENERGY_BITS[name]
+            elif name == "gaussian_curvature":
+                from ..modules.energy import gaussian_curvature as _gc
+
+                self._energy_offset = _gc.constant_energy(self.mesh, gp)  # gaussian_curvature.py:117-134
             elif name in ("tilt_disk_target_in", "tilt_disk_target_out"):
                 prm = _lc.disk_target_params(self.mesh, self.param_resolver, gp, name[17:])
                 if prm is not None:  # tilt_disk_target_in.py:175-191
@@ -318,7 +325,7 @@ class Minimizer:
         """Total energy and dense gradient (minimizer.py:941-992)."""
         _mir, dm = self._device()
         e, g = dm.energy_and_gradient(want_grad=True)
-        return float(e.sum()), g
+        return float(e.sum()) + self._energy_offset, g
 
     def compute_energy_and_gradient(self):
         E, g = self.compute_energy_and_gradient_array()
@@ -327,7 +334,7 @@ class Minimizer:
     def compute_energy(self) -> float:
         """minimizer.py:1051-1054."""
         _mir, dm = self._device()
-        return float(dm.energy().sum())
+        return float(dm.energy().sum()) + self._energy_offset
 
     def compute_energy_breakdown(self) -> Dict[str, float]:
         """Per-module energies (minimizer.py:1056-1065)."""
@@ -335,7 +342,7 @@ class Minimizer:
         e = dm.energy()
         out = {}
         for name in self.energy_module_names:
-            out[name] = float(e[_ENERGY_SLOT[name]])
+            out[name] = self._energy_offset if _ENERGY_SLOT[name] is None else float(e[_ENERGY_SLOT[name]])
         for table in (_TILT_SCALAR, _BEND_SCALAR):
             sharing = [n for n in out if n in table]
             if len(sharing) > 1:  # they share one entry of the energy vector: split via the scalars
@@ -490,9 +497,9 @@ class Minimizer:
             if not out.zero_step_exit:  # minimizer.py:1324-1337 / :1516-1535 finalize the constraints
                 moved |= self._enforce(dm, "finalize")
             if out.converged:
-                energy = float(out.energy_eval)
+                energy = float(out.energy_eval) + self._energy_offset
             else:
-                energy = float(dm.energy().sum())
+                energy = float(dm.energy().sum()) + self._energy_offset
             if moved or self._device_ahead:
                 if sync_mesh:
                     write_back_positions(self.mesh, dm, mir)
@@ -545,7 +552,8 @@ class Minimizer:
             if r.converged:  # minimizer.py:1324-1337
                 logger.info("Converged in %d iterations; |grad E|=%.3e", i, r.grad_norm)
                 dirty_box[0] |= self._enforce(dm, "finalize")
-                return finish({"energy": r.energy_eval, "gradient": GradientRows(self.mesh, dm.get_gradient()),
+                return finish({"energy": r.energy_eval + self._energy_offset,
+                               "gradient": GradientRows(self.mesh, dm.get_gradient()),
                                "mesh": self.mesh, "step_success": True, "iterations": i + 1,
                                "terminated_early": True})
             step_success = r.success
@@ -561,7 +569,7 @@ class Minimizer:
                     zero_step_counter += 1
                     if zero_step_counter >= self.max_zero_steps:
                         logger.info("Terminating early after %d consecutive zero-steps", zero_step_counter)
-                        return finish({"energy": float(dm.energy().sum()),
+                        return finish({"energy": float(dm.energy().sum()) + self._energy_offset,
                                        "gradient": GradientRows(self.mesh, dm.get_gradient()),
                                        "mesh": self.mesh, "step_success": False, "iterations": i + 1,
                                        "terminated_early": True})
@@ -577,7 +585,7 @@ class Minimizer:
                         dirty_box[0] |= self._enforce(dm, "mesh_operation")
                         self.stepper.reset()
         dirty_box[0] |= self._enforce(dm, "finalize")
-        final_energy = float(dm.energy().sum())
+        final_energy = float(dm.energy().sum()) + self._energy_offset
         grad = GradientRows(self.mesh, dm.get_gradient() if sync_mesh else dm.get_gradient) if have_grad else {}
         return finish({"energy": final_energy, "gradient": grad, "mesh": self.mesh,
                        "step_success": step_success, "iterations": n_steps, "terminated_early": False})

@@ -35,6 +35,7 @@ ap.add_argument("--only-ts", action="store_true", help="tilt_smoothness vectors 
 ap.add_argument("--only-leaflet", action="store_true", help="two-leaflet tilt vectors only")
 ap.add_argument("--only-btl", action="store_true", help="bending_tilt_in/out vectors only")
 ap.add_argument("--only-disk", action="store_true", help="tilt_disk_target_in/out vectors only")
+ap.add_argument("--only-defects", action="store_true", help="angle-defect vectors only")
 args = ap.parse_args()
 
 sys.dont_write_bytecode = True
@@ -944,6 +945,32 @@ def gen_disk_target():
 _DISK_TAG = False
 
 
+
+def gen_angle_defects():
+    """compute_angle_defects (geometry/curvature.py:335-403) and the closed-surface gaussian_curvature energy."""
+    from geometry.curvature import compute_angle_defects
+    from modules.energy import gaussian_curvature as gcm
+
+    out = {"meta_fortran": META}
+    rng = np.random.default_rng(3)
+    P, T = meshgen.icosphere(5)
+    P = meshgen.smooth_displace(P, 0.08) + 4e-3 * rng.normal(size=P.shape)
+    Pd, Td, _ = meshgen.disk_patch(5, bulge=0.35, jitter=0.03, seed=5)
+    for name, (P_, T_) in {"ico5": (P, T), "disk5": (Pd, Td)}.items():
+        m = build_mesh(P_, T_, {"gaussian_modulus": -0.7})
+        pos, tri, isb, fixed = mesh_arrays(m)
+        d = compute_angle_defects(m, pos, m.vertex_index_to_row)
+        out[name + "_positions"], out[name + "_tri"], out[name + "_is_boundary"], out[name + "_defects"] = pos, tri, isb, d
+        if name == "ico5":
+            g = np.zeros_like(pos)
+            E = gcm.compute_energy_and_gradient_array(m, m.global_parameters, ParameterResolver(m.global_parameters),
+                                                      positions=pos, index_map=m.vertex_index_to_row, grad_arr=g)
+            assert not np.any(g)
+            out["ico5_gaussian_E"] = np.array(E)
+        print("angle defects", name, "sum=%.15g" % d.sum())
+    np.savez_compressed(os.path.join(OUT, "angle_defect_cases.npz"), **out)
+
+
 def run_leaflet_trajectory_fixed(fname, P, T, gp, mods, stepper, n_steps, step_size, fixed):
     global build_mesh
     orig = build_mesh
@@ -966,6 +993,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-leaflet" in sys.argv:
         gen_leaflet()
+        sys.exit(0)
+    if "--only-defects" in sys.argv:
+        gen_angle_defects()
         sys.exit(0)
     if "--only-disk" in sys.argv:
         gen_disk_target()
@@ -990,3 +1020,4 @@ if __name__ == "__main__":
     gen_leaflet()
     gen_bending_tilt_leaflet()
     gen_disk_target()
+    gen_angle_defects()

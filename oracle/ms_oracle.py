@@ -647,3 +647,35 @@ def tilt_disk_target_energy_and_gradient(pos, tilts, tri, disk_rows, k_target, t
             np.add.at(va, rows[:, kcol], areas / 3.0)
         tilt_grad += k_target * diff * va[:, None]
     return energy
+
+
+# --- angle defects / Gaussian curvature ------------------------------------------------
+def angle_defects(pos, tri, is_boundary):
+    """geometry/curvature.py:335-403 compute_angle_defects: 2 pi - sum of incident angles (law of cosines, edge
+    lengths clamped at 1e-15, cosines clipped to [-1, 1]), 0 on boundary rows."""
+    pos, tri = _f64(pos), _i32(tri)
+    nv = pos.shape[0]
+    if tri.shape[0] == 0:
+        return np.zeros(nv)
+    v0, v1, v2 = pos[tri[:, 0]], pos[tri[:, 1]], pos[tri[:, 2]]
+    a = np.maximum(np.linalg.norm(v2 - v1, axis=1), 1e-15)
+    b = np.maximum(np.linalg.norm(v0 - v2, axis=1), 1e-15)
+    c = np.maximum(np.linalg.norm(v1 - v0, axis=1), 1e-15)
+    ang0 = np.arccos(np.clip((b * b + c * c - a * a) / (2.0 * b * c), -1.0, 1.0))
+    ang1 = np.arccos(np.clip((c * c + a * a - b * b) / (2.0 * c * a), -1.0, 1.0))
+    ang2 = np.arccos(np.clip((a * a + b * b - c * c) / (2.0 * a * b), -1.0, 1.0))
+    sums = np.zeros(nv)
+    np.add.at(sums, tri[:, 0], ang0)
+    np.add.at(sums, tri[:, 1], ang1)
+    np.add.at(sums, tri[:, 2], ang2)
+    defects = (2.0 * np.pi) - sums
+    defects[np.asarray(is_boundary, dtype=bool)] = 0.0
+    return defects
+
+
+def euler_characteristic(nv, tri):
+    """modules/energy/gaussian_curvature.py:41-43: V - E + F of the triangle complex."""
+    tri = _i32(tri)
+    e = np.sort(np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]]), axis=1)
+    n_edges = np.unique(e, axis=0).shape[0] if e.size else 0
+    return int(nv - n_edges + tri.shape[0])

@@ -233,3 +233,50 @@ def test_atomic_and_fixed_order_vertex_sums_agree(L, shape):
         assert np.allclose(out[0][:, 1], out[1][:, 1], rtol=1e-11)
         assert np.allclose(out[0][:, 2], out[1][:, 2], rtol=1e-8)
     dm.close()
+
+
+def test_angle_defects_and_gaussian_curvature(L):
+    """ms_angle_defects against the reference's compute_angle_defects vectors (closed and open mesh), Gauss-Bonnet at a
+    size with many tiles, and the gaussian_curvature module (a topological constant: offset, no force)."""
+    from conftest import load_golden
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+    from membrane_solver_amd.geometry.mesh import ArrayMesh
+    from membrane_solver_amd.runtime.constraint_manager import ConstraintModuleManager
+    from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
+    from membrane_solver_amd.runtime.minimizer import Minimizer
+    from membrane_solver_amd.runtime.steppers import GradientDescent
+
+    g = load_golden("angle_defect_cases.npz")
+    for name in ("ico5", "disk5"):
+        dm = DeviceMesh(g[name + "_positions"], g[name + "_tri"], boundary=g[name + "_is_boundary"], tile_vertices=64)
+        d = dm.angle_defects()
+        assert np.max(np.abs(d - g[name + "_defects"])) <= 1e-12
+        dm.close()
+    P, T = meshgen.icosphere(40)
+    P = meshgen.smooth_displace(P, 0.1)
+    dm = DeviceMesh(P, T)
+    assert abs(dm.angle_defects().sum() - 4.0 * np.pi) < 1e-9  # 2 pi chi, chi = 2
+    dm.close()
+    gp = {"surface_tension": 1.0, "gaussian_modulus": -0.7, "gaussian_curvature_check_defects": True}
+    mods = ["surface", "gaussian_curvature"]
+    mesh = ArrayMesh(g["ico5_positions"], g["ico5_tri"], global_parameters=gp, energy_modules=mods)
+    mz = Minimizer(mesh, mesh.global_parameters, GradientDescent(), EnergyModuleManager(mods), ConstraintModuleManager([]),
+                   quiet=True)
+    bd = mz.compute_energy_breakdown()
+    assert abs(bd["gaussian_curvature"] - float(g["ico5_gaussian_E"])) <= 1e-14
+    E, grad = mz.compute_energy_and_gradient_array()
+    assert abs(E - (bd["surface"] + bd["gaussian_curvature"])) <= 1e-12 * abs(E)
+    res = mz.minimize(3)
+    assert abs(res["energy"] - (mz.compute_energy())) <= 1e-12 * abs(res["energy"])
+    module = EnergyModuleManager(mods).get_module("gaussian_curvature")
+    from membrane_solver_amd.core.parameters import ParameterResolver
+    E_mod = module.compute_energy_and_gradient_array(mesh, mesh.global_parameters, ParameterResolver(mesh.global_parameters),
+                                                     positions=mesh.positions_view(), index_map=mesh.vertex_index_to_row,
+                                                     grad_arr=np.zeros_like(P[:1]))
+    assert abs(E_mod - float(g["ico5_gaussian_E"])) <= 1e-14
+    open_mesh = ArrayMesh(g["disk5_positions"], g["disk5_tri"], global_parameters=gp, energy_modules=mods)
+    mz2 = Minimizer(open_mesh, open_mesh.global_parameters, GradientDescent(), EnergyModuleManager(mods),
+                    ConstraintModuleManager([]), quiet=True)
+    with pytest.raises(L.MembraneHipError, match="boundary"):
+        mz2.compute_energy()

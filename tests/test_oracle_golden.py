@@ -470,3 +470,13 @@ def test_port_reproduces_disk_target_trajectory(fname):
     assert relerr(p.positions, g["positions_final"]) < 1e-8
     assert relerr(p.tilts_in, g["tilts_in_final"]) < 1e-8
     assert relerr(p.tilts_out, g["tilts_out_final"]) < 1e-8
+
+
+def test_angle_defects_match_reference():
+    g = load_golden("angle_defect_cases.npz")
+    for name in ("ico5", "disk5"):
+        d = orc.angle_defects(g[name + "_positions"], g[name + "_tri"], g[name + "_is_boundary"])
+        assert np.max(np.abs(d - g[name + "_defects"])) <= 1e-14
+    chi = orc.euler_characteristic(len(g["ico5_positions"]), g["ico5_tri"])
+    assert chi == 2 and abs(np.sum(g["ico5_defects"]) - 2.0 * np.pi * chi) < 1e-10  # Gauss-Bonnet
+    assert abs(float(g["ico5_gaussian_E"]) - (-0.7) * 2.0 * np.pi * chi) <= 1e-14
