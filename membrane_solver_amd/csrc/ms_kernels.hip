@@ -197,6 +197,7 @@ __device__ __forceinline__ TileCtx tile_ctx(const DeviceMesh& m, int tile) {
 // Per-tile CSR words held in registers between "issue" and "commit": every global load of a
 // tile's stage-in is issued before the first LDS write, so the whole prologue costs two HBM
 // round trips (ids/rows/CSR, then the halo rows the ids name) instead of one per array.
+// occupancy attributes of the two tile kernels for A/B builds (tools/ab_variants.sh); empty by default
 #ifndef MS_WPE_ENERGY
 #define MS_WPE_ENERGY
 #endif
