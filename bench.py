@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 ach
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--freq", type=int, default=320, help="icosphere frequency (320 -> 2 048 000 facets)")
     ap.add_argument("--tile", type=int, default=0, help="owned vertices per tile (0 = library default)")
     ap.add_argument("--step-size", type=float, default=1e-6)
