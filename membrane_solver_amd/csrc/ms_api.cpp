@@ -687,6 +687,11 @@ int fetch(ms_ctx* c) {
     }
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  // everything queued has run: a slot that is still behind belongs to a gated launch that found its gate closed
+  // although the host expected it to run -- host and device disagreed on an Armijo test.  Never continue on that.
+  for (int sl = 0; sl < MS_NSCAL; ++sl)
+    if (c->tile1 > c->tile0 && __atomic_load_n(&c->h_seq[sl], __ATOMIC_ACQUIRE) < c->expected[sl])
+      return fail(c, MS_ERR_STATE, "line-search queue: a gated launch the host waited for did not run");
   return MS_OK;
 }
 
