@@ -536,8 +536,10 @@ class Minimizer:
         dirty_box = [dirty]
         for i in range(n_steps):
             if callback:
-                if dirty_box[0]:
+                if dirty_box[0]:  # the callback sees the mesh as the reference's does: positions and tilt fields
                     write_back_positions(self.mesh, dm, mir)
+                    if dm.modules & (_TILT_BITS):
+                        self._write_back_tilts(dm, mir)
                     dirty_box[0] = False
                 callback(self.mesh, i)
                 mir, dm = self._device()

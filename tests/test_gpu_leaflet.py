@@ -446,3 +446,22 @@ def test_leaflet_trajectories_with_small_tiles(fname):
     assert relerr(mesh.tilts_in_view(), g["tilts_in_final"]) < 1e-8
     assert relerr(mesh.tilts_out_view(), g["tilts_out_final"]) < 1e-8
     assert abs(res["energy"] - g["E_final"]) <= 1e-9 * abs(g["E_final"])
+
+
+@pytest.mark.parametrize("fname", ["traj_ico4_gd_leaflet_nested_cg.npz", "traj_ico4_gd_btl_nested_cg.npz"])
+def test_callback_sees_reference_states(fname):
+    """minimize(callback=...) hands the callback the mesh of the reference at the top of every iteration: positions and
+    both leaflet tilt fields (relaxed and projected so far) equal the reference's per-iteration snapshots."""
+    g = load_golden(fname)
+    mesh, mz, _ = _leaflet_minimizer(g, "gd", observe=False)
+    snaps = []
+
+    def cb(m, i):
+        snaps.append((m.positions_view().copy(), m.tilts_in_view().copy(), m.tilts_out_view().copy()))
+
+    mz.minimize(int(g["n_steps"]), callback=cb)
+    assert len(snaps) == len(g["positions_iter"])
+    for k, (x, tin, tout) in enumerate(snaps):
+        assert relerr(x, g["positions_iter"][k]) < 1e-8, k
+        assert relerr(tin, g["tilts_in_iter"][k]) < 1e-8, k
+        assert relerr(tout, g["tilts_out_iter"][k]) < 1e-8, k
