@@ -51,11 +51,13 @@ _ENERGY_BITS = {"surface": L.MS_MOD_SURFACE, "bending": L.MS_MOD_BENDING, "volum
                 "bending_tilt_in": L.MS_MOD_BENDING_TILT_IN, "bending_tilt_out": L.MS_MOD_BENDING_TILT_OUT,
                 "tilt_disk_target_in": L.MS_MOD_TILT_DISK_TARGET_IN,
                 "tilt_disk_target_out": L.MS_MOD_TILT_DISK_TARGET_OUT,
-                "gaussian_curvature": 0}  # a topological constant on closed surfaces: host-side offset, no kernel
+                # host-side constants, no kernel: a topological constant on closed surfaces; a module that is only
+                # accepted in its switched-off state (strength 0, as in the caveolin decks)
+                "gaussian_curvature": 0, "rim_slope_match_out": 0}
 _ENERGY_SLOT = {"surface": 0, "bending": 1, "volume": 2, "tilt": 3, "bending_tilt": 1, "tilt_smoothness": 3,
                 "tilt_in": 3, "tilt_out": 3, "tilt_smoothness_in": 3, "tilt_smoothness_out": 3,
                 "bending_tilt_in": 1, "bending_tilt_out": 1, "tilt_disk_target_in": 3, "tilt_disk_target_out": 3,
-                "gaussian_curvature": None}
+                "gaussian_curvature": None, "rim_slope_match_out": None}
 _SINGLE_TILT_BITS = L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT | L.MS_MOD_TILT_SMOOTH
 _LEAFLET_BT_BITS = L.MS_MOD_BENDING_TILT_IN | L.MS_MOD_BENDING_TILT_OUT
 _LEAFLET_BITS = (L.MS_MOD_TILT_IN | L.MS_MOD_TILT_OUT | L.MS_MOD_TILT_SMOOTH_IN | L.MS_MOD_TILT_SMOOTH_OUT
@@ -198,7 +200,7 @@ class Minimizer:
         if self.deterministic is not None:
             dm.set_deterministic(self.deterministic)
         mods = 0
-        self._energy_offset = 0.0
+        self._const_energy = {}
         disk_params = {}
         vol_mode = gp.get("volume_constraint_mode", "lagrange")
         for name in self.energy_module_names:
@@ -220,7 +222,11 @@ class Minimizer:
             elif name == "gaussian_curvature":
                 from ..modules.energy import gaussian_curvature as _gc
 
-                self._energy_offset = _gc.constant_energy(self.mesh, gp)  # gaussian_curvature.py:117-134
+                self._const_energy[name] = _gc.constant_energy(self.mesh, gp)  # gaussian_curvature.py:117-134
+            elif name == "rim_slope_match_out":
+                from ..modules.energy import rim_slope_match_out as _rs
+
+                self._const_energy[name] = _rs.constant_energy(self.mesh, gp, self.param_resolver)
             elif name in ("tilt_disk_target_in", "tilt_disk_target_out"):
                 prm = _lc.disk_target_params(self.mesh, self.param_resolver, gp, name[17:])
                 if prm is not None:  # tilt_disk_target_in.py:175-191
@@ -342,7 +348,7 @@ class Minimizer:
         e = dm.energy()
         out = {}
         for name in self.energy_module_names:
-            out[name] = self._energy_offset if _ENERGY_SLOT[name] is None else float(e[_ENERGY_SLOT[name]])
+            out[name] = self._const_energy.get(name, 0.0) if _ENERGY_SLOT[name] is None else float(e[_ENERGY_SLOT[name]])
         for table in (_TILT_SCALAR, _BEND_SCALAR):
             sharing = [n for n in out if n in table]
             if len(sharing) > 1:  # they share one entry of the energy vector: split via the scalars
@@ -406,6 +412,11 @@ class Minimizer:
         else:
             dm.relax_tilts(**rp)
         return True
+
+    @property
+    def _energy_offset(self) -> float:
+        """Sum of the host-side constant modules (set by _device())."""
+        return float(sum(getattr(self, "_const_energy", {}).values()))
 
     def _write_back_tilts(self, dm, mir):
         """Device tilt fields -> mesh (the reference leaves relaxed / projected tilts on the mesh)."""

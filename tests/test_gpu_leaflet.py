@@ -465,3 +465,31 @@ def test_callback_sees_reference_states(fname):
         assert relerr(x, g["positions_iter"][k]) < 1e-8, k
         assert relerr(tin, g["tilts_in_iter"][k]) < 1e-8, k
         assert relerr(tout, g["tilts_out_iter"][k]) < 1e-8, k
+
+
+def test_rim_slope_match_out_only_switched_off():
+    """The caveolin decks list rim_slope_match_out among the energy modules with strength 0: accepted as a zero,
+    refused loudly with a non-zero strength."""
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.geometry.mesh import ArrayMesh
+    from membrane_solver_amd.runtime.constraint_manager import ConstraintModuleManager
+    from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
+    from membrane_solver_amd.runtime.minimizer import Minimizer
+    from membrane_solver_amd.runtime.steppers import GradientDescent
+
+    P, T = meshgen.icosphere(3)
+    mods = ["surface", "rim_slope_match_out"]
+    for strength, ok in ((0.0, True), (2.0, False)):
+        gp = {"surface_tension": 1.0, "rim_slope_match_strength": strength, "rim_slope_match_group": "rim",
+              "rim_slope_match_outer_group": "outer"}
+        mesh = ArrayMesh(P, T, global_parameters=gp, energy_modules=mods)
+        mz = Minimizer(mesh, mesh.global_parameters, GradientDescent(), EnergyModuleManager(mods),
+                       ConstraintModuleManager([]), quiet=True)
+        if ok:
+            bd = mz.compute_energy_breakdown()
+            assert bd["rim_slope_match_out"] == 0.0 and bd["surface"] > 0.0
+            assert mz.minimize(2)["energy"] > 0.0
+        else:
+            with pytest.raises(L.MembraneHipError, match="rim_slope_match_strength"):
+                mz.compute_energy()
