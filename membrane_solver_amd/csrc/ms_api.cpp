@@ -148,6 +148,7 @@ struct ms_ctx {
   unsigned long long xticket = 0;
   double sh_scal[MS_NSCAL] = {0};  // rank-ordered fold of the last exchanges
   bool sh_carry_valid = false, sh_grad_valid = false;
+  bool sh_maxg2_valid = false;  // the last direction exchange also carried the gradient rows and max|g_i|^2
   long sh_exchanges = 0;
   bool carry_valid = false;
   // true while buffer G holds the finalized gradient of the current x (set by ms_step's fused
@@ -2143,13 +2144,16 @@ int ms_phase_accept(ms_ctx* c, int keep_history) {
   c->factors_valid = false;
   c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
   c->sh_carry_valid = c->sh_grad_valid = false;
+  c->sh_maxg2_valid = false;
   if (keep_history) {
     std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
     std::swap(c->buf[MS_BUF_D], c->buf[MS_BUF_PD]);
+    c->pd_neg_pg = c->dir_implicit;  // the accepted direction was -G = -PG from now on
     c->last_g = c->buf[MS_BUF_PG];
     c->cg_have_history = true;
     ++c->cg_iter_count;
   }
+  c->dir_implicit = false;
   return MS_OK;
 }
 
@@ -2162,7 +2166,7 @@ int ms_phase_commit_trial(ms_ctx* c, double alpha, int keep_history) {
     const Tiling& t = c->til;
     const int64_t rows_per = (int64_t)t.tiles_per_shard * t.T;
     HIPCHK(c, launch_axpy_rows(c->shard_rank * rows_per, (c->shard_rank + 1) * rows_per, c->d_halo_rows,
-                               c->n_halo_rows, c->d_vflags, c->buf[MS_BUF_X], c->buf[MS_BUF_D], alpha,
+                               c->n_halo_rows, c->d_vflags, c->buf[MS_BUF_X], trial_dir(c), trial_alpha(c, alpha),
                                c->stream));
     std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);  // undone by ms_phase_accept's swap
     return ms_phase_accept(c, keep_history);
@@ -2170,7 +2174,7 @@ int ms_phase_commit_trial(ms_ctx* c, double alpha, int keep_history) {
   const size_t n3 = 3 * (size_t)c->til.nvp;
   HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_XT], c->buf[MS_BUF_X], n3 * sizeof(double),
                            hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(c, launch_axpy_masked(c->til.nvp, c->d_vflags, c->buf[MS_BUF_XT], c->buf[MS_BUF_D], alpha,
+  HIPCHK(c, launch_axpy_masked(c->til.nvp, c->d_vflags, c->buf[MS_BUF_XT], trial_dir(c), trial_alpha(c, alpha),
                                c->stream));
   return ms_phase_accept(c, keep_history);
 }
@@ -2311,7 +2315,7 @@ const int SH_SUM[] = {MS_S_ESURF, MS_S_VOL, MS_S_EBEND, MS_S_GGC, MS_S_GCGC, MS_
 constexpr uint32_t SH_ENERGY = (1u << MS_S_ESURF) | (1u << MS_S_VOL) | (1u << MS_S_EBEND) |
                                (1u << MS_S_MINEDGE2) | (1u << MS_S_GUARD);
 constexpr uint32_t SH_GRAD = (1u << MS_S_GGC) | (1u << MS_S_GCGC);
-constexpr uint32_t SH_DIR = (1u << MS_S_GNORM2) | (1u << MS_S_GDOTD) | (1u << MS_S_MAXD2);
+constexpr uint32_t SH_DIR = (1u << MS_S_GNORM2) | (1u << MS_S_GDOTD) | (1u << MS_S_MAXD2) | (1u << MS_S_MAXG2);
 
 // One exchange: boundary rows of `ids` + the 16 scalars of every rank; `slots` of the
 // rank-ordered fold go to c->sh_scal (push: also to the device scalars).
@@ -2365,7 +2369,7 @@ int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push) 
     for (int r = 1; r < W; ++r) m = std::min(m, c->h_scal_all[(size_t)r * MS_NSCAL + MS_S_MINEDGE2]);
     c->sh_scal[MS_S_MINEDGE2] = m;
   }
-  for (int sl : {(int)MS_S_GUARD, (int)MS_S_MAXD2})
+  for (int sl : {(int)MS_S_GUARD, (int)MS_S_MAXD2, (int)MS_S_MAXG2})
     if (slots & (1u << sl)) {
       double m = c->h_scal_all[sl];
       for (int r = 1; r < W; ++r) m = std::max(m, c->h_scal_all[(size_t)r * MS_NSCAL + sl]);
@@ -2441,9 +2445,10 @@ int ms_shard_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, doub
   const bool carry_mode = sp->reuse_energy0 >= 2;
   const int fbufs[2] = {MS_BUF_FK, MS_BUF_FA};
   const int n_fb = bend ? 2 : 0;
-  const int dbuf[1] = {MS_BUF_D};
+  const int dbuf[2] = {MS_BUF_D, MS_BUF_G};
   const bool carried = carry_mode && c->sh_carry_valid;
   int rc;
+  bool implicit_restart = false, fused = false;
   if (!carried) {
     rc = phase_energy(c, mods, false, 0.0, false, false, true);
     if (rc) return rc;
@@ -2451,7 +2456,16 @@ int ms_shard_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, doub
     if (rc) return rc;
     c->sh_grad_valid = false;
   }
-  if (carried && c->sh_grad_valid && !constraint) {
+  if (carried && c->sh_grad_valid && !constraint && !use_history && c->sh_maxg2_valid) {
+    // steepest-descent restart on an unchanged gradient: d = -g.  The last direction exchange carried the
+    // finalized gradient rows as well, so G is valid on every row this rank reads and the scalars follow from
+    // the ones already folded -- no kernel and, above all, no exchange
+    c->dir_implicit = true;
+    c->sh_scal[MS_S_GDOTD] = -c->sh_scal[MS_S_GNORM2];
+    c->sh_scal[MS_S_MAXD2] = c->sh_scal[MS_S_MAXG2];
+    implicit_restart = true;
+    rc = MS_OK;
+  } else if (carried && c->sh_grad_valid && !constraint) {
     rc = phase_direction(c, sp->stepper, use_history, /*g_finalized=*/true);
   } else if (constraint) {
     rc = phase_gradient(c, mods, c->buf[MS_BUF_G], false);
@@ -2462,10 +2476,17 @@ int ms_shard_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, doub
   } else {
     const int dir_mode = (cg && use_history) ? 2 : 1;
     rc = phase_gradient(c, mods, c->buf[MS_BUF_G], false, dir_mode);
+    fused = true;  // (its epilogue also reduced max|g_i|^2)
   }
   if (rc) return rc;
-  rc = shard_exchange(c, 1, dbuf, SH_DIR, false);
-  if (rc) return rc;
+  if (!implicit_restart) {
+    // without a constraint row the fused pass has just finalized G: send its boundary rows along with D's, so a
+    // steepest-descent restart after a failed search needs no exchange of its own
+    const bool with_g = !constraint;
+    rc = shard_exchange(c, with_g ? 2 : 1, dbuf, SH_DIR, false);
+    if (rc) return rc;
+    c->sh_maxg2_valid = with_g && fused;
+  }
   c->sh_carry_valid = carry_mode;
   c->sh_grad_valid = carry_mode && !constraint;
   const double E_eval = shard_energy(c);
