@@ -2305,8 +2305,9 @@ int shard_buffers(ms_ctx* c) {
   HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_scal_all), sb, hipHostMallocMapped));
   memset(c->h_scal_all, 0, sb);
   HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_scal_all), c->h_scal_all, 0));
-  HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_xseq), sizeof(unsigned long long), hipHostMallocMapped));
-  *c->h_xseq = 0;
+  HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_xseq), sizeof(unsigned long long) * (size_t)c->shard_count,
+                          hipHostMallocMapped));
+  for (int r = 0; r < c->shard_count; ++r) c->h_xseq[r] = 0;
   HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_xseq), c->h_xseq, 0));
   return MS_OK;
 }
@@ -2344,16 +2345,15 @@ int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push) 
   } else {
     return fail(c, MS_ERR_STATE, "ms_shard_step: no communicator (ms_shard_comm_init / ms_shard_set_allgather)");
   }
-  HIPCHK(c, launch_unpack_boundary(c->d_bnd_rows, c->d_bnd_off, me, W, c->bnd_max, p, nc, n, c->d_xrecv, count,
-                                   c->d_h_scal_all, c->stream));
   ++c->xticket;
-  HIPCHK(c, launch_post_seq(c->d_h_xseq, c->xticket, c->stream));
+  // the unpack kernel posts one sequence word per rank as soon as that rank's scalar header is in the mailbox
+  HIPCHK(c, launch_unpack_boundary(c->d_bnd_rows, c->d_bnd_off, me, W, c->bnd_max, p, nc, n, c->d_xrecv, count,
+                                   c->d_h_scal_all, c->stream, c->d_h_xseq, c->xticket));
   bool seen = false;
   for (long spin = 0; spin < 20000000L; ++spin) {
-    if (__atomic_load_n(c->h_xseq, __ATOMIC_ACQUIRE) >= c->xticket) {
-      seen = true;
-      break;
-    }
+    seen = true;
+    for (int r = 0; r < W && seen; ++r) seen = __atomic_load_n(c->h_xseq + r, __ATOMIC_ACQUIRE) >= c->xticket;
+    if (seen) break;
     __builtin_ia32_pause();
   }
   if (!seen) HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -234,7 +234,8 @@ hipError_t launch_pack_boundary(const int32_t* rows, int n_rows, const double* c
                                 hipStream_t s);
 hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_off, int me, int world,
                                   int max_rows, double* const* bufs, const int* ncomp, int n_bufs,
-                                  const double* recv, size_t stride, double* scal_all, hipStream_t s);
+                                  const double* recv, size_t stride, double* scal_all, hipStream_t s,
+                                  unsigned long long* host_seq = nullptr, unsigned long long ticket = 0);
 hipError_t launch_post_seq(unsigned long long* host_seq, unsigned long long ticket, hipStream_t s);
 hipError_t launch_axpy_rows(int64_t row0, int64_t row1, const int32_t* extra, int n_extra,
                             const uint8_t* vflags, double* x, const double* y, double coef,

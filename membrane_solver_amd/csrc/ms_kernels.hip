@@ -2218,11 +2218,21 @@ __global__ void k_pack_boundary(const int32_t* rows, int n_rows, RowBufs b, cons
 
 // grid (ceil(max_rows/256), world); recv = world x stride doubles
 __global__ void k_unpack_boundary(const int32_t* rows_all, const int32_t* row_off, int me,
-                                  RowBufs b, const double* recv, size_t stride, double* scal_all) {
+                                  RowBufs b, const double* recv, size_t stride, double* scal_all,
+                                  unsigned long long* host_seq, unsigned long long ticket) {
   const int r = blockIdx.y;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const double* src = recv + (size_t)r * stride;
   if (j < MS_NSCAL) scal_all[r * MS_NSCAL + j] = src[j];
+  if (host_seq != nullptr && blockIdx.x == 0) {
+    // the host only waits for the scalars (the rows are consumed by later kernels of the same stream): rank r's
+    // header is complete once this workgroup has written it -> post its sequence word, no extra kernel
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence_system();
+      *reinterpret_cast<volatile unsigned long long*>(host_seq + r) = ticket;
+    }
+  }
   if (r == me) return;
   const int n_rows = row_off[r + 1] - row_off[r];
   if (j >= n_rows) return;
@@ -2249,7 +2259,8 @@ hipError_t launch_pack_boundary(const int32_t* rows, int n_rows, const double* c
 
 hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_off, int me, int world,
                                   int max_rows, double* const* bufs, const int* ncomp, int n_bufs,
-                                  const double* recv, size_t stride, double* scal_all, hipStream_t s) {
+                                  const double* recv, size_t stride, double* scal_all, hipStream_t s,
+                                  unsigned long long* host_seq, unsigned long long ticket) {
   RowBufs b{};
   b.n = n_bufs;
   for (int k = 0; k < n_bufs; ++k) {
@@ -2259,7 +2270,7 @@ hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_of
   }
   const int n = max_rows > MS_NSCAL ? max_rows : MS_NSCAL;
   hipLaunchKernelGGL(k_unpack_boundary, dim3((n + 255) / 256, world), dim3(256), 0, s, rows_all, row_off,
-                     me, b, recv, stride, scal_all);
+                     me, b, recv, stride, scal_all, host_seq, ticket);
   return hipGetLastError();
 }
 
