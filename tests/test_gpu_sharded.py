@@ -88,6 +88,8 @@ def test_shards_match_single_context(with_volume, world, level, freq, tile, driv
 
     grp = ThreadGroup(world)
     logs, finals, errors = [None] * world, [None] * world, []
+    n_exchanges = [0] * world
+    trial_counts = [None] * world
 
     def run(rank):
         try:
@@ -100,14 +102,17 @@ def test_shards_match_single_context(with_volume, world, level, freq, tile, driv
                 drv = LibraryShardedStepper(be, stepper=L.MS_STEPPER_CG, reuse_energy0=level)
             else:
                 drv = ShardedStepper(be, stepper=L.MS_STEPPER_CG, reuse_energy0=level)
-            log, step = [], step0
+            log, step, tr = [], step0, []
             for _ in range(n_steps):
                 r = drv.step(step, tol=1e-9)
                 log.append((float(r.success), r.next_step, r.energy, r.grad_norm))
+                tr.append((int(r.trials), int(r.guard_rejects)))
                 step = r.next_step
                 if not r.success:
                     drv.reset()
             logs[rank] = np.array(log)
+            n_exchanges[rank] = drv.exchanges
+            trial_counts[rank] = tr
             finals[rank] = be.gather_positions()
             torch.cuda.synchronize()
         except Exception as e:  # pragma: no cover
@@ -134,3 +139,18 @@ def test_shards_match_single_context(with_volume, world, level, freq, tile, driv
         assert relerr(finals[rank], x_ref) < 1e-11
     for rank in range(1, world):
         assert np.array_equal(finals[0], finals[rank]), "ranks diverged"
+    assert len(set(n_exchanges)) == 1 and n_exchanges[0] > 0
+    if level == 2 and not with_volume:
+        # expected exchange count: one for the energy pass when the factors are not carried over, one for the
+        # direction, one per trial.  The library driver sends the gradient rows with the direction, so a
+        # steepest-descent restart after a search that failed before its first trial (non-descent direction)
+        # needs no direction exchange
+        expect, carried, prev_failed_without_trials = 0, False, False
+        for i in range(n_steps):
+            ok = bool(ref[i, 0])
+            trials, guards = trial_counts[0][i]
+            implicit = driver == "library" and carried and prev_failed_without_trials
+            expect += (0 if carried else 1) + (0 if implicit else 1) + trials + guards
+            carried = ok or (trials + guards == 0 and carried)
+            prev_failed_without_trials = (not ok) and trials + guards == 0
+        assert n_exchanges[0] == expect, (n_exchanges[0], expect, trial_counts[0], ref[:, 0])
