@@ -82,9 +82,8 @@ struct ms_ctx {
   // same doubles, so the trajectory does not change -- only the host round trips between trials disappear.
   static constexpr int SPEC_STAGES = 3;  // extra mailboxes (stage 0 uses the main one)
   struct Mailbox {
-    double* h_scal = nullptr;
-    double* d_h_scal = nullptr;
-    unsigned long long* h_seq = nullptr;
+    double* h_scal = nullptr;              // host copy of the values (filled by fetch)
+    unsigned long long* h_seq = nullptr;   // pinned, mapped: 2*MS_NSCAL words, {value bits, sequence word} per slot
     unsigned long long* d_h_seq = nullptr;
     unsigned long long expected[MS_NSCAL] = {0};
   } spec[SPEC_STAGES];
@@ -110,9 +109,10 @@ struct ms_ctx {
   double* buf[MS_BUF_COUNT] = {nullptr};
   double* d_partials = nullptr;
   double* d_scal = nullptr;
-  double* h_scal = nullptr;    // pinned, device-mapped mailbox (k_reduce writes it directly)
-  double* d_h_scal = nullptr;  // device-side address of h_scal
-  unsigned long long* h_seq = nullptr;    // per-slot sequence words (pinned, mapped)
+  double* h_scal = nullptr;    // host copy of the mailbox values (fetch() fills it once every slot has arrived)
+  // pinned, device-mapped mailbox: one 16-byte {value bits, sequence word} entry per slot, written by k_reduce
+  // in a single store
+  unsigned long long* h_seq = nullptr;
   unsigned long long* d_h_seq = nullptr;
   unsigned long long ticket = 0;          // ticket of the latest reduce launch
   unsigned long long expected[MS_NSCAL] = {0};  // latest ticket that folds each slot
@@ -413,7 +413,7 @@ int reduce_slots(ms_ctx* c, uint32_t mask) {
   for (int sl = 0; sl < MS_NSCAL; ++sl)
     if (mask & (1u << sl)) c->expected[sl] = c->ticket;
   HIPCHK(c, launch_reduce(c->d_partials, c->til.n_tiles, c->tile0, c->tile1, mask, c->d_scal,
-                          c->d_h_scal, c->d_h_seq, c->ticket, c->stream, c->cur_gate));
+                          c->d_h_seq, c->ticket, c->stream, c->cur_gate));
   return MS_OK;
 }
 
@@ -674,16 +674,35 @@ int phase_direction(ms_ctx* c, int stepper, bool use_history, bool g_finalized =
 // k_reduce mirrors every slot it folds into the pinned mailbox and then bumps that slot's
 // sequence word; fetching = spinning on those words (a few microseconds less than waking up
 // from hipStreamSynchronize).  Falls back to a stream sync after ~50 ms of spinning.
+// value and sequence word of a slot arrive in one 16-byte write; the acquire load of the sequence word in fetch()
+// orders these reads after it
+int take_mailbox(ms_ctx* c) {
+  for (int sl = 0; sl < MS_NSCAL; ++sl) {
+    const unsigned long long bits = __atomic_load_n(&c->h_seq[2 * sl], __ATOMIC_RELAXED);
+    memcpy(&c->h_scal[sl], &bits, sizeof(double));
+  }
+  return MS_OK;
+}
+
+// host-side write of a slot (a stage mailbox's result moved into the main one): both the host copy and the value
+// word, so a later take_mailbox() keeps it
+void put_mailbox(ms_ctx* c, int sl, double v) {
+  c->h_scal[sl] = v;
+  unsigned long long bits;
+  memcpy(&bits, &v, sizeof(double));
+  __atomic_store_n(&c->h_seq[2 * sl], bits, __ATOMIC_RELAXED);
+}
+
 int fetch(ms_ctx* c) {
   if (c->tile1 > c->tile0) {
     for (long spin = 0; spin < 20000000L; ++spin) {
       bool done = true;
       for (int sl = 0; sl < MS_NSCAL; ++sl)
-        if (__atomic_load_n(&c->h_seq[sl], __ATOMIC_ACQUIRE) < c->expected[sl]) {
+        if (__atomic_load_n(&c->h_seq[2 * sl + 1], __ATOMIC_ACQUIRE) < c->expected[sl]) {
           done = false;
           break;
         }
-      if (done) return MS_OK;
+      if (done) return take_mailbox(c);
       __builtin_ia32_pause();
     }
   }
@@ -691,9 +710,9 @@ int fetch(ms_ctx* c) {
   // everything queued has run: a slot that is still behind belongs to a gated launch that found its gate closed
   // although the host expected it to run -- host and device disagreed on an Armijo test.  Never continue on that.
   for (int sl = 0; sl < MS_NSCAL; ++sl)
-    if (c->tile1 > c->tile0 && __atomic_load_n(&c->h_seq[sl], __ATOMIC_ACQUIRE) < c->expected[sl])
+    if (c->tile1 > c->tile0 && __atomic_load_n(&c->h_seq[2 * sl + 1], __ATOMIC_ACQUIRE) < c->expected[sl])
       return fail(c, MS_ERR_STATE, "line-search queue: a gated launch the host waited for did not run");
-  return MS_OK;
+  return take_mailbox(c);
 }
 
 double penalty_energy(const ms_ctx* c, double V) {
@@ -908,13 +927,10 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
   CREATE_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_scal), sizeof(double) * MS_NSCAL));
   CREATE_HIP(hipMemset(c->d_scal, 0, sizeof(double) * MS_NSCAL));
   c->buf[MS_BUF_SCAL] = c->d_scal;
-  CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scal), sizeof(double) * MS_NSCAL,
+  c->h_scal = static_cast<double*>(calloc(MS_NSCAL, sizeof(double)));
+  CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_seq), sizeof(unsigned long long) * 2 * MS_NSCAL,
                            hipHostMallocMapped));
-  memset(c->h_scal, 0, sizeof(double) * MS_NSCAL);
-  CREATE_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_scal), c->h_scal, 0));
-  CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_seq), sizeof(unsigned long long) * MS_NSCAL,
-                           hipHostMallocMapped));
-  memset(c->h_seq, 0, sizeof(unsigned long long) * MS_NSCAL);
+  memset(c->h_seq, 0, sizeof(unsigned long long) * 2 * MS_NSCAL);
   CREATE_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_seq), c->h_seq, 0));
   CREATE_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_stage), sizeof(double) * 3 * (size_t)nv));
   {
@@ -1005,13 +1021,13 @@ void ms_destroy(ms_ctx* c) {
   if (c->h_scal_all) (void)hipHostFree(c->h_scal_all);
   if (c->h_xseq) (void)hipHostFree(c->h_xseq);
   for (auto& m : c->spec) {
-    if (m.h_scal) (void)hipHostFree(m.h_scal);
+    free(m.h_scal);
     if (m.h_seq) (void)hipHostFree(m.h_seq);
   }
-  if (c->grad_mb.h_scal) (void)hipHostFree(c->grad_mb.h_scal);
+  free(c->grad_mb.h_scal);
   if (c->grad_mb.h_seq) (void)hipHostFree(c->grad_mb.h_seq);
   if (c->d_gate) (void)hipFree(c->d_gate);
-  if (c->h_scal) (void)hipHostFree(c->h_scal);
+  free(c->h_scal);
   if (c->h_seq) (void)hipHostFree(c->h_seq);
   for (auto& r : c->prof_pending) {
     (void)hipEventDestroy(r.a);
@@ -1723,12 +1739,10 @@ int spec_prepare(ms_ctx* c) {
   boxes[ms_ctx::SPEC_STAGES] = &c->grad_mb;
   for (ms_ctx::Mailbox* mp : boxes) {
     ms_ctx::Mailbox& m = *mp;
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&m.h_scal), sizeof(double) * MS_NSCAL, hipHostMallocMapped));
-    memset(m.h_scal, 0, sizeof(double) * MS_NSCAL);
-    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&m.d_h_scal), m.h_scal, 0));
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&m.h_seq), sizeof(unsigned long long) * MS_NSCAL,
+    m.h_scal = static_cast<double*>(calloc(MS_NSCAL, sizeof(double)));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&m.h_seq), sizeof(unsigned long long) * 2 * MS_NSCAL,
                             hipHostMallocMapped));
-    memset(m.h_seq, 0, sizeof(unsigned long long) * MS_NSCAL);
+    memset(m.h_seq, 0, sizeof(unsigned long long) * 2 * MS_NSCAL);
     HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&m.d_h_seq), m.h_seq, 0));
   }
   return MS_OK;
@@ -1736,7 +1750,6 @@ int spec_prepare(ms_ctx* c) {
 // make stage mailbox `m` the context's mailbox (and back: the swap is its own inverse)
 void swap_mailbox(ms_ctx* c, ms_ctx::Mailbox& m) {
   std::swap(c->h_scal, m.h_scal);
-  std::swap(c->d_h_scal, m.d_h_scal);
   std::swap(c->h_seq, m.h_seq);
   std::swap(c->d_h_seq, m.d_h_seq);
   for (int sl = 0; sl < MS_NSCAL; ++sl) std::swap(c->expected[sl], m.expected[sl]);
@@ -1790,7 +1803,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     for (int sl = 0; sl < MS_NSCAL; ++sl) vals[sl] = c->h_scal[sl];
     swap_mailbox(c, c->grad_mb);
     for (int sl = 0; sl < MS_NSCAL; ++sl)
-      if (MASK_DIR & (1u << sl)) c->h_scal[sl] = vals[sl];
+      if (MASK_DIR & (1u << sl)) put_mailbox(c, sl, vals[sl]);
     c->last_g = c->buf[MS_BUF_G];
     c->dir_implicit = false;
     c->maxg2_valid = true;
@@ -1988,7 +2001,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       if (j > 0) swap_mailbox(c, c->spec[j - 1]);
       if (rc) return rc;
       for (int sl = 0; sl < MS_NSCAL; ++sl)
-        if (MASK_ENERGY & (1u << sl)) c->h_scal[sl] = vals[sl];
+        if (MASK_ENERGY & (1u << sl)) put_mailbox(c, sl, vals[sl]);
       ++out->trials;
       energies_from_mailbox(c, e);
       const double E_t = e[0] + e[1] + e[2] + e[3];
@@ -2590,7 +2603,7 @@ int ms_fetch_scalars(ms_ctx* c, double* out) {
 
 int ms_store_scalars(ms_ctx* c, const double* in) {
   if (!c || !in) return MS_ERR_INVALID;
-  memcpy(c->h_scal, in, sizeof(double) * MS_NSCAL);
+  for (int sl = 0; sl < MS_NSCAL; ++sl) put_mailbox(c, sl, in[sl]);
   c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
   c->sh_carry_valid = c->sh_grad_valid = false;
   HIPCHK(c, hipMemcpyAsync(c->d_scal, c->h_scal, sizeof(double) * MS_NSCAL, hipMemcpyHostToDevice,

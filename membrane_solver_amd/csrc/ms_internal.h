@@ -225,8 +225,8 @@ hipError_t launch_tvec(int mode, int tile0, int tile1, int nv, int T, const uint
                        int n_tiles, hipStream_t s, uint8_t fixed_bit = VF_TILT_FIXED,
                        int s_gn2 = MS_S_TGNORM2, int s_rz = MS_S_TRZ);
 hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
-                         uint32_t slot_mask, double* scal, double* host_mirror,
-                         unsigned long long* host_seq, unsigned long long ticket, hipStream_t s,
+                         uint32_t slot_mask, double* scal, unsigned long long* host_box,
+                         unsigned long long ticket, hipStream_t s,
                          const int* gate = nullptr);
 
 hipError_t launch_pack_boundary(const int32_t* rows, int n_rows, const double* const* bufs,

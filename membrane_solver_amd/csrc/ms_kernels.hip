@@ -2043,8 +2043,7 @@ hipError_t launch_disk_target(const DiskTargetArgs& a, int mode, hipStream_t s) 
 constexpr int RBLOCK = 512;  // 512 threads x 8 loads in flight cover 4096 tiles in one round trip
 __global__ __launch_bounds__(RBLOCK) void k_reduce(const double* partials, int n_tiles, int tile0,
                                                   int tile1, uint32_t slot_mask, double* scal,
-                                                  double* host_mirror,
-                                                  unsigned long long* host_seq,
+                                                  unsigned long long* host_box,
                                                   unsigned long long ticket, const int* gate) {
   __shared__ double red[16];
   if (gate != nullptr && *gate == 0) return;
@@ -2089,23 +2088,26 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(const double* partials, int n
   if (threadIdx.x == 0) {
     const double r = (slot == MS_S_VOL) ? v / 6.0 : v;
     scal[slot] = r;
-    if (host_mirror) {
-      // pinned, device-mapped mailbox: the value, a system-scope fence, then this slot's
-      // sequence word -- the host polls the sequence word instead of synchronising the stream
-      host_mirror[slot] = r;
-      __threadfence_system();
-      *reinterpret_cast<volatile unsigned long long*>(&host_seq[slot]) = ticket;
+    if (host_box) {
+      // pinned, device-mapped mailbox: {value, sequence word} of a slot share one 16-byte entry and leave in ONE
+      // 16-byte store, so the host can never see the new sequence word next to the old value and no system-scope
+      // fence has to drain between the two -- the host polls the sequence word instead of synchronising the stream
+      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+      u64x2 e;
+      e.x = (unsigned long long)__double_as_longlong(r);
+      e.y = ticket;
+      __builtin_nontemporal_store(e, reinterpret_cast<u64x2*>(host_box) + slot);
     }
   }
 }
 
 hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
-                         uint32_t slot_mask, double* scal, double* host_mirror,
-                         unsigned long long* host_seq, unsigned long long ticket, hipStream_t s, const int* gate) {
+                         uint32_t slot_mask, double* scal, unsigned long long* host_box,
+                         unsigned long long ticket, hipStream_t s, const int* gate) {
   const int nslots = __builtin_popcount(slot_mask);
   if (nslots == 0) return hipSuccess;
   hipLaunchKernelGGL(k_reduce, dim3(nslots), dim3(RBLOCK), 0, s, partials, n_tiles, tile0, tile1,
-                     slot_mask, scal, host_mirror, host_seq, ticket, gate);
+                     slot_mask, scal, host_box, ticket, gate);
   return hipGetLastError();
 }
 
