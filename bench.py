@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--volume", action="store_true", help="add the volume Lagrange constraint row")
     ap.add_argument("--cpu-steps", type=int, default=6, help="CPU oracle steps for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the secondary sections (reuse level 0, deterministic mode): for kernel traces")
     ap.add_argument("--reuse-level", type=int, default=2, choices=(0, 1, 2),
                     help="ms_stepper_params.reuse_energy0: 0 repeats every pass the reference repeats, "
                          "2 (library default) never repeats a pass whose result is already on the device")
@@ -61,6 +63,9 @@ def algorithmic_bytes(nv, nf, volume=False):
         # trial energy that also writes the factors (reuse level 2: an accepted trial is the
         # next step's energy pass)
         "energy_trial_factors": 20 * nf + (48 + 16 + 1) * nv + 24 * nv + 40 * nv,
+        # pair launch: two trial evaluations of one line search in one launch -- the inputs are
+        # compulsory ONCE (the second evaluation's reads are meant to hit L2), the outputs twice
+        "energy_pair": 20 * nf + (48 + 16 + 1) * nv + 2 * (24 + 40) * nv,
         # gradient (+ fused direction pass when no constraint row): x 24 + fK,fA 40 + flags 1 in,
         # g 24 and d 24 out.  The CG-history reads (pg, pd: 48 B/vertex on non-restart steps) are
         # NOT counted, so the figure is a lower bound of the compulsory traffic.
@@ -68,7 +73,12 @@ def algorithmic_bytes(nv, nf, volume=False):
     }
 
 
-def pmc_traffic(kernel_prefix, deterministic=False):
+def _template_args(name):
+    i, j = name.find("<"), name.rfind(">")
+    return [a.strip() for a in name[i + 1:j].split(",")] if 0 <= i < j else []
+
+
+def pmc_traffic(kernel_prefix, deterministic=False, pair=False):
     """HBM bytes per launch of one kernel from the committed rocprofv3 PMC summary
     (profiles/<tag>_pmc_summary.csv; separate FETCH_SIZE / WRITE_SIZE passes of this same
     bench command).  gfx950 correction: FETCH_SIZE counts 1/2 of the fetched bytes
@@ -85,8 +95,12 @@ def pmc_traffic(kernel_prefix, deterministic=False):
         for row in csv.reader(line for line in f if not line.startswith("#")):
             if len(row) < 4 or kernel_prefix not in row[1] or row[0] not in acc:
                 continue
-            # the last template argument selects the accumulation mode (true = LDS atomics)
-            if row[1].count(",") >= 4 and not row[1].rstrip().endswith(", false>" if deterministic else ", true>"):
+            # template arguments: the fifth selects the accumulation mode (true = LDS atomics), k_energy's sixth
+            # the pair launch
+            ta = _template_args(row[1])
+            if len(ta) >= 5 and ta[4] != ("false" if deterministic else "true"):
+                continue
+            if "k_energy" in kernel_prefix and (len(ta) >= 6 and ta[5] == "true") != pair:
                 continue
             n = float(row[2])
             acc[row[0]][0] += n * float(row[3])
@@ -181,7 +195,7 @@ def main():
     # -- the same K steps with every pass the reference repeats (reuse level 0): energy0
     #    re-evaluated, a fresh energy/factor pass after every accepted step, a full gradient
     #    pass after a failed search.  Same doubles out (tests/test_gpu_minimizer.py), more launches.
-    if args.reuse_level != 0:
+    if args.reuse_level != 0 and not args.headline_only:
         stepper.reuse_energy0 = 0
         mz.minimize(5, sync_mesh=False)
         torch.cuda.synchronize()
@@ -196,7 +210,7 @@ def main():
     # -- the same K steps with fixed-order (bitwise reproducible) vertex sums -------------------
     mir = mesh._hip_mirror
     dm = mir.dm
-    if not args.deterministic:
+    if not args.deterministic and not args.headline_only:
         mz.deterministic = True
         mz.minimize(5, sync_mesh=False)
         torch.cuda.synchronize()
@@ -230,8 +244,13 @@ def main():
         # without the factor write) and trial passes -> weight by what was actually launched
         n_e = prof["energy"][1]
         n_g = prof["gradient"][1]
+        n_p = prof.get("energy_pair", (0.0, 0))[1]
+        if n_p:
+            kernels["energy_pair"]["algorithmic_bytes"] = ab["energy_pair"]
+            kernels["energy_pair"]["GBps"] = ab["energy_pair"] / (kernels["energy_pair"]["avg_us"] * 1e-6) / 1e9
+            kernels["energy_pair"]["evaluations_per_launch"] = 2
         if n_e:
-            n_trial = min(n_e, stats["trial_passes"])
+            n_trial = min(n_e, max(0, stats["trial_passes"] - 2 * n_p))
             n_plain = n_e - n_trial
             level = int(stepper.reuse_energy0)
             n_fact = min(n_plain, n_g)          # factor-writing passes at x
@@ -244,12 +263,15 @@ def main():
         if n_g:
             kernels["gradient"]["algorithmic_bytes"] = ab["gradient"]
             kernels["gradient"]["GBps"] = ab["gradient"] / (kernels["gradient"]["avg_us"] * 1e-6) / 1e9
-        dom = max((k for k in ("energy", "gradient") if k in kernels),
+        dom = max((k for k in ("energy", "energy_pair", "gradient") if k in kernels),
                   key=lambda k: kernels[k]["share_of_profiled_ms"])
         ach = kernels[dom]["GBps"]
-        traffic, traffic_src = pmc_traffic({"energy": "ms::k_energy", "gradient": "ms::k_gradient"}[dom],
-                                           deterministic=bool(args.deterministic))
-        out["roofline"] = {"bound": "hbm", "kernel": {"energy": "ms::k_energy* (energy pass)",
+        traffic, traffic_src = pmc_traffic({"energy": "ms::k_energy", "energy_pair": "ms::k_energy",
+                                            "gradient": "ms::k_gradient"}[dom],
+                                           deterministic=bool(args.deterministic), pair=dom == "energy_pair")
+        out["roofline"] = {"bound": "hbm", "kernel": {"energy": "ms::k_energy<.., PAIR=false> (energy pass)",
+                                                     "energy_pair": "ms::k_energy<.., PAIR=true> (energy pass, two "
+                                                                    "trial evaluations per launch)",
                                                      "gradient": "ms::k_gradient* (gradient pass)"}[dom],
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

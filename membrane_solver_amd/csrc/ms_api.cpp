@@ -94,7 +94,26 @@ struct ms_ctx {
   int* d_gate = nullptr;         // SPEC_STAGES + 1 gate words + the "accepted" word
   const int* cur_gate = nullptr; // gate word of the k_reduce launches being queued (nullptr: unconditional)
   double cur_gate_rhs = 0.0;     // Armijo right-hand side the gated tile kernel tests the device scalars against
+  // pair launch: when the last search needed two or more trials, the first two are evaluated in ONE energy launch
+  // (k_energy<PAIR>); the second trial uses the ordinary outputs, the first one the "2" set below
+  bool pair_enable = true;       // MS_PAIR=0 switches it off
+  bool pair_force = false;       // MS_PAIR=2: pair whenever possible, whatever the history predicts (tests)
+  bool pair_on = false;          // phase_energy / reduce_slots: queue a pair (second evaluation at pair_alpha2)
+  double pair_alpha2 = 0.0;
+  double* xt2 = nullptr;
+  double* fK2 = nullptr;
+  double* fA2 = nullptr;
+  double* d_partials2 = nullptr;
+  double* d_scal2 = nullptr;
+  const double* cur_veto = nullptr;  // gradient pass behind a pair: do not run if these energies pass cur_veto_rhs
+  double cur_veto_rhs = 0.0;
   int pred_trials = 1;           // trials the last successful search needed
+  // line-search history of the last LS_HIST accepted steps (prediction only -- never changes a result):
+  // the accepted alpha and the smallest alpha rejected on the way to it (INFINITY: accepted at once)
+  static constexpr int LS_HIST = 8;
+  double ls_acc[LS_HIST] = {0};
+  double ls_rej[LS_HIST] = {0};
+  int ls_n = 0;
   bool speculate = true;         // MS_SPECULATE=0 switches the ladder off
   bool relax_va_valid = false;  // a leaflet relaxation is running: tf[l].va describes the current x
   int factors_leaflet = 0;  // which leaflet's back-prop factors fK/fA hold (1 in, 2 out; 0: not a leaflet's)
@@ -412,6 +431,13 @@ int reduce_slots(ms_ctx* c, uint32_t mask) {
   ++c->ticket;
   for (int sl = 0; sl < MS_NSCAL; ++sl)
     if (mask & (1u << sl)) c->expected[sl] = c->ticket;
+  if (c->pair_on) {
+    for (int sl = 0; sl < MS_NSCAL; ++sl)
+      if (mask & (1u << sl)) c->spec[0].expected[sl] = c->ticket;
+    HIPCHK(c, launch_reduce(c->d_partials, c->til.n_tiles, c->tile0, c->tile1, mask, c->d_scal, c->d_h_seq,
+                            c->ticket, c->stream, nullptr, c->d_partials2, c->d_scal2, c->spec[0].d_h_seq));
+    return MS_OK;
+  }
   HIPCHK(c, launch_reduce(c->d_partials, c->til.n_tiles, c->tile0, c->tile1, mask, c->d_scal,
                           c->d_h_seq, c->ticket, c->stream, c->cur_gate));
   return MS_OK;
@@ -441,12 +467,25 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   a.gate_mods = c->params.modules;
   a.gate_out = const_cast<int*>(c->cur_gate);
   a.atomic = c->deterministic ? 0 : 1;
+  a.pair = 0;
+  a.alpha2 = 0.0;
+  a.xt2 = a.fK2 = a.fA2 = a.partials2 = nullptr;
+  if (c->pair_on) {
+    if (!use_dir || !write_trial || guard || !write_factors || !(modules & MS_MOD_BENDING) || bt || lbt || !c->xt2)
+      return fail(c, MS_ERR_STATE, "pair launch: not an ordinary bending trial");
+    a.pair = 1;
+    a.alpha2 = trial_alpha(c, c->pair_alpha2);
+    a.xt2 = c->xt2;
+    a.fK2 = c->fK2;
+    a.fA2 = c->fA2;
+    a.partials2 = c->d_partials2;
+  }
   if (bt && !c->d_bt_vert) return fail(c, MS_ERR_STATE, "bending_tilt: ms_set_params did not allocate its buffers");
   a.partials = c->d_partials;
   a.bending_model = c->params.bending_model;
   a.modules = modules;
   if (!lbt) {
-    ProfScope ps(c, 0, c->cur_gate != nullptr);
+    ProfScope ps(c, a.pair ? 7 : 0, c->cur_gate != nullptr);
     HIPCHK(c, launch_energy(a, guard && use_dir, c->cap, c->til.max_ent, c->stream));
   } else {
     // leaflet bending_tilt: the tilt projections and the unit vertex normals of the evaluated positions come
@@ -598,6 +637,8 @@ int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulat
   a.gate_rhs = c->cur_gate_rhs;
   a.gate_mods = c->params.modules;
   a.gate_out = const_cast<int*>(c->cur_gate);
+  a.veto_scal = c->cur_gate ? c->cur_veto : nullptr;
+  a.veto_rhs = c->cur_veto_rhs;
   a.atomic = c->deterministic ? 0 : 1;
   a.bt_vert = nullptr;
   a.tilts = nullptr;
@@ -984,6 +1025,10 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
     f2.mod_bt = MS_MOD_BENDING_TILT_OUT; f2.s_ebt = MS_S_EBT_OUT; f2.div_sign = 1.0;
     f2.mod_dt = MS_MOD_TILT_DISK_TARGET_OUT; f2.s_edt = MS_S_EDT_OUT; f2.s_dtr = MS_S_DTR_OUT;
   }
+  if (const char* pe = getenv("MS_PAIR")) {
+    c->pair_enable = atoi(pe) != 0;
+    c->pair_force = atoi(pe) == 2;
+  }
   c->speculate = !(getenv("MS_SPECULATE") != nullptr && atoi(getenv("MS_SPECULATE")) == 0);
   c->deterministic = getenv("MS_DETERMINISTIC") != nullptr && atoi(getenv("MS_DETERMINISTIC")) != 0;
   c->params.modules = MS_MOD_SURFACE;
@@ -1027,6 +1072,8 @@ void ms_destroy(ms_ctx* c) {
   free(c->grad_mb.h_scal);
   if (c->grad_mb.h_seq) (void)hipHostFree(c->grad_mb.h_seq);
   if (c->d_gate) (void)hipFree(c->d_gate);
+  for (double* q : {c->xt2, c->fK2, c->fA2, c->d_partials2, c->d_scal2})
+    if (q) (void)hipFree(q);
   free(c->h_scal);
   if (c->h_seq) (void)hipHostFree(c->h_seq);
   for (auto& r : c->prof_pending) {
@@ -1732,6 +1779,17 @@ int ms_reset_stepper(ms_ctx* c) {
 namespace {
 int spec_prepare(ms_ctx* c) {
   if (c->d_gate) return MS_OK;
+  if (c->pair_enable) {
+    const size_t nvp = (size_t)std::max<int64_t>(1, c->til.nvp);
+    const size_t pb = sizeof(double) * MS_NSCAL * (size_t)std::max(1, c->til.n_tiles);
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->xt2), sizeof(double) * 3 * nvp));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->fK2), sizeof(double) * 3 * nvp));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->fA2), sizeof(double) * 2 * nvp));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_partials2), pb));
+    HIPCHK(c, hipMemset(c->d_partials2, 0, pb));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_scal2), sizeof(double) * MS_NSCAL));
+    HIPCHK(c, hipMemset(c->d_scal2, 0, sizeof(double) * MS_NSCAL));
+  }
   HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_gate), sizeof(int) * (ms_ctx::SPEC_STAGES + 3)));
   HIPCHK(c, hipMemset(c->d_gate, 0, sizeof(int) * (ms_ctx::SPEC_STAGES + 3)));
   ms_ctx::Mailbox* boxes[ms_ctx::SPEC_STAGES + 1];
@@ -1863,6 +1921,15 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   const double alpha_max = sp->alpha_max_factor * step_size;
   const int max_iter = sp->max_iter > 0 ? sp->max_iter : 10;
   bool kc_queued = false;  // the next step's gradient pass is in the queue, gated on an acceptance
+  double min_rejected = INFINITY;  // smallest alpha this search has rejected
+  // what the recent searches say about the acceptance threshold: no alpha above a_hi was accepted, and alphas
+  // down to r_lo were rejected (INFINITY: nothing was rejected lately -- the step size is still growing)
+  double a_hi = 0.0, r_lo = INFINITY;
+  for (int k = 0; k < std::min(c->ls_n, (int)ms_ctx::LS_HIST); ++k) {
+    a_hi = std::max(a_hi, c->ls_acc[k]);
+    r_lo = std::min(r_lo, c->ls_rej[k]);
+  }
+  const bool ls_warm = c->ls_n >= 2;
   // what an accepted trial at `alpha` does (positions, carry flags, CG history, result fields)
   auto accept = [&](double alpha_acc, double E_t) {
     std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
@@ -1889,12 +1956,15 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     out->volume = c->h_scal[MS_S_VOL];
     out->next_step = std::min(alpha_acc * sp->gamma, alpha_max);
     c->pred_trials = std::max(1, out->trials);
+    c->ls_acc[c->ls_n % ms_ctx::LS_HIST] = alpha_acc;
+    c->ls_rej[c->ls_n % ms_ctx::LS_HIST] = min_rejected;
+    ++c->ls_n;
     c->kc_pending = kc_queued;
   };
   // the ladder needs: carry mode (a trial is a complete energy pass), energies the device can add up the way the
   // host does (surface + bending only), no tilt projections between trials
   const bool can_chain = c->speculate && carry_mode && !tilt && !(c->params.modules & MS_MOD_VOLUME_PENALTY);
-  const bool can_spec = can_chain && c->pred_trials > 1;
+  const bool can_spec = can_chain && (c->pair_force || (ls_warm ? r_lo < INFINITY : c->pred_trials > 1));
   // ... and the fused gradient + direction pass of the accepted point can follow in the same queue (no
   // constraint row to reduce first), gated on "some stage accepted"
   const bool can_spec_kc = can_chain && !constraint;
@@ -1907,8 +1977,13 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     alphas[0] = alpha;
     if (can_spec && safe_small) {
       // queue the trials the last search needed; each further stage must be an ordinary (unguarded) trial
-      const int want = std::min({c->pred_trials - out->trials, 1 + ms_ctx::SPEC_STAGES, max_iter - it});
+      // how many trials to queue: as many as the last search needed (cold), or -- once there is a history --
+      // one per alpha that still lies above (most of) the range where alphas were accepted lately
+      const int room = std::min(1 + ms_ctx::SPEC_STAGES, max_iter - it);
+      const int want = c->pair_force ? std::min(2, room)
+                                     : (ls_warm ? room : std::min(c->pred_trials - out->trials, room));
       while (depth < want) {
+        if (!c->pair_force && ls_warm && !(alphas[depth - 1] > 0.9 * a_hi)) break;
         const double a_next = alphas[depth - 1] * sp->beta;
         if (a_next < 1e-8) break;
         alphas[depth++] = a_next;
@@ -1919,6 +1994,13 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       rc = spec_prepare(c);
       if (rc) return rc;
     }
+    // two or more trials expected: the first two share one launch (and the ladder stops there for this round)
+    // ... and only when the first one is expected to fail: it lies above every alpha accepted lately, and alphas
+    // were rejected lately (a wasted evaluation costs more than a saved round trip gains)
+    const bool pair = chain && depth > 1 && c->pair_enable && c->xt2 != nullptr &&
+                      (c->params.modules & MS_MOD_BENDING) != 0 &&
+                      (c->pair_force || (ls_warm && alpha > a_hi && r_lo < INFINITY));
+    if (pair) depth = 2;
     if (!chain) {
       rc = phase_energy(c, c->params.modules, true, alpha, true, !safe_small, carry_mode);
       if (rc) return rc;
@@ -1926,6 +2008,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       if (rc) return rc;
       if (!safe_small && c->h_scal[MS_S_GUARD] > 0.0) {
         ++out->guard_rejects;
+        min_rejected = alpha;
         alpha *= sp->beta;
         ++it;
         if (alpha < 1e-8) break;
@@ -1941,6 +2024,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       // a rejected trial restores the positions, not the tilts: energy_fn stored their projection
       // onto the trial surface (line_search.py:456-487 without an enforcer)
       for (int k = 0; k < n_tf; ++k) std::swap(tfl[k]->tilts, tfl[k]->trial);
+      min_rejected = alpha;
       alpha *= sp->beta;
       ++it;
       if (alpha < 1e-8) break;
@@ -1949,7 +2033,17 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     // ---- speculative ladder: queue `depth` trials, stage j > 0 gated on the rejection of stage j-1 ----
     double rhs[1 + ms_ctx::SPEC_STAGES];
     int* const d_acc = c->d_gate + ms_ctx::SPEC_STAGES + 2;
-    for (int j = 0; j < depth; ++j) {
+    if (pair) {
+      // trial 0 -> the "2" outputs and spec[0]'s mailbox, trial 1 -> the ordinary outputs and the main mailbox
+      rhs[0] = energy0 + sp->c * alphas[0] * g_dot_d;
+      rhs[1] = energy0 + sp->c * alphas[1] * g_dot_d;
+      c->pair_on = true;
+      c->pair_alpha2 = alphas[0];
+      rc = phase_energy(c, c->params.modules, true, alphas[1], true, false, carry_mode);
+      c->pair_on = false;
+      if (rc) return rc;
+    }
+    for (int j = 0; j < depth && !pair; ++j) {
       rhs[j] = energy0 + sp->c * alphas[j] * g_dot_d;
       if (j > 0) swap_mailbox(c, c->spec[j - 1]);
       c->cur_gate = j > 0 ? c->d_gate + j : nullptr;  // stage j > 0 runs iff stage j-1 failed its Armijo test
@@ -1975,8 +2069,12 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       swap_mailbox(c, c->grad_mb);
       c->cur_gate = d_acc;  // runs iff the energies left in device memory pass the last stage's test
       c->cur_gate_rhs = rhs[depth - 1];
+      // behind a pair the pass evaluates trial 1's point: it must also stay out when trial 0 was accepted
+      c->cur_veto = pair ? c->d_scal2 : nullptr;
+      c->cur_veto_rhs = rhs[0];
       rc = phase_gradient(c, c->params.modules, c->buf[MS_BUF_G], false, next_hist ? 2 : 1, /*reduce_now=*/true);
       c->cur_gate = nullptr;
+      c->cur_veto = nullptr;
       swap_mailbox(c, c->grad_mb);
       if (cg) {
         std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
@@ -1991,6 +2089,48 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       kc_queued = true;
       c->kc_stepper = sp->stepper;
       c->kc_use_history = next_hist;
+    }
+    if (pair) {
+      // trial 0 reported to spec[0]'s mailbox, trial 1 to the main one (same fold: both have landed together)
+      double v0[MS_NSCAL], v1[MS_NSCAL];
+      swap_mailbox(c, c->spec[0]);
+      rc = fetch(c);
+      memcpy(v0, c->h_scal, sizeof(v0));
+      swap_mailbox(c, c->spec[0]);
+      if (rc) return rc;
+      rc = fetch(c);
+      if (rc) return rc;
+      memcpy(v1, c->h_scal, sizeof(v1));
+      for (int j = 0; j < 2; ++j) {
+        const double* vals = j == 0 ? v0 : v1;
+        for (int sl = 0; sl < MS_NSCAL; ++sl)
+          if (MASK_ENERGY & (1u << sl)) put_mailbox(c, sl, vals[sl]);
+        ++out->trials;
+        energies_from_mailbox(c, e);
+        const double E_t = e[0] + e[1] + e[2] + e[3];
+        if (!(E_t <= rhs[j])) {
+          min_rejected = alphas[j];
+          continue;
+        }
+        if (j == 0) {
+          // the unexpected case: trial 0's positions and factors are in the "2" buffers, and the queued gradient
+          // pass vetoed itself
+          const size_t nvp = (size_t)c->til.nvp;
+          HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_XT], c->xt2, sizeof(double) * 3 * nvp, hipMemcpyDeviceToDevice,
+                                   c->stream));
+          HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FK], c->fK2, sizeof(double) * 3 * nvp, hipMemcpyDeviceToDevice,
+                                   c->stream));
+          HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FA], c->fA2, sizeof(double) * 2 * nvp, hipMemcpyDeviceToDevice,
+                                   c->stream));
+          kc_queued = false;
+        }
+        accept(alphas[j], E_t);
+        return MS_OK;
+      }
+      alpha = alphas[1] * sp->beta;
+      it += 2;
+      if (alpha < 1e-8) break;
+      continue;
     }
     bool accepted = false;
     for (int j = 0; j < depth; ++j) {
@@ -2010,6 +2150,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
         accepted = true;
         break;
       }
+      min_rejected = alphas[j];
     }
     if (accepted) return MS_OK;
     alpha = alphas[depth - 1] * sp->beta;

@@ -249,9 +249,25 @@ __device__ __forceinline__ void csr_commit(const CsrStage& r, const DeviceMesh& 
 // ---------------------------------------------------------------------------
 // TT / CAPC: compile-time tile size and LDS patch capacity (0 = take the runtime values);
 // with constants every LDS address becomes base + immediate offset.
-template <bool BEND, bool GUARD, int TT, int CAPC, bool ATOMIC>
+// PAIR: two trial evaluations of one line search in ONE launch (grid = 2 x tiles): the workgroups of a tile's two
+// evaluations sit 8 apart in the launch order -- same XCD, dispatched together -- so the second read of the
+// tile's x / d / facet rows hits that XCD's L2.  The odd ones evaluate at alpha2 into the "2" outputs.
+template <bool BEND, bool GUARD, int TT, int CAPC, bool ATOMIC, bool PAIR = false>
 __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyArgs a, int cap_rt, int max_ent) {
   extern __shared__ double lds[];
+  int bid = blockIdx.x;
+  if (PAIR) {
+    const int k = bid % NXCD, j2 = bid / NXCD;
+    bid = (j2 >> 1) * NXCD + k;
+    if (bid >= a.tile1 - a.tile0) return;
+    if (j2 & 1) {
+      a.alpha = a.alpha2;
+      a.xt = a.xt2;
+      a.fK = a.fK2;
+      a.fA = a.fA2;
+      a.partials = a.partials2;
+    }
+  }
   const int T = TT ? TT : a.m.T;  // == blockDim.x
   const int cap = CAPC ? CAPC : cap_rt;
   double* px = lds;
@@ -277,7 +293,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
     if (!run) return;
   }
 
-  const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
+  const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(bid, a.tile1 - a.tile0));
   const int tid = threadIdx.x;
   const bool have_d = a.d != nullptr;
 
@@ -701,6 +717,24 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
     if (fast) MS_LAUNCH_E(B, G, FAST_T, FAST_CAP, AT);    \
     else MS_LAUNCH_E(B, G, 0, 0, AT);                     \
   } while (0)
+  if (a.pair) {
+    // pair launch: bending factors on, no guard (the caller checked both)
+    if (!bend || guard) return hipErrorInvalidValue;
+    const int nb2 = 2 * NXCD * ((nb + NXCD - 1) / NXCD);
+#define MS_LAUNCH_P(TT, CC, AT)                                                                              \
+  do {                                                                                                       \
+    e = ensure_lds(k_energy<true, false, TT, CC, AT, true>, lds);                                            \
+    if (e != hipSuccess) return e;                                                                           \
+    hipLaunchKernelGGL((k_energy<true, false, TT, CC, AT, true>), dim3(nb2), dim3(a.m.T), lds, s, a, cap, max_ent); \
+  } while (0)
+    if (atomic) {
+      if (fast) MS_LAUNCH_P(FAST_T, FAST_CAP, true); else MS_LAUNCH_P(0, 0, true);
+    } else {
+      if (fast) MS_LAUNCH_P(FAST_T, FAST_CAP, false); else MS_LAUNCH_P(0, 0, false);
+    }
+#undef MS_LAUNCH_P
+    return hipGetLastError();
+  }
   if (bend && atomic) {
     if (guard) MS_PICK_E(true, true, true); else MS_PICK_E(true, false, true);
   } else if (bend) {
@@ -756,7 +790,14 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
   if (a.gate_scal != nullptr) {
     const double E_last = ((a.gate_mods & MS_MOD_SURFACE) ? a.gate_scal[MS_S_ESURF] : 0.0) +
                           ((a.gate_mods & MS_MOD_BENDING) ? a.gate_scal[MS_S_EBEND] : 0.0);
-    const bool run = E_last <= a.gate_rhs;
+    bool run = E_last <= a.gate_rhs;
+    if (a.veto_scal != nullptr) {
+      // pair launch: gate_scal holds the SECOND trial's energies; the pass belongs to it only if the first trial
+      // (energies in veto_scal) was rejected -- otherwise the accepted point is the first trial's
+      const double E_first = ((a.gate_mods & MS_MOD_SURFACE) ? a.veto_scal[MS_S_ESURF] : 0.0) +
+                             ((a.gate_mods & MS_MOD_BENDING) ? a.veto_scal[MS_S_EBEND] : 0.0);
+      run = run && !(E_first <= a.veto_rhs);
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.gate_out) *a.gate_out = run ? 1 : 0;
     if (!run) return;
   }
@@ -2044,14 +2085,23 @@ constexpr int RBLOCK = 512;  // 512 threads x 8 loads in flight cover 4096 tiles
 __global__ __launch_bounds__(RBLOCK) void k_reduce(const double* partials, int n_tiles, int tile0,
                                                   int tile1, uint32_t slot_mask, double* scal,
                                                   unsigned long long* host_box,
-                                                  unsigned long long ticket, const int* gate) {
+                                                  unsigned long long ticket, const int* gate,
+                                                  const double* partials2, double* scal2,
+                                                  unsigned long long* host_box2) {
   __shared__ double red[16];
   if (gate != nullptr && *gate == 0) return;
+  int rb = blockIdx.x;
+  if (partials2 != nullptr && rb >= __popc(slot_mask)) {  // second set of a pair launch
+    rb -= __popc(slot_mask);
+    partials = partials2;
+    scal = scal2;
+    host_box = host_box2;
+  }
   // one workgroup per requested slot; partials are slot-major so lanes read
   // consecutive doubles.
   int slot = -1;
   {
-    int k = blockIdx.x;
+    int k = rb;
     for (int s = 0; s < MS_NSCAL; ++s)
       if (slot_mask & (1u << s)) {
         if (k == 0) {
@@ -2103,11 +2153,12 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(const double* partials, int n
 
 hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
                          uint32_t slot_mask, double* scal, unsigned long long* host_box,
-                         unsigned long long ticket, hipStream_t s, const int* gate) {
+                         unsigned long long ticket, hipStream_t s, const int* gate, const double* partials2,
+                         double* scal2, unsigned long long* host_box2) {
   const int nslots = __builtin_popcount(slot_mask);
   if (nslots == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_reduce, dim3(nslots), dim3(RBLOCK), 0, s, partials, n_tiles, tile0, tile1,
-                     slot_mask, scal, host_box, ticket, gate);
+  hipLaunchKernelGGL(k_reduce, dim3(partials2 ? 2 * nslots : nslots), dim3(RBLOCK), 0, s, partials, n_tiles, tile0,
+                     tile1, slot_mask, scal, host_box, ticket, gate, partials2, scal2, host_box2);
   return hipGetLastError();
 }
 

@@ -448,7 +448,7 @@ class DeviceMesh:
         ms = np.zeros(8)
         n = np.zeros(8, dtype=np.int64)
         self._chk(L.lib().ms_profile_read(self._h, _pd(ms), n.ctypes.data_as(L._I64)), "ms_profile_read")
-        names = ("energy", "gradient", "direction", "reduce", "tilt", "bending_tilt", "tilt_vec", "other")
+        names = ("energy", "gradient", "direction", "reduce", "tilt", "bending_tilt", "tilt_vec", "energy_pair")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
     def shard_info(self):

@@ -232,9 +232,7 @@ def _body_facet_mask(mesh, nf):
     return mask, body
 
 
-def per_vertex_bending_params(mesh, global_params, model: str):
-    """modules/energy/bending_params.py:41-115 restated for both mesh kinds."""
-    nv = len(mesh.vertex_ids)
+def _bending_defaults(global_params, model: str):
     kappa_default = float(global_params.get("bending_modulus", 0.0) or 0.0)
     if model == "helfrich":
         val = global_params.get("spontaneous_curvature")
@@ -243,6 +241,13 @@ def per_vertex_bending_params(mesh, global_params, model: str):
         c0_default = float(val or 0.0)
     else:
         c0_default = 0.0
+    return kappa_default, c0_default
+
+
+def per_vertex_bending_params(mesh, global_params, model: str):
+    """modules/energy/bending_params.py:41-115 restated for both mesh kinds."""
+    nv = len(mesh.vertex_ids)
+    kappa_default, c0_default = _bending_defaults(global_params, model)
     kappa = np.full(nv, kappa_default)
     c0 = np.full(nv, c0_default)
     if hasattr(mesh, "get_vertex_parameter_array"):
@@ -333,6 +338,17 @@ class HipMirror:
         self._pos_version = getattr(self.mesh, "_version", None)
 
     def upload_surface_tension(self):
+        fp = getattr(self.mesh, "_facet_params", None)
+        if isinstance(fp, dict) and fp.get("surface_tension") is None:
+            # ArrayMesh without a per-facet array: one global value -- the key needs no nf-sized temporary
+            # (this runs at the top of every minimize() call)
+            val = float(self.mesh.global_parameters.get("surface_tension") or 0.0)
+            key = (self._topo_key, "uniform", val)
+            if key != self._gamma_key:
+                self.dm.set_surface_tension(np.asarray(self.mesh.get_facet_parameter_array("surface_tension"),
+                                                       dtype=np.float64))
+                self._gamma_key = key
+            return
         gamma = np.asarray(self.mesh.get_facet_parameter_array("surface_tension"), dtype=np.float64)
         key = (self._topo_key, gamma.tobytes() if gamma.size < 4096 else (float(gamma.sum()), float(gamma[0]), gamma.size))
         if key != self._gamma_key:
@@ -382,6 +398,14 @@ class HipMirror:
                           self._tilt_key[2] if getattr(self, "_tilt_key", None) else 0.0, None)
 
     def upload_bending_params(self, global_params, model: str):
+        get = getattr(self.mesh, "get_vertex_parameter_array", None)
+        if get is not None and get("bending_modulus") is None and (model != "helfrich"
+                                                                   or get("spontaneous_curvature") is None):
+            key = (self._topo_key, model, "uniform") + _bending_defaults(global_params, model)
+            if key != self._bend_key:
+                self.dm.set_bending_params(*per_vertex_bending_params(self.mesh, global_params, model))
+                self._bend_key = key
+            return
         kappa, c0 = per_vertex_bending_params(self.mesh, global_params, model)
         key = (self._topo_key, model, float(kappa.sum()), float(c0.sum()), float(kappa[0]), float(c0[0]))
         if key != self._bend_key:

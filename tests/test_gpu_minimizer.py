@@ -424,3 +424,48 @@ def test_topology_change_rebuilds_the_device_mirror(deterministic):
     res_b = mz_b.minimize(5)
     assert np.array_equal(mesh.positions_view(), mesh_b.positions_view())
     assert res["energy"] == res_b["energy"] and mz.step_size == mz_b.step_size
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_pair_launch_does_not_change_the_trajectory(mode, monkeypatch):
+    """Two trial evaluations in one launch (k_energy<PAIR>, ms_step): MS_PAIR=1 lets the line-search history decide,
+    MS_PAIR=2 pairs whenever it can (so trial 0 is accepted inside a pair now and then: the copy-back path) --
+    both must give the doubles of the one-trial-per-launch search, bit for bit with fixed-order sums."""
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+
+    pos, tri = meshgen.icosphere(24)
+    pos = meshgen.smooth_displace(pos, 0.05)
+    pos = pos + 2.0e-3 * np.random.default_rng(3).standard_normal(pos.shape)
+    nv = pos.shape[0]
+
+    def run(pair, speculate="1"):
+        monkeypatch.setenv("MS_PAIR", pair)
+        monkeypatch.setenv("MS_SPECULATE", speculate)
+        dm = DeviceMesh(pos, tri)
+        dm.set_deterministic(True)
+        dm.set_surface_tension(np.full(tri.shape[0], 1.0))
+        dm.set_bending_params(np.full(nv, 1.0), np.full(nv, 0.2))
+        dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING)
+        dm.profile_enable(True)
+        step, rows = 5.0e-2, []
+        for _ in range(70):
+            r = dm.step(stepper=L.MS_STEPPER_CG, step_size=step, reuse_energy0=2)
+            rows.append((r.success, r.trials, r.energy, r.energy_eval, r.grad_norm, r.g_dot_d, r.alpha))
+            step = r.next_step
+            if not r.success:
+                dm.reset_stepper()
+        prof = dm.profile_read()
+        x = dm.get_positions()
+        dm.close()
+        return np.array(rows, dtype=np.float64), x, prof
+
+    ref_rows, ref_x, ref_prof = run("0", "0")
+    assert ref_prof.get("energy_pair", (0.0, 0))[1] == 0
+    rows, x, prof = run(mode)
+    assert prof["energy_pair"][1] > 0, "the case is meant to exercise the pair launch"
+    assert np.array_equal(rows, ref_rows)
+    assert np.array_equal(x, ref_x)
+    acc = ref_rows[ref_rows[:, 0] == 1]
+    assert (acc[:, 1] == 1).any() and (acc[:, 1] >= 2).any(), "needs first-trial and later-trial acceptances"

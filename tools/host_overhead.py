@@ -62,3 +62,17 @@ t0 = time.perf_counter()
 mz.minimize(200, sync_mesh=False)
 dt = time.perf_counter() - t0
 print("Minimizer.minimize: %.1f us/step" % (1e6 * dt / 200))
+for n in (1, 2, 200, 1000):
+    t0 = time.perf_counter()
+    mz.minimize(n, sync_mesh=False)
+    dt = time.perf_counter() - t0
+    print("Minimizer.minimize(%d): %.1f us total, %.1f us/step" % (n, 1e6 * dt, 1e6 * dt / n))
+import cProfile  # noqa: E402
+import pstats  # noqa: E402
+
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(20):
+    mz.minimize(2, sync_mesh=False)
+pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
