@@ -97,7 +97,8 @@ struct ms_ctx {
   // pair launch: when the last search needed two or more trials, the first two are evaluated in ONE energy launch
   // (k_energy<PAIR>); the second trial uses the ordinary outputs, the first one the "2" set below
   bool pair_enable = true;       // MS_PAIR=0 switches it off
-  bool pair_force = false;       // MS_PAIR=2: pair whenever possible, whatever the history predicts (tests)
+  int pair_force = 0;            // MS_PAIR=2 / 3: pair (/ pair + a gated third trial) whenever possible, whatever
+                                 // the history predicts (tests)
   bool pair_on = false;          // phase_energy / reduce_slots: queue a pair (second evaluation at pair_alpha2)
   double pair_alpha2 = 0.0;
   double* xt2 = nullptr;
@@ -1027,7 +1028,7 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
   }
   if (const char* pe = getenv("MS_PAIR")) {
     c->pair_enable = atoi(pe) != 0;
-    c->pair_force = atoi(pe) == 2;
+    c->pair_force = atoi(pe) >= 2 ? std::min(atoi(pe), 3) : 0;
   }
   c->speculate = !(getenv("MS_SPECULATE") != nullptr && atoi(getenv("MS_SPECULATE")) == 0);
   c->deterministic = getenv("MS_DETERMINISTIC") != nullptr && atoi(getenv("MS_DETERMINISTIC")) != 0;
@@ -1980,7 +1981,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       // how many trials to queue: as many as the last search needed (cold), or -- once there is a history --
       // one per alpha that still lies above (most of) the range where alphas were accepted lately
       const int room = std::min(1 + ms_ctx::SPEC_STAGES, max_iter - it);
-      const int want = c->pair_force ? std::min(2, room)
+      const int want = c->pair_force ? std::min(c->pair_force, room)
                                      : (ls_warm ? room : std::min(c->pred_trials - out->trials, room));
       while (depth < want) {
         if (!c->pair_force && ls_warm && !(alphas[depth - 1] > 0.9 * a_hi)) break;
@@ -2000,7 +2001,12 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     const bool pair = chain && depth > 1 && c->pair_enable && c->xt2 != nullptr &&
                       (c->params.modules & MS_MOD_BENDING) != 0 &&
                       (c->pair_force || (ls_warm && alpha > a_hi && r_lo < INFINITY));
-    if (pair) depth = 2;
+    if (pair) {
+      // the pair, and one gated trial behind it when trial 1 is as sure to fail as trial 0 (an empty gated stage
+      // costs about what the host round trip it saves does, so "probably" is not enough)
+      depth = std::min(depth, 3);
+      if (depth == 3 && !c->pair_force && !(alphas[1] > a_hi)) depth = 2;
+    }
     if (!chain) {
       rc = phase_energy(c, c->params.modules, true, alpha, true, !safe_small, carry_mode);
       if (rc) return rc;
@@ -2042,6 +2048,18 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       rc = phase_energy(c, c->params.modules, true, alphas[1], true, false, carry_mode);
       c->pair_on = false;
       if (rc) return rc;
+      if (depth == 3) {
+        // a third trial, expected to be needed as well: gated on trial 1's rejection like any ladder stage (if it
+        // is trial 0 that gets accepted, this stage may run for nothing; the copy-back below comes after it)
+        rhs[2] = energy0 + sp->c * alphas[2] * g_dot_d;
+        swap_mailbox(c, c->spec[1]);
+        c->cur_gate = c->d_gate + 2;
+        c->cur_gate_rhs = rhs[1];
+        rc = phase_energy(c, c->params.modules, true, alphas[2], true, false, carry_mode);
+        c->cur_gate = nullptr;
+        swap_mailbox(c, c->spec[1]);
+        if (rc) return rc;
+      }
     }
     for (int j = 0; j < depth && !pair; ++j) {
       rhs[j] = energy0 + sp->c * alphas[j] * g_dot_d;
@@ -2127,8 +2145,25 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
         accept(alphas[j], E_t);
         return MS_OK;
       }
-      alpha = alphas[1] * sp->beta;
-      it += 2;
+      if (depth == 3) {
+        swap_mailbox(c, c->spec[1]);
+        rc = fetch(c);
+        memcpy(v0, c->h_scal, sizeof(v0));
+        swap_mailbox(c, c->spec[1]);
+        if (rc) return rc;
+        for (int sl = 0; sl < MS_NSCAL; ++sl)
+          if (MASK_ENERGY & (1u << sl)) put_mailbox(c, sl, v0[sl]);
+        ++out->trials;
+        energies_from_mailbox(c, e);
+        const double E_t = e[0] + e[1] + e[2] + e[3];
+        if (E_t <= rhs[2]) {
+          accept(alphas[2], E_t);
+          return MS_OK;
+        }
+        min_rejected = alphas[2];
+      }
+      alpha = alphas[depth - 1] * sp->beta;
+      it += depth;
       if (alpha < 1e-8) break;
       continue;
     }

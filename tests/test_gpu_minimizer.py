@@ -426,10 +426,11 @@ def test_topology_change_rebuilds_the_device_mirror(deterministic):
     assert res["energy"] == res_b["energy"] and mz.step_size == mz_b.step_size
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("mode", ["1", "2", "3"])
 def test_pair_launch_does_not_change_the_trajectory(mode, monkeypatch):
     """Two trial evaluations in one launch (k_energy<PAIR>, ms_step): MS_PAIR=1 lets the line-search history decide,
-    MS_PAIR=2 pairs whenever it can (so trial 0 is accepted inside a pair now and then: the copy-back path) --
+    MS_PAIR=2 pairs whenever it can (so trial 0 is accepted inside a pair now and then: the copy-back path), MS_PAIR=3
+    also queues a gated third trial behind every pair --
     both must give the doubles of the one-trial-per-launch search, bit for bit with fixed-order sums."""
     from membrane_solver_amd import _lib as L
     from membrane_solver_amd import meshgen
@@ -468,4 +469,5 @@ def test_pair_launch_does_not_change_the_trajectory(mode, monkeypatch):
     assert np.array_equal(rows, ref_rows)
     assert np.array_equal(x, ref_x)
     acc = ref_rows[ref_rows[:, 0] == 1]
-    assert (acc[:, 1] == 1).any() and (acc[:, 1] >= 2).any(), "needs first-trial and later-trial acceptances"
+    assert (acc[:, 1] == 1).any() and (acc[:, 1] == 2).any() and (acc[:, 1] >= 3).any(), \
+        "needs acceptances at the first, second and a later trial"
