@@ -167,6 +167,8 @@ struct ms_ctx {
   unsigned long long* d_h_xseq = nullptr;
   unsigned long long xticket = 0;
   double sh_scal[MS_NSCAL] = {0};  // rank-ordered fold of the last exchanges
+  double sh_scal2[MS_NSCAL] = {0}; // ... of a pair launch's other trial (header slots SH_ALT + slot)
+  double* pair_scal2 = nullptr;    // where a pair launch's second fold goes (nullptr: d_scal2)
   bool sh_carry_valid = false, sh_grad_valid = false;
   bool sh_maxg2_valid = false;  // the last direction exchange also carried the gradient rows and max|g_i|^2
   long sh_exchanges = 0;
@@ -430,13 +432,24 @@ constexpr uint32_t MASK_DIR = (1u << MS_S_GNORM2) | (1u << MS_S_GDOTD) | (1u << 
 int reduce_slots(ms_ctx* c, uint32_t mask) {
   ProfScope ps(c, 3, c->cur_gate != nullptr);
   ++c->ticket;
+  // a pair launch has no tilt module: only the core slots carry anything (and the sharded driver parks the other
+  // trial's fold in the tilt slots of the device scalars, which the full mask would overwrite)
+  if (c->pair_on) {
+    const uint32_t core = (1u << MS_S_ESURF) | (1u << MS_S_VOL) | (1u << MS_S_EBEND) | (1u << MS_S_MINEDGE2) |
+                          (1u << MS_S_GUARD);
+    // (nobody is to wait for the dropped slots: an older, gated-out launch may have left a ticket there)
+    for (int sl = 0; sl < MS_NSCAL; ++sl)
+      if (mask & ~core & (1u << sl)) c->expected[sl] = c->spec[0].expected[sl] = 0;
+    mask &= core;
+  }
   for (int sl = 0; sl < MS_NSCAL; ++sl)
     if (mask & (1u << sl)) c->expected[sl] = c->ticket;
   if (c->pair_on) {
     for (int sl = 0; sl < MS_NSCAL; ++sl)
       if (mask & (1u << sl)) c->spec[0].expected[sl] = c->ticket;
     HIPCHK(c, launch_reduce(c->d_partials, c->til.n_tiles, c->tile0, c->tile1, mask, c->d_scal, c->d_h_seq,
-                            c->ticket, c->stream, nullptr, c->d_partials2, c->d_scal2, c->spec[0].d_h_seq));
+                            c->ticket, c->stream, nullptr, c->d_partials2,
+                            c->pair_scal2 ? c->pair_scal2 : c->d_scal2, c->spec[0].d_h_seq));
     return MS_OK;
   }
   HIPCHK(c, launch_reduce(c->d_partials, c->til.n_tiles, c->tile0, c->tile1, mask, c->d_scal,
@@ -472,11 +485,11 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   a.alpha2 = 0.0;
   a.xt2 = a.fK2 = a.fA2 = a.partials2 = nullptr;
   if (c->pair_on) {
-    if (!use_dir || !write_trial || guard || !write_factors || !(modules & MS_MOD_BENDING) || bt || lbt || !c->xt2)
+    if (!use_dir || guard || !write_factors || !(modules & MS_MOD_BENDING) || bt || lbt || !c->fK2)
       return fail(c, MS_ERR_STATE, "pair launch: not an ordinary bending trial");
     a.pair = 1;
     a.alpha2 = trial_alpha(c, c->pair_alpha2);
-    a.xt2 = c->xt2;
+    a.xt2 = write_trial ? c->xt2 : nullptr;
     a.fK2 = c->fK2;
     a.fA2 = c->fA2;
     a.partials2 = c->d_partials2;
@@ -2384,10 +2397,20 @@ int ms_phase_set_factors_valid(ms_ctx* c, int valid) {
 }
 
 namespace {
+constexpr int SH_BUF_FK2 = -1, SH_BUF_FA2 = -2;
+constexpr int SH_ALT = 16;  // header slots SH_ALT + s carry slot s of a pair launch's other trial (tilt slots: the
+                            // tilt modules are not sharded)
 int row_buffers(ms_ctx* c, int n, const int* ids, double* p[4], int ncomp[4], int* comps) {
   if (n < 0 || n > 4 || (n > 0 && !ids)) return fail(c, MS_ERR_INVALID, "boundary exchange: 0..4 buffers");
   *comps = 0;
   for (int k = 0; k < n; ++k) {
+    if (ids[k] == SH_BUF_FK2 || ids[k] == SH_BUF_FA2) {  // (internal) a pair launch's second factor set
+      if (!c->fK2) return fail(c, MS_ERR_STATE, "boundary exchange: pair buffers not allocated");
+      p[k] = ids[k] == SH_BUF_FK2 ? c->fK2 : c->fA2;
+      ncomp[k] = ids[k] == SH_BUF_FA2 ? 2 : 3;
+      *comps += ncomp[k];
+      continue;
+    }
     if (ids[k] < 0 || ids[k] > MS_BUF_FA) return fail(c, MS_ERR_INVALID, "boundary exchange: bad buffer id");
     p[k] = c->buf[ids[k]];
     ncomp[k] = ids[k] == MS_BUF_FA ? 2 : 3;
@@ -2485,7 +2508,7 @@ int rccl_bind() {
 
 int shard_buffers(ms_ctx* c) {
   if (c->d_xsend) return MS_OK;
-  const size_t n_max = (size_t)MS_NSCAL + 8 * (size_t)c->bnd_max;  // fK 3 + fA 2 + d 3 per boundary row
+  const size_t n_max = (size_t)MS_NSCAL + 10 * (size_t)c->bnd_max;  // at most 2 x (fK 3 + fA 2) per boundary row
   HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xsend), sizeof(double) * n_max));
   HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_xrecv), sizeof(double) * n_max * (size_t)c->shard_count));
   HIPCHK(c, hipMemset(c->d_xsend, 0, sizeof(double) * n_max));
@@ -2509,7 +2532,7 @@ constexpr uint32_t SH_DIR = (1u << MS_S_GNORM2) | (1u << MS_S_GDOTD) | (1u << MS
 
 // One exchange: boundary rows of `ids` + the 16 scalars of every rank; `slots` of the
 // rank-ordered fold go to c->sh_scal (push: also to the device scalars).
-int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push) {
+int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push, bool fold_alt = false) {
   double* p[4];
   int nc[4], comps = 0;
   int rc = row_buffers(c, n, ids, p, nc, &comps);
@@ -2564,20 +2587,31 @@ int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push) 
       for (int r = 1; r < W; ++r) m = std::max(m, c->h_scal_all[(size_t)r * MS_NSCAL + sl]);
       c->sh_scal[sl] = m;
     }
+  if (fold_alt) {  // the pair launch's other trial: same folds, same rank order, from the SH_ALT header slots
+    for (int sl : {(int)MS_S_ESURF, (int)MS_S_VOL, (int)MS_S_EBEND}) {
+      double acc = 0.0;
+      for (int r = 0; r < W; ++r) acc += c->h_scal_all[(size_t)r * MS_NSCAL + SH_ALT + sl];
+      c->sh_scal2[sl] = acc;
+    }
+    double m = c->h_scal_all[SH_ALT + MS_S_MINEDGE2];
+    for (int r = 1; r < W; ++r) m = std::min(m, c->h_scal_all[(size_t)r * MS_NSCAL + SH_ALT + MS_S_MINEDGE2]);
+    c->sh_scal2[MS_S_MINEDGE2] = m;
+  }
   if (push)
     HIPCHK(c, hipMemcpyAsync(c->d_scal, c->sh_scal, sizeof(double) * MS_NSCAL, hipMemcpyHostToDevice, c->stream));
   ++c->sh_exchanges;
   return MS_OK;
 }
 
-double shard_energy(const ms_ctx* c) {
+double shard_energy_of(const ms_ctx* c, const double* scal) {
   const uint32_t m = c->params.modules;
   double e = 0.0;
-  if (m & MS_MOD_SURFACE) e += c->sh_scal[MS_S_ESURF];
-  if (m & MS_MOD_BENDING) e += c->sh_scal[MS_S_EBEND];
-  e += penalty_energy(c, c->sh_scal[MS_S_VOL]);
+  if (m & MS_MOD_SURFACE) e += scal[MS_S_ESURF];
+  if (m & MS_MOD_BENDING) e += scal[MS_S_EBEND];
+  e += penalty_energy(c, scal[MS_S_VOL]);
   return e;
 }
+double shard_energy(const ms_ctx* c) { return shard_energy_of(c, c->sh_scal); }
 }  // namespace
 
 static void shard_comm_destroy(void* comm) {
@@ -2709,7 +2743,77 @@ int ms_shard_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, doub
     alpha = std::min(alpha, sp->edge_fraction * min_edge / max_dir);
   const double alpha_max = sp->alpha_max_factor * step_size;
   const int max_iter = sp->max_iter > 0 ? sp->max_iter : 10;
-  for (int it = 0; it < max_iter; ++it) {
+  // line-search history (same bookkeeping as ms_step: prediction only)
+  double min_rejected = INFINITY, a_hi = 0.0, r_lo = INFINITY;
+  for (int k = 0; k < std::min(c->ls_n, (int)ms_ctx::LS_HIST); ++k) {
+    a_hi = std::max(a_hi, c->ls_acc[k]);
+    r_lo = std::min(r_lo, c->ls_rej[k]);
+  }
+  auto remember = [&](double alpha_acc) {
+    c->ls_acc[c->ls_n % ms_ctx::LS_HIST] = alpha_acc;
+    c->ls_rej[c->ls_n % ms_ctx::LS_HIST] = min_rejected;
+    ++c->ls_n;
+  };
+  auto accepted = [&](double alpha_acc, double E_t) -> int {
+    int r2 = ms_phase_commit_trial(c, alpha_acc, cg ? 1 : 0);
+    if (r2) return r2;
+    c->sh_grad_valid = false;
+    if (carry_mode) {
+      c->factors_valid = true;
+      if (penalty)
+        HIPCHK(c, hipMemcpyAsync(c->d_scal, c->sh_scal, sizeof(double) * MS_NSCAL, hipMemcpyHostToDevice,
+                                 c->stream));
+      c->sh_carry_valid = true;
+    }
+    out->success = 1;
+    out->alpha = alpha_acc;
+    out->energy = E_t;
+    out->volume = c->sh_scal[MS_S_VOL];
+    out->next_step = std::min(alpha_acc * sp->gamma, alpha_max);
+    remember(alpha_acc);
+    return MS_OK;
+  };
+  int it0 = 0;
+  // pair launch: trial 0 is expected to fail -> trials 0 and 1 in one energy launch and ONE
+  // exchange (both trials' scalars in the header, both factor sets' boundary rows behind it)
+  const bool pair = c->pair_enable && carry_mode && bend && !penalty && max_iter >= 2 &&
+                    alpha * max_dir < safe_limit && alpha * sp->beta >= 1e-8 &&
+                    (c->pair_force || (c->ls_n >= 2 && alpha > a_hi && r_lo < INFINITY));
+  if (pair) {
+    rc = spec_prepare(c);
+    if (rc) return rc;
+    const double alpha0 = alpha, alpha1 = alpha * sp->beta;
+    c->pair_on = true;
+    c->pair_alpha2 = alpha0;
+    c->pair_scal2 = c->d_scal + SH_ALT;
+    rc = phase_energy(c, mods, true, alpha1, false, false, true);
+    c->pair_on = false;
+    c->pair_scal2 = nullptr;
+    if (rc) return rc;
+    c->sh_carry_valid = false;
+    const int pbufs[4] = {MS_BUF_FK, MS_BUF_FA, SH_BUF_FK2, SH_BUF_FA2};
+    rc = shard_exchange(c, 4, pbufs, SH_ENERGY, false, /*fold_alt=*/true);
+    if (rc) return rc;
+    ++out->trials;
+    const double E0 = shard_energy_of(c, c->sh_scal2);
+    if (E0 <= energy0 + sp->c * alpha0 * g_dot_d) {
+      // the unexpected case: trial 0's factors (boundary rows included) are in the second set
+      const size_t nvp = (size_t)c->til.nvp;
+      HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FK], c->fK2, sizeof(double) * 3 * nvp, hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FA], c->fA2, sizeof(double) * 2 * nvp, hipMemcpyDeviceToDevice, c->stream));
+      for (int sl : {(int)MS_S_ESURF, (int)MS_S_VOL, (int)MS_S_EBEND, (int)MS_S_MINEDGE2}) c->sh_scal[sl] = c->sh_scal2[sl];
+      return accepted(alpha0, E0);
+    }
+    min_rejected = alpha0;
+    ++out->trials;
+    const double E1 = shard_energy(c);
+    if (E1 <= energy0 + sp->c * alpha1 * g_dot_d) return accepted(alpha1, E1);
+    min_rejected = alpha1;
+    alpha = alpha1 * sp->beta;
+    it0 = 2;
+    if (alpha < 1e-8) it0 = max_iter;
+  }
+  for (int it = it0; it < max_iter; ++it) {
     const bool safe_small = alpha * max_dir < safe_limit;
     rc = phase_energy(c, mods, true, alpha, false, !safe_small, carry_mode);
     if (rc) return rc;
@@ -2718,30 +2822,15 @@ int ms_shard_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, doub
     if (rc) return rc;
     if (!safe_small && c->sh_scal[MS_S_GUARD] > 0.0) {
       ++out->guard_rejects;
+      min_rejected = alpha;
       alpha *= sp->beta;
       if (alpha < 1e-8) break;
       continue;
     }
     ++out->trials;
     const double E_t = shard_energy(c);
-    if (E_t <= energy0 + sp->c * alpha * g_dot_d) {
-      rc = ms_phase_commit_trial(c, alpha, cg ? 1 : 0);
-      if (rc) return rc;
-      c->sh_grad_valid = false;
-      if (carry_mode) {
-        c->factors_valid = true;
-        if (penalty)
-          HIPCHK(c, hipMemcpyAsync(c->d_scal, c->sh_scal, sizeof(double) * MS_NSCAL, hipMemcpyHostToDevice,
-                                   c->stream));
-        c->sh_carry_valid = true;
-      }
-      out->success = 1;
-      out->alpha = alpha;
-      out->energy = E_t;
-      out->volume = c->sh_scal[MS_S_VOL];
-      out->next_step = std::min(alpha * sp->gamma, alpha_max);
-      return MS_OK;
-    }
+    if (E_t <= energy0 + sp->c * alpha * g_dot_d) return accepted(alpha, E_t);
+    min_rejected = alpha;
     alpha *= sp->beta;
     if (alpha < 1e-8) break;
   }

@@ -304,7 +304,7 @@ class HipShardBackend:
         self.debug_poison = bool(debug_poison)  # tests: NaN every non-owned row before an exchange
         self.boundary = self.dm.boundary_info()
         # message buffers for the widest exchange (fK 3 + fA 2 + d 3 components per boundary row)
-        n_max = L.MS_NSCAL + 8 * self.boundary["max_rows"]
+        n_max = L.MS_NSCAL + 10 * self.boundary["max_rows"]  # at most 2 x (fK 3 + fA 2) per boundary row (pair launch)
         self._send = torch.zeros(n_max, dtype=torch.float64, device=self.device)
         self._recv = torch.zeros(world * n_max, dtype=torch.float64, device=self.device)
         self._plans = {}
