@@ -5,9 +5,9 @@ set -e
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 30 --warmup 20 --cpu-steps 0"
+B="python3 $R/bench.py --steps 60 --warmup 20 --cpu-steps 0"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- $B > $R/gpurun_out/${TAG}_stats.json 2> $R/gpurun_out/${TAG}_stats.err
-B2="python3 $R/bench.py --steps 10 --warmup 10 --cpu-steps 0 --no-roofline"
+B2="python3 $R/bench.py --steps 40 --warmup 20 --cpu-steps 0 --no-roofline --headline-only"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_fetch -- $B2 > /dev/null 2> $R/gpurun_out/${TAG}_fetch.err
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_write -- $B2 > /dev/null 2> $R/gpurun_out/${TAG}_write.err
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/gpurun_out/${TAG}_sq -- $B2 > /dev/null 2> $R/gpurun_out/${TAG}_sq.err
