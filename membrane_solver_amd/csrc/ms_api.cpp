@@ -1774,6 +1774,12 @@ int ms_energy_and_gradient(ms_ctx* c, double energies[4], double* grad) {
 int ms_energy(ms_ctx* c, double energies[4]) {
   if (!c || !energies) return fail(c, MS_ERR_INVALID, "ms_energy: NULL argument");
   if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "ms_energy: sharded contexts use the phase API");
+  if (c->carry_valid) {
+    // the last accepted trial (or the pass before a failed search) evaluated exactly this x and its energies are
+    // still in the mailbox: no pass, and the carried state survives for the next step
+    energies_from_mailbox(c, energies);
+    return MS_OK;
+  }
   int rc = phase_energy(c, c->params.modules, false, 0.0, false, false, false);
   if (rc) return rc;
   rc = fetch(c);
