@@ -66,6 +66,7 @@ def algorithmic_bytes(nv, nf, volume=False):
         # pair launch: two trial evaluations of one line search in one launch -- the inputs are
         # compulsory ONCE (the second evaluation's reads are meant to hit L2), the outputs twice
         "energy_pair": 20 * nf + (48 + 16 + 1) * nv + 2 * (24 + 40) * nv,
+        "energy_triple": 20 * nf + (48 + 16 + 1) * nv + 3 * (24 + 40) * nv,
         # gradient (+ fused direction pass when no constraint row): x 24 + fK,fA 40 + flags 1 in,
         # g 24 and d 24 out.  The CG-history reads (pg, pd: 48 B/vertex on non-restart steps) are
         # NOT counted, so the figure is a lower bound of the compulsory traffic.
@@ -78,7 +79,7 @@ def _template_args(name):
     return [a.strip() for a in name[i + 1:j].split(",")] if 0 <= i < j else []
 
 
-def pmc_traffic(kernel_prefix, deterministic=False, pair=False):
+def pmc_traffic(kernel_prefix, deterministic=False, multi=0):
     """HBM bytes per launch of one kernel from the committed rocprofv3 PMC summary
     (profiles/<tag>_pmc_summary.csv; separate FETCH_SIZE / WRITE_SIZE passes of this same
     bench command).  gfx950 correction: FETCH_SIZE counts 1/2 of the fetched bytes
@@ -96,11 +97,11 @@ def pmc_traffic(kernel_prefix, deterministic=False, pair=False):
             if len(row) < 4 or kernel_prefix not in row[1] or row[0] not in acc:
                 continue
             # template arguments: the fifth selects the accumulation mode (true = LDS atomics), k_energy's sixth
-            # the pair launch
+            # the number of evaluations per launch (0 = one, 2 = pair, 3 = triple)
             ta = _template_args(row[1])
             if len(ta) >= 5 and ta[4] != ("false" if deterministic else "true"):
                 continue
-            if "k_energy" in kernel_prefix and (len(ta) >= 6 and ta[5] == "true") != pair:
+            if "k_energy" in kernel_prefix and (int(ta[5]) if len(ta) >= 6 and ta[5].isdigit() else 0) != multi:
                 continue
             n = float(row[2])
             acc[row[0]][0] += n * float(row[3])
@@ -249,8 +250,13 @@ def main():
             kernels["energy_pair"]["algorithmic_bytes"] = ab["energy_pair"]
             kernels["energy_pair"]["GBps"] = ab["energy_pair"] / (kernels["energy_pair"]["avg_us"] * 1e-6) / 1e9
             kernels["energy_pair"]["evaluations_per_launch"] = 2
+        n_t = prof.get("energy_triple", (0.0, 0))[1]
+        if n_t:
+            kernels["energy_triple"]["algorithmic_bytes"] = ab["energy_triple"]
+            kernels["energy_triple"]["GBps"] = ab["energy_triple"] / (kernels["energy_triple"]["avg_us"] * 1e-6) / 1e9
+            kernels["energy_triple"]["evaluations_per_launch"] = 3
         if n_e:
-            n_trial = min(n_e, max(0, stats["trial_passes"] - 2 * n_p))
+            n_trial = min(n_e, max(0, stats["trial_passes"] - 2 * n_p - 3 * n_t))
             n_plain = n_e - n_trial
             level = int(stepper.reuse_energy0)
             n_fact = min(n_plain, n_g)          # factor-writing passes at x
@@ -263,21 +269,43 @@ def main():
         if n_g:
             kernels["gradient"]["algorithmic_bytes"] = ab["gradient"]
             kernels["gradient"]["GBps"] = ab["gradient"] / (kernels["gradient"]["avg_us"] * 1e-6) / 1e9
-        dom = max((k for k in ("energy", "energy_pair", "gradient") if k in kernels),
-                  key=lambda k: kernels[k]["share_of_profiled_ms"])
+        # dominant kernel: the family (k_energy in all its instantiations vs k_gradient) with the larger share of the
+        # kernel time, and within k_energy the instantiation (evaluations per launch) with the largest share --
+        # that is one row of the rocprofv3 summary under profiles/
+        fam_e = [k for k in ("energy", "energy_pair", "energy_triple") if k in kernels]
+        share_e = sum(kernels[k]["share_of_profiled_ms"] for k in fam_e)
+        share_g = kernels["gradient"]["share_of_profiled_ms"] if "gradient" in kernels else 0.0
+        if fam_e and share_e >= share_g:
+            dom = max(fam_e, key=lambda k: kernels[k]["share_of_profiled_ms"])
+        else:
+            dom = "gradient"
         ach = kernels[dom]["GBps"]
         traffic, traffic_src = pmc_traffic({"energy": "ms::k_energy", "energy_pair": "ms::k_energy",
-                                            "gradient": "ms::k_gradient"}[dom],
-                                           deterministic=bool(args.deterministic), pair=dom == "energy_pair")
-        out["roofline"] = {"bound": "hbm", "kernel": {"energy": "ms::k_energy<.., PAIR=false> (energy pass)",
-                                                     "energy_pair": "ms::k_energy<.., PAIR=true> (energy pass, two "
+                                            "energy_triple": "ms::k_energy", "gradient": "ms::k_gradient"}[dom],
+                                           deterministic=bool(args.deterministic),
+                                           multi={"energy_pair": 2, "energy_triple": 3}.get(dom, 0))
+        out["roofline"] = {"bound": "hbm", "kernel": {"energy": "ms::k_energy<.., MULTI=0> (energy pass)",
+                                                     "energy_pair": "ms::k_energy<.., MULTI=2> (energy pass, two "
                                                                     "trial evaluations per launch)",
+                                                     "energy_triple": "ms::k_energy<.., MULTI=3> (energy pass, "
+                                                                      "three trial evaluations per launch)",
                                                      "gradient": "ms::k_gradient* (gradient pass)"}[dom],
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                            "avg_launch_us": kernels[dom]["avg_us"],
                            "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"],
                            "measured": f"HIP events around every launch over {n_prof} steps after the timed region"}
+        if dom in ("energy_pair", "energy_triple"):
+            # the same launch priced per evaluation: SURVEY 8(d)'s per-evaluation bytes x the 2 evaluations it
+            # processes.  NOT used for `frac` above: a pair needs its inputs from HBM only once, so the compulsory
+            # traffic of the launch is the smaller figure and `frac` is measured against that
+            per_eval = ab["energy_trial_factors"]
+            n_ev = 2 if dom == "energy_pair" else 3
+            out["roofline"]["per_evaluation_equivalent"] = {
+                "us_per_evaluation": kernels[dom]["avg_us"] / n_ev, "algorithmic_bytes_per_evaluation": per_eval,
+                "GBps": per_eval / (kernels[dom]["avg_us"] / n_ev * 1e-6) / 1e9,
+                "frac": per_eval / (kernels[dom]["avg_us"] / n_ev * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "single_launch_frac": (kernels["energy"]["GBps"] / HBM_PEAK_GBS) if "energy" in kernels else None}
         eg = None
         if "energy" in kernels and "gradient" in kernels:
             pair_us = kernels["energy"]["avg_us"] + kernels["gradient"]["avg_us"]

@@ -439,8 +439,9 @@ int ms_tile_stats(ms_ctx *ctx, int64_t *n_tiles, int64_t *facet_instances,
  * an event pair; ms_profile_read synchronises, returns the summed milliseconds
  * and launch counts per kind {0 energy, 1 gradient, 2 direction, 3 reduce,
  * 4 tilt, 5 bending_tilt facet pass, 6 tilt vector ops, 7 energy pair launch (two
- * trial evaluations of one line search in one launch)} and resets the counters.  Used by bench.py for the roofline figure. */
-#define MS_PROF_KINDS 8
+ * trial evaluations of one line search in one launch), 8 energy triple launch
+ * (three)} and resets the counters.  Used by bench.py for the roofline figure. */
+#define MS_PROF_KINDS 9
 int ms_profile_enable(ms_ctx *ctx, int on);
 int ms_profile_read(ms_ctx *ctx, double total_ms[MS_PROF_KINDS],
                     int64_t launches[MS_PROF_KINDS]);

@@ -99,8 +99,16 @@ struct ms_ctx {
   bool pair_enable = true;       // MS_PAIR=0 switches it off
   int pair_force = 0;            // MS_PAIR=2 / 3: pair (/ pair + a gated third trial) whenever possible, whatever
                                  // the history predicts (tests)
-  bool pair_on = false;          // phase_energy / reduce_slots: queue a pair (second evaluation at pair_alpha2)
-  double pair_alpha2 = 0.0;
+  int pair_on = 0;               // phase_energy / reduce_slots: queue a pair (2: second evaluation at pair_alpha2)
+                                 // or a triple (3: a third one at pair_alpha3)
+  double pair_alpha2 = 0.0, pair_alpha3 = 0.0;
+  double* xt3 = nullptr;
+  double* fK3 = nullptr;
+  double* fA3 = nullptr;
+  double* d_partials3 = nullptr;
+  double* d_scal3 = nullptr;
+  const double* cur_veto3 = nullptr;
+  double cur_veto_rhs3 = 0.0;
   double* xt2 = nullptr;
   double* fK2 = nullptr;
   double* fA2 = nullptr;
@@ -439,17 +447,22 @@ int reduce_slots(ms_ctx* c, uint32_t mask) {
                           (1u << MS_S_GUARD);
     // (nobody is to wait for the dropped slots: an older, gated-out launch may have left a ticket there)
     for (int sl = 0; sl < MS_NSCAL; ++sl)
-      if (mask & ~core & (1u << sl)) c->expected[sl] = c->spec[0].expected[sl] = 0;
+      if (mask & ~core & (1u << sl)) c->expected[sl] = c->spec[0].expected[sl] = c->spec[1].expected[sl] = 0;
     mask &= core;
   }
   for (int sl = 0; sl < MS_NSCAL; ++sl)
     if (mask & (1u << sl)) c->expected[sl] = c->ticket;
   if (c->pair_on) {
+    const bool three = c->pair_on == 3;
     for (int sl = 0; sl < MS_NSCAL; ++sl)
-      if (mask & (1u << sl)) c->spec[0].expected[sl] = c->ticket;
+      if (mask & (1u << sl)) {
+        c->spec[0].expected[sl] = c->ticket;
+        if (three) c->spec[1].expected[sl] = c->ticket;
+      }
     HIPCHK(c, launch_reduce(c->d_partials, c->til.n_tiles, c->tile0, c->tile1, mask, c->d_scal, c->d_h_seq,
                             c->ticket, c->stream, nullptr, c->d_partials2,
-                            c->pair_scal2 ? c->pair_scal2 : c->d_scal2, c->spec[0].d_h_seq));
+                            c->pair_scal2 ? c->pair_scal2 : c->d_scal2, c->spec[0].d_h_seq,
+                            three ? c->d_partials3 : nullptr, c->d_scal3, c->spec[1].d_h_seq));
     return MS_OK;
   }
   HIPCHK(c, launch_reduce(c->d_partials, c->til.n_tiles, c->tile0, c->tile1, mask, c->d_scal,
@@ -484,10 +497,20 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   a.pair = 0;
   a.alpha2 = 0.0;
   a.xt2 = a.fK2 = a.fA2 = a.partials2 = nullptr;
+  a.alpha3 = 0.0;
+  a.xt3 = a.fK3 = a.fA3 = a.partials3 = nullptr;
   if (c->pair_on) {
     if (!use_dir || guard || !write_factors || !(modules & MS_MOD_BENDING) || bt || lbt || !c->fK2)
       return fail(c, MS_ERR_STATE, "pair launch: not an ordinary bending trial");
-    a.pair = 1;
+    a.pair = c->pair_on;
+    if (c->pair_on == 3) {
+      if (!c->fK3) return fail(c, MS_ERR_STATE, "triple launch: buffers not allocated");
+      a.alpha3 = trial_alpha(c, c->pair_alpha3);
+      a.xt3 = write_trial ? c->xt3 : nullptr;
+      a.fK3 = c->fK3;
+      a.fA3 = c->fA3;
+      a.partials3 = c->d_partials3;
+    }
     a.alpha2 = trial_alpha(c, c->pair_alpha2);
     a.xt2 = write_trial ? c->xt2 : nullptr;
     a.fK2 = c->fK2;
@@ -499,7 +522,7 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   a.bending_model = c->params.bending_model;
   a.modules = modules;
   if (!lbt) {
-    ProfScope ps(c, a.pair ? 7 : 0, c->cur_gate != nullptr);
+    ProfScope ps(c, a.pair == 3 ? 8 : (a.pair ? 7 : 0), c->cur_gate != nullptr);
     HIPCHK(c, launch_energy(a, guard && use_dir, c->cap, c->til.max_ent, c->stream));
   } else {
     // leaflet bending_tilt: the tilt projections and the unit vertex normals of the evaluated positions come
@@ -653,6 +676,8 @@ int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulat
   a.gate_out = const_cast<int*>(c->cur_gate);
   a.veto_scal = c->cur_gate ? c->cur_veto : nullptr;
   a.veto_rhs = c->cur_veto_rhs;
+  a.veto_scal3 = (c->cur_gate && c->cur_veto) ? c->cur_veto3 : nullptr;
+  a.veto_rhs3 = c->cur_veto_rhs3;
   a.atomic = c->deterministic ? 0 : 1;
   a.bt_vert = nullptr;
   a.tilts = nullptr;
@@ -1041,7 +1066,7 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
   }
   if (const char* pe = getenv("MS_PAIR")) {
     c->pair_enable = atoi(pe) != 0;
-    c->pair_force = atoi(pe) >= 2 ? std::min(atoi(pe), 3) : 0;
+    c->pair_force = atoi(pe) >= 2 ? std::min(atoi(pe), 4) : 0;  // 4: triple launches whenever possible
   }
   c->speculate = !(getenv("MS_SPECULATE") != nullptr && atoi(getenv("MS_SPECULATE")) == 0);
   c->deterministic = getenv("MS_DETERMINISTIC") != nullptr && atoi(getenv("MS_DETERMINISTIC")) != 0;
@@ -1086,7 +1111,8 @@ void ms_destroy(ms_ctx* c) {
   free(c->grad_mb.h_scal);
   if (c->grad_mb.h_seq) (void)hipHostFree(c->grad_mb.h_seq);
   if (c->d_gate) (void)hipFree(c->d_gate);
-  for (double* q : {c->xt2, c->fK2, c->fA2, c->d_partials2, c->d_scal2})
+  for (double* q : {c->xt2, c->fK2, c->fA2, c->d_partials2, c->d_scal2, c->xt3, c->fK3, c->fA3, c->d_partials3,
+                    c->d_scal3})
     if (q) (void)hipFree(q);
   free(c->h_scal);
   if (c->h_seq) (void)hipHostFree(c->h_seq);
@@ -1809,6 +1835,15 @@ int spec_prepare(ms_ctx* c) {
     HIPCHK(c, hipMemset(c->d_partials2, 0, pb));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_scal2), sizeof(double) * MS_NSCAL));
     HIPCHK(c, hipMemset(c->d_scal2, 0, sizeof(double) * MS_NSCAL));
+    if (c->shard_count == 1) {  // (the sharded driver pairs, it does not triple)
+      HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->xt3), sizeof(double) * 3 * nvp));
+      HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->fK3), sizeof(double) * 3 * nvp));
+      HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->fA3), sizeof(double) * 2 * nvp));
+      HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_partials3), pb));
+      HIPCHK(c, hipMemset(c->d_partials3, 0, pb));
+      HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_scal3), sizeof(double) * MS_NSCAL));
+      HIPCHK(c, hipMemset(c->d_scal3, 0, sizeof(double) * MS_NSCAL));
+    }
   }
   HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_gate), sizeof(int) * (ms_ctx::SPEC_STAGES + 3)));
   HIPCHK(c, hipMemset(c->d_gate, 0, sizeof(int) * (ms_ctx::SPEC_STAGES + 3)));
@@ -2000,7 +2035,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       // how many trials to queue: as many as the last search needed (cold), or -- once there is a history --
       // one per alpha that still lies above (most of) the range where alphas were accepted lately
       const int room = std::min(1 + ms_ctx::SPEC_STAGES, max_iter - it);
-      const int want = c->pair_force ? std::min(c->pair_force, room)
+      const int want = c->pair_force ? std::min(std::min(c->pair_force, 3), room)
                                      : (ls_warm ? room : std::min(c->pred_trials - out->trials, room));
       while (depth < want) {
         if (!c->pair_force && ls_warm && !(alphas[depth - 1] > 0.9 * a_hi)) break;
@@ -2020,11 +2055,14 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     const bool pair = chain && depth > 1 && c->pair_enable && c->xt2 != nullptr &&
                       (c->params.modules & MS_MOD_BENDING) != 0 &&
                       (c->pair_force || (ls_warm && alpha > a_hi && r_lo < INFINITY));
+    // triple launch: trial 1 is expected to fail as well -- its alpha is not below one that was rejected lately
+    bool triple = false;
     if (pair) {
-      // the pair, and one gated trial behind it when trial 1 is as sure to fail as trial 0 (an empty gated stage
-      // costs about what the host round trip it saves does, so "probably" is not enough)
       depth = std::min(depth, 3);
-      if (depth == 3 && !c->pair_force && !(alphas[1] > a_hi)) depth = 2;
+      triple = depth == 3 && c->fK3 != nullptr && (c->pair_force ? c->pair_force == 4 : alphas[1] > r_lo);
+      // otherwise the pair, and one gated trial behind it when trial 1 is as sure to fail as trial 0 (an empty gated
+      // stage costs about what the host round trip it saves does, so "probably" is not enough)
+      if (depth == 3 && !triple && !c->pair_force && !(alphas[1] > a_hi)) depth = 2;
     }
     if (!chain) {
       rc = phase_energy(c, c->params.modules, true, alpha, true, !safe_small, carry_mode);
@@ -2060,14 +2098,17 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     int* const d_acc = c->d_gate + ms_ctx::SPEC_STAGES + 2;
     if (pair) {
       // trial 0 -> the "2" outputs and spec[0]'s mailbox, trial 1 -> the ordinary outputs and the main mailbox
+      // (triple: trial 0 -> "2" / spec[0], trial 1 -> "3" / spec[1], trial 2 -> the ordinary ones)
       rhs[0] = energy0 + sp->c * alphas[0] * g_dot_d;
       rhs[1] = energy0 + sp->c * alphas[1] * g_dot_d;
-      c->pair_on = true;
+      if (triple) rhs[2] = energy0 + sp->c * alphas[2] * g_dot_d;
+      c->pair_on = triple ? 3 : 2;
       c->pair_alpha2 = alphas[0];
-      rc = phase_energy(c, c->params.modules, true, alphas[1], true, false, carry_mode);
-      c->pair_on = false;
+      c->pair_alpha3 = alphas[1];
+      rc = phase_energy(c, c->params.modules, true, alphas[triple ? 2 : 1], true, false, carry_mode);
+      c->pair_on = 0;
       if (rc) return rc;
-      if (depth == 3) {
+      if (depth == 3 && !triple) {
         // a third trial, expected to be needed as well: gated on trial 1's rejection like any ladder stage (if it
         // is trial 0 that gets accepted, this stage may run for nothing; the copy-back below comes after it)
         rhs[2] = energy0 + sp->c * alphas[2] * g_dot_d;
@@ -2109,9 +2150,12 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       // behind a pair the pass evaluates trial 1's point: it must also stay out when trial 0 was accepted
       c->cur_veto = pair ? c->d_scal2 : nullptr;
       c->cur_veto_rhs = rhs[0];
+      c->cur_veto3 = triple ? c->d_scal3 : nullptr;
+      c->cur_veto_rhs3 = rhs[1];
       rc = phase_gradient(c, c->params.modules, c->buf[MS_BUF_G], false, next_hist ? 2 : 1, /*reduce_now=*/true);
       c->cur_gate = nullptr;
       c->cur_veto = nullptr;
+      c->cur_veto3 = nullptr;
       swap_mailbox(c, c->grad_mb);
       if (cg) {
         std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
@@ -2128,20 +2172,23 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       c->kc_use_history = next_hist;
     }
     if (pair) {
-      // trial 0 reported to spec[0]'s mailbox, trial 1 to the main one (same fold: both have landed together)
-      double v0[MS_NSCAL], v1[MS_NSCAL];
-      swap_mailbox(c, c->spec[0]);
+      // trial 0 reported to spec[0]'s mailbox, (triple: trial 1 to spec[1]'s,) the last one to the main mailbox --
+      // one fold, so they have landed together
+      const int n_multi = triple ? 3 : 2;
+      double v[3][MS_NSCAL];
+      for (int j = 0; j + 1 < n_multi; ++j) {
+        swap_mailbox(c, c->spec[j]);
+        rc = fetch(c);
+        memcpy(v[j], c->h_scal, sizeof(v[j]));
+        swap_mailbox(c, c->spec[j]);
+        if (rc) return rc;
+      }
       rc = fetch(c);
-      memcpy(v0, c->h_scal, sizeof(v0));
-      swap_mailbox(c, c->spec[0]);
       if (rc) return rc;
-      rc = fetch(c);
-      if (rc) return rc;
-      memcpy(v1, c->h_scal, sizeof(v1));
-      for (int j = 0; j < 2; ++j) {
-        const double* vals = j == 0 ? v0 : v1;
+      memcpy(v[n_multi - 1], c->h_scal, sizeof(v[0]));
+      for (int j = 0; j < n_multi; ++j) {
         for (int sl = 0; sl < MS_NSCAL; ++sl)
-          if (MASK_ENERGY & (1u << sl)) put_mailbox(c, sl, vals[sl]);
+          if (MASK_ENERGY & (1u << sl)) put_mailbox(c, sl, v[j][sl]);
         ++out->trials;
         energies_from_mailbox(c, e);
         const double E_t = e[0] + e[1] + e[2] + e[3];
@@ -2149,29 +2196,29 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
           min_rejected = alphas[j];
           continue;
         }
-        if (j == 0) {
-          // the unexpected case: trial 0's positions and factors are in the "2" buffers, and the queued gradient
+        if (j + 1 < n_multi) {
+          // the unexpected case: this trial's positions and factors are in a side set, and the queued gradient
           // pass vetoed itself
           const size_t nvp = (size_t)c->til.nvp;
-          HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_XT], c->xt2, sizeof(double) * 3 * nvp, hipMemcpyDeviceToDevice,
-                                   c->stream));
-          HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FK], c->fK2, sizeof(double) * 3 * nvp, hipMemcpyDeviceToDevice,
-                                   c->stream));
-          HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FA], c->fA2, sizeof(double) * 2 * nvp, hipMemcpyDeviceToDevice,
-                                   c->stream));
+          const double* sx = j == 0 ? c->xt2 : c->xt3;
+          const double* sk = j == 0 ? c->fK2 : c->fK3;
+          const double* sa = j == 0 ? c->fA2 : c->fA3;
+          HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_XT], sx, sizeof(double) * 3 * nvp, hipMemcpyDeviceToDevice, c->stream));
+          HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FK], sk, sizeof(double) * 3 * nvp, hipMemcpyDeviceToDevice, c->stream));
+          HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FA], sa, sizeof(double) * 2 * nvp, hipMemcpyDeviceToDevice, c->stream));
           kc_queued = false;
         }
         accept(alphas[j], E_t);
         return MS_OK;
       }
-      if (depth == 3) {
+      if (depth == 3 && !triple) {
         swap_mailbox(c, c->spec[1]);
         rc = fetch(c);
-        memcpy(v0, c->h_scal, sizeof(v0));
+        memcpy(v[0], c->h_scal, sizeof(v[0]));
         swap_mailbox(c, c->spec[1]);
         if (rc) return rc;
         for (int sl = 0; sl < MS_NSCAL; ++sl)
-          if (MASK_ENERGY & (1u << sl)) put_mailbox(c, sl, v0[sl]);
+          if (MASK_ENERGY & (1u << sl)) put_mailbox(c, sl, v[0][sl]);
         ++out->trials;
         energies_from_mailbox(c, e);
         const double E_t = e[0] + e[1] + e[2] + e[3];
@@ -2789,11 +2836,11 @@ int ms_shard_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, doub
     rc = spec_prepare(c);
     if (rc) return rc;
     const double alpha0 = alpha, alpha1 = alpha * sp->beta;
-    c->pair_on = true;
+    c->pair_on = 2;
     c->pair_alpha2 = alpha0;
     c->pair_scal2 = c->d_scal + SH_ALT;
     rc = phase_energy(c, mods, true, alpha1, false, false, true);
-    c->pair_on = false;
+    c->pair_on = 0;
     c->pair_scal2 = nullptr;
     if (rc) return rc;
     c->sh_carry_valid = false;

@@ -101,13 +101,19 @@ struct EnergyArgs {
   int* gate_out;
   const double* bt_normals;  // leaflet bending_tilt: unit vertex normals of the evaluated positions (signed H, K_dir = n)
   int atomic;             // accumulate per-vertex sums with LDS atomics (not bitwise reproducible)
-  // pair launch: a second evaluation at alpha2 in the same launch, with its own outputs
+  // pair / triple launch (pair = 2 / 3): more evaluations at alpha2 (alpha3) in the same launch, with their own
+  // outputs
   int pair;
   double alpha2;
   double* xt2;
   double* fK2;
   double* fA2;
   double* partials2;
+  double alpha3;
+  double* xt3;
+  double* fK3;
+  double* fA3;
+  double* partials3;
 };
 
 struct GradientArgs {
@@ -137,6 +143,8 @@ struct GradientArgs {
   int* gate_out;
   const double* veto_scal;  // pair launch: do NOT run if these energies (the first trial's) pass veto_rhs
   double veto_rhs;
+  const double* veto_scal3; // triple launch: ... nor if these (the second trial's) pass veto_rhs3
+  double veto_rhs3;
   int pd_neg_pg;           // the previous direction is -pg (an implicit steepest-descent step): derive, do not load
   int atomic;
   // leaflet bending_tilt (BENDMODE 3): per-corner fA_eff = 1/2 kappa_k (base_k + s div_f t)^2
@@ -237,7 +245,8 @@ hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int til
                          uint32_t slot_mask, double* scal, unsigned long long* host_box,
                          unsigned long long ticket, hipStream_t s,
                          const int* gate = nullptr, const double* partials2 = nullptr, double* scal2 = nullptr,
-                         unsigned long long* host_box2 = nullptr);
+                         unsigned long long* host_box2 = nullptr, const double* partials3 = nullptr,
+                         double* scal3 = nullptr, unsigned long long* host_box3 = nullptr);
 
 hipError_t launch_pack_boundary(const int32_t* rows, int n_rows, const double* const* bufs,
                                 const int* ncomp, int n_bufs, const double* scal, double* send,

@@ -252,20 +252,28 @@ __device__ __forceinline__ void csr_commit(const CsrStage& r, const DeviceMesh& 
 // PAIR: two trial evaluations of one line search in ONE launch (grid = 2 x tiles): the workgroups of a tile's two
 // evaluations sit 8 apart in the launch order -- same XCD, dispatched together -- so the second read of the
 // tile's x / d / facet rows hits that XCD's L2.  The odd ones evaluate at alpha2 into the "2" outputs.
-template <bool BEND, bool GUARD, int TT, int CAPC, bool ATOMIC, bool PAIR = false>
+// MULTI = 3: the same with three evaluations (trials 0, 1, 2; the LAST one uses the ordinary outputs).
+template <bool BEND, bool GUARD, int TT, int CAPC, bool ATOMIC, int MULTI = 0>
 __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyArgs a, int cap_rt, int max_ent) {
   extern __shared__ double lds[];
   int bid = blockIdx.x;
-  if (PAIR) {
+  if (MULTI) {
     const int k = bid % NXCD, j2 = bid / NXCD;
-    bid = (j2 >> 1) * NXCD + k;
+    const int st = j2 % MULTI;
+    bid = (j2 / MULTI) * NXCD + k;
     if (bid >= a.tile1 - a.tile0) return;
-    if (j2 & 1) {
+    if (st == 1) {
       a.alpha = a.alpha2;
       a.xt = a.xt2;
       a.fK = a.fK2;
       a.fA = a.fA2;
       a.partials = a.partials2;
+    } else if (MULTI == 3 && st == 2) {
+      a.alpha = a.alpha3;
+      a.xt = a.xt3;
+      a.fK = a.fK3;
+      a.fA = a.fA3;
+      a.partials = a.partials3;
     }
   }
   const int T = TT ? TT : a.m.T;  // == blockDim.x
@@ -720,18 +728,24 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
   if (a.pair) {
     // pair launch: bending factors on, no guard (the caller checked both)
     if (!bend || guard) return hipErrorInvalidValue;
-    const int nb2 = 2 * NXCD * ((nb + NXCD - 1) / NXCD);
-#define MS_LAUNCH_P(TT, CC, AT)                                                                              \
+    if (a.pair != 2 && a.pair != 3) return hipErrorInvalidValue;
+    const int nb2 = a.pair * NXCD * ((nb + NXCD - 1) / NXCD);
+#define MS_LAUNCH_P(TT, CC, AT, NM)                                                                          \
   do {                                                                                                       \
-    e = ensure_lds(k_energy<true, false, TT, CC, AT, true>, lds);                                            \
+    e = ensure_lds(k_energy<true, false, TT, CC, AT, NM>, lds);                                              \
     if (e != hipSuccess) return e;                                                                           \
-    hipLaunchKernelGGL((k_energy<true, false, TT, CC, AT, true>), dim3(nb2), dim3(a.m.T), lds, s, a, cap, max_ent); \
+    hipLaunchKernelGGL((k_energy<true, false, TT, CC, AT, NM>), dim3(nb2), dim3(a.m.T), lds, s, a, cap, max_ent); \
   } while (0)
-    if (atomic) {
-      if (fast) MS_LAUNCH_P(FAST_T, FAST_CAP, true); else MS_LAUNCH_P(0, 0, true);
-    } else {
-      if (fast) MS_LAUNCH_P(FAST_T, FAST_CAP, false); else MS_LAUNCH_P(0, 0, false);
-    }
+#define MS_PICK_P(NM)                                                                  \
+  do {                                                                                 \
+    if (atomic) {                                                                      \
+      if (fast) MS_LAUNCH_P(FAST_T, FAST_CAP, true, NM); else MS_LAUNCH_P(0, 0, true, NM);   \
+    } else {                                                                           \
+      if (fast) MS_LAUNCH_P(FAST_T, FAST_CAP, false, NM); else MS_LAUNCH_P(0, 0, false, NM); \
+    }                                                                                  \
+  } while (0)
+    if (a.pair == 2) MS_PICK_P(2); else MS_PICK_P(3);
+#undef MS_PICK_P
 #undef MS_LAUNCH_P
     return hipGetLastError();
   }
@@ -797,6 +811,11 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
       const double E_first = ((a.gate_mods & MS_MOD_SURFACE) ? a.veto_scal[MS_S_ESURF] : 0.0) +
                              ((a.gate_mods & MS_MOD_BENDING) ? a.veto_scal[MS_S_EBEND] : 0.0);
       run = run && !(E_first <= a.veto_rhs);
+      if (a.veto_scal3 != nullptr) {  // triple launch: neither may trial 1 have been accepted
+        const double E_second = ((a.gate_mods & MS_MOD_SURFACE) ? a.veto_scal3[MS_S_ESURF] : 0.0) +
+                                ((a.gate_mods & MS_MOD_BENDING) ? a.veto_scal3[MS_S_EBEND] : 0.0);
+        run = run && !(E_second <= a.veto_rhs3);
+      }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.gate_out) *a.gate_out = run ? 1 : 0;
     if (!run) return;
@@ -2087,15 +2106,22 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(const double* partials, int n
                                                   unsigned long long* host_box,
                                                   unsigned long long ticket, const int* gate,
                                                   const double* partials2, double* scal2,
-                                                  unsigned long long* host_box2) {
+                                                  unsigned long long* host_box2, const double* partials3,
+                                                  double* scal3, unsigned long long* host_box3) {
   __shared__ double red[16];
   if (gate != nullptr && *gate == 0) return;
   int rb = blockIdx.x;
-  if (partials2 != nullptr && rb >= __popc(slot_mask)) {  // second set of a pair launch
+  if (partials2 != nullptr && rb >= __popc(slot_mask)) {  // second / third set of a pair / triple launch
     rb -= __popc(slot_mask);
     partials = partials2;
     scal = scal2;
     host_box = host_box2;
+    if (partials3 != nullptr && rb >= __popc(slot_mask)) {
+      rb -= __popc(slot_mask);
+      partials = partials3;
+      scal = scal3;
+      host_box = host_box3;
+    }
   }
   // one workgroup per requested slot; partials are slot-major so lanes read
   // consecutive doubles.
@@ -2154,11 +2180,13 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(const double* partials, int n
 hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
                          uint32_t slot_mask, double* scal, unsigned long long* host_box,
                          unsigned long long ticket, hipStream_t s, const int* gate, const double* partials2,
-                         double* scal2, unsigned long long* host_box2) {
+                         double* scal2, unsigned long long* host_box2, const double* partials3, double* scal3,
+                         unsigned long long* host_box3) {
   const int nslots = __builtin_popcount(slot_mask);
   if (nslots == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_reduce, dim3(partials2 ? 2 * nslots : nslots), dim3(RBLOCK), 0, s, partials, n_tiles, tile0,
-                     tile1, slot_mask, scal, host_box, ticket, gate, partials2, scal2, host_box2);
+  const int sets = partials2 ? (partials3 ? 3 : 2) : 1;
+  hipLaunchKernelGGL(k_reduce, dim3(sets * nslots), dim3(RBLOCK), 0, s, partials, n_tiles, tile0, tile1, slot_mask,
+                     scal, host_box, ticket, gate, partials2, scal2, host_box2, partials3, scal3, host_box3);
   return hipGetLastError();
 }
 

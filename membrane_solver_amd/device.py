@@ -445,10 +445,10 @@ class DeviceMesh:
 
     def profile_read(self):
         """-> {kind: (total_ms, launches)} per kernel kind (include/membrane_hip.h, ms_profile_read)."""
-        ms = np.zeros(8)
-        n = np.zeros(8, dtype=np.int64)
+        ms = np.zeros(9)
+        n = np.zeros(9, dtype=np.int64)
         self._chk(L.lib().ms_profile_read(self._h, _pd(ms), n.ctypes.data_as(L._I64)), "ms_profile_read")
-        names = ("energy", "gradient", "direction", "reduce", "tilt", "bending_tilt", "tilt_vec", "energy_pair")
+        names = ("energy", "gradient", "direction", "reduce", "tilt", "bending_tilt", "tilt_vec", "energy_pair", "energy_triple")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
     def shard_info(self):

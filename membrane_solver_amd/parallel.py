@@ -508,7 +508,7 @@ def bench_main(args, rank: int, world: int, local_rank: int):
                 e_bytes = 20 * nf_l + (48 + 16 + 1) * nv_l + 2 * 40 * nv_l
             us = 1e3 * ms_e / n_e
             ach = e_bytes / (us * 1e-6) / 1e9
-            roofline = {"bound": "hbm", "kernel": ("ms::k_energy<.., PAIR=true> (two trial evaluations per launch)"
+            roofline = {"bound": "hbm", "kernel": ("ms::k_energy<.., MULTI=2> (two trial evaluations per launch)"
                                                    if pair_dominates else "ms::k_energy* (energy pass)")
                                                   + ", rank 0's shard", "achieved": ach,
                         "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,

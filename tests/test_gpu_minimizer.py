@@ -426,11 +426,11 @@ def test_topology_change_rebuilds_the_device_mirror(deterministic):
     assert res["energy"] == res_b["energy"] and mz.step_size == mz_b.step_size
 
 
-@pytest.mark.parametrize("mode", ["1", "2", "3"])
+@pytest.mark.parametrize("mode", ["1", "2", "3", "4"])
 def test_pair_launch_does_not_change_the_trajectory(mode, monkeypatch):
     """Two trial evaluations in one launch (k_energy<PAIR>, ms_step): MS_PAIR=1 lets the line-search history decide,
     MS_PAIR=2 pairs whenever it can (so trial 0 is accepted inside a pair now and then: the copy-back path), MS_PAIR=3
-    also queues a gated third trial behind every pair --
+    also queues a gated third trial behind every pair, MS_PAIR=4 evaluates three trials per launch whenever it can --
     both must give the doubles of the one-trial-per-launch search, bit for bit with fixed-order sums."""
     from membrane_solver_amd import _lib as L
     from membrane_solver_amd import meshgen
@@ -465,7 +465,7 @@ def test_pair_launch_does_not_change_the_trajectory(mode, monkeypatch):
     ref_rows, ref_x, ref_prof = run("0", "0")
     assert ref_prof.get("energy_pair", (0.0, 0))[1] == 0
     rows, x, prof = run(mode)
-    assert prof["energy_pair"][1] > 0, "the case is meant to exercise the pair launch"
+    assert prof["energy_triple" if mode == "4" else "energy_pair"][1] > 0, "the case is meant to exercise the pair launch"
     assert np.array_equal(rows, ref_rows)
     assert np.array_equal(x, ref_x)
     acc = ref_rows[ref_rows[:, 0] == 1]
