@@ -24,7 +24,8 @@ def short(n):
     n = n.split("(")[0]
     for k in ("k_energy", "k_gradient", "k_reduce", "k_direction"):
         if k in n:
-            return k + ("<PAIR>" if k == "k_energy" and n.rstrip(">").endswith("true") and n.count(",") >= 5 else "")
+            multi = n[n.find("<") + 1:n.rfind(">")].split(",")[-1].strip() if k == "k_energy" and n.count(",") >= 5 else "0"
+            return k + (f"<MULTI={multi}>" if multi in ("2", "3") else "")
     return n[:30]
 
 
