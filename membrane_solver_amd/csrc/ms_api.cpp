@@ -2054,7 +2054,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     // were rejected lately (a wasted evaluation costs more than a saved round trip gains)
     const bool pair = chain && depth > 1 && c->pair_enable && c->xt2 != nullptr &&
                       (c->params.modules & MS_MOD_BENDING) != 0 &&
-                      (c->pair_force || (ls_warm && alpha > a_hi && r_lo < INFINITY));
+                      (c->pair_force || (ls_warm && alpha > 1.05 * a_hi && r_lo < INFINITY));
     // triple launch: trial 1 is expected to fail as well -- its alpha is not below one that was rejected lately
     bool triple = false;
     if (pair) {
@@ -2831,7 +2831,7 @@ int ms_shard_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, doub
   // exchange (both trials' scalars in the header, both factor sets' boundary rows behind it)
   const bool pair = c->pair_enable && carry_mode && bend && !penalty && max_iter >= 2 &&
                     alpha * max_dir < safe_limit && alpha * sp->beta >= 1e-8 &&
-                    (c->pair_force || (c->ls_n >= 2 && alpha > a_hi && r_lo < INFINITY));
+                    (c->pair_force || (c->ls_n >= 2 && alpha > 1.05 * a_hi && r_lo < INFINITY));
   if (pair) {
     rc = spec_prepare(c);
     if (rc) return rc;
