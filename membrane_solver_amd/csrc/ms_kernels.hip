@@ -253,6 +253,29 @@ __device__ __forceinline__ void csr_commit(const CsrStage& r, const DeviceMesh& 
 // evaluations sit 8 apart in the launch order -- same XCD, dispatched together -- so the second read of the
 // tile's x / d / facet rows hits that XCD's L2.  The odd ones evaluate at alpha2 into the "2" outputs.
 // MULTI = 3: the same with three evaluations (trials 0, 1, 2; the LAST one uses the ordinary outputs).
+// Diagnostic build (-DMS_STAMPS=1, tools/kprobe.py --stamps): every workgroup of the two tile kernels records when
+// it started, finished its stage-in, finished its facet loop and ended (s_memrealtime, 100 MHz) plus the XCC / CU it
+// ran on.  No stamp executes in the normal build.
+#ifndef MS_STAMPS
+#define MS_STAMPS 0
+#endif
+#if MS_STAMPS
+__device__ unsigned long long g_stamps[8 * 16384];
+#define MS_STAMP(k)                                                                   \
+  do {                                                                                \
+    if (threadIdx.x == 0) g_stamps[8 * (size_t)blk + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#define MS_STAMP_ID()                                                                                  \
+  do {                                                                                                 \
+    if (threadIdx.x == 0) {                                                                            \
+      g_stamps[8 * (size_t)blk + 4] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); /* XCC_ID */ \
+      g_stamps[8 * (size_t)blk + 5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  /* HW_ID */  \
+    }                                                                                                  \
+  } while (0)
+#else
+#define MS_STAMP(k) do {} while (0)
+#define MS_STAMP_ID() do {} while (0)
+#endif
 template <bool BEND, bool GUARD, int TT, int CAPC, bool ATOMIC, int MULTI = 0>
 __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyArgs a, int cap_rt, int max_ent) {
   extern __shared__ double lds[];
@@ -301,6 +324,10 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
     if (!run) return;
   }
 
+  const int blk = bid;
+  (void)blk;
+  MS_STAMP(0);
+  MS_STAMP_ID();
   const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(bid, a.tile1 - a.tile0));
   const int tid = threadIdx.x;
   const bool have_d = a.d != nullptr;
@@ -431,6 +458,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
     }
   }
   __syncthreads();
+  MS_STAMP(1);
 
   double e_surf = 0.0, vol = 0.0, min_e2 = 1.0e300, guard = 0.0;
   const bool want_surf = a.modules & MS_MOD_SURFACE;
@@ -570,6 +598,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
 
   if (BEND && ATOMIC) {
     __syncthreads();
+    MS_STAMP(2);
     if (tid < t.n_owned) {
       aKx = stg[tid];
       aKy = stg[T + tid];
@@ -629,16 +658,22 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
       fe = kappa * (He * He);
       fv = -2.0 * kappa * (He * He) * ratio;
     }
+#ifndef MS_ABL_KA
+#define MS_ABL_KA 0  // K_A epilogue ablation (timing only): 1 no factor stores, 2 no rare vertex-normal path, 3 both
+#endif
     if (a.fK) {
       V3 Kd;
       if (signed_h) {
         Kd = nh;
-      } else if (k_mag > 1.0e-15) {
+      } else if ((MS_ABL_KA & 2) || k_mag > 1.0e-15) {
         const double inv_k = 1.0 / k_mag;
         Kd = mk(K.x * inv_k, K.y * inv_k, K.z * inv_k);
       } else {
         // bending.py:154-158 falls back to the vertex normal (bending_utils.py:13-34)
         // where K vanishes (flat patches): sum the incident facet normals now.
+#if MS_STAMPS
+        atomicAdd(&g_stamps[8 * 16384 - 1], 1ull);
+#endif
         V3 N = mk(0, 0, 0);
         int qb = ent_begin, qe = end;
         const uint16_t* ve = vent;
@@ -656,11 +691,15 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
         const double nn = norm(N);
         Kd = nn > 1.0e-15 ? mk(N.x / nn, N.y / nn, N.z / nn) : N;
       }
+#if (MS_ABL_KA & 1)
+      e_bend += 1e-300 * (Kd.x * scale_K + Kd.y * scale_K + Kd.z * scale_K + fe + fv);
+#else
       a.fK[3 * (size_t)v] = Kd.x * scale_K;
       a.fK[3 * (size_t)v + 1] = Kd.y * scale_K;
       a.fK[3 * (size_t)v + 2] = Kd.z * scale_K;
       a.fA[2 * (size_t)v] = fe;
       a.fA[2 * (size_t)v + 1] = fv;
+#endif
     }
   }
 
@@ -682,6 +721,10 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
       pout[MS_S_GUARD * pstride] = 0.0;
     }
   }
+#if MS_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  MS_STAMP(3);
+#endif
 }
 
 static size_t u16_bytes(int T, int max_ent) { return 2 * ((size_t)((max_ent + 3) & ~3)); }
@@ -777,6 +820,25 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
 // LDS: px[3][cap] | (BEND) fk[3][cap] fae[cap] fav[cap] | stg[9 or 18][T] | red[4*16]
 //      | vent[max_ent] (u16) | fl[cap] (u8)
 // ---------------------------------------------------------------------------
+// Phase-ablation switches (tools/kprobe.py; results are WRONG with any of them on -- timing only).
+#ifndef MS_ABL_NOATOM
+#define MS_ABL_NOATOM 0   // per-corner LDS atomics replaced by a register sink
+#endif
+#ifndef MS_ABL_NOMATH
+#define MS_ABL_NOMATH 0   // facet arithmetic replaced by sums of the gathered values
+#endif
+#ifndef MS_ABL_NOGATHER
+#define MS_ABL_NOGATHER 0 // corner rows synthesised in registers instead of read from LDS
+#endif
+#ifndef MS_ABL_NOLOOP
+#define MS_ABL_NOLOOP 0   // no facet loop at all (stage-in + epilogue skeleton)
+#endif
+#ifndef MS_ABL_NOSTORE
+#define MS_ABL_NOSTORE 0  // epilogue row stores dropped
+#endif
+#ifndef MS_ABL_NOHIST
+#define MS_ABL_NOHIST 0   // CG history rows not loaded
+#endif
 template <int BENDMODE, bool VOLROW, int TT, int CAPC, bool ATOMIC>
 __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
   extern __shared__ double lds[];
@@ -821,6 +883,10 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
     if (!run) return;
   }
 
+  const int blk = blockIdx.x;
+  (void)blk;
+  MS_STAMP(0);
+  MS_STAMP_ID();
   const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
   const int tid = threadIdx.x;
 
@@ -951,6 +1017,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
     }
   }
   __syncthreads();
+  MS_STAMP(1);
 
   const bool surf = a.modules & MS_MOD_SURFACE;
   const bool volpen = a.modules & MS_MOD_VOLUME_PENALTY;
@@ -961,13 +1028,16 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
   if (tid >= t.n_owned) cur = end = 0;
   // CG history rows of the fused direction pass: requested now, consumed in the epilogue
   V3 h_pg = mk(0, 0, 0), h_pd = mk(0, 0, 0);
-  if (a.dir_mode == 2 && tid < t.n_owned) {
+  if (!MS_ABL_NOHIST && a.dir_mode == 2 && tid < t.n_owned) {
     const size_t o = 3 * (size_t)(t.v_lo + tid);
     h_pg = mk(a.pg[o], a.pg[o + 1], a.pg[o + 2]);
     h_pd = a.pd_neg_pg ? -h_pg : mk(a.pd[o], a.pd[o + 1], a.pd[o + 2]);
   }
 
-  for (int c0f = t.f0; c0f < t.f1; c0f += T) {
+#if MS_ABL_NOATOM
+  double abl_sink = 0.0;
+#endif
+  for (int c0f = t.f0; c0f < (MS_ABL_NOLOOP ? t.f0 : t.f1); c0f += T) {
     const int p = c0f + tid;
     const TileFacet tf = tf_nx;
     const double gam = gam_nx;
@@ -976,7 +1046,11 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
       gam_nx = a.m.tf_gamma[p + T];
     }
     if (p < t.f1) {
+#if MS_ABL_NOGATHER
+      const V3 v0 = mk(tf.l0 * 1e-3, gam, 1.0), v1 = mk(0.5, tf.l1 * 1e-3, gam), v2 = mk(gam, 0.25, tf.l2 * 1e-3);
+#else
       const V3 v0 = lds_v3(px, cap, tf.l0), v1 = lds_v3(px, cap, tf.l1), v2 = lds_v3(px, cap, tf.l2);
+#endif
       const V3 e0 = v2 - v1, e1 = v0 - v2, e2 = v1 - v0;
       V3 G0 = mk(0, 0, 0), G1 = mk(0, 0, 0), G2 = mk(0, 0, 0);
       const V3 n = cross(e2, -e1);
@@ -1019,8 +1093,22 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
 #pragma unroll
         for (int k = 0; k < 9; ++k) s[k * T] = 0.0;
       }
+#if MS_ABL_NOMATH
       if (BEND) {
         const V3 k0 = lds_v3(fk, cap, tf.l0), k1 = lds_v3(fk, cap, tf.l1), k2 = lds_v3(fk, cap, tf.l2);
+        G0 = (fae[tf.l0] + fav[tf.l0]) * (k0 + e0);
+        G1 = (fae[tf.l1] + fav[tf.l1]) * (k1 + e1);
+        G2 = (fae[tf.l2] + fav[tf.l2]) * (k2 + e2);
+      }
+      if (false) {
+#else
+      if (BEND) {
+#endif
+#if MS_ABL_NOGATHER
+        const V3 k0 = mk(gam, tf.l0 * 1e-3, 2.0), k1 = mk(tf.l1 * 1e-3, 1.5, gam), k2 = mk(0.75, gam, tf.l2 * 1e-3);
+#else
+        const V3 k0 = lds_v3(fk, cap, tf.l0), k1 = lds_v3(fk, cap, tf.l1), k2 = lds_v3(fk, cap, tf.l2);
+#endif
         // cotans exactly as compute_curvature_data produces `weights`
         const double inv_ad = S < 1.0e-12 ? 1.0e12 : invS;  // 1 / max(S, 1e-12)
         const double d12 = dot(e1, e2), d20 = dot(e2, e0), d01 = dot(e0, e1);
@@ -1045,7 +1133,11 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
             t2 = (lfl[tf.l2] & VF_BOUNDARY) ? 0 : 1;
           }
           const int cnt = t0 + t1 + t2;
+#if MS_ABL_NOGATHER
+          double fe0 = gam, fe1 = 2 * gam, fe2 = 3 * gam;
+#else
           double fe0 = fae[tf.l0], fe1 = fae[tf.l1], fe2 = fae[tf.l2];
+#endif
           if (LEAF) {
             // per-corner factor 1/2 kappa_k (base_k + s div_f t)^2 (bending_tilt_leaflet.py:608-610);
             // div_f t = sum_k t_k . (n x e_k) / max(|n|^2, 1e-20) (tilt_operators.py:191-330)
@@ -1063,9 +1155,13 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
             fe2 = 0.5 * kp[tf.l2] * (u2 * u2);
           }
           const double avg = cnt > 0 ? (fe0 * t0 + fe1 * t1 + fe2 * t2) / (double)cnt : 0.0;
+#if MS_ABL_NOGATHER
+          const double C0 = (t0 ? fe0 : avg) + gam, C1 = (t1 ? fe1 : avg) + gam, C2 = (t2 ? fe2 : avg) + gam;
+#else
           const double C0 = (t0 ? fe0 : avg) + fav[tf.l0];
           const double C1 = (t1 ? fe1 : avg) + fav[tf.l1];
           const double C2 = (t2 ? fe2 : avg) + fav[tf.l2];
+#endif
           const bool obtuse = (c0 < 0.0) || (c1 < 0.0) || (c2 < 0.0);
           double q0 = 0.0, q1 = 0.0, q2 = 0.0;
           if (!obtuse) {
@@ -1098,7 +1194,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
           a12 = (2.0 * p1 + q2) + q0;
         }
       }
-      {
+      if (!MS_ABL_NOMATH) {
         const V3 Rn = R * n;
         const V3 X1 = cross(e1, Rn), X2 = cross(e2, Rn);
         const V3 H0 = (T0 + (a01 * e1 + a02 * e2)) - (X1 + X2);  // e0 x n = -(e1 + e2) x n
@@ -1107,6 +1203,11 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
         G1 = G1 + H1;
         G2 = G2 - (H0 + H1);
       }
+#if MS_ABL_NOATOM
+      if (ATOMIC) {
+        abl_sink += (G0.x + G0.y + G0.z) + (G1.x + G1.y + G1.z) + (G2.x + G2.y + G2.z);
+      } else
+#endif
       if (ATOMIC) {
         const int no = t.n_owned;
         if (tf.l0 < no) { atomicAdd(&stg[tf.l0], G0.x); atomicAdd(&stg[T + tf.l0], G0.y); atomicAdd(&stg[2 * T + tf.l0], G0.z); }
@@ -1145,8 +1246,12 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
 
   if (ATOMIC) {
     __syncthreads();
+    MS_STAMP(2);
     if (tid < t.n_owned) {
       gx = stg[tid];
+#if MS_ABL_NOATOM
+      gx += abl_sink;
+#endif
       gy = stg[T + tid];
       gz = stg[2 * T + tid];
       if (VOLROW) {
@@ -1181,12 +1286,14 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
         }
       }
       if (fixed) di = mk(0, 0, 0);
-      a.g[o] = gi.x;
-      a.g[o + 1] = gi.y;
-      a.g[o + 2] = gi.z;
-      a.d[o] = di.x;
-      a.d[o + 1] = di.y;
-      a.d[o + 2] = di.z;
+      if (!MS_ABL_NOSTORE) {
+        a.g[o] = gi.x;
+        a.g[o + 1] = gi.y;
+        a.g[o + 2] = gi.z;
+        a.d[o] = di.x;
+        a.d[o + 1] = di.y;
+        a.d[o + 2] = di.z;
+      }
       gn2 = dot_pinned(gi, gi);
       gdd = dot_pinned(gi, di);
       md2 = fixed ? 0.0 : dot_pinned(di, di);
@@ -1226,6 +1333,10 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
     const int slots[2] = {MS_S_GGC, MS_S_GCGC};
     block_reduce_store<2>(vals, ops, slots, red, a.partials + t.tile, (size_t)a.m.n_tiles);
   }
+#if MS_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row stores have left the wave
+  MS_STAMP(3);
+#endif
 }
 
 size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow, bool atomic, bool leaf) {
@@ -2569,3 +2680,12 @@ hipError_t launch_curvature_raw(int nv, int nf, const double* pos, const int32_t
 }
 
 }  // namespace ms
+#if MS_STAMPS
+extern "C" int ms_debug_read_stamps(unsigned long long* out, int n_blocks) {
+  if (n_blocks < 0) {  // the rare-path counter
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ms::g_stamps), sizeof(unsigned long long),
+                                    sizeof(unsigned long long) * (8 * 16384 - 1));
+  }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ms::g_stamps), sizeof(unsigned long long) * 8 * (size_t)n_blocks);
+}
+#endif
