@@ -454,6 +454,14 @@ int ms_profile_read(ms_ctx *ctx, double total_ms[MS_PROF_KINDS],
 int ms_plan_tiling(int nv, int nf, const double *positions, const int32_t *tri,
                    int tile_vertices, int shard_count, int64_t stats[8],
                    int32_t *perm_out);
+/* Host-only: LDS bank model of the lane order inside the tiles (no GPU needed).
+ * model[0] = mean LDS cycles of one corner gather (8-byte reads: lane groups of 32
+ * over 64 four-byte banks, identical addresses broadcast; 1.0 = conflict-free),
+ * model[1] = the same for one per-corner accumulator update (ds_add_f64 on owned
+ * corners: lane groups of 16 over 32 banks, identical addresses serialise),
+ * model[2], model[3] = fraction of lane groups that are conflict-free for each. */
+int ms_plan_tiling_conflicts(int nv, int nf, const double *positions,
+                             const int32_t *tri, int tile_vertices, double model[4]);
 
 /* ---- kernel-provider seam: the five procedures under fortran_kernels/ ----
  * Host arrays in, host arrays out (H2D/D2H per call: for parity, not speed).

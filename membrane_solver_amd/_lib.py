@@ -187,6 +187,7 @@ SIGNATURES = {
     "ms_profile_read": (ctypes.c_int, [_P, _D, _I64]),
     "ms_plan_tiling": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _D, _I32, ctypes.c_int, ctypes.c_int,
                                       _I64, _I32]),
+    "ms_plan_tiling_conflicts": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _D, _I32, ctypes.c_int, _D]),
     "ms_surface_energy_and_gradient_host": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _D, _I32, _D,
                                                            _D, _D]),
     "ms_grad_cotan_batch_host": (ctypes.c_int, [ctypes.c_int, _D, _D, _D, _D]),

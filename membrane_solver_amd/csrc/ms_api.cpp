@@ -3024,6 +3024,63 @@ int ms_plan_tiling(int nv, int nf, const double* positions, const int32_t* tri, 
   return MS_OK;
 }
 
+int ms_plan_tiling_conflicts(int nv, int nf, const double* positions, const int32_t* tri, int tile_vertices,
+                             double model[4]) {
+  if (!model) return fail(nullptr, MS_ERR_INVALID, "ms_plan_tiling_conflicts: model is NULL");
+  Tiling t;
+  std::string err;
+  int rc = build_tiling(nv, nf, positions, tri, nullptr, tile_vertices, 1, t, err);
+  if (rc != MS_OK) return fail(nullptr, rc, err);
+  double rd_cyc = 0, at_cyc = 0, rd_free = 0, at_free = 0;
+  int64_t rd_groups = 0, at_groups = 0;
+  for (int tile = 0; tile < t.n_tiles; ++tile) {
+    const int n_owned = std::min(t.T, t.nv - tile * t.T);
+    const int f0 = t.tile_facet_off[tile], f1 = t.tile_facet_off[tile + 1];
+    for (int k = 0; k < 3; ++k) {
+      for (int g0 = f0; g0 < f1; g0 += 32) {  // reads: 32 lanes, bank pair = slot mod 32, same slot broadcasts
+        int slots[32], ns = 0, cnt[32] = {0};
+        for (int p = g0; p < std::min(f1, g0 + 32); ++p) {
+          const TileFacet& f = t.tile_facets[p];
+          const int s = k == 0 ? f.l0 : (k == 1 ? f.l1 : f.l2);
+          bool dup = false;
+          for (int q = 0; q < ns; ++q) dup |= slots[q] == s;
+          if (!dup) {
+            slots[ns++] = s;
+            ++cnt[s & 31];
+          }
+        }
+        int mx = 1;
+        for (int q = 0; q < 32; ++q) mx = std::max(mx, cnt[q]);
+        rd_cyc += mx;
+        rd_free += mx == 1;
+        ++rd_groups;
+      }
+      for (int g0 = f0; g0 < f1; g0 += 16) {  // atomics: 16 lanes, bank pair = slot mod 16, owned corners only
+        int cnt[16] = {0}, any = 0;
+        for (int p = g0; p < std::min(f1, g0 + 16); ++p) {
+          const TileFacet& f = t.tile_facets[p];
+          const int s = k == 0 ? f.l0 : (k == 1 ? f.l1 : f.l2);
+          if (s < n_owned) {
+            ++cnt[s & 15];
+            any = 1;
+          }
+        }
+        if (!any) continue;
+        int mx = 1;
+        for (int q = 0; q < 16; ++q) mx = std::max(mx, cnt[q]);
+        at_cyc += mx;
+        at_free += mx == 1;
+        ++at_groups;
+      }
+    }
+  }
+  model[0] = rd_groups ? rd_cyc / rd_groups : 0.0;
+  model[1] = at_groups ? at_cyc / at_groups : 0.0;
+  model[2] = rd_groups ? rd_free / rd_groups : 0.0;
+  model[3] = at_groups ? at_free / at_groups : 0.0;
+  return MS_OK;
+}
+
 // ---- kernel-provider seam ---------------------------------------------------
 
 int ms_surface_energy_and_gradient_host(int nv, int nf, const double* pos, const int32_t* tri,

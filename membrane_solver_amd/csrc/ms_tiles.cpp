@@ -171,46 +171,26 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
     }
   }
 
-  // ---- 2b. spread neighbouring facets over different waves -------------------
-  // In walk order consecutive facets share their first corner (and mostly a second one), so the 64
-  // lanes of a wave would send their per-corner LDS atomics (or staged gathers) to a handful of
-  // vertices: same-address atomics serialise.  A stride permutation inside each tile puts facets
-  // that were adjacent ~n/64 lanes apart, i.e. into different waves.
-  {
-    const char* env = getenv("MS_FACET_STRIDE");
-    const int mode = env ? atoi(env) : 1;  // 0: keep the walk order
-    std::vector<TileFacet> tf_tmp;
-    std::vector<int32_t> ext_tmp, v_tmp;
-    for (int t = 0; t < out.n_tiles && mode != 0; ++t) {
-      const size_t b = (size_t)out.tile_facet_off[t], e = (size_t)out.tile_facet_off[t + 1];
-      const size_t n = e - b;
-      if (n < 128) continue;
-      size_t S = std::max<size_t>(mode > 1 ? (size_t)mode : 7, (n + 63) / 64);
-      while (std::gcd(S, n) != 1) ++S;
-      tf_tmp.assign(out.tile_facets.begin() + b, out.tile_facets.begin() + e);
-      ext_tmp.assign(out.tile_facet_ext.begin() + b, out.tile_facet_ext.begin() + e);
-      v_tmp.assign(inst_v.begin() + 3 * b, inst_v.begin() + 3 * e);
-      for (size_t i = 0; i < n; ++i) {
-        const size_t o = (i * S) % n;  // new slot i takes old instance o
-        out.tile_facets[b + i] = tf_tmp[o];
-        out.tile_facet_ext[b + i] = ext_tmp[o];
-        inst_v[3 * (b + i)] = v_tmp[3 * o];
-        inst_v[3 * (b + i) + 1] = v_tmp[3 * o + 1];
-        inst_v[3 * (b + i) + 2] = v_tmp[3 * o + 2];
-      }
-    }
-  }
-
   // ---- 3. halo lists + local slots ----------------------------------------
   out.tile_halo_off.assign(out.n_tiles + 1, 0);
   out.tile_ent_off.assign(out.n_tiles + 1, 0);
   out.tile_voff.assign((size_t)out.n_tiles * (T + 1), 0);
   std::vector<int32_t> halo_tmp;
   std::vector<int32_t> vcnt(T + 1);
+  // lane order inside a tile (MS_FACET_ORDER): 0 walk order, 1 stride permutation, 2 (default) bank-aware
+  const char* env_order = getenv("MS_FACET_ORDER");
+  const int order_mode = env_order ? atoi(env_order) : 2;
+  const char* env_stride = getenv("MS_FACET_STRIDE");
+  const int stride_mode = env_stride ? atoi(env_stride) : 1;
+  std::vector<TileFacet> tf_tmp;
+  std::vector<int32_t> ext_tmp;
+  std::vector<int32_t> order;
+  std::vector<uint8_t> taken;
   for (int t = 0; t < out.n_tiles; ++t) {
     const int v_lo = t * T;
     const int v_hi = std::min(nv, v_lo + T);
     const size_t b = (size_t)out.tile_facet_off[t], e = (size_t)out.tile_facet_off[t + 1];
+    const size_t n = e - b;
     halo_tmp.clear();
     for (size_t p = b; p < e; ++p)
       for (int k = 0; k < 3; ++k) {
@@ -239,6 +219,73 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
       out.tile_facets[p].l1 = loc[1];
       out.tile_facets[p].l2 = loc[2];
     }
+
+    // ---- 3b. which lane computes which facet ----------------------------------
+    // In walk order consecutive facets share their first corner (and mostly a second one), so the 64 lanes of a
+    // wave would send their per-corner LDS gathers and ds_add_f64 atomics to a handful of vertex slots.  The LDS
+    // serves an 8-byte access of 32 lanes per cycle when the lanes' slots differ mod 32 (reads: 64 banks of 4
+    // bytes, lane groups of 32) and writes / atomics in lane groups of 16 over 32 banks (slots distinct mod 16).
+    // Bank-aware order: fill every group of 32 lanes greedily with facets whose three corner slots are free in
+    // the group's three residue sets (mod 32 over the group, mod 16 over each half); what does not fit anywhere
+    // goes to the end.  Same-vertex corners (same address) are the special case "same residue".
+    if (n >= 128 && order_mode != 0) {
+      tf_tmp.assign(out.tile_facets.begin() + b, out.tile_facets.begin() + e);
+      ext_tmp.assign(out.tile_facet_ext.begin() + b, out.tile_facet_ext.begin() + e);
+      order.clear();
+      order.reserve(n);
+      // start from the stride permutation (spreads neighbours over the waves)
+      size_t S = std::max<size_t>(stride_mode > 1 ? (size_t)stride_mode : 7, (n + 63) / 64);
+      while (std::gcd(S, n) != 1) ++S;
+      std::vector<int32_t>& cand = order;  // candidates in stride order
+      for (size_t i = 0; i < n; ++i) cand.push_back((int32_t)((i * S) % n));
+      if (order_mode >= 2) {
+        std::vector<int32_t> seq(cand);
+        taken.assign(n, 0);
+        order.clear();
+        size_t first_free = 0;
+        while (order.size() < n) {
+          uint32_t m32[3] = {0, 0, 0};
+          const size_t group_end = std::min(n, order.size() + 32);
+          for (int half = 0; half < 2 && order.size() < group_end; ++half) {
+            uint32_t m16[3] = {0, 0, 0};
+            const size_t half_end = std::min(group_end, order.size() + 16);
+            for (size_t q = first_free; q < n && order.size() < half_end; ++q) {
+              if (taken[q]) continue;
+              const TileFacet& f = tf_tmp[seq[q]];
+              const uint32_t r[3] = {f.l0, f.l1, f.l2};
+              bool ok = true;
+              for (int k = 0; k < 3 && ok; ++k)
+                ok = !((m32[k] >> (r[k] & 31)) & 1u) && !((m16[k] >> (r[k] & 15)) & 1u);
+              if (!ok) continue;
+              for (int k = 0; k < 3; ++k) {
+                m32[k] |= 1u << (r[k] & 31);
+                m16[k] |= 1u << (r[k] & 15);
+              }
+              taken[q] = 1;
+              order.push_back(seq[q]);
+            }
+            // nothing admissible left for this half: take the next free ones as they come
+            for (size_t q = first_free; q < n && order.size() < half_end; ++q) {
+              if (taken[q]) continue;
+              const TileFacet& f = tf_tmp[seq[q]];
+              const uint32_t r[3] = {f.l0, f.l1, f.l2};
+              for (int k = 0; k < 3; ++k) {
+                m32[k] |= 1u << (r[k] & 31);
+                m16[k] |= 1u << (r[k] & 15);
+              }
+              taken[q] = 1;
+              order.push_back(seq[q]);
+            }
+            while (first_free < n && taken[first_free]) ++first_free;
+          }
+        }
+      }
+      for (size_t i = 0; i < n; ++i) {
+        out.tile_facets[b + i] = tf_tmp[order[i]];
+        out.tile_facet_ext[b + i] = ext_tmp[order[i]];
+      }
+    }
+
     // vertex -> corner CSR of this tile (counting sort keeps facet_local ascending)
     {
       if (e - b > 16383u) {
