@@ -53,18 +53,37 @@ __device__ __forceinline__ int xcd_tile(int b, int nb) {
   return k * q + (k < r ? k : r) + j;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
+// Wave64 reductions with DPP row shifts / row broadcasts (VALU-speed lane exchange; the ds_bpermute form of
+// __shfl_down costs an LDS round trip per step).  The result is valid in EVERY lane (read back from lane 63).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double fill, double v) {
+  const long long vi = __double_as_longlong(v), fi = __double_as_longlong(fill);
+  const int lo = __builtin_amdgcn_update_dpp((int)fi, (int)vi, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(fi >> 32), (int)(vi >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-__device__ __forceinline__ double wave_min(double v) {
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_down(v, o, 64));
-  return v;
+template <int OP>  // 0 sum, 1 min, 2 max
+__device__ __forceinline__ double wave_reduce(double v) {
+  const double id = OP == 0 ? 0.0 : (OP == 1 ? 1.0e300 : -1.0e300);
+#define MS_RED_STEP(CTRL, MASK)                                         \
+  {                                                                     \
+    const double t = dpp_move<CTRL, MASK>(id, v);                       \
+    v = OP == 0 ? v + t : (OP == 1 ? fmin(v, t) : fmax(v, t));          \
+  }
+  MS_RED_STEP(0x111, 0xf)  // row_shr:1
+  MS_RED_STEP(0x112, 0xf)  // row_shr:2
+  MS_RED_STEP(0x114, 0xf)  // row_shr:4
+  MS_RED_STEP(0x118, 0xf)  // row_shr:8   -> lane 15 of every row holds the row's result
+  MS_RED_STEP(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+  MS_RED_STEP(0x143, 0xc)  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's result
+#undef MS_RED_STEP
+  const long long vi = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)vi, 63), hi = __builtin_amdgcn_readlane((int)(vi >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-__device__ __forceinline__ double wave_max(double v) {
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
-  return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce<0>(v); }
+__device__ __forceinline__ double wave_min(double v) { return wave_reduce<1>(v); }
+__device__ __forceinline__ double wave_max(double v) { return wave_reduce<2>(v); }
 // op: 0 sum, 1 min, 2 max.  red = 16 doubles of LDS scratch.  Result valid in thread 0.
 __device__ __forceinline__ double block_reduce(double v, int op, double* red) {
   v = op == 0 ? wave_sum(v) : (op == 1 ? wave_min(v) : wave_max(v));
@@ -163,6 +182,18 @@ __device__ __forceinline__ double dot_pinned(V3 a, V3 b) {
 
 __device__ __forceinline__ V3 lds_v3(const double* base, int cap, int slot) {
   return mk(base[slot], base[cap + slot], base[2 * cap + slot]);
+}
+// 24-byte rows (x y z) in LDS: one address register per corner, the components at immediate offsets.  For 8-byte
+// reads the bank pair of row s, component c is (3 s + c) mod 32 -- 3 is odd, so rows that differ mod 32 do not conflict.
+__device__ __forceinline__ V3 lds_row3(const double* rows, int slot) {
+  const double* r = rows + 3 * slot;
+  return mk(r[0], r[1], r[2]);
+}
+__device__ __forceinline__ void lds_put3(double* rows, int slot, double x, double y, double z) {
+  double* r = rows + 3 * slot;
+  r[0] = x;
+  r[1] = y;
+  r[2] = z;
 }
 
 // ---------------------------------------------------------------------------
@@ -820,6 +851,16 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
 // LDS: px[3][cap] | (BEND) fk[3][cap] fae[cap] fav[cap] | stg[9 or 18][T] | red[4*16]
 //      | vent[max_ent] (u16) | fl[cap] (u8)
 // ---------------------------------------------------------------------------
+// Scheduling fences between the stages of the facet arithmetic: without them the compiler hoists every LDS gather
+// of a facet to the top, which keeps ~50 more registers live and costs a resident workgroup per CU.
+#ifndef MS_SCHED_FENCES
+#define MS_SCHED_FENCES 1
+#endif
+#if MS_SCHED_FENCES
+#define MS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MS_SCHED_FENCE() do {} while (0)
+#endif
 // Phase-ablation switches (tools/kprobe.py; results are WRONG with any of them on -- timing only).
 #ifndef MS_ABL_NOATOM
 #define MS_ABL_NOATOM 0   // per-corner LDS atomics replaced by a register sink
@@ -849,11 +890,11 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
   constexpr bool ANALYTIC = BENDMODE == 1 || BENDMODE == 3;
   const int T = TT ? TT : a.m.T;
   const int cap = CAPC ? CAPC : cap_rt;
+  // rows: px[cap][3] positions | fk[cap][3] | fa[cap][2] = (fA_eff or base, fA_vor) -- the layouts of the global arrays
   double* px = lds;
   double* fk = px + 3 * cap;
-  double* fae = fk + (BEND ? 3 * cap : 0);
-  double* fav = fae + (BEND ? cap : 0);
-  double* kp = fav + (BEND ? cap : 0);        // LEAF: kappa
+  double* fa = fk + (BEND ? 3 * cap : 0);
+  double* kp = fa + (BEND ? 2 * cap : 0);     // LEAF: kappa
   double* tl = kp + (LEAF ? cap : 0);         // LEAF: tilts
   double* stg = tl + (LEAF ? 3 * cap : 0);
   // ATOMIC: stg holds the per-vertex accumulators (ds_add_f64) instead of per-corner columns
@@ -957,15 +998,11 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
     }
     if (own) {
       lfl[tid] = fl;
-      px[tid] = x0;
-      px[cap + tid] = x1;
-      px[2 * cap + tid] = x2;
+      lds_put3(px, tid, x0, x1, x2);
       if (BEND) {
-        fk[tid] = k0;
-        fk[cap + tid] = k1;
-        fk[2 * cap + tid] = k2;
-        fae[tid] = ae;
-        fav[tid] = av;
+        lds_put3(fk, tid, k0, k1, k2);
+        fa[2 * tid] = ae;
+        fa[2 * tid + 1] = av;
       }
       if (LEAF) {
         kp[tid] = okp;
@@ -982,15 +1019,11 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
     if (has_h) {
       const int s = t.n_owned + tid;
       lfl[s] = hfl;
-      px[s] = hx0;
-      px[cap + s] = hx1;
-      px[2 * cap + s] = hx2;
+      lds_put3(px, s, hx0, hx1, hx2);
       if (BEND) {
-        fk[s] = hk0;
-        fk[cap + s] = hk1;
-        fk[2 * cap + s] = hk2;
-        fae[s] = hae;
-        fav[s] = hav;
+        lds_put3(fk, s, hk0, hk1, hk2);
+        fa[2 * s] = hae;
+        fa[2 * s + 1] = hav;
       }
       if (LEAF) {
         kp[s] = hkp;
@@ -1005,13 +1038,13 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
       lfl[s] = a.m.vflags[v];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        px[c * cap + s] = a.x[3 * (size_t)v + c];
-        if (BEND) fk[c * cap + s] = a.fK[3 * (size_t)v + c];
+        px[3 * s + c] = a.x[3 * (size_t)v + c];
+        if (BEND) fk[3 * s + c] = a.fK[3 * (size_t)v + c];
         if (LEAF) tl[c * cap + s] = a.tilts[3 * (size_t)v + c];
       }
       if (BEND) {
-        fae[s] = LEAF ? a.bt_vert[4 * (size_t)v] : a.fA[2 * (size_t)v];
-        fav[s] = a.fA[2 * (size_t)v + 1];
+        fa[2 * s] = LEAF ? a.bt_vert[4 * (size_t)v] : a.fA[2 * (size_t)v];
+        fa[2 * s + 1] = a.fA[2 * (size_t)v + 1];
       }
       if (LEAF) kp[s] = a.m.kappa[v];
     }
@@ -1049,11 +1082,13 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
 #if MS_ABL_NOGATHER
       const V3 v0 = mk(tf.l0 * 1e-3, gam, 1.0), v1 = mk(0.5, tf.l1 * 1e-3, gam), v2 = mk(gam, 0.25, tf.l2 * 1e-3);
 #else
-      const V3 v0 = lds_v3(px, cap, tf.l0), v1 = lds_v3(px, cap, tf.l1), v2 = lds_v3(px, cap, tf.l2);
+      const V3 v0 = lds_row3(px, tf.l0), v1 = lds_row3(px, tf.l1), v2 = lds_row3(px, tf.l2);
 #endif
-      const V3 e0 = v2 - v1, e1 = v0 - v2, e2 = v1 - v0;
+      // two edges carry the facet: e0 = -(e1 + e2), and every inner product of edges follows from
+      // l1 = e1.e1, l2 = e2.e2, d12 = e1.e2
+      const V3 e1 = v0 - v2, e2 = v1 - v0;
       V3 G0 = mk(0, 0, 0), G1 = mk(0, 0, 0), G2 = mk(0, 0, 0);
-      const V3 n = cross(e2, -e1);
+      const V3 n = cross(e1, e2);
       const double S = norm(n);
       // Every geometric contribution of this facet has the form
       //     G_k = (a_k1 e1 + a_k2 e2) + R (e_k x n) [+ the -L fK difference vectors]:
@@ -1095,36 +1130,53 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
       }
 #if MS_ABL_NOMATH
       if (BEND) {
-        const V3 k0 = lds_v3(fk, cap, tf.l0), k1 = lds_v3(fk, cap, tf.l1), k2 = lds_v3(fk, cap, tf.l2);
-        G0 = (fae[tf.l0] + fav[tf.l0]) * (k0 + e0);
-        G1 = (fae[tf.l1] + fav[tf.l1]) * (k1 + e1);
-        G2 = (fae[tf.l2] + fav[tf.l2]) * (k2 + e2);
+        const V3 k0 = lds_row3(fk, tf.l0), k1 = lds_row3(fk, tf.l1), k2 = lds_row3(fk, tf.l2);
+        G0 = (fa[2 * tf.l0] + fa[2 * tf.l0 + 1]) * (k0 - (e1 + e2));
+        G1 = (fa[2 * tf.l1] + fa[2 * tf.l1 + 1]) * (k1 + e1);
+        G2 = (fa[2 * tf.l2] + fa[2 * tf.l2 + 1]) * (k2 + e2);
       }
       if (false) {
 #else
       if (BEND) {
 #endif
-#if MS_ABL_NOGATHER
-        const V3 k0 = mk(gam, tf.l0 * 1e-3, 2.0), k1 = mk(tf.l1 * 1e-3, 1.5, gam), k2 = mk(0.75, gam, tf.l2 * 1e-3);
-#else
-        const V3 k0 = lds_v3(fk, cap, tf.l0), k1 = lds_v3(fk, cap, tf.l1), k2 = lds_v3(fk, cap, tf.l2);
-#endif
         // cotans exactly as compute_curvature_data produces `weights`
         const double inv_ad = S < 1.0e-12 ? 1.0e12 : invS;  // 1 / max(S, 1e-12)
-        const double d12 = dot(e1, e2), d20 = dot(e2, e0), d01 = dot(e0, e1);
+        const double l1 = dot(e1, e1), l2 = dot(e2, e2), d12 = dot(e1, e2);
+        const double d20 = -(d12 + l2), d01 = -(l1 + d12);  // e2.e0, e0.e1
         const double c0 = -d12 * inv_ad, c1 = -d20 * inv_ad, c2 = -d01 * inv_ad;
-        // term 1: -L fK  (bending_kernels.f90:118-129): G0 -= b + c, G1 -= a - c, G2 += a + b
-        const V3 f02 = k0 - k2, f01 = k0 - k1, f12 = k1 - k2;
+        // term 1: -L fK  (bending_kernels.f90:118-129): G0 -= b + c, G1 -= a - c, G2 += a + b, and the term-2
+        // weights (bending_gradient.py:37-42; (v1-v2) == -e0 etc.), one component of fK at a time so that the
+        // nine factor values are never all live
+        double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+        MS_SCHED_FENCE();
         {
-          const V3 ta = (0.5 * c0) * f12, tb = (0.5 * c1) * f02, tc = (0.5 * c2) * f01;
-          T0 = -(tb + tc);
-          T1 = tc - ta;
+          const double hc0 = 0.5 * c0, hc1 = 0.5 * c1, hc2 = 0.5 * c2;
+#if MS_ABL_NOGATHER
+          const double kk[9] = {gam, tf.l0 * 1e-3, 2.0, tf.l1 * 1e-3, 1.5, gam, 0.75, gam, tf.l2 * 1e-3};
+          const double *r0 = kk, *r1 = kk + 3, *r2 = kk + 6;
+#else
+          const double *r0 = fk + 3 * tf.l0, *r1 = fk + 3 * tf.l1, *r2 = fk + 3 * tf.l2;
+#endif
+          double t0[3], t1[3];
+          const double e1c[3] = {e1.x, e1.y, e1.z}, e2c[3] = {e2.x, e2.y, e2.z};
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const double k0 = r0[c], k1 = r1[c], k2 = r2[c];
+            const double f12 = k1 - k2, f02 = k0 - k2, f01 = k0 - k1;
+            t0[c] = -(hc1 * f02 + hc2 * f01);
+            t1[c] = hc2 * f01 - hc0 * f12;
+            w0 -= f12 * (e1c[c] + e2c[c]);  // f12 . e0
+            w1 += f02 * e1c[c];
+            w2 += f01 * e2c[c];
+          }
+          T0 = mk(t0[0], t0[1], t0[2]);
+          T1 = mk(t1[0], t1[1], t1[2]);
         }
+        MS_SCHED_FENCE();
         if (ANALYTIC) {
-          // term 2 weights (bending_gradient.py:37-42); (v1-v2) == -e0 etc.
-          double w0 = 0.5 * dot(f12, e0);
-          double w1 = -0.5 * dot(f02, e1);
-          double w2 = 0.5 * dot(f01, e2);
+          w0 = 0.5 * w0;
+          w1 = -0.5 * w1;
+          w2 = 0.5 * w2;
           // term 3 coefficients (bending_gradient.py:80-95)
           int t0 = 1, t1 = 1, t2 = 1;
           if (a.m.has_boundary) {
@@ -1135,14 +1187,21 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
           const int cnt = t0 + t1 + t2;
 #if MS_ABL_NOGATHER
           double fe0 = gam, fe1 = 2 * gam, fe2 = 3 * gam;
+          const double fv0 = gam, fv1 = gam, fv2 = gam;
 #else
-          double fe0 = fae[tf.l0], fe1 = fae[tf.l1], fe2 = fae[tf.l2];
+          // (fA_eff, fA_vor) of a corner is one 16-byte row
+          const double2 fa0 = *reinterpret_cast<const double2*>(fa + 2 * tf.l0);
+          const double2 fa1 = *reinterpret_cast<const double2*>(fa + 2 * tf.l1);
+          const double2 fa2 = *reinterpret_cast<const double2*>(fa + 2 * tf.l2);
+          double fe0 = fa0.x, fe1 = fa1.x, fe2 = fa2.x;
+          const double fv0 = fa0.y, fv1 = fa1.y, fv2 = fa2.y;
 #endif
           if (LEAF) {
             // per-corner factor 1/2 kappa_k (base_k + s div_f t)^2 (bending_tilt_leaflet.py:608-610);
             // div_f t = sum_k t_k . (n x e_k) / max(|n|^2, 1e-20) (tilt_operators.py:191-330)
             const double n2 = dot(n, n);
             const double den = n2 > 1.0e-20 ? n2 : 1.0e-20;
+            const V3 e0 = -(e1 + e2);
             const V3 q0 = cross(n, e0), q1 = cross(n, e1), q2 = cross(n, e2);
             const V3 g0 = mk(q0.x / den, q0.y / den, q0.z / den);
             const V3 g1 = mk(q1.x / den, q1.y / den, q1.z / den);
@@ -1155,13 +1214,9 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
             fe2 = 0.5 * kp[tf.l2] * (u2 * u2);
           }
           const double avg = cnt > 0 ? (fe0 * t0 + fe1 * t1 + fe2 * t2) / (double)cnt : 0.0;
-#if MS_ABL_NOGATHER
-          const double C0 = (t0 ? fe0 : avg) + gam, C1 = (t1 ? fe1 : avg) + gam, C2 = (t2 ? fe2 : avg) + gam;
-#else
-          const double C0 = (t0 ? fe0 : avg) + fav[tf.l0];
-          const double C1 = (t1 ? fe1 : avg) + fav[tf.l1];
-          const double C2 = (t2 ? fe2 : avg) + fav[tf.l2];
-#endif
+          const double C0 = (t0 ? fe0 : avg) + fv0;
+          const double C1 = (t1 ? fe1 : avg) + fv1;
+          const double C2 = (t2 ? fe2 : avg) + fv2;
           const bool obtuse = (c0 < 0.0) || (c1 < 0.0) || (c2 < 0.0);
           double q0 = 0.0, q1 = 0.0, q2 = 0.0;
           if (!obtuse) {
@@ -1171,9 +1226,9 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
             q0 = 0.25 * c0 * (C1 + C2);
             q1 = 0.25 * c1 * (C0 + C2);
             q2 = 0.25 * c2 * (C0 + C1);
-            w0 += 0.125 * dot(e0, e0) * (C1 + C2);
-            w1 += 0.125 * dot(e1, e1) * (C0 + C2);
-            w2 += 0.125 * dot(e2, e2) * (C0 + C1);
+            w0 += 0.125 * ((l1 + l2) + 2.0 * d12) * (C1 + C2);  // |e0|^2
+            w1 += 0.125 * l1 * (C0 + C2);
+            w2 += 0.125 * l2 * (C0 + C1);
           } else {
             // (:154-173) grad T with u = v1-v0, v = v2-v0: +factor/(2S) (n x e_k) at vertex k
             double factor = 0.0;
@@ -1194,6 +1249,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
           a12 = (2.0 * p1 + q2) + q0;
         }
       }
+      MS_SCHED_FENCE();
       if (!MS_ABL_NOMATH) {
         const V3 Rn = R * n;
         const V3 X1 = cross(e1, Rn), X2 = cross(e2, Rn);
