@@ -33,6 +33,8 @@ struct ms_ctx {
   int32_t* d_tile_facet_off = nullptr;
   TileFacet* d_tile_facets = nullptr;
   double* d_tf_gamma = nullptr;
+  bool gamma_uniform = true, kc_uniform = true;  // ms_set_surface_tension / ms_set_bending_params decide
+  double gamma_const = 1.0, kappa_const = 0.0, c0_const = 0.0;
   int32_t* d_tile_halo_off = nullptr;
   int32_t* d_halo_ids = nullptr;
   int32_t* d_tile_ent_off = nullptr;
@@ -230,6 +232,11 @@ DeviceMesh device_mesh(const ms_ctx* c) {
   m.tile_facet_off = c->d_tile_facet_off;
   m.tile_facets = c->d_tile_facets;
   m.tf_gamma = c->d_tf_gamma;
+  m.gamma_uniform = c->gamma_uniform ? 1 : 0;
+  m.gamma_const = c->gamma_const;
+  m.kc_uniform = c->kc_uniform ? 1 : 0;
+  m.kappa_const = c->kappa_const;
+  m.c0_const = c->c0_const;
   m.tile_halo_off = c->d_tile_halo_off;
   m.halo_ids = c->d_halo_ids;
   m.tile_ent_off = c->d_tile_ent_off;
@@ -344,6 +351,7 @@ int bt_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, con
   a.m = device_mesh(c);
   if (leaflet) {
     a.m.kappa = f.kappa;
+    a.m.kc_uniform = 0;  // per-leaflet arrays
     a.m.c0 = f.c0;
   }
   a.tile0 = c->tile0;
@@ -569,6 +577,7 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
         return fail(c, MS_ERR_STATE, "bending_tilt_in/out active but ms_set_leaflet_tilts / ms_set_leaflet_bending were not called");
       EnergyArgs al = a;
       al.m.kappa = f.kappa;
+      al.m.kc_uniform = 0;  // per-leaflet arrays
       al.m.c0 = f.c0;
       al.bt_vert = f.bt_vert;
       al.bt_normals = c->d_tn;
@@ -694,6 +703,7 @@ int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulat
     }
     GradientArgs al = a;
     al.m.kappa = f.kappa;
+    al.m.kc_uniform = 0;  // per-leaflet arrays
     al.m.c0 = f.c0;
     al.bt_vert = f.bt_vert;
     al.tilts = f.tilts;
@@ -1147,6 +1157,9 @@ int ms_set_surface_tension(ms_ctx* c, const double* gamma) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::vector<double> g(t.tile_facets.size());
   for (size_t p = 0; p < g.size(); ++p) g[p] = gamma[t.tile_facet_ext[p]];
+  c->gamma_uniform = true;
+  c->gamma_const = t.nf > 0 ? gamma[0] : 1.0;
+  for (int f = 1; f < t.nf && c->gamma_uniform; ++f) c->gamma_uniform = gamma[f] == c->gamma_const;
   if (!g.empty())
     HIPCHK(c, hipMemcpy(c->d_tf_gamma, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice));
   c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
@@ -1159,9 +1172,13 @@ int ms_set_bending_params(ms_ctx* c, const double* kappa, const double* c0) {
   const Tiling& t = c->til;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::vector<double> k((size_t)t.nvp, 0.0), z((size_t)t.nvp, 0.0);
+  c->kc_uniform = true;
+  c->kappa_const = kappa[0];
+  c->c0_const = c0[0];
   for (int i = 0; i < t.nv; ++i) {
     k[i] = kappa[t.perm[i]];
     z[i] = c0[t.perm[i]];
+    c->kc_uniform = c->kc_uniform && kappa[i] == c->kappa_const && c0[i] == c->c0_const;
   }
   HIPCHK(c, hipMemcpy(c->d_kappa, k.data(), k.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_c0, z.data(), z.size() * sizeof(double), hipMemcpyHostToDevice));

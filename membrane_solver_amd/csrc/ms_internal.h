@@ -68,6 +68,10 @@ struct DeviceMesh {
   const int32_t* tile_facet_off;
   const TileFacet* tile_facets;
   const double* tf_gamma;  // surface tension per facet instance
+  // uniform-parameter shortcuts: when every facet carries the same surface tension (every vertex the same kappa and
+  // c0) the kernels take the value from here and the per-facet / per-vertex arrays are not read at all
+  int gamma_uniform, kc_uniform;
+  double gamma_const, kappa_const, c0_const;
   const int32_t* tile_halo_off;
   const int32_t* halo_ids;
   const int32_t* tile_ent_off;

@@ -275,7 +275,7 @@ __device__ __forceinline__ void csr_commit(const CsrStage& r, const DeviceMesh& 
 //   alpha d, line_search.py:362-368) and can write that trial block to xt.
 // One normal n = (v1-v0)x(v2-v0) and one sqrt per facet serve the surface term,
 // the cotans (|e1 x e2| is the same vector) and both area clamps.
-// LDS: px[3][cap] | (GUARD) ox[3][cap] | (BEND) stg[9][T] (the reduction scratch aliases it)
+// LDS: px[cap][3] rows | (GUARD) ox[cap][3] | (BEND) stg[9][T] (the reduction scratch aliases it)
 //      | (BEND) vent[max_ent] (u16) | fl[cap] (u8, only with boundary vertices / GUARD)
 // ---------------------------------------------------------------------------
 // TT / CAPC: compile-time tile size and LDS patch capacity (0 = take the runtime values);
@@ -369,14 +369,14 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
   double gam_nx = 0.0;
   if (t.f0 + tid < t.f1) {
     tf_nx = a.m.tile_facets[t.f0 + tid];
-    gam_nx = a.m.tf_gamma[t.f0 + tid];
+    gam_nx = a.m.gamma_uniform ? a.m.gamma_const : a.m.tf_gamma[t.f0 + tid];
   }
 
   // per-vertex parameters of the epilogue are requested now, used ~all the way down
   double kappa_v = 0.0, c0_v = 0.0;
   if (BEND && tid < t.n_owned) {
-    kappa_v = a.m.kappa[t.v_lo + tid];
-    c0_v = a.m.c0[t.v_lo + tid];
+    kappa_v = a.m.kc_uniform ? a.m.kappa_const : a.m.kappa[t.v_lo + tid];
+    c0_v = a.m.kc_uniform ? a.m.c0_const : a.m.c0[t.v_lo + tid];
   }
 
   uint8_t own_fl = 0;  // this thread's own vertex flags (epilogue)
@@ -432,14 +432,8 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
       const double x1 = mv ? xo1 + a.alpha * dd1 : xo1;
       const double x2 = mv ? xo2 + a.alpha * dd2 : xo2;
       if (stage_flags) lfl[tid] = fl;
-      px[tid] = x0;
-      px[cap + tid] = x1;
-      px[2 * cap + tid] = x2;
-      if (GUARD) {
-        ox[tid] = xo0;
-        ox[cap + tid] = xo1;
-        ox[2 * cap + tid] = xo2;
-      }
+      lds_put3(px, tid, x0, x1, x2);
+      if (GUARD) lds_put3(ox, tid, xo0, xo1, xo2);
       if (a.xt) {
         a.xt[g] = x0;
         a.xt[g + 1] = x1;
@@ -455,14 +449,8 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
       const int s = t.n_owned + tid;
       const bool mv = have_d && !(hfl & VF_FIXED);
       if (stage_flags) lfl[s] = hfl;
-      px[s] = mv ? h0 + a.alpha * e0 : h0;
-      px[cap + s] = mv ? h1 + a.alpha * e1 : h1;
-      px[2 * cap + s] = mv ? h2 + a.alpha * e2 : h2;
-      if (GUARD) {
-        ox[s] = h0;
-        ox[cap + s] = h1;
-        ox[2 * cap + s] = h2;
-      }
+      lds_put3(px, s, mv ? h0 + a.alpha * e0 : h0, mv ? h1 + a.alpha * e1 : h1, mv ? h2 + a.alpha * e2 : h2);
+      if (GUARD) lds_put3(ox, s, h0, h1, h2);
     }
     for (int h = tid + T; h < t.nh; h += T) {  // halo longer than the workgroup (small tiles)
       const int v = a.m.halo_ids[t.h0 + h];
@@ -478,14 +466,8 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
       const int s = t.n_owned + h;
       const bool mv = have_d && !(f2 & VF_FIXED);
       if (stage_flags) lfl[s] = f2;
-      px[s] = mv ? q0 + a.alpha * r0 : q0;
-      px[cap + s] = mv ? q1 + a.alpha * r1 : q1;
-      px[2 * cap + s] = mv ? q2 + a.alpha * r2 : q2;
-      if (GUARD) {
-        ox[s] = q0;
-        ox[cap + s] = q1;
-        ox[2 * cap + s] = q2;
-      }
+      lds_put3(px, s, mv ? q0 + a.alpha * r0 : q0, mv ? q1 + a.alpha * r1 : q1, mv ? q2 + a.alpha * r2 : q2);
+      if (GUARD) lds_put3(ox, s, q0, q1, q2);
     }
   }
   __syncthreads();
@@ -505,13 +487,13 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
     const double gam = gam_nx;
     if (p + T < t.f1) {
       tf_nx = a.m.tile_facets[p + T];
-      gam_nx = a.m.tf_gamma[p + T];
+      gam_nx = a.m.gamma_uniform ? a.m.gamma_const : a.m.tf_gamma[p + T];
     }
     double va0 = 0, va1 = 0, va2 = 0, ve0 = 0, ve1 = 0, ve2 = 0;
     if (p < t.f1) {
       const bool owner = tf.flags & TF_OWNER;
       if (BEND || owner) {
-        const V3 v0 = lds_v3(px, cap, tf.l0), v1 = lds_v3(px, cap, tf.l1), v2 = lds_v3(px, cap, tf.l2);
+        const V3 v0 = lds_row3(px, tf.l0), v1 = lds_row3(px, tf.l1), v2 = lds_row3(px, tf.l2);
         const V3 e0 = v2 - v1, e1 = v0 - v2, e2 = v1 - v0;
         const double l0 = dot(e0, e0), l1 = dot(e1, e1), l2 = dot(e2, e2);
         const V3 n = cross(e2, -e1);  // (v1-v0) x (v2-v0) == e1 x e2
@@ -521,7 +503,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
           if (want_vol && (tf.flags & TF_BODY)) vol += dot(cross(v1, v2), v0);
           min_e2 = fmin(min_e2, fmin(l0, fmin(l1, l2)));
           if (GUARD) {
-            const V3 o0 = lds_v3(ox, cap, tf.l0), o1 = lds_v3(ox, cap, tf.l1), o2 = lds_v3(ox, cap, tf.l2);
+            const V3 o0 = lds_row3(ox, tf.l0), o1 = lds_row3(ox, tf.l1), o2 = lds_row3(ox, tf.l2);
             const V3 no = cross(o1 - o0, o2 - o0);
             const double nno = norm(no);
             if (nno > 1.0e-12) {
@@ -716,7 +698,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
         }
         for (int q = qb; q < qe; ++q) {
           const TileFacet f = a.m.tile_facets[t.f0 + (ve[q] >> 2)];
-          const V3 q0 = lds_v3(px, cap, f.l0), q1 = lds_v3(px, cap, f.l1), q2 = lds_v3(px, cap, f.l2);
+          const V3 q0 = lds_row3(px, f.l0), q1 = lds_row3(px, f.l1), q2 = lds_row3(px, f.l2);
           N = N + cross(q1 - q0, q2 - q0);
         }
         const double nn = norm(N);
@@ -935,7 +917,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
   double gam_nx = 0.0;
   if (t.f0 + tid < t.f1) {
     tf_nx = a.m.tile_facets[t.f0 + tid];
-    gam_nx = a.m.tf_gamma[t.f0 + tid];
+    gam_nx = a.m.gamma_uniform ? a.m.gamma_const : a.m.tf_gamma[t.f0 + tid];
   }
 
   int cur = 0, end = 0;  // this vertex's CSR range
@@ -1076,7 +1058,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
     const double gam = gam_nx;
     if (p + T < t.f1) {
       tf_nx = a.m.tile_facets[p + T];
-      gam_nx = a.m.tf_gamma[p + T];
+      gam_nx = a.m.gamma_uniform ? a.m.gamma_const : a.m.tf_gamma[p + T];
     }
     if (p < t.f1) {
 #if MS_ABL_NOGATHER

@@ -249,32 +249,35 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
           for (int half = 0; half < 2 && order.size() < group_end; ++half) {
             uint32_t m16[3] = {0, 0, 0};
             const size_t half_end = std::min(group_end, order.size() + 16);
-            for (size_t q = first_free; q < n && order.size() < half_end; ++q) {
-              if (taken[q]) continue;
-              const TileFacet& f = tf_tmp[seq[q]];
+            while (order.size() < half_end) {
+              // the first candidate that is free in all six residue sets, else the one with the fewest collisions
+              // among the next free candidates
+              size_t best = n;
+              int best_cost = 99, seen = 0;
+              for (size_t q = first_free; q < n && seen < 192; ++q) {
+                if (taken[q]) continue;
+                ++seen;
+                const TileFacet& f = tf_tmp[seq[q]];
+                const uint32_t r[3] = {f.l0, f.l1, f.l2};
+                int cost = 0;
+                for (int k = 0; k < 3; ++k)
+                  cost += (int)((m32[k] >> (r[k] & 31)) & 1u) + (int)((m16[k] >> (r[k] & 15)) & 1u);
+                if (cost < best_cost) {
+                  best_cost = cost;
+                  best = q;
+                  if (cost == 0) break;
+                }
+              }
+              if (best == n) break;
+              const TileFacet& f = tf_tmp[seq[best]];
               const uint32_t r[3] = {f.l0, f.l1, f.l2};
-              bool ok = true;
-              for (int k = 0; k < 3 && ok; ++k)
-                ok = !((m32[k] >> (r[k] & 31)) & 1u) && !((m16[k] >> (r[k] & 15)) & 1u);
-              if (!ok) continue;
               for (int k = 0; k < 3; ++k) {
                 m32[k] |= 1u << (r[k] & 31);
                 m16[k] |= 1u << (r[k] & 15);
               }
-              taken[q] = 1;
-              order.push_back(seq[q]);
-            }
-            // nothing admissible left for this half: take the next free ones as they come
-            for (size_t q = first_free; q < n && order.size() < half_end; ++q) {
-              if (taken[q]) continue;
-              const TileFacet& f = tf_tmp[seq[q]];
-              const uint32_t r[3] = {f.l0, f.l1, f.l2};
-              for (int k = 0; k < 3; ++k) {
-                m32[k] |= 1u << (r[k] & 31);
-                m16[k] |= 1u << (r[k] & 15);
-              }
-              taken[q] = 1;
-              order.push_back(seq[q]);
+              taken[best] = 1;
+              order.push_back(seq[best]);
+              while (first_free < n && taken[first_free]) ++first_free;
             }
             while (first_free < n && taken[first_free]) ++first_free;
           }
