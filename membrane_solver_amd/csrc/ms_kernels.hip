@@ -748,6 +748,15 @@ size_t energy_lds_bytes(int T, int cap, int max_ent, bool bend, bool guard, bool
          ((flags || guard) ? (((size_t)cap + 15) / 16) * 16 : 0);
 }
 
+static bool no_lean() {  // MS_NO_LEAN=1: A/B switch for the lean gradient instance
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MS_NO_LEAN");
+    v = (e && atoi(e) != 0) ? 1 : 0;
+  }
+  return v != 0;
+}
+
 template <typename K>
 static hipError_t ensure_lds(K kernel, size_t lds) {
   if (lds <= 48 * 1024) return hipSuccess;
@@ -839,7 +848,11 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
 #define MS_SCHED_FENCES 1
 #endif
 #if MS_SCHED_FENCES
-#define MS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define MS_SCHED_FENCE()                 \
+  do {                                   \
+    asm volatile("" ::: "memory");       \
+    __builtin_amdgcn_sched_barrier(0);   \
+  } while (0)
 #else
 #define MS_SCHED_FENCE() do {} while (0)
 #endif
@@ -862,8 +875,11 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
 #ifndef MS_ABL_NOHIST
 #define MS_ABL_NOHIST 0   // CG history rows not loaded
 #endif
-template <int BENDMODE, bool VOLROW, int TT, int CAPC, bool ATOMIC>
-__global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
+// LEAN: the instance of the headline loop -- uniform surface tension (no per-facet gamma registers) and no separate
+// previous-direction rows (dir_mode != 2, or pd = -pg after an implicit steepest-descent step): 8 registers fewer live
+// through the facet loop, which is what lets the kernel fit 128 VGPRs = 4 resident workgroups per CU instead of 3.
+template <int BENDMODE, bool VOLROW, int TT, int CAPC, bool ATOMIC, bool LEAN = false>
+__global__ __launch_bounds__(TT ? TT : 512, LEAN ? 4 : 1) MS_WPE_GRADIENT void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
   extern __shared__ double lds[];
   constexpr bool BEND = BENDMODE != 0;
   // BENDMODE 3: leaflet bending_tilt (bt_gradient.py:89-389): analytic back-propagation whose effective-area
@@ -917,7 +933,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
   double gam_nx = 0.0;
   if (t.f0 + tid < t.f1) {
     tf_nx = a.m.tile_facets[t.f0 + tid];
-    gam_nx = a.m.gamma_uniform ? a.m.gamma_const : a.m.tf_gamma[t.f0 + tid];
+    gam_nx = (LEAN || a.m.gamma_uniform) ? a.m.gamma_const : a.m.tf_gamma[t.f0 + tid];
   }
 
   int cur = 0, end = 0;  // this vertex's CSR range
@@ -1043,10 +1059,22 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
   if (tid >= t.n_owned) cur = end = 0;
   // CG history rows of the fused direction pass: requested now, consumed in the epilogue
   V3 h_pg = mk(0, 0, 0), h_pd = mk(0, 0, 0);
-  if (!MS_ABL_NOHIST && a.dir_mode == 2 && tid < t.n_owned) {
+  if (LEAN) {
+    // The lean instance has no registers to park the history row in for the length of the facet loop (the compiler
+    // spills exactly these six).  Instead one wave pulls the tile's pg rows into L2 now -- a 4-byte LDS-DMA per
+    // 128-byte line into the (still unused) reduction scratch, no destination registers -- and the rows are loaded
+    // after the loop, from L2.
+    if (!MS_ABL_NOHIST && a.dir_mode == 2 && tid < 64) {
+      const int n_lines = (t.n_owned * 24 + 127) >> 7;
+      if (tid < n_lines)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)((const char*)a.pg + (size_t)t.v_lo * 24 + (size_t)tid * 128),
+            (__attribute__((address_space(3))) void*)red, 4, 0, 0);
+    }
+  } else if (!MS_ABL_NOHIST && a.dir_mode == 2 && tid < t.n_owned) {
     const size_t o = 3 * (size_t)(t.v_lo + tid);
     h_pg = mk(a.pg[o], a.pg[o + 1], a.pg[o + 2]);
-    h_pd = a.pd_neg_pg ? -h_pg : mk(a.pd[o], a.pd[o + 1], a.pd[o + 2]);
+    if (!LEAN) h_pd = a.pd_neg_pg ? -h_pg : mk(a.pd[o], a.pd[o + 1], a.pd[o + 2]);
   }
 
 #if MS_ABL_NOATOM
@@ -1058,7 +1086,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
     const double gam = gam_nx;
     if (p + T < t.f1) {
       tf_nx = a.m.tile_facets[p + T];
-      gam_nx = a.m.gamma_uniform ? a.m.gamma_const : a.m.tf_gamma[p + T];
+      if (!LEAN) gam_nx = a.m.gamma_uniform ? a.m.gamma_const : a.m.tf_gamma[p + T];
     }
     if (p < t.f1) {
 #if MS_ABL_NOGATHER
@@ -1282,6 +1310,10 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
     __syncthreads();
   }
 
+  if (LEAN && !MS_ABL_NOHIST && a.dir_mode == 2 && tid < t.n_owned) {
+    const size_t o = 3 * (size_t)(t.v_lo + tid);
+    h_pg = mk(a.pg[o], a.pg[o + 1], a.pg[o + 2]);
+  }
   if (ATOMIC) {
     __syncthreads();
     MS_STAMP(2);
@@ -1319,7 +1351,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_GRADIENT void k_gradient(Grad
         const V3 pgv = h_pg;
         const double beta = dot_pinned(gi, gi - pgv) / (dot_pinned(pgv, pgv) + 1.0e-20);
         if (!(beta < 0.0)) {
-          const V3 q = h_pd;
+          const V3 q = LEAN ? -h_pg : h_pd;
           di = mk(fma(beta, q.x, -gi.x), fma(beta, q.y, -gi.y), fma(beta, q.z, -gi.z));
         }
       }
@@ -1399,6 +1431,15 @@ hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStrea
     if (e != hipSuccess) return e;                                                                   \
     hipLaunchKernelGGL((k_gradient<M, V, TT, CC, AT>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent); \
   } while (0)
+  // the lean instance (see k_gradient): analytic bending, no constraint row, uniform gamma, no pd rows to load
+  const bool lean = fast && atomic && !volrow && !leaf && bend && a.bending_grad_mode != MS_GRAD_APPROX &&
+                    a.m.gamma_uniform && (a.dir_mode != 2 || a.pd_neg_pg) && !no_lean();
+  if (lean) {
+    e = ensure_lds(k_gradient<1, false, FAST_T, FAST_CAP, true, true>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_gradient<1, false, FAST_T, FAST_CAP, true, true>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);
+    return hipGetLastError();
+  }
 #define MS_PICK_G(M, V)                                           \
   do {                                                            \
     if (fast && atomic) MS_LAUNCH_G(M, V, FAST_T, FAST_CAP, true); \
