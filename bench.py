@@ -2,14 +2,14 @@
 """Headline benchmark: minimizer steps/sec (energy + gradient + CG) on the
 2 048 000-facet icosphere (BASELINE.json configs[2]; configs[3] when --gpus > 1).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: spawns its own ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one iteration of Minimizer.minimize (runtime/minimizer.py:1230-1515
 of the reference): energy+gradient of all modules, fixed-row zeroing, per-row
-Polak-Ribiere CG direction, Armijo backtracking line search (energy0 is
-re-evaluated like line_search.py:294, then >= 1 trial energy evaluation) and the
-position commit.  All state is resident in HBM before the timed region starts.
+Polak-Ribiere CG direction, Armijo backtracking line search (>= 1 trial energy
+evaluation) and the position commit.  All state is resident in HBM before the
+timed region starts.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md section "Measurement").
 """
@@ -19,6 +19,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,18 +31,33 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+METRIC = "minimizer steps/sec (energy+grad+CG) on 2M-facet icosphere"
+
+# profile kind (ms_profile_read) -> the kernel instantiation as rocprofv3 names it (default LDS-atomic mode; the
+# deterministic mode's fifth template argument is `false`)
+KERNEL_NAMES = {
+    "energy": "ms::k_energy<true, false, 256, 0, true, 0>",
+    "energy_pair": "ms::k_energy<true, false, 256, 0, true, 2>",
+    "energy_triple": "ms::k_energy<true, false, 256, 0, true, 3>",
+    "gradient": "ms::k_gradient<1, false, 256, 0, true, false>",
+    "gradient_lean": "ms::k_gradient<1, false, 256, 0, true, true>",
+}
 
 
-def parse():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--freq", type=int, default=320, help="icosphere frequency (320 -> 2 048 000 facets)")
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling: 2 048 000 facets PER GPU (frequency 320*sqrt(N)) instead of one 2M-facet "
+                         "mesh sharded over the N GPUs")
     ap.add_argument("--tile", type=int, default=0, help="owned vertices per tile (0 = library default)")
     ap.add_argument("--step-size", type=float, default=1e-6)
     ap.add_argument("--volume", action="store_true", help="add the volume Lagrange constraint row")
-    ap.add_argument("--cpu-steps", type=int, default=6, help="CPU oracle steps for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=-1,
+                    help="CPU oracle steps per cpu_baseline leg (0 = skip; default 6 at N=1, 2 at N>1)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the secondary sections (reuse level 0, deterministic mode): for kernel traces")
@@ -50,27 +67,34 @@ def parse():
     ap.add_argument("--deterministic", action="store_true",
                     help="fixed-order per-vertex sums (ms_set_deterministic): bitwise reproducible run to "
                          "run, slower than the default LDS-atomic accumulation")
-    return ap.parse_args()
+    return ap
 
 
-def algorithmic_bytes(nv, nf, volume=False):
-    """Compulsory HBM bytes per launch (DESIGN.md 'Kernels'); each array touched once."""
+def weak_frequency(gpus: int, base: int = 320) -> int:
+    """Icosphere frequency with ~2 048 000 facets per GPU (20 f^2 facets in all)."""
+    return int(round(base * gpus ** 0.5))
+
+
+def algorithmic_bytes(nv, nf, *, uniform=True, volume=False):
+    """Compulsory HBM bytes per launch (DESIGN.md 'Kernels'); each array touched once.  `uniform`: every facet has
+    the same surface tension and every vertex the same kappa / c0 -- then those arrays are kernel constants and are
+    neither read nor counted (ms_set_surface_tension / ms_set_bending_params decide; the bench's case)."""
+    fac = 12 * nf + (0 if uniform else 8 * nf)      # packed triangle rows (+ gamma per facet)
+    vp = 1 + (0 if uniform else 16)                 # vertex flags (+ kappa, c0)
     return {
-        # tri rows 12 B + gamma 8 B per facet; x 24 + kappa,c0 16 + flags 1 per vertex; fK,fA 40 out
-        "energy_factors": 20 * nf + (24 + 16 + 1) * nv + 40 * nv,
-        # trial energy: x and d in (48), xt out (24), no factor write
-        "energy_trial": 20 * nf + (48 + 16 + 1) * nv + 24 * nv,
-        # trial energy that also writes the factors (reuse level 2: an accepted trial is the
-        # next step's energy pass)
-        "energy_trial_factors": 20 * nf + (48 + 16 + 1) * nv + 24 * nv + 40 * nv,
-        # pair launch: two trial evaluations of one line search in one launch -- the inputs are
-        # compulsory ONCE (the second evaluation's reads are meant to hit L2), the outputs twice
-        "energy_pair": 20 * nf + (48 + 16 + 1) * nv + 2 * (24 + 40) * nv,
-        "energy_triple": 20 * nf + (48 + 16 + 1) * nv + 3 * (24 + 40) * nv,
-        # gradient (+ fused direction pass when no constraint row): x 24 + fK,fA 40 + flags 1 in,
-        # g 24 and d 24 out.  The CG-history reads (pg, pd: 48 B/vertex on non-restart steps) are
-        # NOT counted, so the figure is a lower bound of the compulsory traffic.
-        "gradient": 20 * nf + (24 + 40 + 1) * nv + 24 * nv + (0 if volume else 24 * nv),
+        "energy_only": fac + (24 + vp) * nv,                          # pass at x, no factor write
+        "energy_factors": fac + (24 + vp) * nv + 40 * nv,             # pass at x writing fK, fA
+        "energy_trial": fac + (48 + vp) * nv + 24 * nv,               # x, d in; xt out
+        "energy_trial_factors": fac + (48 + vp) * nv + 24 * nv + 40 * nv,
+        # pair / triple launch: the inputs are compulsory ONCE (the other evaluations' reads are meant to hit L2),
+        # the outputs once per evaluation
+        "energy_pair": fac + (48 + vp) * nv + 2 * (24 + 40) * nv,
+        "energy_triple": fac + (48 + vp) * nv + 3 * (24 + 40) * nv,
+        # gradient with the fused direction pass: x 24 + fK,fA 40 + flags 1 in; g 24 and d 24 out; CG history in:
+        # the previous gradient (24) and, unless it is minus that (after an implicit steepest-descent step: the lean
+        # instance), the previous direction (24).  With a constraint row the direction is not fused: g and gC out.
+        "gradient_lean": fac + (24 + 40 + 1) * nv + 24 * nv + 48 * nv,
+        "gradient": fac + (24 + 40 + 1) * nv + (48 * nv if volume else 48 * nv + 48 * nv),
     }
 
 
@@ -79,74 +103,248 @@ def _template_args(name):
     return [a.strip() for a in name[i + 1:j].split(",")] if 0 <= i < j else []
 
 
-def pmc_traffic(kernel_prefix, deterministic=False, multi=0):
-    """HBM bytes per launch of one kernel from the committed rocprofv3 PMC summary
-    (profiles/<tag>_pmc_summary.csv; separate FETCH_SIZE / WRITE_SIZE passes of this same
-    bench command).  gfx950 correction: FETCH_SIZE counts 1/2 of the fetched bytes
-    (MI355X_MICROARCH.md, calibrated here on the direction pass's known byte count)."""
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of one kernel instantiation from the newest committed rocprofv3 PMC summary
+    (profiles/<tag>_pmc_summary.csv: separate FETCH_SIZE / WRITE_SIZE passes of this same bench command).
+    NOT measured in this run -- the source file is named next to the figure.  gfx950 correction: FETCH_SIZE counts
+    1/2 of the fetched bytes (MI355X_MICROARCH.md, calibrated on the direction pass's known byte count)."""
     import csv
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.csv")))
-    if not files:
-        return None, None
-    # dispatch-weighted mean over every instantiation of the kernel family in the summary
-    acc = {"FETCH_SIZE": [0.0, 0.0], "WRITE_SIZE": [0.0, 0.0]}
-    with open(files[-1]) as f:
-        for row in csv.reader(line for line in f if not line.startswith("#")):
-            if len(row) < 4 or kernel_prefix not in row[1] or row[0] not in acc:
-                continue
-            # template arguments: the fifth selects the accumulation mode (true = LDS atomics), k_energy's sixth
-            # the number of evaluations per launch (0 = one, 2 = pair, 3 = triple)
-            ta = _template_args(row[1])
-            if len(ta) >= 5 and ta[4] != ("false" if deterministic else "true"):
-                continue
-            if "k_energy" in kernel_prefix and (int(ta[5]) if len(ta) >= 6 and ta[5].isdigit() else 0) != multi:
-                continue
-            n = float(row[2])
-            acc[row[0]][0] += n * float(row[3])
-            acc[row[0]][1] += n
-    if not acc["FETCH_SIZE"][1] or not acc["WRITE_SIZE"][1]:
-        return None, None
-    fetch = acc["FETCH_SIZE"][0] / acc["FETCH_SIZE"][1]
-    write = acc["WRITE_SIZE"][0] / acc["WRITE_SIZE"][1]
-    return (2.0 * fetch + write) * 1024.0, os.path.basename(files[-1])
+    want = _template_args(kernel_name)
+    base = kernel_name.split("<")[0]
+    for path in reversed(files):
+        acc = {"FETCH_SIZE": [0.0, 0.0], "WRITE_SIZE": [0.0, 0.0]}
+        with open(path) as f:
+            for row in csv.reader(line for line in f if not line.startswith("#")):
+                if len(row) < 4 or row[0] not in acc or not row[1].startswith(base + "<"):
+                    continue
+                if _template_args(row[1]) != want:
+                    continue
+                n = float(row[2])
+                acc[row[0]][0] += n * float(row[3])
+                acc[row[0]][1] += n
+        if acc["FETCH_SIZE"][1] and acc["WRITE_SIZE"][1]:
+            fetch = acc["FETCH_SIZE"][0] / acc["FETCH_SIZE"][1]
+            write = acc["WRITE_SIZE"][0] / acc["WRITE_SIZE"][1]
+            return (2.0 * fetch + write) * 1024.0, os.path.basename(path)
+    return None, None
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch --gpus N > 1 through torch.distributed.run (one rank per GPU)")
-    if world > 1 or os.environ.get("MS_BENCH_FORCE_SHARDED"):
-        from membrane_solver_amd import parallel
+def kernel_table(prof, ab, *, trial_passes, level, nv, deterministic):
+    """Per-instantiation averages, time shares, algorithmic bytes and GB/s from ms_profile_read."""
+    kernels = {}
+    for kind, (ms, n) in prof.items():
+        if n:
+            kernels[kind] = {"avg_us": 1e3 * ms / n, "launches": n, "share_of_profiled_ms": ms}
+    tot = sum(v["share_of_profiled_ms"] for v in kernels.values()) or 1.0
+    for v in kernels.values():
+        v["share_of_profiled_ms"] = v["share_of_profiled_ms"] / tot
+    n_e = prof.get("energy", (0.0, 0))[1]
+    n_p = prof.get("energy_pair", (0.0, 0))[1]
+    n_t = prof.get("energy_triple", (0.0, 0))[1]
+    n_g = prof.get("gradient", (0.0, 0))[1] + prof.get("gradient_lean", (0.0, 0))[1]
+    for kind, key, n_ev in (("energy_pair", "energy_pair", 2), ("energy_triple", "energy_triple", 3)):
+        if kind in kernels:
+            kernels[kind]["algorithmic_bytes"] = ab[key]
+            kernels[kind]["evaluations_per_launch"] = n_ev
+    if n_e:
+        # single launches are a mix of passes at x (with or without the factor write) and trial passes: weight by
+        # what was actually launched
+        n_trial = min(n_e, max(0, trial_passes - 2 * n_p - 3 * n_t))
+        n_plain = n_e - n_trial
+        n_fact = min(n_plain, n_g)      # factor-writing passes at x
+        n_e0 = n_plain - n_fact         # energy0 re-evaluations (level 0)
+        trial_key = "energy_trial_factors" if level >= 2 else "energy_trial"
+        kernels["energy"]["algorithmic_bytes"] = (n_fact * ab["energy_factors"] + n_e0 * ab["energy_only"]
+                                                  + n_trial * ab[trial_key]) / n_e
+    for kind in ("gradient", "gradient_lean"):
+        if kind in kernels:
+            kernels[kind]["algorithmic_bytes"] = ab[kind]
+    for kind, v in kernels.items():
+        if "algorithmic_bytes" in v:
+            v["GBps"] = v["algorithmic_bytes"] / (v["avg_us"] * 1e-6) / 1e9
+            v["frac_of_hbm_peak"] = v["GBps"] / HBM_PEAK_GBS
+            name = KERNEL_NAMES[kind]
+            if deterministic:
+                a = _template_args(name)
+                a[4] = "false"
+                name = name.split("<")[0] + "<" + ", ".join(a) + ">"
+            v["kernel"] = name
+    return kernels
 
-        return parallel.bench_main(args, rank, world, local_rank)
 
-    import torch  # device plumbing: barrier/synchronize bracket of the contract
+def roofline_block(kernels, n_prof):
+    """`roofline` of the contract: the kernel INSTANTIATION with the largest share of the profiled kernel time --
+    one row of the rocprofv3 summary under profiles/ -- plus the figures the verdicts asked to see next to it."""
+    cands = [k for k in KERNEL_NAMES if k in kernels and "GBps" in kernels[k]]
+    if not cands:
+        return None
+    dom = max(cands, key=lambda k: kernels[k]["share_of_profiled_ms"])
+    d = kernels[dom]
+    traffic, src = pmc_traffic(d["kernel"])
+    out = {"bound": "hbm", "kernel": d["kernel"], "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+           "traffic_source": (f"profiles/{src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command, "
+                              "committed; NOT measured in this run") if src else None,
+           "avg_launch_us": d["avg_us"], "algorithmic_bytes_per_launch": d["algorithmic_bytes"],
+           "share_of_kernel_time": d["share_of_profiled_ms"],
+           "selection": "the instantiation with the largest share of the profiled kernel time",
+           "measured": f"HIP events around every launch over {n_prof} steps after the timed region"}
+    fam = [k for k in ("energy", "energy_pair", "energy_triple") if k in kernels and "GBps" in kernels[k]]
+    if fam:
+        b = sum(kernels[k]["algorithmic_bytes"] * kernels[k]["launches"] for k in fam)
+        t = sum(kernels[k]["avg_us"] * kernels[k]["launches"] for k in fam)
+        out["energy_family_time_weighted"] = {"GBps": b / (t * 1e-6) / 1e9, "frac": b / (t * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                              "share_of_kernel_time": sum(kernels[k]["share_of_profiled_ms"] for k in fam)}
+    gfam = [k for k in ("gradient", "gradient_lean") if k in kernels and "GBps" in kernels[k]]
+    if gfam:
+        b = sum(kernels[k]["algorithmic_bytes"] * kernels[k]["launches"] for k in gfam)
+        t = sum(kernels[k]["avg_us"] * kernels[k]["launches"] for k in gfam)
+        out["gradient_family_time_weighted"] = {"GBps": b / (t * 1e-6) / 1e9, "frac": b / (t * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                "share_of_kernel_time": sum(kernels[k]["share_of_profiled_ms"] for k in gfam)}
+    return out
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(x_now, T, mods, cons, bodies, gp, step_size, n_steps):
+    """The oracle port timed on the host cores: one core (the checker build, strict order of operations) and all
+    cores (the same C source built with OpenMP: facet loops split over the cores, vertex sums by atomics)."""
+    from oracle import minimizer_port as mp
+    from oracle import ms_oracle as orc
+
+    nf = len(T)
+    legs = {}
+    n_cores = os.cpu_count() or 1
+    try:
+        n_cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    host_cores = n_cores
+    n_cores = min(n_cores, 16)  # a one-GPU box's CPU share; more threads only fight over the atomics
+    for name, omp in (("one_core", False), ("all_cores", True)):
+        orc.use_openmp(omp)
+        os.environ["OMP_NUM_THREADS"] = str(n_cores if omp else 1)
+        try:
+            p = mp.Problem(positions=x_now, tri=T, energy_modules=mods, constraint_modules=cons,
+                           target_volume=bodies[0].target_volume if bodies else None, gp=dict(gp))
+            if omp:
+                mp.energy_and_gradient(p, p.positions)  # thread pool start-up outside the timing
+            t0 = time.perf_counter()
+            cres = mp.minimize(p, mp.ConjugateGradient(), n_steps, step_size=step_size)
+            cdt = time.perf_counter() - t0
+            legs[name] = {"value": n_steps / cdt, "unit": "steps/s", "cores": n_cores if omp else 1, "seconds": cdt,
+                          "line_search_trials": int(sum(t["trials"] for t in cres["trace"]))}
+        finally:
+            orc.use_openmp(False)
+    one = legs["one_core"]
+    return {"value": one["value"], "unit": "steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n_steps} minimizer steps of the C/NumPy oracle port (oracle/minimizer_port.py over "
+                      f"oracle/ms_oracle.c) on the same {nf}-facet mesh, starting from the GPU run's state and step "
+                      f"size; {one['line_search_trials']} line-search trials",
+            "seconds": one["seconds"], "cpu_model": cpu_model(), "host_cores": host_cores,
+            "all_cores": {**legs["all_cores"],
+                          "note": "the same C source built with -fopenmp (libms_oracle_omp.so): facet loops over all "
+                                  "host cores, vertex scatter-adds by `omp atomic`; the NumPy control flow and the "
+                                  "per-vertex passes stay serial.  Timed only, never a checker."}}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def launcher_command(argv, gpus, port, python=None):
+    """The command `bench.py --gpus N` spawns when it was started as a plain process (one rank per GPU, RCCL)."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args, argv):
+    """Started without a rendezvous (no WORLD_SIZE) but with --gpus N > 1: start the N ranks as fresh child processes
+    -- this process has made no GPU call and makes none -- relay rank 0's JSON line, fail if any rank failed."""
+    cmd = launcher_command(argv, args.gpus, free_port())
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"[bench] {args.gpus}-rank run failed (exit code {proc.returncode}, JSON line {'found' if line else 'missing'})",
+              file=sys.stderr)
+        return proc.returncode or 1
+    print(line)
+    return 0
+
+
+def bench_mesh(freq):
+    from membrane_solver_amd import meshgen
+
+    P, T = meshgen.icosphere(freq)
+    return meshgen.smooth_displace(P, 0.05), T
+
+
+GP = {"surface_tension": 1.0, "bending_modulus": 1.0, "bending_energy_model": "helfrich",
+      "spontaneous_curvature": 0.0, "bending_gradient_mode": "analytic",
+      "volume_constraint_mode": "lagrange", "volume_projection_during_minimization": False,
+      "mesh_quality_auto_repair_enabled": False}
+
+
+def workload_text(freq, nv, nf, level, deterministic, volume=False):
+    return (f"class-I icosphere f={freq} (nv={nv}, nf={nf}), surface + Helfrich bending (analytic cotan gradient), "
+            f"CG stepper, Armijo line search, evaluation reuse level {level} (0 = every pass the reference re-runs, "
+            "2 = passes already on the device are not repeated; same trajectories), per-vertex sums "
+            + ("in fixed order (bitwise reproducible)" if deterministic
+               else "by LDS atomics (default; --deterministic for fixed-order sums)")
+            + (", volume Lagrange row" if volume else ""))
+
+
+def rates(steps, accepted, trials, guard_rejects, level, dt):
+    """What the steps did, so the headline does not hinge on how many of them were rejected: accepted steps/s and
+    evaluations/s (an evaluation = one energy pass E(x + alpha d) of a line search, or one energy + gradient
+    evaluation at a new x; at level 0 the reference's repeated passes count as well)."""
+    e_evals = trials + guard_rejects + (steps if level == 0 else 0)
+    g_evals = steps if level == 0 else max(accepted, 1)
+    return {"accepted_steps_per_s": accepted / dt, "evaluations_per_s": (e_evals + g_evals) / dt,
+            "evaluations": {"line_search_energy_passes": e_evals, "energy_plus_gradient": g_evals}}
+
+
+def main_single(args):
+    import torch  # device plumbing: synchronize bracket of the contract
 
     from membrane_solver_amd import _lib as L
-    from membrane_solver_amd import meshgen
     from membrane_solver_amd.geometry.mesh import ArrayBody, ArrayMesh
     from membrane_solver_amd.runtime.constraint_manager import ConstraintModuleManager
     from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
     from membrane_solver_amd.runtime.minimizer import Minimizer
     from membrane_solver_amd.runtime.steppers import ConjugateGradient
 
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if L.lib().ms_device_count() < 1:
         raise SystemExit("bench.py needs a GPU: " + L.lib().ms_last_error(None).decode())
     torch.cuda.set_device(local_rank)
 
-    P, T = meshgen.icosphere(args.freq)
-    P = meshgen.smooth_displace(P, 0.05)
+    P, T = bench_mesh(args.freq)
     nv, nf = P.shape[0], T.shape[0]
-    gp = {"surface_tension": 1.0, "bending_modulus": 1.0, "bending_energy_model": "helfrich",
-          "spontaneous_curvature": 0.0, "bending_gradient_mode": "analytic",
-          "volume_constraint_mode": "lagrange", "volume_projection_during_minimization": False,
-          "mesh_quality_auto_repair_enabled": False}
+    gp = dict(GP)
     mods, cons, bodies = ["surface", "bending"], [], []
     if args.volume:
         cons = ["volume"]
@@ -169,27 +367,19 @@ def main():
     res = mz.minimize(args.steps, sync_mesh=False)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    timed = {"accepted": res["steps_accepted"], "trials": res["line_search_trials"]}
-    ms_per_step = 1e3 * dt / args.steps
-    value = args.steps / dt
+    run = dict(mz.last_run)
 
     out = {
-        "metric": "minimizer steps/sec (energy+grad+CG) on 2M-facet icosphere",
-        "value": value, "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+        "metric": METRIC, "value": args.steps / dt, "unit": "steps/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"class-I icosphere f={args.freq} (nv={nv}, nf={nf}), surface + Helfrich "
-                               "bending (analytic cotan gradient), CG stepper, Armijo line search, "
-                               f"evaluation reuse level {stepper.reuse_energy0} (0 = every pass the "
-                               "reference re-runs, 2 = passes already on the device are not repeated; "
-                               "same trajectories), per-vertex sums "
-                               + ("in fixed order (bitwise reproducible)" if args.deterministic
-                                  else "by LDS atomics (default; --deterministic for fixed-order sums)")
-                               + (", volume Lagrange row" if args.volume else ""),
+        "config": {"workload": workload_text(args.freq, nv, nf, stepper.reuse_energy0, args.deterministic, args.volume),
                    "stepper": "conjugate_gradient", "tile_vertices": args.tile or 256,
                    "initial_step_size": args.step_size, "parallelism": "1 GPU",
                    "deterministic": bool(args.deterministic)},
-        "steps_accepted": timed["accepted"], "line_search_trials": timed["trials"],
+        "steps_accepted": res["steps_accepted"], "line_search_trials": res["line_search_trials"],
+        **rates(args.steps, res["steps_accepted"], res["line_search_trials"], run.get("guard_rejects", 0),
+                int(stepper.reuse_energy0), dt),
         "energy_start": E_start, "energy_end": res["energy"],
     }
 
@@ -209,8 +399,7 @@ def main():
         stepper.reuse_energy0 = args.reuse_level
 
     # -- the same K steps with fixed-order (bitwise reproducible) vertex sums -------------------
-    mir = mesh._hip_mirror
-    dm = mir.dm
+    dm = mesh._hip_mirror.dm
     if not args.deterministic and not args.headline_only:
         mz.deterministic = True
         mz.minimize(5, sync_mesh=False)
@@ -224,117 +413,195 @@ def main():
         mz.deterministic = False
         mz.minimize(2, sync_mesh=False)
 
-    # -- roofline of the dominant kernel: HIP events inside the library --------
+    # -- roofline: HIP events inside the library around every launch --------------------------
     if not args.no_roofline:
         n_prof = min(args.steps, 40)
         dm.profile_enable(True)
         dm.profile_read()
         mz.minimize(n_prof, sync_mesh=False)
-        stats = {"trial_passes": mz.last_run["trials"] + mz.last_run["guard_rejects"]}
+        trial_passes = mz.last_run["trials"] + mz.last_run["guard_rejects"]
         prof = dm.profile_read()
         dm.profile_enable(False)
-        ab = algorithmic_bytes(nv, nf, args.volume)
-        kernels = {}
-        for kind, (ms, n) in prof.items():
-            if n:
-                kernels[kind] = {"avg_us": 1e3 * ms / n, "launches": n, "share_of_profiled_ms": ms}
-        tot = sum(v["share_of_profiled_ms"] for v in kernels.values()) or 1.0
-        for v in kernels.values():
-            v["share_of_profiled_ms"] = v["share_of_profiled_ms"] / tot
-        # per-launch algorithmic bytes: energy launches are a mix of plain passes at x (with or
-        # without the factor write) and trial passes -> weight by what was actually launched
-        n_e = prof["energy"][1]
-        n_g = prof["gradient"][1]
-        n_p = prof.get("energy_pair", (0.0, 0))[1]
-        if n_p:
-            kernels["energy_pair"]["algorithmic_bytes"] = ab["energy_pair"]
-            kernels["energy_pair"]["GBps"] = ab["energy_pair"] / (kernels["energy_pair"]["avg_us"] * 1e-6) / 1e9
-            kernels["energy_pair"]["evaluations_per_launch"] = 2
-        n_t = prof.get("energy_triple", (0.0, 0))[1]
-        if n_t:
-            kernels["energy_triple"]["algorithmic_bytes"] = ab["energy_triple"]
-            kernels["energy_triple"]["GBps"] = ab["energy_triple"] / (kernels["energy_triple"]["avg_us"] * 1e-6) / 1e9
-            kernels["energy_triple"]["evaluations_per_launch"] = 3
-        if n_e:
-            n_trial = min(n_e, max(0, stats["trial_passes"] - 2 * n_p - 3 * n_t))
-            n_plain = n_e - n_trial
-            level = int(stepper.reuse_energy0)
-            n_fact = min(n_plain, n_g)          # factor-writing passes at x
-            n_e0 = n_plain - n_fact             # energy0 re-evaluations (level 0)
-            trial_key = "energy_trial_factors" if level >= 2 else "energy_trial"
-            e_bytes = (n_fact * ab["energy_factors"] + n_e0 * (ab["energy_factors"] - 40 * nv)
-                       + n_trial * ab[trial_key]) / n_e
-            kernels["energy"]["algorithmic_bytes"] = e_bytes
-            kernels["energy"]["GBps"] = e_bytes / (kernels["energy"]["avg_us"] * 1e-6) / 1e9
-        if n_g:
-            kernels["gradient"]["algorithmic_bytes"] = ab["gradient"]
-            kernels["gradient"]["GBps"] = ab["gradient"] / (kernels["gradient"]["avg_us"] * 1e-6) / 1e9
-        # dominant kernel: the family (k_energy in all its instantiations vs k_gradient) with the larger share of the
-        # kernel time, and within k_energy the instantiation (evaluations per launch) with the largest share --
-        # that is one row of the rocprofv3 summary under profiles/
-        fam_e = [k for k in ("energy", "energy_pair", "energy_triple") if k in kernels]
-        share_e = sum(kernels[k]["share_of_profiled_ms"] for k in fam_e)
-        share_g = kernels["gradient"]["share_of_profiled_ms"] if "gradient" in kernels else 0.0
-        if fam_e and share_e >= share_g:
-            dom = max(fam_e, key=lambda k: kernels[k]["share_of_profiled_ms"])
-        else:
-            dom = "gradient"
-        ach = kernels[dom]["GBps"]
-        traffic, traffic_src = pmc_traffic({"energy": "ms::k_energy", "energy_pair": "ms::k_energy",
-                                            "energy_triple": "ms::k_energy", "gradient": "ms::k_gradient"}[dom],
-                                           deterministic=bool(args.deterministic),
-                                           multi={"energy_pair": 2, "energy_triple": 3}.get(dom, 0))
-        out["roofline"] = {"bound": "hbm", "kernel": {"energy": "ms::k_energy<.., MULTI=0> (energy pass)",
-                                                     "energy_pair": "ms::k_energy<.., MULTI=2> (energy pass, two "
-                                                                    "trial evaluations per launch)",
-                                                     "energy_triple": "ms::k_energy<.., MULTI=3> (energy pass, "
-                                                                      "three trial evaluations per launch)",
-                                                     "gradient": "ms::k_gradient* (gradient pass)"}[dom],
-                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                           "avg_launch_us": kernels[dom]["avg_us"],
-                           "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes"],
-                           "measured": f"HIP events around every launch over {n_prof} steps after the timed region"}
-        if dom in ("energy_pair", "energy_triple"):
-            # the same launch priced per evaluation: SURVEY 8(d)'s per-evaluation bytes x the 2 evaluations it
-            # processes.  NOT used for `frac` above: a pair needs its inputs from HBM only once, so the compulsory
-            # traffic of the launch is the smaller figure and `frac` is measured against that
-            per_eval = ab["energy_trial_factors"]
-            n_ev = 2 if dom == "energy_pair" else 3
-            out["roofline"]["per_evaluation_equivalent"] = {
-                "us_per_evaluation": kernels[dom]["avg_us"] / n_ev, "algorithmic_bytes_per_evaluation": per_eval,
-                "GBps": per_eval / (kernels[dom]["avg_us"] / n_ev * 1e-6) / 1e9,
-                "frac": per_eval / (kernels[dom]["avg_us"] / n_ev * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                "single_launch_frac": (kernels["energy"]["GBps"] / HBM_PEAK_GBS) if "energy" in kernels else None}
+        ab = algorithmic_bytes(nv, nf, uniform=True, volume=args.volume)
+        kernels = kernel_table(prof, ab, trial_passes=trial_passes, level=int(stepper.reuse_energy0), nv=nv,
+                               deterministic=bool(args.deterministic))
+        out["roofline"] = roofline_block(kernels, n_prof)
+        e_kind = "energy" if "energy" in kernels else None
+        g_kind = max((k for k in ("gradient", "gradient_lean") if k in kernels),
+                     key=lambda k: kernels[k]["launches"], default=None)
         eg = None
-        if "energy" in kernels and "gradient" in kernels:
-            pair_us = kernels["energy"]["avg_us"] + kernels["gradient"]["avg_us"]
-            pair_bytes = ab["energy_factors"] + ab["gradient"]
-            eg = {"us": pair_us, "algorithmic_bytes": pair_bytes,
-                  "GBps": pair_bytes / (pair_us * 1e-6) / 1e9,
-                  "frac": pair_bytes / (pair_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+        if e_kind and g_kind:
+            pair_us = kernels[e_kind]["avg_us"] + kernels[g_kind]["avg_us"]
+            # bytes of the single energy launches as they were actually launched (at reuse level 2 these are trial
+            # passes that also write the factors: the accepted one IS the next step's energy pass)
+            pair_bytes = kernels[e_kind]["algorithmic_bytes"] + ab[g_kind]
+            eg = {"us": pair_us, "algorithmic_bytes": pair_bytes, "GBps": pair_bytes / (pair_us * 1e-6) / 1e9,
+                  "frac": pair_bytes / (pair_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                  "kernels": [kernels[e_kind]["kernel"], kernels[g_kind]["kernel"]],
+                  "what": "one single-evaluation energy launch (average of those profiled) + one gradient pass: the "
+                          "per-step energy+gradient evaluation the north star names"}
         out["kernels"] = kernels
         out["energy_plus_gradient_evaluation"] = eg
+        if out["roofline"] is not None:
+            out["roofline"]["energy_plus_gradient_evaluation_frac"] = eg["frac"] if eg else None
 
     # -- CPU baseline: the oracle port on the host cores, bounded sample ---------
-    if args.cpu_steps > 0:
-        from oracle import minimizer_port as mp
-
-        x_now = dm.get_positions()
-        p = mp.Problem(positions=x_now, tri=T, energy_modules=mods, constraint_modules=cons,
-                       target_volume=bodies[0].target_volume if bodies else None, gp=dict(gp))
-        t0 = time.perf_counter()
-        cres = mp.minimize(p, mp.ConjugateGradient(), args.cpu_steps, step_size=mz.step_size)
-        cdt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": args.cpu_steps / cdt, "unit": "steps/s", "cores": 1, "kind": "port",
-                               "sample": f"{args.cpu_steps} minimizer steps of the C/NumPy oracle port "
-                                         f"(oracle/minimizer_port.py) on the same {nf}-facet mesh, starting "
-                                         f"from the GPU run's state and step size; "
-                                         f"{sum(t['trials'] for t in cres['trace'])} line-search trials",
-                               "seconds": cdt}
+    n_cpu = 6 if args.cpu_steps < 0 else args.cpu_steps
+    if n_cpu > 0:
+        out["cpu_baseline"] = cpu_baseline(dm.get_positions(), T, mods, cons, bodies, gp, mz.step_size, n_cpu)
         out["step_size_after_warmup"] = step_size_after_warmup
     print(json.dumps(out))
 
 
+def main_sharded(args, rank, world, local_rank):
+    """--gpus N (N > 1, or MS_BENCH_FORCE_SHARDED=1 at N = 1): tiles sharded over the ranks, one process per GPU,
+    halo all-gathers over RCCL; timed with barrier + synchronize on both sides and the MAX over ranks."""
+    import torch
+    import torch.distributed as dist
+
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd.parallel import HipShardBackend, LibraryShardedStepper, ShardedStepper
+
+    torch.cuda.set_device(local_rank)
+    if "WORLD_SIZE" not in os.environ:  # MS_BENCH_FORCE_SHARDED=1 at N = 1 without a launcher
+        os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()), "RANK": "0",
+                           "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    freq = weak_frequency(world, args.freq) if args.weak else args.freq
+    P, T = bench_mesh(freq)
+    nv, nf = P.shape[0], T.shape[0]
+    be = HipShardBackend(P, T, rank=rank, world=world, device=local_rank, tile_vertices=args.tile)
+    if args.deterministic:
+        be.dm.set_deterministic(True)
+    be.configure(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING, gamma=np.ones(nf), kappa=np.ones(nv), c0=np.zeros(nv))
+    # every rank must end up with the SAME driver: the library driver's collectives run on its own communicator
+    ok, why = 1, ""
+    try:
+        if os.environ.get("MS_SHARD_PYTHON_DRIVER"):
+            raise RuntimeError("MS_SHARD_PYTHON_DRIVER set")
+        be.enable_library_driver()
+    except Exception as exc:
+        ok, why = 0, str(exc)
+    flag = torch.tensor([ok], dtype=torch.int32, device=be.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        driver = "library (ms_shard_step, direct ncclAllGather)"
+        drv = LibraryShardedStepper(be, stepper=L.MS_STEPPER_CG)
+    else:
+        if rank == 0 or not ok:
+            print(f"[bench] rank {rank}: library shard driver not used on every rank ({why or 'a peer failed'}); "
+                  "all ranks use the Python / torch.distributed driver", file=sys.stderr)
+        driver = "python (ShardedStepper, torch.distributed all_gather_into_tensor)"
+        drv = ShardedStepper(be, stepper=L.MS_STEPPER_CG)
+    step = args.step_size
+
+    def run(n):
+        nonlocal step
+        acc = trials = guards = 0
+        if isinstance(drv, LibraryShardedStepper):
+            o = drv.run(n, step, tol=1e-6)
+            step = float(o.step_size)
+            return int(o.accepted), int(o.trials), int(o.guard_rejects), o
+        r = None
+        for _ in range(n):
+            r = drv.step(step, tol=1e-6)
+            step = r.next_step
+            acc += int(r.success)
+            trials += r.trials
+            guards += r.guard_rejects
+            if not r.success:
+                drv.reset()  # minimizer.py:1462-1464
+        return acc, trials, guards, r
+
+    run(args.warmup)
+    ex0 = drv.exchanges
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    acc, trials, guards, r = run(args.steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=be.device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    n_exchanges = drv.exchanges - ex0
+    level = int(drv.reuse_energy0)
+    # roofline on THIS rank's shard: HIP events inside the library over a few more steps
+    roofline, kernels = None, None
+    if not args.no_roofline:
+        try:
+            n_prof = min(args.steps, 30)
+            be.dm.profile_enable(True)
+            be.dm.profile_read()
+            _a, tr, gd, _r = run(n_prof)
+            prof = be.dm.profile_read()
+            be.dm.profile_enable(False)
+            info = be.dm.shard_info()
+            nv_l = int(info["row1"] - info["row0"])
+            nf_l = int(round(nf * nv_l / max(nv, 1)))
+            ab = algorithmic_bytes(nv_l, nf_l, uniform=True)
+            # the sharded trial passes write no trial positions (the accepted step is committed in place)
+            for key in ("energy_trial", "energy_trial_factors"):
+                ab[key] -= 24 * nv_l
+            ab["energy_pair"] -= 2 * 24 * nv_l
+            ab["energy_triple"] -= 3 * 24 * nv_l
+            kernels = kernel_table(prof, ab, trial_passes=tr + gd, level=level, nv=nv_l,
+                                   deterministic=bool(args.deterministic))
+            roofline = roofline_block(kernels, n_prof)
+            if roofline is not None:
+                roofline["per_gpu"] = True
+                roofline["shard"] = {"rank": rank, "owned_vertices": nv_l, "facets_equivalent": nf_l}
+                roofline["traffic_note"] = ("profiles/ holds single-GPU PMC passes only: at N > 1 `traffic` is the "
+                                            "full-mesh figure of the same instantiation, not this shard's")
+        except Exception as exc:  # the measurement is an extra: never lose the bench line over it
+            print(f"[bench] roofline measurement skipped: {exc}", file=sys.stderr)
+    rccl_ranks = be.dm.shard_comm_ranks() if isinstance(drv, LibraryShardedStepper) else dist.get_world_size()
+    cpu = None
+    n_cpu = (6 if world == 1 else 2) if args.cpu_steps < 0 else args.cpu_steps
+    if n_cpu > 0:
+        x_full = be.gather_positions()  # collective: every rank takes part
+        if rank == 0:
+            cpu = cpu_baseline(x_full, T, ["surface", "bending"], [], [], dict(GP), step, n_cpu)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({
+            "metric": METRIC, "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload_text(freq, nv, nf, level, args.deterministic)
+                                   + (f"; WEAK scaling: ~2 048 000 facets per GPU, {nf} in all" if args.weak else ""),
+                       "parallelism": f"tiles (facet blocks) sharded over {world} GPUs; per exchange one RCCL "
+                                      f"all-gather of [{L.MS_NSCAL} scalars | <= {be.boundary['max_rows']} boundary rows] "
+                                      f"per rank; driver: {driver}",
+                       "tile_vertices": args.tile or 256, "initial_step_size": args.step_size,
+                       "deterministic": bool(args.deterministic)},
+            "steps_accepted": acc, "line_search_trials": trials,
+            **rates(args.steps, acc, trials, guards, level, dt),
+            "rccl_ranks": int(rccl_ranks), "exchanges": int(n_exchanges),
+            "exchanges_per_step": n_exchanges / max(args.steps, 1),
+            "exchange_bytes_per_rank_max": int((L.MS_NSCAL + 10 * be.boundary["max_rows"]) * 8),
+            "energy_end": float(getattr(r, "energy", getattr(r, "energy_eval", float("nan")))),
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+        }))
+    dist.destroy_process_group()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = build_parser().parse_args(argv)
+    have_rendezvous = "WORLD_SIZE" in os.environ
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and not have_rendezvous:
+        return spawn_ranks(args, argv)  # before anything touches the GPU
+    if have_rendezvous and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1 or os.environ.get("MS_BENCH_FORCE_SHARDED"):
+        return main_sharded(args, rank, world, local_rank)
+    return main_single(args)
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

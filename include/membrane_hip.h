@@ -416,6 +416,8 @@ int ms_shard_step(ms_ctx *ctx, const ms_stepper_params *params, double step_size
                   double tol, ms_step_result *out);
 /* number of exchanges done so far by ms_shard_step on this context */
 int64_t ms_shard_exchange_count(const ms_ctx *ctx);
+/* ranks of the context's RCCL communicator as ncclCommCount reports them (0: no communicator) */
+int ms_shard_comm_ranks(ms_ctx *ctx);
 
 /* Per-vertex state in caller-owned device memory (e.g. a torch tensor, so RCCL
  * collectives can run on it in place).  ms_state_bytes gives the size;
@@ -440,8 +442,10 @@ int ms_tile_stats(ms_ctx *ctx, int64_t *n_tiles, int64_t *facet_instances,
  * and launch counts per kind {0 energy, 1 gradient, 2 direction, 3 reduce,
  * 4 tilt, 5 bending_tilt facet pass, 6 tilt vector ops, 7 energy pair launch (two
  * trial evaluations of one line search in one launch), 8 energy triple launch
- * (three)} and resets the counters.  Used by bench.py for the roofline figure. */
-#define MS_PROF_KINDS 9
+ * (three), 9 gradient, lean instantiation (k_gradient<1,false,256,0,true,true>: analytic
+ * bending, uniform surface tension, no separate previous-direction rows)} and resets the
+ * counters.  Used by bench.py for the roofline figure. */
+#define MS_PROF_KINDS 10
 int ms_profile_enable(ms_ctx *ctx, int on);
 int ms_profile_read(ms_ctx *ctx, double total_ms[MS_PROF_KINDS],
                     int64_t launches[MS_PROF_KINDS]);

@@ -692,7 +692,7 @@ int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulat
   a.tilts = nullptr;
   a.div_sign = 1.0;
   if (n_lbt == 0) {
-    ProfScope ps(c, 1, c->cur_gate != nullptr);
+    ProfScope ps(c, gradient_lean_instance(a) ? 9 : 1, c->cur_gate != nullptr);
     HIPCHK(c, launch_gradient(a, c->cap, c->til.max_ent, c->stream));
   }
   for (int k = 0; k < n_lbt; ++k) {
@@ -2551,6 +2551,7 @@ struct Rccl {
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
 };
 Rccl g_rccl;
 
@@ -2570,6 +2571,7 @@ int rccl_bind() {
   g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(lib, "ncclAllGather"));
   g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
   g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+  g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(dlsym(lib, "ncclCommCount"));
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather)
     return fail(nullptr, MS_ERR_STATE, "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather");
   g_rccl.lib = lib;
@@ -2722,6 +2724,12 @@ int ms_shard_set_allgather(ms_ctx* c, ms_allgather_fn fn, void* user) {
 }
 
 int64_t ms_shard_exchange_count(const ms_ctx* c) { return c ? (int64_t)c->sh_exchanges : 0; }
+
+int ms_shard_comm_ranks(ms_ctx* c) {
+  if (!c || !c->comm || !g_rccl.CommCount) return 0;
+  int n = 0;
+  return g_rccl.CommCount(c->comm, &n) == 0 ? n : 0;
+}
 
 // The control flow of parallel.ShardedStepper.step (itself a restatement of ms_step).
 int ms_shard_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol, ms_step_result* out) {

@@ -230,6 +230,7 @@ size_t energy_lds_bytes(int T, int cap, int max_ent, bool bend, bool guard, bool
 size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow, bool atomic = false, bool leaf = false);
 hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, hipStream_t s);
 hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStream_t s);
+bool gradient_lean_instance(const GradientArgs& a);  // which k_gradient instantiation launch_gradient picks
 // mode 0: energy partial (MS_S_ETILT); 1: energy + gradients; 2: project tilts to tangent
 size_t tilt_lds_bytes(int T, int cap, int max_ent, bool consistent = false);
 hipError_t launch_tilt(const TiltArgs& a, int mode, int cap, int max_ent, hipStream_t s);

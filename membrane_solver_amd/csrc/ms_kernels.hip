@@ -1415,6 +1415,15 @@ size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow, b
   return d * sizeof(double) + (atomic ? 0 : u16_bytes(T, max_ent)) + (((size_t)cap + 15) / 16) * 16;
 }
 
+// the lean instance (see k_gradient): analytic bending, no constraint row, uniform gamma, no pd rows to load
+bool gradient_lean_instance(const GradientArgs& a) {
+  const bool bend = (a.modules & MS_MOD_BENDING) != 0;
+  const bool volrow = a.gC != nullptr && (a.modules & MS_CON_VOLUME);
+  const bool leaf = bend && a.bt_vert != nullptr;
+  return a.m.T == FAST_T && a.atomic != 0 && !volrow && !leaf && bend && a.bending_grad_mode != MS_GRAD_APPROX &&
+         a.m.gamma_uniform && (a.dir_mode != 2 || a.pd_neg_pg) && !no_lean();
+}
+
 hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStream_t s) {
   const int nb = a.tile1 - a.tile0;
   if (nb <= 0) return hipSuccess;
@@ -1431,10 +1440,7 @@ hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStrea
     if (e != hipSuccess) return e;                                                                   \
     hipLaunchKernelGGL((k_gradient<M, V, TT, CC, AT>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent); \
   } while (0)
-  // the lean instance (see k_gradient): analytic bending, no constraint row, uniform gamma, no pd rows to load
-  const bool lean = fast && atomic && !volrow && !leaf && bend && a.bending_grad_mode != MS_GRAD_APPROX &&
-                    a.m.gamma_uniform && (a.dir_mode != 2 || a.pd_neg_pg) && !no_lean();
-  if (lean) {
+  if (gradient_lean_instance(a)) {
     e = ensure_lds(k_gradient<1, false, FAST_T, FAST_CAP, true, true>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_gradient<1, false, FAST_T, FAST_CAP, true, true>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);

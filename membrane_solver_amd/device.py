@@ -390,6 +390,10 @@ class DeviceMesh:
         return StepResult(r.success != 0, r.converged != 0, r.trials, r.guard_rejects, r.next_step, r.energy,
                           r.alpha, r.energy_eval, r.grad_norm, r.g_dot_d, r.volume)
 
+    def shard_comm_ranks(self) -> int:
+        """Ranks of the context's RCCL communicator (ncclCommCount); 0 without one."""
+        return int(L.lib().ms_shard_comm_ranks(self._h))
+
     def shard_exchange_count(self) -> int:
         return int(L.lib().ms_shard_exchange_count(self._h))
 
@@ -445,10 +449,11 @@ class DeviceMesh:
 
     def profile_read(self):
         """-> {kind: (total_ms, launches)} per kernel kind (include/membrane_hip.h, ms_profile_read)."""
-        ms = np.zeros(9)
-        n = np.zeros(9, dtype=np.int64)
+        ms = np.zeros(10)
+        n = np.zeros(10, dtype=np.int64)
         self._chk(L.lib().ms_profile_read(self._h, _pd(ms), n.ctypes.data_as(L._I64)), "ms_profile_read")
-        names = ("energy", "gradient", "direction", "reduce", "tilt", "bending_tilt", "tilt_vec", "energy_pair", "energy_triple")
+        names = ("energy", "gradient", "direction", "reduce", "tilt", "bending_tilt", "tilt_vec", "energy_pair", "energy_triple",
+                 "gradient_lean")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
     def shard_info(self):

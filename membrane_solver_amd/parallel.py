@@ -296,7 +296,14 @@ class HipShardBackend:
         nbytes = self.dm.state_bytes()
         self.state = torch.empty(nbytes // 8, dtype=torch.float64, device=self.device)
         torch.cuda.synchronize()
-        self.dm.set_stream(torch.cuda.current_stream().cuda_stream)
+        # ONE explicit stream orders everything this backend does: the library's kernels (pack / unpack / passes),
+        # torch's collectives (ProcessGroupNCCL orders its all-gather against the CURRENT stream) and the few torch
+        # ops on the state tensor.  torch's default stream has handle 0, for which ms_set_stream would create a
+        # private stream that nothing else synchronises with.
+        self.stream = torch.cuda.Stream(device=self.device)
+        torch.cuda.set_stream(self.stream)
+        assert self.stream.cuda_stream != 0
+        self.dm.set_stream(self.stream.cuda_stream)
         self.dm.rebind_state(self.state.data_ptr(), nbytes)
         self.modules = L.MS_MOD_SURFACE
         self.volume_stiffness = 0.0
@@ -310,6 +317,11 @@ class HipShardBackend:
         self._plans = {}
 
     def configure(self, *, modules, gamma=None, kappa=None, c0=None, **params):
+        tilt_bits = modules & ~(L.MS_MOD_SURFACE | L.MS_MOD_BENDING | L.MS_MOD_VOLUME_PENALTY | L.MS_CON_VOLUME
+                                | getattr(L, "MS_TRACK_VOLUME", 0))
+        if tilt_bits:
+            raise L.MembraneHipError(f"module bits {tilt_bits:#x}: only surface / bending / volume are sharded "
+                                     "(ms_shard_step refuses the tilt modules as well)")
         if gamma is not None:
             self.dm.set_surface_tension(gamma)
         if kappa is not None:
@@ -366,10 +378,11 @@ class HipShardBackend:
                 hip = ctypes.CDLL(L.HIP_RUNTIME_PATH)
                 hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
                 send, recv = self._send[:n], self._recv[: self.world * n]
+                # the library has synchronised its stream; the callback is synchronous as a whole
                 hip.hipMemcpy(send.data_ptr(), send_ptr, nbytes, 3)
                 dist.all_gather_into_tensor(recv, send)
+                torch.cuda.current_stream().synchronize()
                 hip.hipMemcpy(recv_ptr, recv.data_ptr(), nbytes * self.world, 3)
-                torch.cuda.synchronize()
 
             self.dm.shard_set_allgather(gather)
             return
@@ -419,119 +432,3 @@ class HipShardBackend:
         self.dm.pack_boundary(buffers, send_ptr, nbytes)
         self.dist.all_gather_into_tensor(recv, send)
         return self.dm.unpack_boundary(buffers, recv_ptr, nbytes, self.world)
-
-
-def bench_main(args, rank: int, world: int, local_rank: int):
-    """bench.py --gpus N (N > 1): same workload as the single-GPU bench, tiles sharded
-    over N ranks (strong scaling), timed with barrier + synchronize on both sides and
-    the MAX over ranks."""
-    import torch
-    import torch.distributed as dist
-
-    from . import meshgen
-
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    P, T = meshgen.icosphere(args.freq)
-    P = meshgen.smooth_displace(P, 0.05)
-    nv, nf = P.shape[0], T.shape[0]
-    be = HipShardBackend(P, T, rank=rank, world=world, device=local_rank, tile_vertices=args.tile)
-    if getattr(args, "deterministic", False):
-        be.dm.set_deterministic(True)
-    be.configure(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING, gamma=np.ones(nf), kappa=np.ones(nv),
-                 c0=np.zeros(nv))
-    driver = "library (ms_shard_step, direct ncclAllGather)"
-    try:
-        if os.environ.get("MS_SHARD_PYTHON_DRIVER"):
-            raise RuntimeError("MS_SHARD_PYTHON_DRIVER set")
-        be.enable_library_driver()
-        drv = LibraryShardedStepper(be, stepper=L.MS_STEPPER_CG)
-    except Exception as exc:  # fall back to the torch.distributed driver, loudly
-        print(f"[bench] library shard driver unavailable ({exc}); using the Python/torch.distributed driver",
-              file=sys.stderr)
-        driver = "python (ShardedStepper, torch.distributed all_gather_into_tensor)"
-        drv = ShardedStepper(be, stepper=L.MS_STEPPER_CG)
-    step = args.step_size
-
-    def run(n):
-        nonlocal step
-        acc = trials = 0
-        if isinstance(drv, LibraryShardedStepper):
-            out = drv.run(n, step, tol=1e-6)
-            step = float(out.step_size)
-            return int(out.accepted), int(out.trials), out
-        for _ in range(n):
-            r = drv.step(step, tol=1e-6)
-            step = r.next_step
-            acc += int(r.success)
-            trials += r.trials
-            if not r.success:
-                drv.reset()  # minimizer.py:1462-1464
-        return acc, trials, r
-
-    run(args.warmup)
-    ex0 = drv.exchanges
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    acc, trials, r = run(args.steps)
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=be.device)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    n_exchanges = drv.exchanges - ex0
-    # roofline of the dominant kernel on THIS rank's shard: HIP events inside the library over a few more steps
-    roofline = None
-    try:
-        n_prof = min(args.steps, 30)
-        be.dm.profile_enable(True)
-        be.dm.profile_read()
-        run(n_prof)
-        prof = be.dm.profile_read()
-        be.dm.profile_enable(False)
-        ms_e, n_e = prof.get("energy", (0.0, 0))
-        ms_p, n_p = prof.get("energy_pair", (0.0, 0))
-        pair_dominates = ms_p > ms_e
-        if pair_dominates:
-            ms_e, n_e = ms_p, n_p
-        if n_e:
-            info = be.dm.shard_info()
-            nv_l = int(info["row1"] - info["row0"])
-            nf_l = nf * nv_l / max(nv, 1)
-            # a trial pass that also writes the factors (reuse level 2); the sharded trial passes write no trial
-            # positions (the accepted step is committed in place).  A pair launch (two trials per launch) reads its
-            # inputs once and writes both factor sets
-            e_bytes = 20 * nf_l + (48 + 16 + 1) * nv_l + 40 * nv_l
-            if pair_dominates:
-                e_bytes = 20 * nf_l + (48 + 16 + 1) * nv_l + 2 * 40 * nv_l
-            us = 1e3 * ms_e / n_e
-            ach = e_bytes / (us * 1e-6) / 1e9
-            roofline = {"bound": "hbm", "kernel": ("ms::k_energy<.., MULTI=2> (two trial evaluations per launch)"
-                                                   if pair_dominates else "ms::k_energy* (energy pass)")
-                                                  + ", rank 0's shard", "achieved": ach,
-                        "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
-                        "avg_launch_us": us, "algorithmic_bytes_per_launch": e_bytes, "per_gpu": True,
-                        "measured": f"HIP events around every launch over {n_prof} steps after the timed region"}
-    except Exception as exc:  # the measurement is an extra: never lose the bench line over it
-        print(f"[bench] roofline measurement skipped: {exc}", file=sys.stderr)
-    if rank == 0:
-        print(json.dumps({
-            "metric": "minimizer steps/sec (energy+grad+CG) on 2M-facet icosphere",
-            "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"class-I icosphere f={args.freq} (nv={nv}, nf={nf}), surface + Helfrich "
-                                   "bending (analytic cotan gradient), CG stepper, Armijo line search, "
-                                   f"evaluation reuse level {drv.reuse_energy0}",
-                       "parallelism": f"tiles (facet blocks) sharded over {world} GPUs; per exchange one RCCL "
-                                      f"all-gather of [{L.MS_NSCAL} scalars | <= {be.boundary['max_rows']} boundary rows] "
-                                      f"per rank ({n_exchanges} exchanges in the timed steps); driver: {driver}",
-                       "tile_vertices": args.tile or 256, "initial_step_size": args.step_size,
-                       "deterministic": bool(getattr(args, "deterministic", False))},
-            "steps_accepted": acc, "line_search_trials": trials,
-            "energy_end": float(getattr(r, "energy", getattr(r, "energy_eval", float("nan")))),
-            "roofline": roofline,
-        }))
-    dist.destroy_process_group()

@@ -24,6 +24,21 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
+/* The same source builds twice: libms_oracle.so (serial, strict order of operations: the
+ * CHECKER) and libms_oracle_omp.so (-fopenmp -DORC_OMP: facet loops split over the host
+ * cores, vertex scatter-adds by `omp atomic`; sums arrive in a different order, so this
+ * build is only ever TIMED -- bench.py's all-cores cpu_baseline leg). */
+#ifdef ORC_OMP
+#define ORC_PRAGMA(x) _Pragma(#x)
+#define ORC_FACETS ORC_PRAGMA(omp parallel for schedule(static))
+#define ORC_FACETS_SUM(v) ORC_PRAGMA(omp parallel for schedule(static) reduction(+ : v))
+#define ORC_AT ORC_PRAGMA(omp atomic)
+#else
+#define ORC_FACETS
+#define ORC_FACETS_SUM(v)
+#define ORC_AT
+#endif
+
 static inline void cross3(const double *a, const double *b, double *c) {
   c[0] = a[1] * b[2] - a[2] * b[1];
   c[1] = a[2] * b[0] - a[0] * b[2];
@@ -52,6 +67,7 @@ ORC_API void orc_surface_energy_and_gradient(int nv, int nf, const double *pos,
                                              double *E_out) {
   const double eps = 1.0e-12;
   double E = 0.0;
+  ORC_FACETS_SUM(E)
   for (int f = 0; f < nf; ++f) {
     int i0 = tri[3 * f], i1 = tri[3 * f + 1], i2 = tri[3 * f + 2];
     if (!in_range(i0, nv) || !in_range(i1, nv) || !in_range(i2, nv)) continue;
@@ -77,8 +93,11 @@ ORC_API void orc_surface_energy_and_gradient(int nv, int nf, const double *pos,
       g0[d] = gamma[f] * (0.5 * g0[d]);
       g1[d] = gamma[f] * (0.5 * g1[d]);
       g2[d] = gamma[f] * (0.5 * g2[d]);
+      ORC_AT
       grad[3 * i0 + d] += g0[d];
+      ORC_AT
       grad[3 * i1 + d] += g1[d];
+      ORC_AT
       grad[3 * i2 + d] += g2[d];
     }
   }
@@ -147,6 +166,7 @@ ORC_API void orc_apply_beltrami_laplacian(int dim, int nv, int nf,
                                           const int32_t *tri,
                                           const double *field, double *out) {
   memset(out, 0, sizeof(double) * (size_t)nv * (size_t)dim);
+  ORC_FACETS
   for (int f = 0; f < nf; ++f) {
     double c0 = weights[3 * f], c1 = weights[3 * f + 1], c2 = weights[3 * f + 2];
     int v0 = tri[3 * f], v1 = tri[3 * f + 1], v2 = tri[3 * f + 2];
@@ -155,8 +175,11 @@ ORC_API void orc_apply_beltrami_laplacian(int dim, int nv, int nf,
       double f0 = field[(size_t)v0 * dim + d];
       double f1 = field[(size_t)v1 * dim + d];
       double f2 = field[(size_t)v2 * dim + d];
+      ORC_AT
       out[(size_t)v0 * dim + d] += 0.5 * (c1 * (f0 - f2) + c2 * (f0 - f1));
+      ORC_AT
       out[(size_t)v1 * dim + d] += 0.5 * (c2 * (f1 - f0) + c0 * (f1 - f2));
+      ORC_AT
       out[(size_t)v2 * dim + d] += 0.5 * (c0 * (f2 - f1) + c1 * (f2 - f0));
     }
   }
@@ -240,6 +263,7 @@ ORC_API void orc_compute_curvature_data(int nv, int nf, const double *pos,
   if (va0_out) memset(va0_out, 0, sizeof(double) * (size_t)nf);
   if (va1_out) memset(va1_out, 0, sizeof(double) * (size_t)nf);
   if (va2_out) memset(va2_out, 0, sizeof(double) * (size_t)nf);
+  ORC_FACETS
   for (int f = 0; f < nf; ++f) {
     int i0 = tri[3 * f], i1 = tri[3 * f + 1], i2 = tri[3 * f + 2];
     if (!in_range(i0, nv) || !in_range(i1, nv) || !in_range(i2, nv)) continue;
@@ -263,14 +287,20 @@ ORC_API void orc_compute_curvature_data(int nv, int nf, const double *pos,
     weights[3 * f + 1] = c1;
     weights[3 * f + 2] = c2;
     for (int d = 0; d < 3; ++d) {
+      ORC_AT
       k_vecs[3 * i0 + d] += 0.5 * (c1 * ne1[d] + c2 * e2[d]);
+      ORC_AT
       k_vecs[3 * i1 + d] += 0.5 * (c2 * ne2[d] + c0 * e0[d]);
+      ORC_AT
       k_vecs[3 * i2 + d] += 0.5 * (c0 * ne0[d] + c1 * e1[d]);
     }
     double va[3];
     corner_areas(c0, c1, c2, l0, l1, l2, tri_area, va);
+    ORC_AT
     vertex_areas[i0] += va[0];
+    ORC_AT
     vertex_areas[i1] += va[1];
+    ORC_AT
     vertex_areas[i2] += va[2];
     if (va0_out) va0_out[f] = va[0];
     if (va1_out) va1_out[f] = va[1];
@@ -291,6 +321,7 @@ ORC_API void orc_effective_areas(int nv, int nf, const double *pos,
                                  const uint8_t *is_boundary,
                                  double *vertex_areas_eff, double *va_eff) {
   if (vertex_areas_eff) memset(vertex_areas_eff, 0, sizeof(double) * (size_t)nv);
+  ORC_FACETS
   for (int f = 0; f < nf; ++f) {
     int i0 = tri[3 * f], i1 = tri[3 * f + 1], i2 = tri[3 * f + 2];
     const double *v0 = pos + 3 * i0, *v1 = pos + 3 * i1, *v2 = pos + 3 * i2;
@@ -324,8 +355,11 @@ ORC_API void orc_effective_areas(int nv, int nf, const double *pos,
     va_eff[3 * f + 1] = va[1];
     va_eff[3 * f + 2] = va[2];
     if (vertex_areas_eff) {
+      ORC_AT
       vertex_areas_eff[i0] += va[0];
+      ORC_AT
       vertex_areas_eff[i1] += va[1];
+      ORC_AT
       vertex_areas_eff[i2] += va[2];
     }
   }
@@ -335,6 +369,7 @@ ORC_API void orc_effective_areas(int nv, int nf, const double *pos,
 ORC_API void orc_vertex_normals(int nv, int nf, const double *pos,
                                 const int32_t *tri, double *normals) {
   memset(normals, 0, sizeof(double) * 3 * (size_t)nv);
+  ORC_FACETS
   for (int f = 0; f < nf; ++f) {
     int i0 = tri[3 * f], i1 = tri[3 * f + 1], i2 = tri[3 * f + 2];
     const double *v0 = pos + 3 * i0, *v1 = pos + 3 * i1, *v2 = pos + 3 * i2;
@@ -343,8 +378,11 @@ ORC_API void orc_vertex_normals(int nv, int nf, const double *pos,
     sub3(v2, v0, b);
     cross3(a, b, n);
     for (int d = 0; d < 3; ++d) {
+      ORC_AT
       normals[3 * i0 + d] += n[d];
+      ORC_AT
       normals[3 * i1 + d] += n[d];
+      ORC_AT
       normals[3 * i2 + d] += n[d];
     }
   }
@@ -380,6 +418,7 @@ static int backprop_bending(int nv, int nf, const double *pos,
   orc_apply_beltrami_laplacian(3, nv, nf, weights, tri, fK, grad_linear);
   for (size_t i = 0; i < n3; ++i) grad_linear[i] = -grad_linear[i];
 
+  ORC_FACETS
   for (int f = 0; f < nf; ++f) {
     int i0 = tri[3 * f], i1 = tri[3 * f + 1], i2 = tri[3 * f + 2];
     const double *v0 = pos + 3 * i0, *v1 = pos + 3 * i1, *v2 = pos + 3 * i2;
@@ -408,8 +447,11 @@ static int backprop_bending(int nv, int nf, const double *pos,
     sub3(v2, v0, w);
     grad_cotan_one(u, w, gu, gv);
     for (int d = 0; d < 3; ++d) {
+      ORC_AT
       grad_cot[3 * i1 + d] += dE_dc0 * gu[d];
+      ORC_AT
       grad_cot[3 * i2 + d] += dE_dc0 * gv[d];
+      ORC_AT
       grad_cot[3 * i0 + d] += dE_dc0 * -(gu[d] + gv[d]);
     }
     /* corner 1: u=v2-v1, v=v0-v1 -> v2, v0, v1 */
@@ -417,8 +459,11 @@ static int backprop_bending(int nv, int nf, const double *pos,
     sub3(v0, v1, w);
     grad_cotan_one(u, w, gu, gv);
     for (int d = 0; d < 3; ++d) {
+      ORC_AT
       grad_cot[3 * i2 + d] += dE_dc1 * gu[d];
+      ORC_AT
       grad_cot[3 * i0 + d] += dE_dc1 * gv[d];
+      ORC_AT
       grad_cot[3 * i1 + d] += dE_dc1 * -(gu[d] + gv[d]);
     }
     /* corner 2: u=v0-v2, v=v1-v2 -> v0, v1, v2 */
@@ -426,8 +471,11 @@ static int backprop_bending(int nv, int nf, const double *pos,
     sub3(v1, v2, w);
     grad_cotan_one(u, w, gu, gv);
     for (int d = 0; d < 3; ++d) {
+      ORC_AT
       grad_cot[3 * i0 + d] += dE_dc2 * gu[d];
+      ORC_AT
       grad_cot[3 * i1 + d] += dE_dc2 * gv[d];
+      ORC_AT
       grad_cot[3 * i2 + d] += dE_dc2 * -(gu[d] + gv[d]);
     }
 
@@ -447,32 +495,44 @@ static int backprop_bending(int nv, int nf, const double *pos,
       double coeff;
       coeff = 0.25 * c1 * C[0];
       for (int d = 0; d < 3; ++d) {
+        ORC_AT
         grad_area[3 * i0 + d] += coeff * e1[d];
+        ORC_AT
         grad_area[3 * i2 + d] += -coeff * e1[d];
       }
       coeff = 0.25 * c2 * C[0];
       for (int d = 0; d < 3; ++d) {
+        ORC_AT
         grad_area[3 * i1 + d] += coeff * e2[d];
+        ORC_AT
         grad_area[3 * i0 + d] += -coeff * e2[d];
       }
       coeff = 0.25 * c2 * C[1];
       for (int d = 0; d < 3; ++d) {
+        ORC_AT
         grad_area[3 * i1 + d] += coeff * e2[d];
+        ORC_AT
         grad_area[3 * i0 + d] += -coeff * e2[d];
       }
       coeff = 0.25 * c0 * C[1];
       for (int d = 0; d < 3; ++d) {
+        ORC_AT
         grad_area[3 * i2 + d] += coeff * e0[d];
+        ORC_AT
         grad_area[3 * i1 + d] += -coeff * e0[d];
       }
       coeff = 0.25 * c0 * C[2];
       for (int d = 0; d < 3; ++d) {
+        ORC_AT
         grad_area[3 * i2 + d] += coeff * e0[d];
+        ORC_AT
         grad_area[3 * i1 + d] += -coeff * e0[d];
       }
       coeff = 0.25 * c1 * C[2];
       for (int d = 0; d < 3; ++d) {
+        ORC_AT
         grad_area[3 * i0 + d] += coeff * e1[d];
+        ORC_AT
         grad_area[3 * i2 + d] += -coeff * e1[d];
       }
       double l0sq = dot3(e0, e0), l1sq = dot3(e1, e1), l2sq = dot3(e2, e2);
@@ -484,24 +544,33 @@ static int backprop_bending(int nv, int nf, const double *pos,
       for (int d = 0; d < 3; ++d) ne[d] = -e1[d];
       grad_cotan_one(e2, ne, gu, gv);
       for (int d = 0; d < 3; ++d) {
+        ORC_AT
         grad_area[3 * i1 + d] += cc0 * gu[d];
+        ORC_AT
         grad_area[3 * i2 + d] += cc0 * gv[d];
+        ORC_AT
         grad_area[3 * i0 + d] += cc0 * -(gu[d] + gv[d]);
       }
       /* gc1 = grad_cotan(e0, -e2) */
       for (int d = 0; d < 3; ++d) ne[d] = -e2[d];
       grad_cotan_one(e0, ne, gu, gv);
       for (int d = 0; d < 3; ++d) {
+        ORC_AT
         grad_area[3 * i2 + d] += cc1 * gu[d];
+        ORC_AT
         grad_area[3 * i0 + d] += cc1 * gv[d];
+        ORC_AT
         grad_area[3 * i1 + d] += cc1 * -(gu[d] + gv[d]);
       }
       /* gc2 = grad_cotan(e1, -e0) */
       for (int d = 0; d < 3; ++d) ne[d] = -e0[d];
       grad_cotan_one(e1, ne, gu, gv);
       for (int d = 0; d < 3; ++d) {
+        ORC_AT
         grad_area[3 * i0 + d] += cc2 * gu[d];
+        ORC_AT
         grad_area[3 * i1 + d] += cc2 * gv[d];
+        ORC_AT
         grad_area[3 * i2 + d] += cc2 * -(gu[d] + gv[d]);
       }
     } else {
@@ -519,8 +588,11 @@ static int backprop_bending(int nv, int nf, const double *pos,
         else
           factor = 0.5 * C[2] + 0.25 * C[0] + 0.25 * C[1];
         for (int d = 0; d < 3; ++d) {
+          ORC_AT
           grad_area[3 * i1 + d] += factor * gu[d];
+          ORC_AT
           grad_area[3 * i2 + d] += factor * gv[d];
+          ORC_AT
           grad_area[3 * i0 + d] += factor * -(gu[d] + gv[d]);
         }
       }

@@ -32,21 +32,37 @@ def build(force: bool = False) -> str:
         force
         or not os.path.exists(_LIB_PATH)
         or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)
+        or not os.path.exists(os.path.join(_HERE, "libms_oracle_omp.so"))
     ):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _LIB_PATH
+
+
+def _load(path: str) -> ctypes.CDLL:
+    h = ctypes.CDLL(path)
+    h.orc_volume.restype = ctypes.c_double
+    h.orc_bending_energy_and_gradient.restype = ctypes.c_int
+    h.orc_bending_energy.restype = ctypes.c_int
+    h.orc_bending_backprop.restype = ctypes.c_int
+    return h
 
 
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
         build()
-        _lib = ctypes.CDLL(_LIB_PATH)
-        _lib.orc_volume.restype = ctypes.c_double
-        _lib.orc_bending_energy_and_gradient.restype = ctypes.c_int
-        _lib.orc_bending_energy.restype = ctypes.c_int
-        _lib.orc_bending_backprop.restype = ctypes.c_int
+        _lib = _load(_LIB_PATH)
     return _lib
+
+
+def use_openmp(on: bool) -> None:
+    """Switch every wrapper below to libms_oracle_omp.so (the same source built with
+    -fopenmp: facet loops over all host cores, vertex sums by `omp atomic`) or back to the
+    serial checker.  The OpenMP build is for bench.py's all-cores cpu_baseline leg ONLY:
+    its sums arrive in a different order, so nothing is ever checked against it."""
+    global _lib
+    build()
+    _lib = _load(os.path.join(_HERE, "libms_oracle_omp.so") if on else _LIB_PATH)
 
 
 def _f64(a, shape=None):

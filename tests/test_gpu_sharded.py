@@ -16,13 +16,16 @@ pytestmark = pytest.mark.gpu
 
 
 class ThreadGroup:
-    """all_gather_into_tensor for `world` threads of one process (device tensors)."""
+    """all_gather_into_tensor for `world` threads of one process (device tensors), ordered the way RCCL orders it:
+    against each rank's CURRENT stream only (events), never by a device-wide synchronize -- so a pack or unpack
+    kernel running on some other stream than the one the collective is ordered against shows up as a wrong row."""
 
     def __init__(self, world):
         import torch
 
         self.torch, self.world = torch, world
         self.slots = [None] * world
+        self.done = [None] * world
         self.bar = threading.Barrier(world)
         self.local = threading.local()
 
@@ -30,14 +33,24 @@ class ThreadGroup:
         self.local.rank = rank
 
     def all_gather_into_tensor(self, out, inp):
+        torch = self.torch
         r = self.local.rank
-        self.torch.cuda.synchronize()
-        self.slots[r] = inp
+        cur = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)  # `inp` is complete once this rank's stream reaches here
+        self.slots[r] = (inp, ready)
         self.bar.wait()
         n = inp.shape[0]
         for k in range(self.world):
-            out[k * n:(k + 1) * n].copy_(self.slots[k])
-        self.torch.cuda.synchronize()
+            src, ev = self.slots[k]
+            cur.wait_event(ev)
+            out[k * n:(k + 1) * n].copy_(src)
+        done = torch.cuda.Event()
+        done.record(cur)
+        self.done[r] = done
+        self.bar.wait()
+        for k in range(self.world):  # nobody reuses its send buffer before every peer has copied it
+            cur.wait_event(self.done[k])
         self.bar.wait()
 
 

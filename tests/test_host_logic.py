@@ -160,3 +160,44 @@ def test_meshgen_counts():
         assert P.shape == (10 * f * f + 2, 3) and T.shape == (20 * f * f, 3)
         assert np.allclose(np.linalg.norm(P, axis=1), 1.0)
         assert not meshgen.boundary_mask_from_triangles(len(P), T).any()
+
+
+def test_bench_launcher_command_and_schema_helpers(monkeypatch):
+    """bench.py --gpus N started as a plain process spawns its ranks through torch.distributed.run (fresh children,
+    127.0.0.1 rendezvous); the roofline block reports the instantiation with the largest time share."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    cmd = bench.launcher_command(["--gpus", "8", "--steps", "5", "--warmup", "2"], 8, 29511, python="python3")
+    assert cmd[:3] == ["python3", "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[cmd.index("--master-port") + 2] == os.path.join(ROOT, "bench.py")
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+    # main() must take the spawn path BEFORE importing anything that touches the GPU
+    called = {}
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(bench, "spawn_ranks", lambda args, argv: called.setdefault("argv", list(argv)) and 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    assert bench.main() == 0 and called["argv"] == ["--gpus", "2", "--steps", "3"]
+    assert bench.weak_frequency(1) == 320 and bench.weak_frequency(4) == 640 and bench.weak_frequency(8) == 905
+
+    nv, nf = 1024002, 2048000
+    ab = bench.algorithmic_bytes(nv, nf)
+    assert ab["gradient_lean"] == 12 * nf + (65 + 24 + 48) * nv          # tri rows; x, fK, fA, flags; pg; g, d
+    assert ab["gradient"] == ab["gradient_lean"] + 24 * nv               # + previous direction rows
+    assert ab["energy_pair"] == ab["energy_trial_factors"] + 64 * nv     # inputs once, outputs twice
+    assert bench.algorithmic_bytes(nv, nf, uniform=False)["energy_only"] == ab["energy_only"] + 8 * nf + 16 * nv
+    prof = {"energy": (0.36, 10), "gradient": (0.0, 0), "gradient_lean": (0.50, 10), "reduce": (0.06, 10),
+            "energy_pair": (0.30, 5), "energy_triple": (0.0, 0), "direction": (0.0, 0)}
+    k = bench.kernel_table(prof, ab, trial_passes=20, level=2, nv=nv, deterministic=False)
+    r = bench.roofline_block(k, 10)
+    assert r["kernel"] == bench.KERNEL_NAMES["gradient_lean"]            # 0.50 ms is the largest share
+    assert abs(r["achieved"] - ab["gradient_lean"] / 50e-6 / 1e9) < 1e-6 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    assert {"energy_family_time_weighted", "gradient_family_time_weighted", "traffic", "traffic_source",
+            "share_of_kernel_time"} <= set(r)
+    rt = bench.rates(20, 10, 21, 0, 2, 0.002)
+    assert rt["accepted_steps_per_s"] == 5000.0 and rt["evaluations_per_s"] == (21 + 10) / 0.002

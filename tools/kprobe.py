@@ -58,7 +58,7 @@ for _ in range(args.reps):
     dm.phase_gradient_direction(L.MS_STEPPER_CG, True)
 dm.fetch_scalars()
 prof = dm.profile_read()
-kc = 1e3 * prof["gradient"][0] / max(1, prof["gradient"][1])
+kc = 1e3 * (prof["gradient"][0] + prof["gradient_lean"][0]) / max(1, prof["gradient"][1] + prof["gradient_lean"][1])
 ka = time_energy(use_direction=True, alpha=1e-9, write_trial=True, write_bending_factors=True)
 if args.last == "gradient":
     dm.phase_set_factors_valid(True)
