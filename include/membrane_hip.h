@@ -347,6 +347,9 @@ typedef struct ms_minimize_result {
   double step_size;        /* out: step size for the next call                 */
   double energy_eval;      /* energy of the last gradient evaluation           */
   double grad_norm;
+  int volume_cache_current; /* the loop ended right after a drift check that did NOT project: Body's cached
+                             * volume is current, so a finalize projection starts from the cached gradient
+                             * (pass it as first_step_cached to ms_project_volume_cached)               */
 } ms_minimize_result;
 
 int ms_minimize(ms_ctx *ctx, const ms_minimize_params *params, int n_steps,
@@ -354,6 +357,14 @@ int ms_minimize(ms_ctx *ctx, const ms_minimize_params *params, int n_steps,
 /* modules/constraints/volume.enforce_constraint projection loop (:117-149) */
 int ms_project_volume(ms_ctx *ctx, double target, double tol, int max_iter,
                       int *iters_out, double *volume_out);
+/* The same projection as the reference's minimizer reaches it.  Body caches the volume gradient of its last
+ * compute_volume_and_gradient evaluation (geometry/body.py:386-407, :463); compute_volume (:70-120) refreshes only
+ * the cached volume and mesh version.  An enforce that follows a compute_volume at the same mesh version -- the
+ * Lagrange drift check, runtime/minimizer.py:1492 -- therefore takes its FIRST step with the current volume but the
+ * gradient the previous enforce evaluated last.  first_step_cached != 0 reproduces that (no effect while nothing is
+ * cached); every fresh evaluation refreshes the cache, also through ms_project_volume. */
+int ms_project_volume_cached(ms_ctx *ctx, double target, double tol, int max_iter,
+                             int first_step_cached, int *iters_out, double *volume_out);
 
 /* ---- phase-level entry points (multi-GPU drivers interleave collectives) -- */
 /* energy pass over this shard's tiles at x (+ alpha*d if use_direction);

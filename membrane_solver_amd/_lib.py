@@ -90,7 +90,8 @@ class ms_minimize_result(ctypes.Structure):
     _fields_ = [("iterations", ctypes.c_int), ("converged", ctypes.c_int), ("zero_step_exit", ctypes.c_int),
                 ("step_success", ctypes.c_int), ("accepted", ctypes.c_int), ("trials", ctypes.c_int),
                 ("guard_rejects", ctypes.c_int), ("moved", ctypes.c_int), ("step_size", ctypes.c_double),
-                ("energy_eval", ctypes.c_double), ("grad_norm", ctypes.c_double)]
+                ("energy_eval", ctypes.c_double), ("grad_norm", ctypes.c_double),
+                ("volume_cache_current", ctypes.c_int)]
 
 
 class ms_step_result(ctypes.Structure):
@@ -155,6 +156,8 @@ SIGNATURES = {
                                    ctypes.POINTER(ms_minimize_result), _D]),
     "ms_project_volume": (ctypes.c_int, [_P, ctypes.c_double, ctypes.c_double, ctypes.c_int,
                                          ctypes.POINTER(ctypes.c_int), _D]),
+    "ms_project_volume_cached": (ctypes.c_int, [_P, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                                ctypes.POINTER(ctypes.c_int), _D]),
     "ms_phase_energy": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int]),
     "ms_phase_gradient": (ctypes.c_int, [_P]),

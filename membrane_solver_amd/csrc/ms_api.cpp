@@ -33,6 +33,11 @@ struct ms_ctx {
   int32_t* d_tile_facet_off = nullptr;
   TileFacet* d_tile_facets = nullptr;
   double* d_tf_gamma = nullptr;
+  // Body's cached volume gradient (geometry/body.py:386-407): what the last fresh evaluation inside
+  // ms_project_volume computed, and its squared norm
+  double* d_volgrad_cache = nullptr;
+  double volgrad_cache_norm2 = 0.0;
+  bool volgrad_cache_valid = false;
   bool gamma_uniform = true, kc_uniform = true;  // ms_set_surface_tension / ms_set_bending_params decide
   double gamma_const = 1.0, kappa_const = 0.0, c0_const = 0.0;
   int32_t* d_tile_halo_off = nullptr;
@@ -724,17 +729,24 @@ int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulat
     c->last_g = g_out;
     c->dir_implicit = false;  // D was written
   }
+  bool added_after = n_lbt > 0;
   for (int k = 0; k < 3 && g_out; ++k) {  // module loop: the tilt magnitude modules add their shape gradient into g
     TiltField& f = c->tf[k];
     if (modules & f.mod_tilt) {
       int rc = tilt_pass_f(c, f, 1, false, 0.0);
       if (rc) return rc;
+      added_after = true;
     }
     if (k > 0 && (modules & f.mod_dt)) {
       int rc = disk_target_pass(c, f, 1, false, 0.0, f.tilts, true, false);
       if (rc) return rc;
+      added_after = true;
     }
   }
+  // the gradient kernel's <g, gC> partials predate those additions: take them again of the complete gradient
+  if (added_after && g_out && (modules & MS_CON_VOLUME))
+    HIPCHK(c, launch_row_dot(c->tile0, c->tile1, c->til.nv, c->til.T, g_out, c->buf[MS_BUF_GC], c->d_partials,
+                             c->til.n_tiles, c->stream));
   if (reduce_now) return reduce_slots(c, dir_mode ? MASK_DIR : MASK_GRAD);
   return MS_OK;
 }
@@ -1098,7 +1110,7 @@ void ms_destroy(ms_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (!c->own_state) c->state = nullptr;
-  void* ptrs[] = {c->d_perm, c->d_tile_facet_off, c->d_tile_facets, c->d_tf_gamma,
+  void* ptrs[] = {c->d_perm, c->d_tile_facet_off, c->d_tile_facets, c->d_tf_gamma, c->d_volgrad_cache,
                   c->d_tile_halo_off, c->d_halo_ids, c->d_tile_ent_off, c->d_tile_voff, c->d_vent,
                   c->d_vflags, c->d_kappa, c->d_c0, c->tf[0].tilts, c->tf[0].grad, c->tf[0].trial, c->d_bt_vert, c->d_tn, c->tf[0].dir, c->tf[0].minv,
                   c->tf[1].tilts, c->tf[1].grad, c->tf[1].trial, c->tf[1].dir, c->tf[1].minv,
@@ -2280,10 +2292,15 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   return MS_OK;
 }
 
-int ms_project_volume(ms_ctx* c, double target, double tol, int max_iter, int* iters_out,
-                      double* volume_out) {
+int ms_project_volume_cached(ms_ctx* c, double target, double tol, int max_iter, int first_step_cached,
+                             int* iters_out, double* volume_out) {
   if (!c) return MS_ERR_INVALID;
   if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "ms_project_volume: single shard only");
+  const size_t row_bytes = sizeof(double) * 3 * (size_t)c->til.nvp;
+  if (!c->d_volgrad_cache) {
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_volgrad_cache), row_bytes));
+    HIPCHK(c, hipMemsetAsync(c->d_volgrad_cache, 0, row_bytes, c->stream));
+  }
   int it = 0;
   double V = 0.0;
   for (; it < max_iter; ++it) {
@@ -2293,20 +2310,36 @@ int ms_project_volume(ms_ctx* c, double target, double tol, int max_iter, int* i
     if (rc) return rc;
     V = c->h_scal[MS_S_VOL];
     const double delta = V - target;
+    // compute_volume_and_gradient (body.py:386-470): the gradient comes with the volume -- from Body's cache on the
+    // first pass when the caller says the cached volume is current (a compute_volume at this mesh version preceded,
+    // which refreshes the cached volume and version but not the gradient), freshly evaluated (and cached) otherwise
+    const bool stale = it == 0 && first_step_cached != 0 && c->volgrad_cache_valid;
+    const double* g = c->d_volgrad_cache;
+    double norm2 = c->volgrad_cache_norm2;
+    if (!stale) {
+      rc = phase_gradient(c, MS_CON_VOLUME, nullptr, false);
+      if (rc) return rc;
+      rc = fetch(c);
+      if (rc) return rc;
+      norm2 = c->h_scal[MS_S_GCGC];
+      HIPCHK(c, hipMemcpyAsync(c->d_volgrad_cache, c->buf[MS_BUF_GC], row_bytes, hipMemcpyDeviceToDevice, c->stream));
+      c->volgrad_cache_norm2 = norm2;
+      c->volgrad_cache_valid = true;
+    }
     if (std::fabs(delta) < tol) break;
-    rc = phase_gradient(c, MS_CON_VOLUME, nullptr, false);
-    if (rc) return rc;
-    rc = fetch(c);
-    if (rc) return rc;
-    const double norm_sq = c->h_scal[MS_S_GCGC] + 1e-12;
-    const double lam = delta / norm_sq;
-    HIPCHK(c, launch_axpy_masked(c->til.nv, c->d_vflags, c->buf[MS_BUF_X], c->buf[MS_BUF_GC], -lam,
-                                 c->stream));
+    const double lam = delta / (norm2 + 1e-12);
+    HIPCHK(c, launch_axpy_masked(c->til.nv, c->d_vflags, c->buf[MS_BUF_X], g, -lam, c->stream));
     c->factors_valid = false;
+    c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
   }
   if (iters_out) *iters_out = it;
   if (volume_out) *volume_out = V;
   return MS_OK;
+}
+
+int ms_project_volume(ms_ctx* c, double target, double tol, int max_iter, int* iters_out,
+                      double* volume_out) {
+  return ms_project_volume_cached(c, target, tol, max_iter, 0, iters_out, volume_out);
 }
 
 int ms_minimize(ms_ctx* c, const ms_minimize_params* mp, int n_steps, ms_minimize_result* out,
@@ -2351,6 +2384,7 @@ int ms_minimize(ms_ctx* c, const ms_minimize_params* mp, int n_steps, ms_minimiz
       return MS_OK;
     }
     out->step_success = r.success;
+    out->volume_cache_current = 0;  // minimizer.py:1415-1416: project_tilts_to_tangent + increment_version
     out->trials += r.trials;
     out->guard_rejects += r.guard_rejects;
     step_size = r.next_step;
@@ -2373,12 +2407,19 @@ int ms_minimize(ms_ctx* c, const ms_minimize_params* mp, int n_steps, ms_minimiz
     } else {
       zero_steps = 0;
       if (mp->drift_check) {  // :1478-1513
+        out->volume_cache_current = 1;  // body.compute_volume: Body's cached volume is current again
         const double denom = std::max(std::fabs(mp->target_volume), 1.0);
         if (std::fabs(r.volume - mp->target_volume) / denom > mp->volume_tolerance) {
           if (mp->project_on_drift) {
             int iters = 0;
-            rc = ms_project_volume(c, mp->target_volume, 1e-12, 12, &iters, nullptr);
+            rc = ms_project_volume_cached(c, mp->target_volume, 1e-12, 12, 1, &iters, nullptr);
             if (rc) return rc;
+            out->volume_cache_current = 0;  // enforce_constraints_after_mesh_ops bumps the mesh version
+            // minimizer.py:1505-1507: enforce, then mesh.project_tilts_to_tangent() on the projected surface
+            if (c->params.modules & MS_ANY_TILT_MODS) {
+              rc = ms_project_tilts_to_tangent(c);
+              if (rc) return rc;
+            }
           }
           ms_reset_stepper(c);
         }

@@ -264,6 +264,8 @@ hipError_t launch_post_seq(unsigned long long* host_seq, unsigned long long tick
 hipError_t launch_axpy_rows(int64_t row0, int64_t row1, const int32_t* extra, int n_extra,
                             const uint8_t* vflags, double* x, const double* y, double coef,
                             hipStream_t s);
+hipError_t launch_row_dot(int tile0, int tile1, int nv, int T, const double* g, const double* gC, double* partials,
+                          int n_tiles, hipStream_t s);
 hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* g,
                             const double* gC, double* d, const double* pg, const double* pd,
                             const double* scal, int use_constraint, int cg_history,

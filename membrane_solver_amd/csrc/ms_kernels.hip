@@ -2470,6 +2470,31 @@ hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* 
   return hipGetLastError();
 }
 
+// <g, gC> per tile, for module sets that add into g AFTER the gradient kernel computed that inner product in its
+// epilogue (the tilt magnitude / disk-target / leaflet bending_tilt shape gradients): the KKT multiplier of
+// runtime/constraint_manager.py:293-301 is taken of the COMPLETE gradient.  <gC, gC> is unchanged.
+__global__ __launch_bounds__(BLOCK) void k_row_dot(int tile0, int nv, int T, const double* g, const double* gC,
+                                                   double* partials, int n_tiles) {
+  __shared__ double red[16];
+  const int tile = tile0 + blockIdx.x;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < T; i += BLOCK) {
+    const int v = tile * T + i;
+    if (v >= nv) break;
+    const size_t o = 3 * (size_t)v;
+    acc += g[o] * gC[o] + g[o + 1] * gC[o + 1] + g[o + 2] * gC[o + 2];
+  }
+  const double r = block_reduce(acc, 0, red);
+  if (threadIdx.x == 0) partials[(size_t)MS_S_GGC * n_tiles + tile] = r;
+}
+
+hipError_t launch_row_dot(int tile0, int tile1, int nv, int T, const double* g, const double* gC, double* partials,
+                          int n_tiles, hipStream_t s) {
+  if (tile1 <= tile0) return hipSuccess;
+  hipLaunchKernelGGL(k_row_dot, dim3(tile1 - tile0), dim3(BLOCK), 0, s, tile0, nv, T, g, gC, partials, n_tiles);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // Shard boundary exchange (multi-GPU): a rank's BOUNDARY rows are the rows it owns that some
 // other rank's tiles list as halo.  pack: send = [16 reduction scalars | boundary rows of up

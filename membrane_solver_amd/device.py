@@ -317,11 +317,14 @@ class DeviceMesh:
     def reset_stepper(self):
         self._chk(L.lib().ms_reset_stepper(self._h), "ms_reset_stepper")
 
-    def project_volume(self, target: float, tol: float = 1e-12, max_iter: int = 3):
+    def project_volume(self, target: float, tol: float = 1e-12, max_iter: int = 3, first_step_cached: bool = False):
+        """volume.enforce_constraint's projection loop; ``first_step_cached``: Body's cached-gradient quirk
+        (include/membrane_hip.h, ms_project_volume_cached)."""
         it = ctypes.c_int(0)
         v = ctypes.c_double(0.0)
-        self._chk(L.lib().ms_project_volume(self._h, float(target), float(tol), int(max_iter),
-                                            ctypes.byref(it), ctypes.byref(v)), "ms_project_volume")
+        self._chk(L.lib().ms_project_volume_cached(self._h, float(target), float(tol), int(max_iter),
+                                                   int(bool(first_step_cached)), ctypes.byref(it), ctypes.byref(v)),
+                  "ms_project_volume_cached")
         return int(it.value), float(v.value)
 
     # -- phase API (multi-GPU drivers) ----------------------------------------

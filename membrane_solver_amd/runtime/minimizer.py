@@ -358,8 +358,10 @@ class Minimizer:
         return out
 
     # -- constraint enforcement (minimizer.py:1103-1188) ---------------------------
-    def _enforce(self, dm, context: str) -> bool:
-        """Volume projection on the device.  Returns True if positions moved."""
+    def _enforce(self, dm, context: str, first_step_cached: bool = False) -> bool:
+        """Volume projection on the device.  Returns True if positions moved.  ``first_step_cached``: the
+        reference's Body still holds the volume gradient of its previous projection and a compute_volume at the
+        current mesh version has made that cache look current (ms_project_volume_cached)."""
         if not self._has_enforceable_constraints:
             return False
         gp = self.global_params
@@ -369,8 +371,15 @@ class Minimizer:
         if target is None:
             return False
         max_iter = 12 if context in ("finalize", "mesh_operation") else 3
-        iters, _v = dm.project_volume(target, tol=1e-12, max_iter=max_iter)
-        return iters > 0
+        iters, _v = dm.project_volume(target, tol=1e-12, max_iter=max_iter, first_step_cached=first_step_cached)
+        moved = iters > 0
+        if context in ("finalize", "mesh_operation") and dm.modules & _TILT_BITS:
+            # minimizer.py:1186, :1224, :1506: every enforce outside the line search is followed by
+            # mesh.project_tilts_to_tangent() -- the tilts must be tangent to the PROJECTED surface before the
+            # next energy / gradient evaluation reads them
+            dm.project_tilts_to_tangent()
+            moved = True
+        return moved
 
     # -- tilt relaxation (runtime/steppers/tilt_relaxation.py:237-300 parameter handling) --
     def _tilt_relax_params(self):
@@ -506,7 +515,7 @@ class Minimizer:
             if out.converged:
                 logger.info("Converged in %d iterations; |grad E|=%.3e", out.iterations - 1, out.grad_norm)
             if not out.zero_step_exit:  # minimizer.py:1324-1337 / :1516-1535 finalize the constraints
-                moved |= self._enforce(dm, "finalize")
+                moved |= self._enforce(dm, "finalize", first_step_cached=bool(out.volume_cache_current))
             if out.converged:
                 energy = float(out.energy_eval) + self._energy_offset
             else:
@@ -527,6 +536,8 @@ class Minimizer:
 
         zero_step_counter = 0
         step_success = True
+        # Body's cached volume is current (minimizer.py:1492 ran at this mesh version and nothing has bumped it since)
+        vol_cache_current = False
         proj_flag = gp.get("volume_projection_during_minimization", True)
         vol_tol = float(gp.get("volume_tolerance", 1e-3))
         vol_mode = gp.get("volume_constraint_mode", "lagrange")
@@ -564,12 +575,13 @@ class Minimizer:
             have_grad = True
             if r.converged:  # minimizer.py:1324-1337
                 logger.info("Converged in %d iterations; |grad E|=%.3e", i, r.grad_norm)
-                dirty_box[0] |= self._enforce(dm, "finalize")
+                dirty_box[0] |= self._enforce(dm, "finalize", first_step_cached=vol_cache_current)
                 return finish({"energy": r.energy_eval + self._energy_offset,
                                "gradient": GradientRows(self.mesh, dm.get_gradient()),
                                "mesh": self.mesh, "step_success": True, "iterations": i + 1,
                                "terminated_early": True})
             step_success = r.success
+            vol_cache_current = False  # minimizer.py:1415-1416: project_tilts_to_tangent + increment_version
             self.step_size = r.next_step
             if r.success:
                 dirty_box[0] = True
@@ -593,11 +605,13 @@ class Minimizer:
                 zero_step_counter = 0
                 # Lagrange volume drift check (minimizer.py:1478-1513)
                 if vol_mode == "lagrange" and not proj_flag and target is not None:
+                    vol_cache_current = True  # body.compute_volume at the current mesh version
                     denom = max(abs(target), 1.0)
                     if abs(r.volume - target) / denom > vol_tol:
-                        dirty_box[0] |= self._enforce(dm, "mesh_operation")
+                        dirty_box[0] |= self._enforce(dm, "mesh_operation", first_step_cached=True)
+                        vol_cache_current = False  # enforce_constraints_after_mesh_ops: increment_version
                         self.stepper.reset()
-        dirty_box[0] |= self._enforce(dm, "finalize")
+        dirty_box[0] |= self._enforce(dm, "finalize", first_step_cached=vol_cache_current)
         final_energy = float(dm.energy().sum()) + self._energy_offset
         grad = GradientRows(self.mesh, dm.get_gradient() if sync_mesh else dm.get_gradient) if have_grad else {}
         return finish({"energy": final_energy, "gradient": grad, "mesh": self.mesh,

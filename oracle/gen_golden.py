@@ -36,6 +36,7 @@ ap.add_argument("--only-leaflet", action="store_true", help="two-leaflet tilt ve
 ap.add_argument("--only-btl", action="store_true", help="bending_tilt_in/out vectors only")
 ap.add_argument("--only-disk", action="store_true", help="tilt_disk_target_in/out vectors only")
 ap.add_argument("--only-defects", action="store_true", help="angle-defect vectors only")
+ap.add_argument("--only-guard", action="store_true", help="guard / exhausted-search / volume-drift trajectories only")
 args = ap.parse_args()
 
 sys.dont_write_bytecode = True
@@ -986,6 +987,139 @@ def run_leaflet_trajectory_fixed(fname, P, T, gp, mods, stepper, n_steps, step_s
         build_mesh = orig
 
 
+# ---------------------------------------------------------------------------
+# (k) line-search guard / exhaustion branches and the Lagrange volume-drift projection
+#     (runtime/topology.py:13-48, runtime/steppers/line_search.py:314-426,
+#      runtime/minimizer.py:1478-1513, modules/constraints/volume.py:69-149)
+# ---------------------------------------------------------------------------
+def _count_guard():
+    """Count what the line search asks the normal-rotation guard and what it answers."""
+    import runtime.steppers.line_search as ls
+
+    stats = {"calls": 0, "rejects": 0}
+    orig = ls.check_max_normal_change_positions
+
+    def counted(mesh, original_positions, new_positions, *a, **kw):
+        ok = orig(mesh, original_positions=original_positions, new_positions=new_positions, *a, **kw)
+        stats["calls"] += 1
+        stats["rejects"] += 0 if ok else 1
+        return ok
+
+    ls.check_max_normal_change_positions = counted
+    return stats, lambda: setattr(ls, "check_max_normal_change_positions", orig)
+
+
+def _count_enforce():
+    stats = {"calls": 0, "volumes": []}
+    orig = cvolume.enforce_constraint
+
+    def counted(mesh, *a, **kw):
+        before = [float(b.compute_volume(mesh)) for b in mesh.bodies.values()]
+        r = orig(mesh, *a, **kw)
+        after = [float(b.compute_volume(mesh)) for b in mesh.bodies.values()]
+        stats["calls"] += 1
+        stats["volumes"].append((before[0], after[0]))
+        return r
+
+    cvolume.enforce_constraint = counted
+    return stats, lambda: setattr(cvolume, "enforce_constraint", orig)
+
+
+def gen_guard_and_enforce():
+    base_gp = {"surface_tension": 1.0, "bending_modulus": 0.5, "bending_energy_model": "helfrich",
+               "spontaneous_curvature": 0.0, "volume_constraint_mode": "lagrange",
+               "volume_projection_during_minimization": False, "mesh_quality_auto_repair_enabled": False}
+    # A: huge initial step -> alpha * max|d| >= 0.3 * min edge: the normal-rotation guard decides trials
+    P, T = meshgen.icosphere(6)
+    P = meshgen.smooth_displace(P, 0.1)
+    mm = build_mesh(P, T, dict(base_gp))
+    mm.energy_modules = ["surface", "bending"]
+    mm.constraint_modules = []
+    stats, undo = _count_guard()
+    try:
+        out = run_trajectory("ico6_cg_guard", mm, ConjugateGradient(), 8, step_size=5.0)
+    finally:
+        undo()
+    out["guard_calls"] = np.array(stats["calls"])
+    out["guard_rejects"] = np.array(stats["rejects"])
+    out["kappa"] = np.array(0.5)
+    assert stats["rejects"] > 0, "the guard was expected to reject trials in this case"
+    np.savez_compressed(os.path.join(OUT, "traj_ico6_cg_guard.npz"), **out)
+    print("traj_ico6_cg_guard.npz E_final=%.16g guard %s" % (out["E_final"], stats), out["step_log"].tolist())
+
+    # B: a search that runs out of its max_iter = 10 trials (line_search.py:425-426): GD from a step so large that
+    # ten shrinkages by 0.7 do not reach an acceptable point
+    for step0 in (20.0,):
+        mm = build_mesh(P, T, dict(base_gp))
+        mm.energy_modules = ["surface", "bending"]
+        mm.constraint_modules = []
+        stats, undo = _count_guard()
+        try:
+            out = run_trajectory("ico6_gd_exhaust", mm, GradientDescent(), 12, step_size=step0)
+        finally:
+            undo()
+        out["guard_calls"] = np.array(stats["calls"])
+        out["guard_rejects"] = np.array(stats["rejects"])
+        out["kappa"] = np.array(0.5)
+        print("traj_ico6_gd_exhaust step0=%g E_final=%.16g guard %s" % (step0, out["E_final"], stats),
+              out["step_log"].tolist())
+        assert (out["step_log"][:, 0] == 0.0).sum() >= 3 and out["step_log"][-1, 0] == 1.0, \
+            "expected exhausted searches followed by a recovery"
+        np.savez_compressed(os.path.join(OUT, "traj_ico6_gd_exhaust.npz"), **out)
+
+    # C: Lagrange volume constraint with a tolerance small enough that the drift check (minimizer.py:1478-1513)
+    # fires after accepted steps and volume.enforce_constraint re-projects the positions
+    P8, T8 = meshgen.icosphere(8)
+    P8 = meshgen.smooth_displace(P8, 0.05)
+    gp = dict(base_gp)
+    gp.update({"bending_modulus": 1.0, "volume_tolerance": 1.0e-11})
+    mm = build_mesh(P8, T8, gp)
+    add_body(mm)
+    mm.energy_modules = ["surface"]
+    mm.constraint_modules = ["volume"]
+    stats, undo = _count_enforce()
+    try:
+        out = run_trajectory("ico8_gd_drift", mm, GradientDescent(), 6, step_size=2e-2)
+    finally:
+        undo()
+    out["enforce_calls"] = np.array(stats["calls"])
+    out["enforce_volumes"] = np.array(stats["volumes"])
+    out["volume_tolerance"] = np.array(1.0e-11)
+    out["volume_final"] = np.array(float(mm.bodies[0].compute_volume(mm)))
+    assert stats["calls"] >= 3, stats
+    np.savez_compressed(os.path.join(OUT, "traj_ico8_gd_volume_drift.npz"), **out)
+    print("traj_ico8_gd_volume_drift.npz E_final=%.16g enforce calls %d" % (out["E_final"], stats["calls"]),
+          out["step_log"][:, 0], stats["volumes"][:3])
+
+    # D: the same with a tilt module: every enforce outside the line search is followed by
+    # mesh.project_tilts_to_tangent() (minimizer.py:1224, :1506, :1186)
+    rng = np.random.default_rng(77)
+    P4, T4 = meshgen.icosphere(4)
+    P4 = meshgen.smooth_displace(P4, 0.08)
+    gp = {"surface_tension": 1.0, "tilt_rigidity": 2.5, "volume_constraint_mode": "lagrange",
+          "volume_projection_during_minimization": False, "mesh_quality_auto_repair_enabled": False,
+          "volume_tolerance": 1.0e-11}
+    tl = 0.3 * rng.normal(size=P4.shape)
+    mm = build_mesh(P4, T4, gp, tilts=tl)
+    add_body(mm)
+    mm.energy_modules = ["surface", "tilt"]
+    mm.constraint_modules = ["volume"]
+    stats, undo = _count_enforce()
+    try:
+        out = run_trajectory("ico4_gd_tilt_drift", mm, GradientDescent(), 5, step_size=2e-2, mesh_path=True)
+    finally:
+        undo()
+    out["tilts0"] = tl
+    out["tilts_final"] = np.ascontiguousarray(mm.tilts_view()).copy()
+    out["k_tilt"] = np.array(2.5)
+    out["enforce_calls"] = np.array(stats["calls"])
+    out["volume_tolerance"] = np.array(1.0e-11)
+    assert stats["calls"] >= 3, stats
+    np.savez_compressed(os.path.join(OUT, "traj_ico4_gd_tilt_volume_drift.npz"), **out)
+    print("traj_ico4_gd_tilt_volume_drift.npz E_final=%.16g enforce calls %d" % (out["E_final"], stats["calls"]),
+          out["step_log"][:, 0])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if "--only-tilt" in sys.argv:
@@ -996,6 +1130,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-defects" in sys.argv:
         gen_angle_defects()
+        sys.exit(0)
+    if "--only-guard" in sys.argv:
+        gen_guard_and_enforce()
         sys.exit(0)
     if "--only-disk" in sys.argv:
         gen_disk_target()
@@ -1021,3 +1158,4 @@ if __name__ == "__main__":
     gen_bending_tilt_leaflet()
     gen_disk_target()
     gen_angle_defects()
+    gen_guard_and_enforce()

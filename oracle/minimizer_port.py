@@ -761,14 +761,25 @@ def check_max_normal_change_positions(tri, old, new, limit_radians=0.5) -> bool:
 
 
 # modules/constraints/volume.py:69-149 enforce_constraint (projection loop)
-def project_volume(p: Problem, pos: np.ndarray, tol=1e-12, max_iter=3) -> np.ndarray:
-    for _ in range(max_iter):
+def project_volume(p: Problem, pos: np.ndarray, tol=1e-12, max_iter=3, first_cached=False) -> np.ndarray:
+    """modules/constraints/volume.py:69-149 as the minimizer reaches it.  ``Body`` caches the volume gradient of
+    its last ``compute_volume_and_gradient`` evaluation (geometry/body.py:386-407, :463) while ``compute_volume``
+    (:70-120) refreshes only the cached volume and mesh version.  An enforce that follows a ``compute_volume`` at the
+    same mesh version -- the Lagrange drift check (minimizer.py:1492) -- therefore takes its FIRST step with the
+    current volume but the gradient the previous enforce evaluated last (``first_cached``); later iterations follow
+    a version bump and are fresh.  The cache lives on the problem (``p._vol_grad_cache``)."""
+    for it in range(max_iter):
         V = orc.volume(pos, p.tri, p.body_rows)
+        cache = getattr(p, "_vol_grad_cache", None)
+        if it == 0 and first_cached and cache is not None:
+            g = cache
+        else:
+            g = np.zeros_like(pos)
+            orc.volume_gradient(pos, p.tri, g, factor=1.0, body_rows=p.body_rows)
+            p._vol_grad_cache = g
         delta = V - float(p.target_volume)
         if abs(delta) < tol:
             break
-        g = np.zeros_like(pos)
-        orc.volume_gradient(pos, p.tri, g, factor=1.0, body_rows=p.body_rows)
         norm_sq = float(np.sum(g * g)) + 1e-12
         lam = delta / norm_sq
         pos = pos.copy()
@@ -926,22 +937,27 @@ def minimize(p: Problem, stepper, n_steps: int, step_size: float = 1e-3, tol: fl
     step_mode = str(p.gp.get("step_size_mode", "adaptive") or "adaptive").lower()
     trace = []
 
-    def enforce(pos, context):
+    def enforce(pos, context, first_cached=False):
         # constraint_manager.enforce_all :843-905 (volume only)
         if context == "minimize" and not proj_flag:
             return pos
         if p.target_volume is None:
             return pos
-        return project_volume(p, pos, max_iter=12 if context in ("finalize", "mesh_operation") else 3)
+        return project_volume(p, pos, max_iter=12 if context in ("finalize", "mesh_operation") else 3,
+                              first_cached=first_cached)
 
     enforcer = (lambda pos: enforce(pos, "minimize")) if has_enforceable else None
 
-    if has_enforceable:
+    if has_enforceable:  # minimizer.py:1222-1225: enforce, then mesh.project_tilts_to_tangent()
         p.positions = enforce(p.positions, "mesh_operation")
+        project_tilts_to_tangent(p, p.positions)
 
     zero_steps = 0
     step_success = True
     grad = None
+    # True while the last thing that happened to the mesh version was the drift check's compute_volume WITHOUT a
+    # projection: the finalize enforce then starts from Body's cached gradient (see project_volume)
+    volume_cache_current = False
     for i in range(n_steps):
         if any(m in p.energy_modules for m in LEAFLET_MODULES):
             relax_leaflet_tilts(p, p.positions)  # minimizer.py:1240-1305 (guard factor 0)
@@ -950,8 +966,9 @@ def minimize(p: Problem, stepper, n_steps: int, step_size: float = 1e-3, tol: fl
         E, grad = energy_and_gradient(p, p.positions)
         grad_norm = float(np.linalg.norm(grad))
         if grad_norm < tol:
-            if has_enforceable:
-                p.positions = enforce(p.positions, "finalize")
+            if has_enforceable:  # _finalize_constraints, minimizer.py:1177-1187
+                p.positions = enforce(p.positions, "finalize", first_cached=volume_cache_current)
+                project_tilts_to_tangent(p, p.positions)
             return {"energy": E, "gradient": grad, "step_success": True, "iterations": i + 1,
                     "terminated_early": True, "trace": trace, "step_size": step_size}
         fixed_step = float(p.gp.get("step_size", step_size) or step_size)
@@ -960,7 +977,8 @@ def minimize(p: Problem, stepper, n_steps: int, step_size: float = 1e-3, tol: fl
         step_success, step_size = res.success, res.next_step
         trace.append({"E": E, "grad_norm": grad_norm, "success": res.success, "alpha": res.alpha,
                       "E_accepted": res.energy, "next_step": res.next_step, "trials": res.trials})
-        project_tilts_to_tangent(p, p.positions)  # minimizer.py:1415
+        project_tilts_to_tangent(p, p.positions)  # minimizer.py:1415 (+ increment_version)
+        volume_cache_current = False
         if step_mode == "fixed":
             step_size = fixed_step
         if not step_success:
@@ -976,13 +994,17 @@ def minimize(p: Problem, stepper, n_steps: int, step_size: float = 1e-3, tol: fl
         else:
             zero_steps = 0
             if p.volume_mode == "lagrange" and not proj_flag and p.target_volume is not None:
-                V = orc.volume(p.positions, p.tri, p.body_rows)
+                V = orc.volume(p.positions, p.tri, p.body_rows)  # body.compute_volume: volume + version cached
+                volume_cache_current = True
                 rel = abs(V - p.target_volume) / max(abs(p.target_volume), 1.0)
                 if rel > vol_tol:
-                    if has_enforceable:
-                        p.positions = enforce(p.positions, "mesh_operation")
+                    if has_enforceable:  # minimizer.py:1505-1507
+                        p.positions = enforce(p.positions, "mesh_operation", first_cached=True)
+                        project_tilts_to_tangent(p, p.positions)
+                        volume_cache_current = False  # increment_version
                     stepper.reset()
     if has_enforceable:
-        p.positions = enforce(p.positions, "finalize")
+        p.positions = enforce(p.positions, "finalize", first_cached=volume_cache_current)
+        project_tilts_to_tangent(p, p.positions)
     return {"energy": energy_total(p, p.positions), "gradient": grad, "step_success": step_success,
             "iterations": n_steps, "terminated_early": False, "trace": trace, "step_size": step_size}

@@ -49,8 +49,10 @@ class ThreadGroup:
         done.record(cur)
         self.done[r] = done
         self.bar.wait()
-        for k in range(self.world):  # nobody reuses its send buffer before every peer has copied it
-            cur.wait_event(self.done[k])
+        for k in range(self.world):
+            # nobody reuses its send buffer before every peer has copied it: a HOST wait, because the library driver's
+            # callback refills the buffer with a null-stream hipMemcpy that no torch stream orders
+            self.done[k].synchronize()
         self.bar.wait()
 
 

@@ -154,6 +154,25 @@ TRAJ = {
     "traj_disk5_gd_surface_bending_fixed.npz": (["surface", "bending"], [], "gd",
                                                 {"bending_modulus": 1.0, "volume_constraint_mode": "lagrange",
                                                  "volume_projection_during_minimization": False}),
+    # the normal-rotation guard decides trials (topology.py:13-48; 72 of the reference's 73 guard calls reject) and
+    # searches run out of their ten trials (line_search.py:425-426)
+    "traj_ico6_cg_guard.npz": (["surface", "bending"], [], "cg",
+                               {"bending_modulus": 0.5, "volume_constraint_mode": "lagrange",
+                                "volume_projection_during_minimization": False}),
+    # ten exhausted searches in a row, then the step size has shrunk enough to pass the guard and the Armijo test
+    "traj_ico6_gd_exhaust.npz": (["surface", "bending"], [], "gd",
+                                 {"bending_modulus": 0.5, "volume_constraint_mode": "lagrange",
+                                  "volume_projection_during_minimization": False}),
+    # volume_tolerance 1e-11: the Lagrange drift check (minimizer.py:1478-1513) fires after every accepted step and
+    # volume.enforce_constraint (volume.py:69-149) re-projects the positions (8 calls: start, 6 steps, finalize)
+    "traj_ico8_gd_volume_drift.npz": (["surface"], ["volume"], "gd",
+                                      {"volume_constraint_mode": "lagrange", "volume_tolerance": 1.0e-11,
+                                       "volume_projection_during_minimization": False}),
+    # the same with a tilt module: every enforce is followed by project_tilts_to_tangent (minimizer.py:1224, :1506)
+    "traj_ico4_gd_tilt_volume_drift.npz": (["surface", "tilt"], ["volume"], "gd",
+                                           {"tilt_rigidity": 2.5, "volume_constraint_mode": "lagrange",
+                                            "volume_tolerance": 1.0e-11,
+                                            "volume_projection_during_minimization": False}),
 }
 
 
