@@ -305,6 +305,12 @@ int ms_get_vertex_buffer(ms_ctx *ctx, int buffer, double *out /* nv*ncomp */);
  * {surface, bending, volume-penalty, tilt}.  grad may be NULL (stays on device).
  */
 int ms_energy_and_gradient(ms_ctx *ctx, double energies[4], double *grad);
+/*
+ * What ONE energy module's compute_energy_and_gradient_array accumulates (the plugin seam,
+ * runtime/energy_manager.py:21, evaluation_manager.py:134-151): the module loop's raw sum -- fixed rows are NOT
+ * zeroed and no constraint row is projected out (the minimizer does both afterwards, minimizer.py:979-990).
+ */
+int ms_energy_and_raw_gradient(ms_ctx *ctx, double energies[4], double *grad);
 /* EvaluationManager.compute_energy_array_total (evaluation_manager.py:184-225) */
 int ms_energy(ms_ctx *ctx, double energies[4]);
 

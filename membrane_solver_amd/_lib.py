@@ -148,6 +148,7 @@ SIGNATURES = {
     "ms_get_gradient": (ctypes.c_int, [_P, _D]),
     "ms_get_vertex_buffer": (ctypes.c_int, [_P, ctypes.c_int, _D]),
     "ms_energy_and_gradient": (ctypes.c_int, [_P, _D, _D]),
+    "ms_energy_and_raw_gradient": (ctypes.c_int, [_P, _D, _D]),
     "ms_energy": (ctypes.c_int, [_P, _D]),
     "ms_step": (ctypes.c_int, [_P, ctypes.POINTER(ms_stepper_params), ctypes.c_double,
                                ctypes.c_double, ctypes.POINTER(ms_step_result)]),

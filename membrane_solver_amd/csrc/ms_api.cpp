@@ -1826,6 +1826,26 @@ int ms_energy_and_gradient(ms_ctx* c, double energies[4], double* grad) {
   return MS_OK;
 }
 
+int ms_energy_and_raw_gradient(ms_ctx* c, double energies[4], double* grad) {
+  if (!c || !energies) return fail(c, MS_ERR_INVALID, "ms_energy_and_raw_gradient: NULL argument");
+  if (c->shard_count != 1)
+    return fail(c, MS_ERR_STATE, "ms_energy_and_raw_gradient: sharded contexts use the phase API");
+  const uint32_t mods = c->params.modules;
+  const bool penalty = (mods & MS_MOD_VOLUME_PENALTY) != 0;  // K_C reads the reduced volume
+  int rc = phase_energy(c, mods, false, 0.0, false, false, true, /*reduce_now=*/penalty);
+  if (rc) return rc;
+  c->grad_valid = false;  // G receives the raw gradient: no fixed-row zeroing, no KKT projection
+  rc = phase_gradient(c, mods, c->buf[MS_BUF_G], false, 0, /*reduce_now=*/false);
+  if (rc) return rc;
+  rc = reduce_slots(c, (penalty ? 0u : MASK_ENERGY) | MASK_GRAD);
+  if (rc) return rc;
+  rc = fetch(c);
+  if (rc) return rc;
+  energies_from_mailbox(c, energies);
+  if (grad) return patch_to_ext(c, c->buf[MS_BUF_G], grad, 3);
+  return MS_OK;
+}
+
 int ms_energy(ms_ctx* c, double energies[4]) {
   if (!c || !energies) return fail(c, MS_ERR_INVALID, "ms_energy: NULL argument");
   if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "ms_energy: sharded contexts use the phase API");

@@ -269,11 +269,15 @@ class DeviceMesh:
     def project_tilts_to_tangent(self):
         self._chk(L.lib().ms_project_tilts_to_tangent(self._h), "ms_project_tilts_to_tangent")
 
-    def energy_and_gradient(self, want_grad: bool = True):
-        """-> (energies[surface, bending, volume_penalty, tilt], grad (nv,3) | None)."""
+    def energy_and_gradient(self, want_grad: bool = True, raw: bool = False):
+        """-> (energies[surface, bending, volume_penalty, tilt], grad (nv,3) | None).  ``raw``: the module loop's
+        plain sum as an energy-module plugin accumulates it -- fixed rows not zeroed, no constraint projection."""
         e = np.zeros(4)
         g = np.empty((self.nv, 3), dtype=np.float64) if want_grad else None
-        self._chk(L.lib().ms_energy_and_gradient(self._h, _pd(e), _pd(g)), "ms_energy_and_gradient")
+        if raw:
+            self._chk(L.lib().ms_energy_and_raw_gradient(self._h, _pd(e), _pd(g)), "ms_energy_and_raw_gradient")
+        else:
+            self._chk(L.lib().ms_energy_and_gradient(self._h, _pd(e), _pd(g)), "ms_energy_and_gradient")
         return e, g
 
     def energy(self) -> np.ndarray:

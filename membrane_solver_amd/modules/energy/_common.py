@@ -44,7 +44,7 @@ def evaluate_single_module(mesh, global_params, *, modules: int, positions, grad
         mir.upload_bending_params(global_params, bending_model(global_params))
     dm.set_params(modules=modules, **params)
     if want_grad and grad_arr is not None:
-        e, g = dm.energy_and_gradient(want_grad=True)
+        e, g = dm.energy_and_gradient(want_grad=True, raw=True)
         np.add(grad_arr, g, out=grad_arr)
     else:
         e = dm.energy()

@@ -50,7 +50,7 @@ def compute_energy_and_gradient_array(mesh, global_params, param_resolver, *, po
         return 0.0
     dm = _device(mesh, global_params, positions, tilts)
     if grad_arr is not None:
-        e, g = dm.energy_and_gradient(want_grad=True)
+        e, g = dm.energy_and_gradient(want_grad=True, raw=True)
         grad_arr += g
         E = float(e[1])
         if tilt_grad_arr is not None:

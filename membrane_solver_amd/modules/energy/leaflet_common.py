@@ -272,20 +272,20 @@ def evaluate(mesh, global_params, param_resolver, *, kind: str, leaflet: str, po
     dm.set_params(modules=LEAFLET_BITS[(kind, leaflet)])
     if kind == "disk":
         if grad_arr is not None:
-            e, g = dm.energy_and_gradient(want_grad=True)
+            e, g = dm.energy_and_gradient(want_grad=True, raw=True)
             grad_arr += g
             E = float(e[3])
         else:
             E = float(dm.energy()[3])
     elif kind == "bt":
         if grad_arr is not None:
-            e, g = dm.energy_and_gradient(want_grad=True)
+            e, g = dm.energy_and_gradient(want_grad=True, raw=True)
             grad_arr += g
             E = float(e[1])
         else:
             E = float(dm.energy()[1])
     elif grad_arr is not None and kind == "tilt":
-        e, g = dm.energy_and_gradient(want_grad=True)
+        e, g = dm.energy_and_gradient(want_grad=True, raw=True)
         grad_arr += g
         E = float(e[3])
     else:

@@ -38,7 +38,7 @@ def _evaluate(mesh, global_params, k_tilt, positions, tilts, want_grad):
     mir._tilt_key = None  # a foreign array may have been uploaded
     dm.set_params(modules=L.MS_MOD_TILT)
     if want_grad:
-        e, g = dm.energy_and_gradient(want_grad=True)
+        e, g = dm.energy_and_gradient(want_grad=True, raw=True)
         return float(e[3]), g, dm
     return float(dm.energy()[3]), None, dm
 

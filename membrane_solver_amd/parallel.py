@@ -376,13 +376,19 @@ class HipShardBackend:
                 n = nbytes // 8
                 assert n <= n_max
                 hip = ctypes.CDLL(L.HIP_RUNTIME_PATH)
-                hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+                hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                               ctypes.c_void_p]
                 send, recv = self._send[:n], self._recv[: self.world * n]
-                # the library has synchronised its stream; the callback is synchronous as a whole
-                hip.hipMemcpy(send.data_ptr(), send_ptr, nbytes, 3)
+                # everything on this rank's ONE stream (the library has synchronised it before calling): a
+                # null-stream hipMemcpy would be ordered with nothing here -- torch streams are non-blocking and a
+                # device-to-device hipMemcpy may return before it has run
+                cur = torch.cuda.current_stream()
+                rc = hip.hipMemcpyAsync(send.data_ptr(), send_ptr, nbytes, 3, cur.cuda_stream)
+                assert rc == 0, rc
                 dist.all_gather_into_tensor(recv, send)
-                torch.cuda.current_stream().synchronize()
-                hip.hipMemcpy(recv_ptr, recv.data_ptr(), nbytes * self.world, 3)
+                rc = hip.hipMemcpyAsync(recv_ptr, recv.data_ptr(), nbytes * self.world, 3, cur.cuda_stream)
+                assert rc == 0, rc
+                cur.synchronize()  # the callback is synchronous as a whole
 
             self.dm.shard_set_allgather(gather)
             return

@@ -37,6 +37,7 @@ ap.add_argument("--only-btl", action="store_true", help="bending_tilt_in/out vec
 ap.add_argument("--only-disk", action="store_true", help="tilt_disk_target_in/out vectors only")
 ap.add_argument("--only-defects", action="store_true", help="angle-defect vectors only")
 ap.add_argument("--only-guard", action="store_true", help="guard / exhausted-search / volume-drift trajectories only")
+ap.add_argument("--only-config5", action="store_true", help="the caveolin deck of BASELINE config 5 only")
 args = ap.parse_args()
 
 sys.dont_write_bytecode = True
@@ -1120,6 +1121,124 @@ def gen_guard_and_enforce():
           out["step_log"][:, 0])
 
 
+# ---------------------------------------------------------------------------
+# (l) BASELINE config 5 on its own deck: meshes/caveolin/kozlov_1disk_3d_tensionless_bilayer_profile.yaml.
+#     Kept from the deck: positions, triangle rows, fixed / tilt_fixed_in / tilt_fixed_out flags, the "disk" group
+#     rows, every global parameter and the energy-module list.  NOT kept: its three constraint modules
+#     (pin_to_plane, pin_to_circle, rim_slope_match_out: SURVEY section 2 puts every constraint but `volume` out of
+#     scope) and the mesh-quality auto repair.
+# ---------------------------------------------------------------------------
+def gen_config5():
+    import importlib
+
+    deck = os.path.join(args.reference, "meshes", "caveolin", "kozlov_1disk_3d_tensionless_bilayer_profile.yaml")
+    m = parse_geometry(load_data(deck))
+    mods = list(m.energy_modules)
+    deck_constraints = list(m.constraint_modules)
+    m.constraint_modules = []
+    m.global_parameters.set("mesh_quality_auto_repair_enabled", False)
+    gp = {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in m.global_parameters.to_dict().items()}
+    pos0, tri, isb, fixed = mesh_arrays(m)
+    ids = m.vertex_ids
+    nv = len(ids)
+    fin = np.array([bool(getattr(m.vertices[int(v)], "tilt_fixed_in", False)) for v in ids])
+    fout = np.array([bool(getattr(m.vertices[int(v)], "tilt_fixed_out", False)) for v in ids])
+    disk_rows = np.array([r for r, v in enumerate(ids)
+                          if (getattr(m.vertices[int(v)], "options", None) or {}).get("tilt_disk_target_group_in")
+                          == gp.get("tilt_disk_target_group_in")], dtype=int)
+    disk_rows_out = np.array([r for r, v in enumerate(ids)
+                              if (getattr(m.vertices[int(v)], "options", None) or {}).get("tilt_disk_target_group_out")
+                              == gp.get("tilt_disk_target_group_out")], dtype=int)
+    assert np.array_equal(disk_rows, disk_rows_out)
+    out = {"meta_fortran": META, "positions0": pos0, "tri": tri, "is_boundary": isb, "fixed": fixed,
+           "tilt_fixed_in": fin, "tilt_fixed_out": fout, "disk_rows": disk_rows,
+           "gamma": m.get_facet_parameter_array("surface_tension").copy(),
+           "tilts_in0": np.ascontiguousarray(m.tilts_in_view()).copy(),
+           "tilts_out0": np.ascontiguousarray(m.tilts_out_view()).copy(),
+           "gp_json": np.array(json.dumps(gp, sort_keys=True)), "modules": np.array(mods),
+           "deck_constraint_modules_not_kept": np.array(deck_constraints)}
+    print("config5 deck: nv=%d nf=%d boundary=%d fixed=%d tilt_fixed_in=%d disk rows=%d modules=%s" %
+          (nv, len(tri), int(isb.sum()), int(fixed.sum()), int(fin.sum()), len(disk_rows), mods))
+
+    # (1) every energy module of the deck on the deck's surface with seeded tangent tilt fields (the deck's own
+    #     fields are zero): energy, shape gradient, both tilt gradients -- the plugin API
+    rng = np.random.default_rng(505)
+    tin = _tangent_tilts(m, rng, 0.2)
+    tout = _tangent_tilts(m, rng, 0.15)
+    tin[fin] = 0.0
+    tout[fout] = 0.0
+    out["state_b_tilts_in"], out["state_b_tilts_out"] = tin, tout
+    m.set_tilts_in_from_array(tin)
+    m.set_tilts_out_from_array(tout)
+    res = ParameterResolver(m.global_parameters)
+    for mod in mods:
+        module = importlib.import_module(f"modules.energy.{mod}")
+        g = np.zeros_like(pos0)
+        tgi, tgo = np.zeros_like(pos0), np.zeros_like(pos0)
+        E = module.compute_energy_and_gradient_array(
+            m, m.global_parameters, res, positions=pos0, index_map=m.vertex_index_to_row, grad_arr=g,
+            tilts_in=tin, tilts_out=tout, tilt_in_grad_arr=tgi, tilt_out_grad_arr=tgo)
+        out[f"mod_{mod}_E"], out[f"mod_{mod}_grad"] = np.array(float(E)), g
+        out[f"mod_{mod}_tilt_grad_in"], out[f"mod_{mod}_tilt_grad_out"] = tgi, tgo
+        print("  config5", mod, "E=%.16g" % float(E), "|grad|max %.3e |tg_in|max %.3e |tg_out|max %.3e" %
+              (np.abs(g).max(), np.abs(tgi).max(), np.abs(tgo).max()))
+    em = EnergyModuleManager(mods)
+    cm = ConstraintModuleManager([])
+    m.energy_modules = list(mods)
+    mz = Minimizer(m, m.global_parameters, GradientDescent(), em, cm, quiet=True, step_size=float(gp["step_size"]))
+    E_b, g_b = mz.compute_energy_and_gradient_array()
+    out["state_b_E"], out["state_b_grad"] = np.array(E_b), np.array(g_b)
+
+    # (2) ONE relax_leaflet_tilts call as the deck configures it (coupled mode, jacobi CG, 40 inner steps, step 0.15)
+    #     from the deck's own zero fields: the disk-target modules drive the tilts
+    m.set_tilts_in_from_array(out["tilts_in0"])
+    m.set_tilts_out_from_array(out["tilts_out0"])
+    m.increment_version()
+    mz._relax_leaflet_tilts(positions=m.positions_view(), mode="coupled")
+    out["relax_tilts_in"] = np.ascontiguousarray(m.tilts_in_view()).copy()
+    out["relax_tilts_out"] = np.ascontiguousarray(m.tilts_out_view()).copy()
+    out["relax_E"] = np.array(float(mz.compute_energy()))
+    print("  config5 relax_leaflet_tilts(coupled): E=%.16g |t_in|max %.4f |t_out|max %.4f" %
+          (out["relax_E"], np.abs(out["relax_tilts_in"]).max(), np.abs(out["relax_tilts_out"]).max()))
+
+    # (3) the deck's own macro `g`: minimizer steps (fixed step mode 0.01, coupled tilt relaxation at the top of
+    #     every iteration) from the deck state -- a short trajectory in the leaflet-trajectory format
+    m2 = parse_geometry(load_data(deck))
+    m2.constraint_modules = []
+    m2.global_parameters.set("mesh_quality_auto_repair_enabled", False)
+    stepper = GradientDescent()
+    mz2 = Minimizer(m2, m2.global_parameters, stepper, EnergyModuleManager(mods), ConstraintModuleManager([]),
+                    quiet=True, step_size=float(gp["step_size"]))
+    log = []
+    orig_step = stepper.step
+
+    def logged_step(mesh, grad, step_size, energy_fn, constraint_enforcer=None):
+        r = orig_step(mesh, grad, step_size, energy_fn, constraint_enforcer=constraint_enforcer)
+        log.append((float(bool(r[0])), float(r[1]), float(r[2])))
+        return r
+
+    stepper.step = logged_step
+    snaps, tin_snaps, tout_snaps = [], [], []
+
+    def cb(mesh, i):
+        snaps.append(mesh.positions_view().copy())
+        tin_snaps.append(np.ascontiguousarray(mesh.tilts_in_view()).copy())
+        tout_snaps.append(np.ascontiguousarray(mesh.tilts_out_view()).copy())
+
+    E0, g0 = mz2.compute_energy_and_gradient_array()
+    n_steps = 4
+    r = mz2.minimize(n_steps, callback=cb)
+    out.update({"E0": np.array(E0), "grad0": np.array(g0), "positions_iter": np.array(snaps),
+                "tilts_in_iter": np.array(tin_snaps), "tilts_out_iter": np.array(tout_snaps),
+                "positions_final": m2.positions_view().copy(),
+                "tilts_in_final": np.ascontiguousarray(m2.tilts_in_view()).copy(),
+                "tilts_out_final": np.ascontiguousarray(m2.tilts_out_view()).copy(),
+                "step_log": np.array(log), "E_final": np.array(r["energy"]), "n_steps": np.array(n_steps),
+                "step_size0": np.array(float(gp["step_size"]))})
+    np.savez_compressed(os.path.join(OUT, "traj_config5_deck_gd.npz"), **out)
+    print("traj_config5_deck_gd.npz E0=%.16g E_final=%.16g" % (E0, out["E_final"]), out["step_log"].tolist())
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if "--only-tilt" in sys.argv:
@@ -1133,6 +1252,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-guard" in sys.argv:
         gen_guard_and_enforce()
+        sys.exit(0)
+    if "--only-config5" in sys.argv:
+        gen_config5()
         sys.exit(0)
     if "--only-disk" in sys.argv:
         gen_disk_target()
@@ -1159,3 +1281,4 @@ if __name__ == "__main__":
     gen_disk_target()
     gen_angle_defects()
     gen_guard_and_enforce()
+    gen_config5()

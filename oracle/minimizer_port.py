@@ -136,6 +136,11 @@ def energy_and_gradient(p: Problem, pos: np.ndarray):
         elif name in ("tilt_disk_target_in", "tilt_disk_target_out"):
             lf = name[17:]
             E += _disk_target(p, pos, leaflet_tilts(p, lf), lf, grad=grad)
+        elif name == "rim_slope_match_out":
+            # modules/energy/rim_slope_match_out.py:376-382: 0.0 while rim_slope_match_strength is 0 (the caveolin
+            # decks load the module with the strength switched off; anything else is outside the hot path)
+            if float(p.gp.get("rim_slope_match_strength", 0.0) or 0.0) != 0.0:
+                raise ValueError("rim_slope_match_out with a non-zero strength is outside the hot-path scope")
         else:
             raise ValueError(f"module {name!r} is outside the hot-path scope")
     # constraint_manager.apply_gradient_modifications_array (k == 1 dense branch :293-301)
@@ -188,6 +193,9 @@ def energy_total(p: Problem, pos: np.ndarray, tilts=None, tilts_in=None, tilts_o
         elif name in ("tilt_disk_target_in", "tilt_disk_target_out"):
             lf = name[17:]
             E += _disk_target(p, pos, lt[lf], lf)
+        elif name == "rim_slope_match_out":  # switched off (strength 0): see energy_and_gradient
+            if float(p.gp.get("rim_slope_match_strength", 0.0) or 0.0) != 0.0:
+                raise ValueError("rim_slope_match_out with a non-zero strength is outside the hot-path scope")
         else:
             raise ValueError(name)
     return float(E)

@@ -493,3 +493,90 @@ def test_rim_slope_match_out_only_switched_off():
         else:
             with pytest.raises(L.MembraneHipError, match="rim_slope_match_strength"):
                 mz.compute_energy()
+
+
+# ---------------------------------------------------------------------------
+# BASELINE config 5 on its own deck: meshes/caveolin/kozlov_1disk_3d_tensionless_bilayer_profile.yaml as the
+# reference parses it (oracle/gen_golden.py: gen_config5) -- 109 vertices, 204 facets, 12 boundary vertices, the
+# deck's tilt_fixed_in/out flags, "disk" group rows, parameters and energy-module list.  Its pin / rim constraint
+# modules are outside the hot path and were not kept when the vectors were generated.
+# ---------------------------------------------------------------------------
+def _config5_mesh(g, tilts_in, tilts_out, modules):
+    from membrane_solver_amd.core.parameters import GlobalParameters
+    from membrane_solver_amd.geometry.mesh import ArrayMesh
+
+    gp = GlobalParameters(_gp(g, "gp_json"))
+    rows = g["disk_rows"]
+    mesh = ArrayMesh(g["positions0"], g["tri"], fixed=g["fixed"], surface_tension=g["gamma"], tilts_in=tilts_in,
+                     tilts_out=tilts_out, tilt_fixed_in=g["tilt_fixed_in"], tilt_fixed_out=g["tilt_fixed_out"],
+                     global_parameters=gp, energy_modules=list(modules), constraint_modules=[],
+                     disk_rows_in=rows, disk_rows_out=rows)
+    return mesh, gp
+
+
+def test_config5_deck_plugins_match_reference():
+    """Every energy module of the deck through the reference's plugin signature, on the deck's surface with seeded
+    tangent tilt fields (the deck's own fields are zero)."""
+    from membrane_solver_amd.core.parameters import ParameterResolver
+    from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
+
+    g = load_golden("traj_config5_deck_gd.npz")
+    mods = [str(m) for m in g["modules"]]
+    assert len(g["positions0"]) == 109 and len(g["tri"]) == 204 and int(g["is_boundary"].sum()) == 12
+    assert "rim_slope_match_out" in mods and "bending_tilt_in" in mods and "tilt_disk_target_out" in mods
+    tin, tout = g["state_b_tilts_in"], g["state_b_tilts_out"]
+    pos = g["positions0"]
+    mesh, gp = _config5_mesh(g, tin, tout, mods)
+    res = ParameterResolver(gp)
+    em = EnergyModuleManager(mods)
+    total_E, total_g = 0.0, np.zeros_like(pos)
+    for mod in mods:
+        module = em.get_module(mod)
+        grad, tgi, tgo = np.zeros_like(pos), np.zeros_like(pos), np.zeros_like(pos)
+        E = module.compute_energy_and_gradient_array(mesh, gp, res, positions=pos, index_map=mesh.vertex_index_to_row,
+                                                     grad_arr=grad, tilts_in=tin, tilts_out=tout,
+                                                     tilt_in_grad_arr=tgi, tilt_out_grad_arr=tgo)
+        ref = float(g[f"mod_{mod}_E"])
+        assert abs(E - ref) <= 1e-12 * max(abs(ref), 1e-300), mod
+        for got, key in ((grad, "grad"), (tgi, "tilt_grad_in"), (tgo, "tilt_grad_out")):
+            want = g[f"mod_{mod}_{key}"]
+            if np.any(want):
+                assert relerr(got, want) < 1e-10, (mod, key)
+            else:
+                assert not np.any(got), (mod, key)
+        total_E += E
+        total_g += grad
+    assert abs(total_E - g["state_b_E"]) <= 1e-12 * abs(g["state_b_E"])
+
+
+def test_config5_deck_relaxation_and_steps_match_reference():
+    """ONE relax_leaflet_tilts call as the deck configures it (coupled mode, Jacobi CG, 40 inner steps, step 0.15)
+    from the deck's zero fields, then the deck's `g` steps (fixed step size 0.01, the relaxation at the top of every
+    iteration) -- through Minimizer / ms_relax_leaflet_tilts / ms_minimize."""
+    g = load_golden("traj_config5_deck_gd.npz")
+    mesh, mz, _ = _leaflet_minimizer(g, "gd", observe=True)
+    mesh.disk_rows_in = mesh.disk_rows_out = g["disk_rows"]
+    _mir, dm = mz._device()
+    assert mz._relax_tilts(dm)
+    mz._write_back_tilts(dm, _mir)
+    assert relerr(mesh.tilts_in_view(), g["relax_tilts_in"]) < 1e-8
+    assert relerr(mesh.tilts_out_view(), g["relax_tilts_out"]) < 1e-8
+    assert abs(mz.compute_energy() - g["relax_E"]) <= 1e-9 * abs(g["relax_E"])
+    for observe in (True, False):
+        mesh, mz, log = _leaflet_minimizer(g, "gd", observe=observe)
+        mesh.disk_rows_in = mesh.disk_rows_out = g["disk_rows"]
+        if observe:
+            E0, grad0 = mz.compute_energy_and_gradient_array()
+            assert abs(E0 - g["E0"]) <= 1e-12 * abs(g["E0"])
+            assert relerr(grad0, g["grad0"]) < 1e-10
+        res = mz.minimize(int(g["n_steps"]))
+        if observe:
+            got, ref = np.array(log), g["step_log"]
+            assert got.shape == ref.shape
+            assert np.array_equal(got[:, 0], ref[:, 0]), "accept/reject sequence differs from the reference"
+            assert np.allclose(got[:, 1], ref[:, 1], rtol=1e-12, atol=0)
+            assert np.allclose(got[:, 2], ref[:, 2], rtol=1e-9, atol=0)
+        assert relerr(mesh.positions_view(), g["positions_final"]) < 1e-8
+        assert relerr(mesh.tilts_in_view(), g["tilts_in_final"]) < 1e-8
+        assert relerr(mesh.tilts_out_view(), g["tilts_out_final"]) < 1e-8
+        assert abs(res["energy"] - g["E_final"]) <= 1e-9 * abs(g["E_final"])

@@ -499,3 +499,66 @@ def test_angle_defects_match_reference():
     chi = orc.euler_characteristic(len(g["ico5_positions"]), g["ico5_tri"])
     assert chi == 2 and abs(np.sum(g["ico5_defects"]) - 2.0 * np.pi * chi) < 1e-10  # Gauss-Bonnet
     assert abs(float(g["ico5_gaussian_E"]) - (-0.7) * 2.0 * np.pi * chi) <= 1e-14
+
+
+# ---------------------------------------------------------------------------
+# BASELINE config 5 on its own deck (oracle/gen_golden.py: gen_config5): the caveolin one-disk bilayer deck's mesh,
+# flags, parameters and energy-module list (its pin / rim constraints are out of scope and were not kept)
+# ---------------------------------------------------------------------------
+def test_port_reproduces_config5_deck():
+    g = load_golden("traj_config5_deck_gd.npz")
+    assert len(g["positions0"]) == 109 and len(g["tri"]) == 204 and int(g["is_boundary"].sum()) == 12
+    p = leaflet_problem(g)
+    p.disk_rows_in = p.disk_rows_out = g["disk_rows"]
+    # the deck's own state: zero tilt fields, the disk-target modules carry all the energy
+    E0, grad0 = mp.energy_and_gradient(p, p.positions)
+    assert abs(E0 - g["E0"]) <= 1e-12 * abs(g["E0"])
+    assert relerr(grad0, g["grad0"]) < 1e-11
+    # every module's share with seeded tangent fields: sum of the reference's per-module energies and gradients
+    pb = leaflet_problem(g)
+    pb.disk_rows_in = pb.disk_rows_out = g["disk_rows"]
+    pb.tilts_in, pb.tilts_out = g["state_b_tilts_in"].copy(), g["state_b_tilts_out"].copy()
+    Eb, gb = mp.energy_and_gradient(pb, pb.positions)
+    mods = [str(m) for m in g["modules"]]
+    assert abs(Eb - sum(float(g[f"mod_{m}_E"]) for m in mods)) <= 1e-12 * abs(Eb)
+    assert abs(Eb - g["state_b_E"]) <= 1e-12 * abs(Eb)
+    fixed = g["fixed"].astype(bool)
+
+    def movable(a):  # Minimizer.compute_energy_and_gradient_array zeroes the fixed rows (minimizer.py:988-990)
+        a = np.array(a, copy=True)
+        a[fixed] = 0.0
+        return a
+
+    assert relerr(gb, movable(sum(g[f"mod_{m}_grad"] for m in mods))) < 1e-11
+    assert relerr(gb, g["state_b_grad"]) < 1e-11
+    for m in mods:
+        pm = leaflet_problem(g)
+        pm.disk_rows_in = pm.disk_rows_out = g["disk_rows"]
+        pm.tilts_in, pm.tilts_out = g["state_b_tilts_in"].copy(), g["state_b_tilts_out"].copy()
+        pm.energy_modules = [m]
+        Em, gm = mp.energy_and_gradient(pm, pm.positions)
+        ref = float(g[f"mod_{m}_E"])
+        assert abs(Em - ref) <= 1e-12 * max(abs(ref), 1e-300), m
+        if np.any(g[f"mod_{m}_grad"]):
+            assert relerr(gm, movable(g[f"mod_{m}_grad"])) < 1e-11, m
+        else:
+            assert not np.any(gm), m
+    # ONE relax_leaflet_tilts call as the deck configures it (coupled, jacobi CG, 40 inner steps, step 0.15)
+    pr = leaflet_problem(g)
+    pr.disk_rows_in = pr.disk_rows_out = g["disk_rows"]
+    mp.relax_leaflet_tilts(pr, pr.positions)
+    assert relerr(pr.tilts_in, g["relax_tilts_in"]) < 1e-9
+    assert relerr(pr.tilts_out, g["relax_tilts_out"]) < 1e-9
+    assert abs(mp.energy_total(pr, pr.positions) - g["relax_E"]) <= 1e-10 * abs(g["relax_E"])
+    # the deck's `g` steps: fixed step size 0.01, coupled tilt relaxation at the top of every iteration
+    res = mp.minimize(p, mp.GradientDescent(), int(g["n_steps"]), step_size=float(g["step_size0"]))
+    log = g["step_log"]
+    got = np.array([[float(t["success"]), t["next_step"], t["E_accepted"]] for t in res["trace"]])
+    assert got.shape == log.shape
+    assert np.array_equal(got[:, 0], log[:, 0])
+    assert np.allclose(got[:, 1], log[:, 1], rtol=1e-12, atol=0)
+    assert np.allclose(got[:, 2], log[:, 2], rtol=1e-9, atol=0)
+    assert relerr(p.positions, g["positions_final"]) < 1e-8
+    assert relerr(p.tilts_in, g["tilts_in_final"]) < 1e-8
+    assert relerr(p.tilts_out, g["tilts_out_final"]) < 1e-8
+    assert abs(res["energy"] - g["E_final"]) <= 1e-9 * abs(g["E_final"])
