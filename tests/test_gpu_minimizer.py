@@ -8,7 +8,7 @@ trajectories are compared per step, not bitwise)."""
 import numpy as np
 import pytest
 
-from conftest import load_golden, relerr
+from conftest import ROOT, load_golden, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -257,7 +257,9 @@ def test_full_size_properties(freq, kind):
     dm.set_positions(P + np.array([0.3, -0.2, 0.1]))
     e2, g2 = dm.energy_and_gradient()
     assert abs(e2.sum() - e0.sum()) <= 1e-11 * abs(e0.sum())
-    assert relerr(g2, g0) < (1e-7 if freq <= 81 else 1e-5)
+    # (how far the gradient may move under the translation is MEASURED against the oracle's own sensitivity in
+    # test_full_size_energy_and_gradient_match_oracle; here only a gross bound)
+    assert relerr(g2, g0) < 1e-5
     dm.set_positions(P)
     dm.set_params(modules=L.MS_MOD_SURFACE)
     es, gs = dm.energy_and_gradient()
@@ -523,3 +525,78 @@ def test_project_volume_matches_oracle_including_the_cached_gradient_step():
     assert relerr(dm.get_positions(), x3) < 1e-13
     assert relerr(x3, x3_fresh) > 1e-9, "the cached first step must be distinguishable from a fresh one here"
     dm.close()
+
+
+@pytest.mark.parametrize("freq", [81, 320])
+def test_full_size_energy_and_gradient_match_oracle(freq):
+    """BASELINE configs 2 and 3 at their FULL sizes (131 220 and 2 048 000 facets) against the CPU oracle
+    (libms_oracle.so, ~2 s of CPU at f = 320): energies to 1e-12; the gradient in max-norm against a tolerance that is
+    MEASURED here, not asserted from an argument: the same oracle source built with another summation order
+    (libms_oracle_omp.so: facet loops split over threads, vertex sums by atomics) differs from the serial build by
+    `noise`; the HIP gradient has to stay within 5 x that (and never worse than 2e-8; measured on MI355X: 1.05e-10
+    against a noise of 8.6e-11 at f = 81, 3.6e-9 against 2.1e-9 at f = 320).  The bending back-propagation
+    differences fK_i - fK_j of neighbouring vertices amplify last-bit noise of H by ~1/h^2, which is what `noise`
+    shows growing with the mesh."""
+    import json
+    import os
+
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+    from oracle import ms_oracle as orc
+
+    P, T = meshgen.icosphere(freq)
+    P = meshgen.smooth_displace(P, 0.05)
+    nv, nf = len(P), len(T)
+    assert nf == 20 * freq * freq
+    kappa, c0 = np.ones(nv), np.full(nv, 0.2)
+    dm = DeviceMesh(P, T)
+    dm.set_surface_tension(np.ones(nf))
+    dm.set_bending_params(kappa, c0)
+    dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING)
+    e, g = dm.energy_and_gradient(raw=True)
+    shift = np.array([0.3, -0.2, 0.1])
+    dm.set_positions(P + shift)
+    e_t, g_t = dm.energy_and_gradient(raw=True)
+    dm.set_positions(P)
+    dm.set_params(modules=L.MS_MOD_SURFACE)
+    _es, g_surf = dm.energy_and_gradient(raw=True)
+    dm.close()
+
+    def oracle(omp, X=P):
+        orc.use_openmp(omp)
+        try:
+            gs = np.zeros_like(X)
+            Es = orc.surface_energy_and_gradient(X, T, np.ones(nf), gs)
+            gb = np.zeros_like(X)
+            Eb = orc.bending_energy_and_gradient(X, T, kappa, c0, np.zeros(nv, bool), grad=gb)
+        finally:
+            orc.use_openmp(False)
+        return Es, Eb, gs, gb
+
+    Es, Eb, gs, gb = oracle(False)
+    _Es2, _Eb2, gs2, gb2 = oracle(True)
+    _Es3, _Eb3, gs3, gb3 = oracle(False, P + shift)
+    noise = relerr(gs2 + gb2, gs + gb)
+    err = relerr(g, gs + gb)
+    err_surf = relerr(g_surf, gs)
+    # translation invariance, measured on both sides: the oracle's own gradient moves by `oracle_shift` when every
+    # coordinate is re-rounded at the shifted origin; the HIP gradient may move by a small multiple of that
+    oracle_shift = relerr(gs3 + gb3, gs + gb)
+    hip_shift = relerr(g_t, g)
+    tol = max(2e-10, 5.0 * noise)
+    report = {"freq": freq, "nf": nf, "E_surface_rel": abs(e[0] - Es) / Es, "E_bending_rel": abs(e[1] - Eb) / Eb,
+              "grad_rel_maxnorm": err, "surface_grad_rel_maxnorm": err_surf,
+              "oracle_summation_order_noise": noise, "tolerance_used": tol,
+              "translation": {"hip_grad_change": hip_shift, "oracle_grad_change": oracle_shift,
+                              "hip_energy_change": abs(e_t.sum() - e.sum()) / abs(e.sum())}}
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, f"fullsize_parity_f{freq}.json"), "w") as fh:
+            json.dump(report, fh, indent=1)
+    assert abs(e[0] - Es) <= 1e-12 * Es, report
+    assert abs(e[1] - Eb) <= 1e-12 * Eb, report
+    assert err_surf < 1e-12, report                      # no cancellation in the surface term
+    assert err < tol and err < 2e-8, report
+    assert hip_shift < max(1e-9, 5.0 * oracle_shift), report
+    assert abs(e_t.sum() - e.sum()) <= 1e-11 * abs(e.sum()), report
