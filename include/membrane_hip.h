@@ -293,6 +293,16 @@ int ms_project_tilts_to_tangent(ms_ctx *ctx);
  * triangle angles (law of cosines, lengths clamped at 1e-15, cosines clipped), 0 on boundary vertices: the
  * integrated Gaussian curvature.  Their sum is 2 pi chi on a closed manifold mesh (Gauss-Bonnet). */
 int ms_angle_defects(ms_ctx *ctx, double *defects /* nv */);
+/* geometry/curvature.compute_curvature_fields (:404-448) at the context's positions, one tile-kernel pass: each output
+ * is (nv,3) in caller row order and may be NULL --
+ *   mean_curvature_normal : K_v / (2 max(A_v, 1e-12)), K_v and the mixed-Voronoi areas A_v as compute_curvature_data;
+ *   h_area_anglesum       : (H = |mean-curvature normal|, mixed area A_v, sum of the incident triangle angles);
+ *   defect_kg             : (angle defect 2 pi - angle sum, 0 on boundary rows; K_G = defect / max(A_v, 1e-12); 0);
+ *   principal             : (k1, k2 = H +- sqrt(max(H^2 - K_G, 0)); 0).
+ * The raw angle sums also serve the open-surface Gauss-Bonnet invariant of modules/energy/gaussian_curvature.py
+ * (runtime/diagnostics/gauss_bonnet.py:260-340). */
+int ms_curvature_fields(ms_ctx *ctx, double *mean_curvature_normal, double *h_area_anglesum,
+                        double *defect_kg, double *principal);
 
 int ms_set_positions(ms_ctx *ctx, const double *positions /* nv*3 */);
 int ms_get_positions(ms_ctx *ctx, double *positions /* nv*3 */);

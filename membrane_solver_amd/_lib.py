@@ -128,6 +128,7 @@ SIGNATURES = {
     "ms_get_tilt_gradient": (ctypes.c_int, [_P, _D]),
     "ms_project_tilts_to_tangent": (ctypes.c_int, [_P]),
     "ms_angle_defects": (ctypes.c_int, [_P, _D]),
+    "ms_curvature_fields": (ctypes.c_int, [_P, _D, _D, _D, _D]),
     "ms_set_tilt_fixed": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint8)]),
     "ms_set_tilt_smoothness": (ctypes.c_int, [_P, ctypes.c_double]),
     "ms_set_deterministic": (ctypes.c_int, [_P, ctypes.c_int]),

@@ -314,6 +314,8 @@ int tilt_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, c
                 int slot_override = -1, bool tg_accumulate = false) {
   if (!f.tilts) return fail(c, MS_ERR_STATE, "tilt module active but its tilt field was never set (ms_set_tilts / ms_set_leaflet_tilts)");
   TiltArgs a;
+  a.fields = nullptr;
+  a.fields_rows = 0;
   a.m = device_mesh(c);
   a.tile0 = c->tile0;
   a.tile1 = c->tile1;
@@ -1259,6 +1261,8 @@ int ms_angle_defects(ms_ctx* c, double* defects) {
   HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(double) * (size_t)std::max<int64_t>(1, t.nvp)));
   HIPCHK(c, hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)std::max<int64_t>(1, t.nvp), c->stream));
   TiltArgs a;
+  a.fields = nullptr;
+  a.fields_rows = 0;
   a.m = device_mesh(c);
   a.tile0 = c->tile0;
   a.tile1 = c->tile1;
@@ -1280,6 +1284,46 @@ int ms_angle_defects(ms_ctx* c, double* defects) {
   int rc = MS_OK;
   if (e != hipSuccess) rc = fail(c, MS_ERR_HIP, std::string("ms_angle_defects: ") + hipGetErrorString(e));
   if (rc == MS_OK) rc = patch_to_ext(c, d_out, defects, 1);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(d_out);
+  return rc;
+}
+
+int ms_curvature_fields(ms_ctx* c, double* mean_curvature_normal, double* h_area_anglesum, double* defect_kg,
+                        double* principal) {
+  if (!c) return MS_ERR_INVALID;
+  if (c->shard_count != 1) return fail(c, MS_ERR_STATE, "ms_curvature_fields: single shard only");
+  const Tiling& t = c->til;
+  const size_t plane = 3 * (size_t)std::max<int64_t>(1, t.nvp);
+  double* d_out = nullptr;
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(double) * 4 * plane));
+  HIPCHK(c, hipMemsetAsync(d_out, 0, sizeof(double) * 4 * plane, c->stream));
+  TiltArgs a;
+  a.m = device_mesh(c);
+  a.tile0 = c->tile0;
+  a.tile1 = c->tile1;
+  a.x = c->buf[MS_BUF_X];
+  a.d = nullptr;
+  a.alpha = 0.0;
+  a.tilts = c->buf[MS_BUF_X];  // (read, not used)
+  a.tilts_out = nullptr;
+  a.k_tilt = 0.0;
+  a.g = nullptr;
+  a.tilt_grad = nullptr;
+  a.minv = nullptr;
+  a.partials = c->d_partials;
+  a.e_slot = MS_S_ETILT;
+  a.consistent = 0;
+  a.tg_accumulate = 0;
+  a.va_out = nullptr;
+  a.fields = d_out;
+  a.fields_rows = t.nvp;
+  hipError_t e = launch_tilt(a, 5, c->cap, t.max_ent, c->stream);
+  int rc = MS_OK;
+  if (e != hipSuccess) rc = fail(c, MS_ERR_HIP, std::string("ms_curvature_fields: ") + hipGetErrorString(e));
+  double* outs[4] = {mean_curvature_normal, h_area_anglesum, defect_kg, principal};
+  for (int k = 0; k < 4 && rc == MS_OK; ++k)
+    if (outs[k]) rc = patch_to_ext(c, d_out + (size_t)k * plane, outs[k], 3);
   (void)hipStreamSynchronize(c->stream);
   (void)hipFree(d_out);
   return rc;
@@ -1460,6 +1504,8 @@ int relax_fields(ms_ctx* c, const ms_tilt_relax_params* rp, TiltField** fl, int 
     norm_mask |= (1u << f.s_gn2) | (1u << f.s_rz);
     {  // frozen geometry: unit vertex normals and the tilt-rigidity part of the Jacobi diagonal
       TiltArgs a;
+  a.fields = nullptr;
+  a.fields_rows = 0;
       a.m = device_mesh(c);
       a.tile0 = c->tile0;
       a.tile1 = c->tile1;

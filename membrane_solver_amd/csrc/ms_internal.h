@@ -174,6 +174,8 @@ struct TiltArgs {
   int consistent;         // tilt_leaflet.py:101-114: consistent P1 mass coeff (energy / shape gradient)
   int tg_accumulate;      // mode 1: ADD the tilt gradient instead of writing it
   double* va_out;         // mode 3: barycentric vertex areas (nvp) or nullptr
+  double* fields;         // mode 5: curvature fields, four planes of (fields_rows, 3) -- see k_tilt
+  int64_t fields_rows;
 };
 
 struct DiskTargetArgs {   // tilt_disk_target_in.py:160-286

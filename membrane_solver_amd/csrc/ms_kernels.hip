@@ -1550,8 +1550,10 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
     cur = voff[tid];
     end = voff[tid + 1];
   }
+  double cf_area = 0.0, cf_theta = 0.0;  // MODE 5 vertex accumulators: mixed area, angle sum (K in ax, ay, az)
   for (int c0 = t.f0; c0 < t.f1; c0 += T) {
     const int p = c0 + tid;
+    double cf_a0 = 0, cf_a1 = 0, cf_a2 = 0, cf_t0 = 0, cf_t1 = 0, cf_t2 = 0;
     if (p < t.f1) {
       const TileFacet tf = a.m.tile_facets[p];
       const V3 v0 = lds_v3(px, cap, tf.l0), v1 = lds_v3(px, cap, tf.l1), v2 = lds_v3(px, cap, tf.l2);
@@ -1559,7 +1561,27 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
       const V3 n = cross(e2, -e1);
       const double A2 = norm(n);
       double* s = stg + tid;
-      if (MODE == 4) {
+      if (MODE == 5) {
+        // compute_curvature_data (tilt_kernels.f90:133-181): cotans with area_doubled = max(|n|, 1e-12), the
+        // integrated curvature vectors K_k and the mixed-Voronoi corner areas; angles as in MODE 4
+        const double ad = A2 < 1.0e-12 ? 1.0e-12 : A2;
+        const double inv_ad = 1.0 / ad;
+        const double c0 = dot(-e1, e2) * inv_ad, c1 = dot(-e2, e0) * inv_ad, c2 = dot(-e0, e1) * inv_ad;
+        const double hc0 = 0.5 * c0, hc1 = 0.5 * c1, hc2 = 0.5 * c2;
+        const V3 K0 = hc2 * e2 - hc1 * e1, K1 = hc0 * e0 - hc2 * e2, K2 = hc1 * e1 - hc0 * e0;
+        s[0 * T] = K0.x; s[1 * T] = K0.y; s[2 * T] = K0.z;
+        s[3 * T] = K1.x; s[4 * T] = K1.y; s[5 * T] = K1.z;
+        s[6 * T] = K2.x; s[7 * T] = K2.y; s[8 * T] = K2.z;
+        const double l0 = dot(e0, e0), l1 = dot(e1, e1), l2 = dot(e2, e2);
+        corner_areas(c0, c1, c2, l0, l1, l2, 0.5 * ad, cf_a0, cf_a1, cf_a2);
+        const double la = fmax(sqrt(l0), 1.0e-15), lb = fmax(sqrt(l1), 1.0e-15), lc = fmax(sqrt(l2), 1.0e-15);
+        const double q0 = ((lb * lb + lc * lc) - la * la) / ((2.0 * lb) * lc);
+        const double q1 = ((lc * lc + la * la) - lb * lb) / ((2.0 * lc) * la);
+        const double q2 = ((la * la + lb * lb) - lc * lc) / ((2.0 * la) * lb);
+        cf_t0 = acos(fmin(1.0, fmax(-1.0, q0)));
+        cf_t1 = acos(fmin(1.0, fmax(-1.0, q1)));
+        cf_t2 = acos(fmin(1.0, fmax(-1.0, q2)));
+      } else if (MODE == 4) {
         // interior angles by the law of cosines, edge lengths clamped at 1e-15, cosines clipped to [-1, 1]
         // (geometry/curvature.py:366-386)
         const double la = fmax(norm(e0), 1.0e-15), lb = fmax(norm(e1), 1.0e-15), lc = fmax(norm(e2), 1.0e-15);
@@ -1605,12 +1627,19 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
     if (MODE != 0) {
       __syncthreads();
       const int lo = c0 - t.f0, hi = min(c0 + T, t.f1) - t.f0;
+      const int cur0 = cur;
+      (void)cur0;
       while (cur < end) {
         const int ent = vent[cur];
         const int fl = ent >> 2;
         if (fl >= hi) break;
         const double* s = stg + (fl - lo);
-        if (MODE == 4) {
+        if (MODE == 5) {
+          const int k = ent & 3;
+          ax += s[(3 * k) * T];
+          ay += s[(3 * k + 1) * T];
+          az += s[(3 * k + 2) * T];
+        } else if (MODE == 4) {
           aw += s[(ent & 3) * T];  // this corner's angle
         } else if (MODE == 2 || MODE == 3) {
           ax += s[0];
@@ -1627,11 +1656,41 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
         ++cur;
       }
       __syncthreads();
+      if (MODE == 5) {  // second sub-phase: corner areas and angles through the same staging block
+        if (p < t.f1) {
+          double* s2 = stg + tid;
+          s2[0 * T] = cf_a0; s2[1 * T] = cf_a1; s2[2 * T] = cf_a2;
+          s2[3 * T] = cf_t0; s2[4 * T] = cf_t1; s2[5 * T] = cf_t2;
+        }
+        __syncthreads();
+        for (int q = cur0; q < cur; ++q) {
+          const int ent = vent[q];
+          const double* s2 = stg + ((ent >> 2) - lo) + (ent & 3) * T;
+          cf_area += s2[0];
+          cf_theta += s2[3 * T];
+        }
+        __syncthreads();
+      }
     }
   }
   if (tid < t.n_owned) {
     const size_t o = 3 * (size_t)(t.v_lo + tid);
-    if (MODE == 1) {
+    if (MODE == 5) {
+      // compute_curvature_fields (geometry/curvature.py:404-448)
+      const size_t plane = 3 * (size_t)a.fields_rows;
+      const double safe = fmax(cf_area, 1.0e-12);
+      const V3 hn = mk(ax / (2.0 * safe), ay / (2.0 * safe), az / (2.0 * safe));
+      const double H = norm(hn);
+      const double two_pi = 2.0 * 3.14159265358979323846;
+      const double defect = (a.m.vflags[t.v_lo + tid] & VF_BOUNDARY) ? 0.0 : two_pi - cf_theta;
+      const double KG = defect / safe;
+      const double root = sqrt(fmax(H * H - KG, 0.0));
+      double* f = a.fields;
+      f[o] = hn.x; f[o + 1] = hn.y; f[o + 2] = hn.z;                                  // mean-curvature normal
+      f[plane + o] = H; f[plane + o + 1] = cf_area; f[plane + o + 2] = cf_theta;      // H, mixed area, angle sum
+      f[2 * plane + o] = defect; f[2 * plane + o + 1] = KG; f[2 * plane + o + 2] = 0.0;  // defect, K_G
+      f[3 * plane + o] = H + root; f[3 * plane + o + 1] = H - root; f[3 * plane + o + 2] = 0.0;  // k1, k2
+    } else if (MODE == 1) {
       if (a.g) {
         a.g[o] += ax;
         a.g[o + 1] += ay;
@@ -1671,7 +1730,7 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
       if (a.va_out) a.va_out[t.v_lo + tid] = aw;         // barycentric vertex area (mesh.py:671-730)
     }
   }
-  if (MODE != 2 && MODE != 3 && MODE != 4) {
+  if (MODE != 2 && MODE != 3 && MODE != 4 && MODE != 5) {
     const double vals[1] = {e_tilt};
     const int ops[1] = {0};
     const int slots[1] = {a.e_slot};
@@ -1696,7 +1755,7 @@ hipError_t launch_tilt(const TiltArgs& a, int mode, int cap, int max_ent, hipStr
     hipLaunchKernelGGL((k_tilt<M>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);    \
   } while (0)
   if (mode == 0) MS_LAUNCH_T(0); else if (mode == 1) MS_LAUNCH_T(1); else if (mode == 2) MS_LAUNCH_T(2);
-  else if (mode == 3) MS_LAUNCH_T(3); else MS_LAUNCH_T(4);
+  else if (mode == 3) MS_LAUNCH_T(3); else if (mode == 4) MS_LAUNCH_T(4); else MS_LAUNCH_T(5);
 #undef MS_LAUNCH_T
   return hipGetLastError();
 }

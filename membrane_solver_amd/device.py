@@ -266,6 +266,15 @@ class DeviceMesh:
         self._chk(L.lib().ms_angle_defects(self._h, _pd(out)), "ms_angle_defects")
         return out
 
+    def curvature_fields(self) -> dict:
+        """geometry/curvature.compute_curvature_fields at the context's positions (ms_curvature_fields) + the raw
+        per-vertex angle sums."""
+        a, b, c, d = (np.empty((self.nv, 3), dtype=np.float64) for _ in range(4))
+        self._chk(L.lib().ms_curvature_fields(self._h, _pd(a), _pd(b), _pd(c), _pd(d)), "ms_curvature_fields")
+        return {"mean_curvature_normal": a, "mean_curvature": b[:, 0].copy(), "mixed_area": b[:, 1].copy(),
+                "angle_sum": b[:, 2].copy(), "angle_defect": c[:, 0].copy(), "gaussian_curvature": c[:, 1].copy(),
+                "principal_curvatures": d[:, :2].copy()}
+
     def project_tilts_to_tangent(self):
         self._chk(L.lib().ms_project_tilts_to_tangent(self._h), "ms_project_tilts_to_tangent")
 

@@ -1,11 +1,13 @@
 """Gaussian curvature (Helfrich Gaussian modulus) energy plugin.
 
-Drop-in for the reference's modules/energy/gaussian_curvature.py:104-176 on closed surfaces: with a constant
-``gaussian_modulus`` the energy is the topological constant 2 pi kappa_bar chi (Gauss-Bonnet) and the shape gradient
-is zero, so the module only adds an offset.  chi = V - E + F comes from the triangle rows; the optional defect check
-(``gaussian_curvature_check_defects``) sums the per-vertex angle defects computed on the device
-(``ms_angle_defects``, geometry/curvature.py:335-403).  Surfaces with boundary loops need the geodesic-curvature terms of
-runtime/diagnostics/gauss_bonnet.py and raise here.
+Drop-in for the reference's modules/energy/gaussian_curvature.py:104-176.  Closed surfaces: with a constant
+``gaussian_modulus`` the energy is the topological constant 2 pi kappa_bar chi (Gauss-Bonnet), chi = V - E + F from the
+triangle rows; the optional defect check (``gaussian_curvature_check_defects``) sums the per-vertex angle defects
+computed on the device (``ms_angle_defects``, geometry/curvature.py:335-403).  Surfaces with boundary loops
+(:128-143): kappa_bar times the Gauss-Bonnet invariant G = sum_interior (2 pi - theta_v) + sum_boundary (pi - theta_v)
+(runtime/diagnostics/gauss_bonnet.py:260-340) from the device's per-vertex angle sums (``ms_curvature_fields``).  The
+shape gradient is zero in both cases, as in the reference.  Facet filters (``gauss_bonnet_exclude``) and the strict
+topology check stay outside the hot path and raise.
 """
 
 from __future__ import annotations
@@ -36,23 +38,32 @@ def euler_characteristic(mesh) -> int:
     return int(len(mesh.vertex_ids) - n_edges + tri.shape[0])
 
 
-def constant_energy(mesh, global_params) -> float:
+def has_boundary(mesh) -> bool:
+    return bool(len(getattr(mesh, "boundary_vertex_ids", ()) or ()))
+
+
+def constant_energy(mesh, global_params, positions=None) -> float:
+    """The module's energy; a topological constant on closed surfaces.  With boundary loops it depends on the
+    positions through the boundary angle sums (``positions`` None = the mesh's own)."""
     kappa_bar = _gaussian_modulus(global_params)
     if kappa_bar == 0.0:
         return 0.0
-    if len(getattr(mesh, "boundary_vertex_ids", ()) or ()):
-        raise L.MembraneHipError("gaussian_curvature on a surface with boundary (geodesic-curvature terms of "
-                                 "runtime/diagnostics/gauss_bonnet.py) is outside the HIP hot path")
     if bool(global_params.get("gaussian_curvature_strict_topology", False)):
         raise L.MembraneHipError("gaussian_curvature_strict_topology is outside the HIP hot path")
+    if has_boundary(mesh):
+        from ...geometry.curvature import gauss_bonnet_invariant
+
+        pos = mesh.positions_view() if positions is None else positions
+        g_total, _k_int, _b_tot = gauss_bonnet_invariant(mesh, pos)
+        return float(kappa_bar * g_total)
     return float(2.0 * np.pi * kappa_bar * euler_characteristic(mesh))
 
 
 def compute_energy_and_gradient_array(mesh, global_params, param_resolver, *, positions: np.ndarray,
                                       index_map: Dict[int, int], grad_arr: np.ndarray) -> float:
     _ = (param_resolver, index_map, grad_arr)
-    energy = constant_energy(mesh, global_params)
-    if energy != 0.0 and bool(global_params.get("gaussian_curvature_check_defects", False)):
+    energy = constant_energy(mesh, global_params, positions)
+    if energy != 0.0 and not has_boundary(mesh) and bool(global_params.get("gaussian_curvature_check_defects", False)):
         dm = mirror_for(mesh).sync(positions=None if positions is mesh.positions_view() else positions)
         defect_sum = float(np.sum(dm.angle_defects()))
         target = float(2.0 * np.pi * euler_characteristic(mesh))

@@ -950,7 +950,7 @@ _DISK_TAG = False
 
 def gen_angle_defects():
     """compute_angle_defects (geometry/curvature.py:335-403) and the closed-surface gaussian_curvature energy."""
-    from geometry.curvature import compute_angle_defects
+    from geometry.curvature import compute_angle_defects, compute_curvature_fields
     from modules.energy import gaussian_curvature as gcm
 
     out = {"meta_fortran": META}
@@ -970,6 +970,27 @@ def gen_angle_defects():
             assert not np.any(g)
             out["ico5_gaussian_E"] = np.array(E)
         print("angle defects", name, "sum=%.15g" % d.sum())
+        # compute_curvature_fields (geometry/curvature.py:404-448): every field of the dataclass
+        cf = compute_curvature_fields(m, pos, m.vertex_index_to_row)
+        out[name + "_cf_mean_curvature_normal"] = np.array(cf.mean_curvature_normal)
+        out[name + "_cf_mean_curvature"] = np.array(cf.mean_curvature)
+        out[name + "_cf_mixed_area"] = np.array(cf.mixed_area)
+        out[name + "_cf_angle_defect"] = np.array(cf.angle_defect)
+        out[name + "_cf_gaussian_curvature"] = np.array(cf.gaussian_curvature)
+        out[name + "_cf_principal_curvatures"] = np.array(cf.principal_curvatures)
+        if name == "disk5":
+            # a surface WITH a boundary loop: E = kappa_bar * G, G = sum_interior (2 pi - theta_v) +
+            # sum_boundary-loop (pi - theta_v)  (gaussian_curvature.py:128-143, diagnostics/gauss_bonnet.py:260-340)
+            from runtime.diagnostics.gauss_bonnet import gauss_bonnet_invariant
+
+            g = np.zeros_like(pos)
+            E = gcm.compute_energy_and_gradient_array(m, m.global_parameters, ParameterResolver(m.global_parameters),
+                                                      positions=pos, index_map=m.vertex_index_to_row, grad_arr=g)
+            assert not np.any(g)
+            G, k_int, b_tot, _ = gauss_bonnet_invariant(m)
+            out["disk5_gaussian_E"], out["disk5_gauss_bonnet_G"] = np.array(E), np.array(G)
+            out["disk5_gauss_bonnet_interior"], out["disk5_gauss_bonnet_boundary"] = np.array(k_int), np.array(b_tot)
+            print("gaussian_curvature with boundary: E=%.15g G=%.15g (interior %.6g + boundary %.6g)" % (E, G, k_int, b_tot))
     np.savez_compressed(os.path.join(OUT, "angle_defect_cases.npz"), **out)
 
 

@@ -689,6 +689,47 @@ def angle_defects(pos, tri, is_boundary):
     return defects
 
 
+def angle_sums(pos, tri):
+    """Per-vertex sums of the incident triangle angles (runtime/diagnostics/gauss_bonnet.py:204-257, the same
+    law-of-cosines arithmetic as compute_angle_defects)."""
+    pos, tri = _f64(pos), _i32(tri)
+    nv = pos.shape[0]
+    sums = np.zeros(nv)
+    if tri.shape[0] == 0:
+        return sums
+    v0, v1, v2 = pos[tri[:, 0]], pos[tri[:, 1]], pos[tri[:, 2]]
+    a = np.maximum(np.linalg.norm(v2 - v1, axis=1), 1e-15)
+    b = np.maximum(np.linalg.norm(v0 - v2, axis=1), 1e-15)
+    c = np.maximum(np.linalg.norm(v1 - v0, axis=1), 1e-15)
+    np.add.at(sums, tri[:, 0], np.arccos(np.clip((b * b + c * c - a * a) / (2.0 * b * c), -1.0, 1.0)))
+    np.add.at(sums, tri[:, 1], np.arccos(np.clip((c * c + a * a - b * b) / (2.0 * c * a), -1.0, 1.0)))
+    np.add.at(sums, tri[:, 2], np.arccos(np.clip((a * a + b * b - c * c) / (2.0 * a * b), -1.0, 1.0)))
+    return sums
+
+
+def curvature_fields(pos, tri, is_boundary) -> dict:
+    """geometry/curvature.py:404-448 compute_curvature_fields."""
+    k_vecs, areas, _w = compute_curvature_data(pos, tri)
+    safe = np.maximum(areas, 1e-12)
+    hn = k_vecs / (2.0 * safe[:, None])
+    H = np.linalg.norm(hn, axis=1)
+    defect = angle_defects(pos, tri, is_boundary)
+    KG = defect / safe
+    root = np.sqrt(np.maximum(H * H - KG, 0.0))
+    return {"mean_curvature_normal": hn, "mean_curvature": H, "mixed_area": areas, "angle_defect": defect,
+            "gaussian_curvature": KG, "principal_curvatures": np.column_stack([H + root, H - root])}
+
+
+def gauss_bonnet_invariant(pos, tri, is_boundary):
+    """runtime/diagnostics/gauss_bonnet.py:305-340 for a manifold triangle mesh whose boundary vertices are those of
+    its boundary loops: G = sum_interior (2 pi - theta_v) + sum_boundary (pi - theta_v) -> (G, interior, boundary)."""
+    th = angle_sums(pos, tri)
+    isb = np.asarray(is_boundary, dtype=bool)
+    k_int = float(np.sum(2.0 * np.pi - th[~isb]))
+    b_tot = float(np.sum(np.pi - th[isb]))
+    return k_int + b_tot, k_int, b_tot
+
+
 def euler_characteristic(nv, tri):
     """modules/energy/gaussian_curvature.py:41-43: V - E + F of the triangle complex."""
     tri = _i32(tri)

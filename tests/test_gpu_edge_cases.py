@@ -278,5 +278,53 @@ def test_angle_defects_and_gaussian_curvature(L):
     open_mesh = ArrayMesh(g["disk5_positions"], g["disk5_tri"], global_parameters=gp, energy_modules=mods)
     mz2 = Minimizer(open_mesh, open_mesh.global_parameters, GradientDescent(), EnergyModuleManager(mods),
                     ConstraintModuleManager([]), quiet=True)
-    with pytest.raises(L.MembraneHipError, match="boundary"):
-        mz2.compute_energy()
+    # a surface WITH a boundary loop: kappa_bar times the Gauss-Bonnet invariant of the reference
+    # (gaussian_curvature.py:128-143), through the Minimizer and through the plugin seam
+    bd2 = mz2.compute_energy_breakdown()
+    assert abs(bd2["gaussian_curvature"] - float(g["disk5_gaussian_E"])) <= 1e-12
+    g_arr = np.zeros_like(g["disk5_positions"])
+    E_open = module.compute_energy_and_gradient_array(open_mesh, open_mesh.global_parameters,
+                                                      ParameterResolver(open_mesh.global_parameters),
+                                                      positions=open_mesh.positions_view(),
+                                                      index_map=open_mesh.vertex_index_to_row, grad_arr=g_arr)
+    assert abs(E_open - float(g["disk5_gaussian_E"])) <= 1e-12 and not np.any(g_arr)
+    strict = ArrayMesh(g["disk5_positions"], g["disk5_tri"], energy_modules=mods,
+                       global_parameters=dict(gp, gaussian_curvature_strict_topology=True))
+    mz3 = Minimizer(strict, strict.global_parameters, GradientDescent(), EnergyModuleManager(mods),
+                    ConstraintModuleManager([]), quiet=True)
+    with pytest.raises(L.MembraneHipError, match="strict_topology"):
+        mz3.compute_energy()
+
+
+def test_curvature_fields_match_reference(L):
+    """ms_curvature_fields / geometry.curvature.compute_curvature_fields against the reference's
+    compute_curvature_fields (geometry/curvature.py:404-448) on a closed noisy sphere and an open bulged disk, two
+    tile sizes; the raw angle sums give the reference's Gauss-Bonnet invariant of the open surface."""
+    from conftest import load_golden, relerr
+    from membrane_solver_amd.device import DeviceMesh
+    from membrane_solver_amd.geometry import curvature as gc
+    from membrane_solver_amd.geometry.mesh import ArrayMesh
+
+    g = load_golden("angle_defect_cases.npz")
+    keys = (("mean_curvature_normal", 1e-11), ("mean_curvature", 1e-11), ("mixed_area", 1e-12),
+            ("angle_defect", 1e-11), ("gaussian_curvature", 1e-10), ("principal_curvatures", 1e-10))
+    for name in ("ico5", "disk5"):
+        for tile in (64, 256):
+            dm = DeviceMesh(g[name + "_positions"], g[name + "_tri"], boundary=g[name + "_is_boundary"],
+                            tile_vertices=tile)
+            f = dm.curvature_fields()
+            for key, tol in keys:
+                assert relerr(f[key], g[f"{name}_cf_{key}"]) < tol, (name, tile, key)
+            dm.close()
+        mesh = ArrayMesh(g[name + "_positions"], g[name + "_tri"])
+        cf = gc.compute_curvature_fields(mesh, mesh.positions_view(), mesh.vertex_index_to_row)
+        assert isinstance(cf, gc.CurvatureFields)
+        for key, tol in keys:
+            assert relerr(getattr(cf, key), g[f"{name}_cf_{key}"]) < tol, (name, key)
+        assert np.max(np.abs(gc.compute_angle_defects(mesh, mesh.positions_view(), mesh.vertex_index_to_row)
+                             - g[name + "_defects"])) <= 1e-12
+    mesh = ArrayMesh(g["disk5_positions"], g["disk5_tri"])
+    G, k_int, b_tot = gc.gauss_bonnet_invariant(mesh, mesh.positions_view())
+    assert abs(G - float(g["disk5_gauss_bonnet_G"])) < 1e-12 and abs(G - 2.0 * np.pi) < 1e-12
+    assert abs(k_int - float(g["disk5_gauss_bonnet_interior"])) < 1e-12
+    assert abs(b_tot - float(g["disk5_gauss_bonnet_boundary"])) < 1e-12

@@ -491,6 +491,21 @@ def test_port_reproduces_disk_target_trajectory(fname):
     assert relerr(p.tilts_out, g["tilts_out_final"]) < 1e-8
 
 
+def test_curvature_fields_and_open_surface_gauss_bonnet_match_reference():
+    """compute_curvature_fields (geometry/curvature.py:404-448) on a closed noisy sphere and an open bulged disk, and
+    the Gaussian-modulus energy of the surface WITH boundary (gaussian_curvature.py:128-143)."""
+    g = load_golden("angle_defect_cases.npz")
+    for name in ("ico5", "disk5"):
+        cf = orc.curvature_fields(g[name + "_positions"], g[name + "_tri"], g[name + "_is_boundary"])
+        for key, tol in (("mean_curvature_normal", 1e-12), ("mean_curvature", 1e-12), ("mixed_area", 1e-13),
+                         ("angle_defect", 1e-12), ("gaussian_curvature", 1e-11), ("principal_curvatures", 1e-11)):
+            assert relerr(cf[key], g[f"{name}_cf_{key}"]) < tol, (name, key)
+    G, k_int, b_tot = orc.gauss_bonnet_invariant(g["disk5_positions"], g["disk5_tri"], g["disk5_is_boundary"])
+    assert abs(G - g["disk5_gauss_bonnet_G"]) < 1e-12 and abs(G - 2.0 * np.pi) < 1e-12  # a disk: chi = 1
+    assert abs(k_int - g["disk5_gauss_bonnet_interior"]) < 1e-12 and abs(b_tot - g["disk5_gauss_bonnet_boundary"]) < 1e-12
+    assert abs(-0.7 * G - g["disk5_gaussian_E"]) < 1e-12
+
+
 def test_angle_defects_match_reference():
     g = load_golden("angle_defect_cases.npz")
     for name in ("ico5", "disk5"):
