@@ -180,6 +180,19 @@ __device__ __forceinline__ double dot_pinned(V3 a, V3 b) {
   return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
 }
 
+// x + alpha d, spelled out ONCE: every trial position (energy pass rows and halo rows, tilt / bending_tilt /
+// smoothness / disk-target passes) and every commit (ms_phase_commit_trial's axpy, the volume projection) goes through
+// this helper, so the committed doubles are the evaluated ones and a vertex gets the same position in every tile that
+// stages it -- independent of where the compiler would or would not contract a mul+add.  Built with
+// -ffp-contract=off (MS_FP_CONTRACT=off, the CPU oracle's rounding) it is the plain two-rounding form.
+__device__ __forceinline__ double axpy1(double x, double alpha, double d) {
+#ifdef MS_FP_CONTRACT_OFF
+  return x + alpha * d;
+#else
+  return fma(alpha, d, x);
+#endif
+}
+
 __device__ __forceinline__ V3 lds_v3(const double* base, int cap, int slot) {
   return mk(base[slot], base[cap + slot], base[2 * cap + slot]);
 }
@@ -428,9 +441,9 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
     if (own) {
       const size_t g = 3 * (size_t)v_own;
       const bool mv = have_d && !(fl & VF_FIXED);
-      const double x0 = mv ? xo0 + a.alpha * dd0 : xo0;
-      const double x1 = mv ? xo1 + a.alpha * dd1 : xo1;
-      const double x2 = mv ? xo2 + a.alpha * dd2 : xo2;
+      const double x0 = mv ? axpy1(xo0, a.alpha, dd0) : xo0;
+      const double x1 = mv ? axpy1(xo1, a.alpha, dd1) : xo1;
+      const double x2 = mv ? axpy1(xo2, a.alpha, dd2) : xo2;
       if (stage_flags) lfl[tid] = fl;
       lds_put3(px, tid, x0, x1, x2);
       if (GUARD) lds_put3(ox, tid, xo0, xo1, xo2);
@@ -449,7 +462,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
       const int s = t.n_owned + tid;
       const bool mv = have_d && !(hfl & VF_FIXED);
       if (stage_flags) lfl[s] = hfl;
-      lds_put3(px, s, mv ? h0 + a.alpha * e0 : h0, mv ? h1 + a.alpha * e1 : h1, mv ? h2 + a.alpha * e2 : h2);
+      lds_put3(px, s, mv ? axpy1(h0, a.alpha, e0) : h0, mv ? axpy1(h1, a.alpha, e1) : h1, mv ? axpy1(h2, a.alpha, e2) : h2);
       if (GUARD) lds_put3(ox, s, h0, h1, h2);
     }
     for (int h = tid + T; h < t.nh; h += T) {  // halo longer than the workgroup (small tiles)
@@ -466,7 +479,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
       const int s = t.n_owned + h;
       const bool mv = have_d && !(f2 & VF_FIXED);
       if (stage_flags) lfl[s] = f2;
-      lds_put3(px, s, mv ? q0 + a.alpha * r0 : q0, mv ? q1 + a.alpha * r1 : q1, mv ? q2 + a.alpha * r2 : q2);
+      lds_put3(px, s, mv ? axpy1(q0, a.alpha, r0) : q0, mv ? axpy1(q1, a.alpha, r1) : q1, mv ? axpy1(q2, a.alpha, r2) : q2);
       if (GUARD) lds_put3(ox, s, q0, q1, q2);
     }
   }
@@ -1506,7 +1519,7 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double xo = a.x[g + c];
-      px[c * cap + tid] = mv ? xo + a.alpha * a.d[g + c] : xo;
+      px[c * cap + tid] = mv ? axpy1(xo, a.alpha, a.d[g + c]) : xo;
     }
     tv = mk(a.tilts[g], a.tilts[g + 1], a.tilts[g + 2]);
     tq[tid] = dot(tv, tv);
@@ -1524,7 +1537,7 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double xo = a.x[g + c];
-      px[c * cap + sl] = mv ? xo + a.alpha * a.d[g + c] : xo;
+      px[c * cap + sl] = mv ? axpy1(xo, a.alpha, a.d[g + c]) : xo;
     }
     const V3 th = mk(a.tilts[g], a.tilts[g + 1], a.tilts[g + 2]);
     tq[sl] = dot(th, th);
@@ -1816,9 +1829,9 @@ __global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
       if (have_d) {
         const double d0 = a.d[g], d1 = a.d[g + 1], d2 = a.d[g + 2];
         if (!(r.fl & VF_FIXED)) {
-          r.x0 = r.x0 + a.alpha * d0;
-          r.x1 = r.x1 + a.alpha * d1;
-          r.x2 = r.x2 + a.alpha * d2;
+          r.x0 = axpy1(r.x0, a.alpha, d0);
+          r.x1 = axpy1(r.x1, a.alpha, d1);
+          r.x2 = axpy1(r.x2, a.alpha, d2);
         }
       }
       r.t0 = a.tilts[g];
@@ -2044,9 +2057,9 @@ __global__ __launch_bounds__(512) void k_tsmooth(TsArgs a, int cap, int max_ent)
       if (have_d) {
         const double d0 = a.d[g], d1 = a.d[g + 1], d2 = a.d[g + 2];
         if (!(a.m.vflags[v] & VF_FIXED)) {
-          r.x0 = r.x0 + a.alpha * d0;
-          r.x1 = r.x1 + a.alpha * d1;
-          r.x2 = r.x2 + a.alpha * d2;
+          r.x0 = axpy1(r.x0, a.alpha, d0);
+          r.x1 = axpy1(r.x1, a.alpha, d1);
+          r.x2 = axpy1(r.x2, a.alpha, d2);
         }
       }
       r.t0 = a.tilts[g];
@@ -2320,7 +2333,7 @@ __global__ __launch_bounds__(BLOCK) void k_disk_target(DiskTargetArgs a, int mod
     if (a.disk[v]) {
       V3 x = mk(a.x[o], a.x[o + 1], a.x[o + 2]);
       if (a.d && !(a.vflags[v] & VF_FIXED))
-        x = mk(x.x + a.alpha * a.d[o], x.y + a.alpha * a.d[o + 1], x.z + a.alpha * a.d[o + 2]);
+        x = mk(axpy1(x.x, a.alpha, a.d[o]), axpy1(x.y, a.alpha, a.d[o + 1]), axpy1(x.z, a.alpha, a.d[o + 2]));
       const V3 c = mk(a.center[0], a.center[1], a.center[2]), n = mk(a.normal[0], a.normal[1], a.normal[2]);
       V3 r = x - c;
       const double rn = dot(r, n);
@@ -2660,7 +2673,7 @@ __global__ void k_axpy_rows(int64_t row0, int64_t row1, const int32_t* extra, in
   else
     return;
   if (vflags[v] & VF_FIXED) return;
-  for (int c = 0; c < 3; ++c) x[3 * v + c] += coef * y[3 * v + c];
+  for (int c = 0; c < 3; ++c) x[3 * v + c] = axpy1(x[3 * v + c], coef, y[3 * v + c]);
 }
 
 hipError_t launch_axpy_rows(int64_t row0, int64_t row1, const int32_t* extra, int n_extra,
@@ -2679,7 +2692,7 @@ __global__ void k_axpy_masked(int64_t n_rows, const uint8_t* vflags, double* x, 
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= 3 * n_rows) return;
   if (vflags[j / 3] & VF_FIXED) return;
-  x[j] += coef * y[j];
+  x[j] = axpy1(x[j], coef, y[j]);
 }
 
 hipError_t launch_axpy_masked(int64_t n_rows, const uint8_t* vflags, double* x, const double* y,

@@ -20,9 +20,17 @@ CG history and trial positions resident in HBM; the host sees a handful of
 scalars per step.  ``Vertex.position`` objects / the mesh position array are
 written back once at the end (or before each ``callback``).
 
-Out of scope here (raises MembraneHipError): tilt relaxation modes, energy
-modules other than surface / bending / volume, constraints other than volume,
-the reference's auto mesh-quality repair hook.
+On the device as well: the tilt relaxation at the top of every iteration
+(``tilt_solve_mode`` nested / coupled, single field and two leaflets:
+ms_relax_tilts / ms_relax_leaflet_tilts, minimizer.py:1237-1307), the tilt
+modules (``tilt``, ``bending_tilt``, ``tilt_smoothness`` and their ``_in`` /
+``_out`` leaflet forms, ``tilt_disk_target_in/out``), ``gaussian_curvature``
+and the switched-off ``rim_slope_match_out`` as host-side constants.
+
+Out of scope here (raises MembraneHipError): every other energy module,
+constraints other than ``volume``, the benchmark toggles of the leaflet modules
+(modules/energy/leaflet_common._UNSUPPORTED_KEYS), the reference's auto
+mesh-quality repair hook.
 """
 
 from __future__ import annotations

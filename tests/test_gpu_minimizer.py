@@ -600,3 +600,43 @@ def test_full_size_energy_and_gradient_match_oracle(freq):
     assert err < tol and err < 2e-8, report
     assert hip_shift < max(1e-9, 5.0 * oracle_shift), report
     assert abs(e_t.sum() - e.sum()) <= 1e-11 * abs(e.sum()), report
+
+
+def test_default_mode_ladder_at_full_size(monkeypatch):
+    """The speculative line-search ladder (queued trials, pair / triple launches, gated gradient pass) where it is
+    actually used: the headline workload at FULL size (2 048 000 facets) in the DEFAULT LDS-atomic mode.  Against the
+    plain one-trial-per-launch search (MS_PAIR=0, MS_SPECULATE=0) the accept/reject sequence, the trial counts and the
+    step sizes must be equal and the energies agree to 1e-10 (atomic sums are not bitwise repeatable)."""
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+
+    P, T = meshgen.icosphere(320)
+    P = meshgen.smooth_displace(P, 0.05)
+    nv, nf = len(P), len(T)
+    logs = []
+    for env in ({"MS_PAIR": "0", "MS_SPECULATE": "0"}, {}):
+        for k in ("MS_PAIR", "MS_SPECULATE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dm = DeviceMesh(P, T)
+        dm.set_surface_tension(np.ones(nf))
+        dm.set_bending_params(np.ones(nv), np.zeros(nv))
+        dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING)
+        step, rows = 1e-6, []
+        for _ in range(40):
+            r = dm.step(stepper=L.MS_STEPPER_CG, step_size=step)
+            rows.append((float(r.success), float(r.trials), r.next_step, r.energy, r.alpha))
+            step = r.next_step
+            if not r.success:
+                dm.reset_stepper()
+        logs.append(np.array(rows))
+        dm.close()
+    plain, ladder = logs
+    assert plain[:, 0].sum() >= 15 and plain[:, 1].max() >= 2, "the run is meant to exercise multi-trial searches"
+    assert np.array_equal(plain[:, 0], ladder[:, 0]), "accept/reject sequence differs"
+    assert np.array_equal(plain[:, 1], ladder[:, 1]), "trial counts differ"
+    assert np.allclose(plain[:, 2], ladder[:, 2], rtol=1e-12, atol=0)
+    assert np.allclose(plain[:, 4], ladder[:, 4], rtol=1e-12, atol=0)
+    assert np.allclose(plain[:, 3], ladder[:, 3], rtol=1e-10, atol=0)
