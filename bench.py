@@ -463,6 +463,11 @@ def main_sharded(args, rank, world, local_rank):
     from membrane_solver_amd.parallel import HipShardBackend, LibraryShardedStepper, ShardedStepper
 
     torch.cuda.set_device(local_rank)
+    # RCCL prints a version banner on STDOUT when a communicator is created; the contract is ONE JSON line there.
+    # Everything until the result line goes to stderr at the file-descriptor level (the banner comes from C code).
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     if "WORLD_SIZE" not in os.environ:  # MS_BENCH_FORCE_SHARDED=1 at N = 1 without a launcher
         os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()), "RANK": "0",
                            "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
@@ -564,6 +569,9 @@ def main_sharded(args, rank, world, local_rank):
         if rank == 0:
             cpu = cpu_baseline(x_full, T, ["surface", "bending"], [], [], dict(GP), step, n_cpu)
         dist.barrier()
+    sys.stdout.flush()
+    os.dup2(stdout_fd, 1)
+    os.close(stdout_fd)
     if rank == 0:
         print(json.dumps({
             "metric": METRIC, "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
@@ -583,7 +591,8 @@ def main_sharded(args, rank, world, local_rank):
             "exchange_bytes_per_rank_max": int((L.MS_NSCAL + 10 * be.boundary["max_rows"]) * 8),
             "energy_end": float(getattr(r, "energy", getattr(r, "energy_eval", float("nan")))),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
-        }))
+        }), flush=True)
+    os.dup2(2, 1)  # (communicator teardown may print as well)
     dist.destroy_process_group()
 
 
