@@ -2433,14 +2433,14 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(const double* partials, int n
     const double r = (slot == MS_S_VOL) ? v / 6.0 : v;
     scal[slot] = r;
     if (host_box) {
-      // pinned, device-mapped mailbox: {value, sequence word} of a slot share one 16-byte entry and leave in ONE
-      // 16-byte store, so the host can never see the new sequence word next to the old value and no system-scope
-      // fence has to drain between the two -- the host polls the sequence word instead of synchronising the stream
-      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-      u64x2 e;
-      e.x = (unsigned long long)__double_as_longlong(r);
-      e.y = ticket;
-      __builtin_nontemporal_store(e, reinterpret_cast<u64x2*>(host_box) + slot);
+      // pinned, device-mapped mailbox entry {value, sequence word}: the value first, a system-scope release, then the
+      // sequence word the host polls with acquire loads.  (One 16-byte store of both was observed untorn on gfx950 and
+      // ~neutral in time, but it is no architectural guarantee: a torn entry would hand the host a stale energy next to
+      // a fresh sequence word, i.e. host and device deciding an Armijo test on different doubles.)
+      volatile unsigned long long* e = host_box + 2 * slot;
+      e[0] = (unsigned long long)__double_as_longlong(r);
+      __threadfence_system();
+      e[1] = ticket;
     }
   }
 }
