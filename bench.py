@@ -118,9 +118,9 @@ def pmc_traffic(kernel_name):
         acc = {"FETCH_SIZE": [0.0, 0.0], "WRITE_SIZE": [0.0, 0.0]}
         with open(path) as f:
             for row in csv.reader(line for line in f if not line.startswith("#")):
-                if len(row) < 4 or row[0] not in acc or not row[1].startswith(base + "<"):
+                if len(row) < 4 or row[0] not in acc or (base + "<") not in row[1]:
                     continue
-                if _template_args(row[1]) != want:
+                if _template_args(row[1][row[1].index(base):]) != want:
                     continue
                 n = float(row[2])
                 acc[row[0]][0] += n * float(row[3])

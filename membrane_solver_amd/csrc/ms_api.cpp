@@ -6,6 +6,8 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <map>
+#include <string>
 #include <new>
 
 #include <dlfcn.h>
@@ -96,6 +98,7 @@ struct ms_ctx {
   } spec[SPEC_STAGES];
   Mailbox grad_mb;               // mailbox of the gradient pass queued behind a ladder
   bool kc_pending = false;       // that pass ran for the accepted x: the next ms_step takes its result
+  long queue_fallbacks = 0;      // queued gradient passes redone without the gate (see ms_step)
   int kc_stepper = 0;
   bool kc_use_history = false;
   int* d_gate = nullptr;         // SPEC_STAGES + 1 gate words + the "accepted" word
@@ -452,9 +455,30 @@ int disk_target_pass(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alp
 constexpr uint32_t MASK_GRAD = (1u << MS_S_GGC) | (1u << MS_S_GCGC);
 constexpr uint32_t MASK_DIR = (1u << MS_S_GNORM2) | (1u << MS_S_GDOTD) | (1u << MS_S_MAXD2) | (1u << MS_S_MAXG2);
 
+// MS_TRACE_QUEUE=1: one stderr line per fold launch / mailbox swap / fetch (debugging the line-search queue)
+bool trace_queue() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MS_TRACE_QUEUE");
+    v = (e && atoi(e) != 0) ? 1 : 0;
+  }
+  return v != 0;
+}
+const char* box_name(ms_ctx* c, const void* h_seq) {
+  // (the mailboxes are swapped in and out of the context: name them by allocation)
+  static std::map<const void*, std::string> names;
+  auto it = names.find(h_seq);
+  if (it == names.end()) it = names.emplace(h_seq, "box" + std::to_string(names.size())).first;
+  (void)c;
+  return it->second.c_str();
+}
+
 int reduce_slots(ms_ctx* c, uint32_t mask) {
   ProfScope ps(c, 3, c->cur_gate != nullptr);
   ++c->ticket;
+  if (trace_queue())
+    fprintf(stderr, "[msq] fold ticket %llu mask %#x -> %s gate %p pair_on %d\n", (unsigned long long)(c->ticket), mask,
+            box_name(c, c->h_seq), (const void*)c->cur_gate, (int)c->pair_on);
   // a pair launch has no tilt module: only the core slots carry anything (and the sharded driver parks the other
   // trial's fold in the tilt slots of the device scalars, which the full mask would overwrite)
   if (c->pair_on) {
@@ -797,7 +821,17 @@ void put_mailbox(ms_ctx* c, int sl, double v) {
   __atomic_store_n(&c->h_seq[2 * sl], bits, __ATOMIC_RELAXED);
 }
 
-int fetch(ms_ctx* c) {
+const char* box_name(ms_ctx* c, const void* h_seq);
+bool trace_queue();
+// soft_miss != nullptr: a post that is still missing after everything queued has run is reported through *soft_miss
+// (MS_OK is returned) instead of as an error -- for callers that can redo the launch without the queue
+int fetch(ms_ctx* c, bool* soft_miss = nullptr) {
+  if (soft_miss) *soft_miss = false;
+  if (trace_queue()) {
+    unsigned long long mx = 0;
+    for (int sl = 0; sl < MS_NSCAL; ++sl) mx = std::max<unsigned long long>(mx, c->expected[sl]);
+    fprintf(stderr, "[msq] fetch %s (latest expected ticket %llu)\n", box_name(c, c->h_seq), mx);
+  }
   if (c->tile1 > c->tile0) {
     for (long spin = 0; spin < 20000000L; ++spin) {
       bool done = true;
@@ -814,8 +848,23 @@ int fetch(ms_ctx* c) {
   // everything queued has run: a slot that is still behind belongs to a gated launch that found its gate closed
   // although the host expected it to run -- host and device disagreed on an Armijo test.  Never continue on that.
   for (int sl = 0; sl < MS_NSCAL; ++sl)
-    if (c->tile1 > c->tile0 && __atomic_load_n(&c->h_seq[2 * sl + 1], __ATOMIC_ACQUIRE) < c->expected[sl])
-      return fail(c, MS_ERR_STATE, "line-search queue: a gated launch the host waited for did not run");
+    if (c->tile1 > c->tile0 && __atomic_load_n(&c->h_seq[2 * sl + 1], __ATOMIC_ACQUIRE) < c->expected[sl]) {
+      if (soft_miss) {
+        *soft_miss = true;
+        for (int k = 0; k < MS_NSCAL; ++k) c->expected[k] = 0;  // nobody waits for that ticket any more
+        return MS_OK;
+      }
+      char msg[512];
+      const char* box = c->h_seq == c->spec[0].h_seq ? "stage-1" : (c->h_seq == c->spec[1].h_seq ? "stage-2"
+                        : (c->h_seq == c->grad_mb.h_seq ? "gradient" : "main"));
+      snprintf(msg, sizeof(msg),
+               "line-search queue: a gated launch the host waited for did not run (mailbox %s, slot %d: sequence %llu "
+               "< expected %llu; ticket %llu, pair_on %d, gate %s; E_surf %.17g E_bend %.17g in this mailbox)",
+               box, sl, (unsigned long long)__atomic_load_n(&c->h_seq[2 * sl + 1], __ATOMIC_ACQUIRE),
+               (unsigned long long)c->expected[sl], (unsigned long long)c->ticket, (int)c->pair_on,
+               c->cur_gate ? "set" : "none", c->h_scal[MS_S_ESURF], c->h_scal[MS_S_EBEND]);
+      return fail(c, MS_ERR_STATE, msg);
+    }
   return take_mailbox(c);
 }
 
@@ -1957,6 +2006,7 @@ int spec_prepare(ms_ctx* c) {
 }
 // make stage mailbox `m` the context's mailbox (and back: the swap is its own inverse)
 void swap_mailbox(ms_ctx* c, ms_ctx::Mailbox& m) {
+  if (trace_queue()) fprintf(stderr, "[msq] swap %s <-> %s\n", box_name(c, c->h_seq), box_name(c, m.h_seq));
   std::swap(c->h_scal, m.h_scal);
   std::swap(c->h_seq, m.h_seq);
   std::swap(c->d_h_seq, m.d_h_seq);
@@ -1982,7 +2032,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
                        (c->factors_valid || !(c->params.modules & (MS_MOD_BENDING | MS_MOD_BENDING_TILT)));
   const bool constraint = (c->params.modules & (MS_CON_VOLUME | MS_TILT_SHAPE_MODS)) != 0;
   int rc;
-  bool restart_sd = false;
+  bool restart_sd = false, kc_taken = false;
   if (carried && c->grad_valid && !constraint && c->til.T <= 256) {
     // x has not moved since the last gradient pass (failed search, stepper reset): only the
     // direction changes.  k_direction on the finalized g repeats the fused epilogue's
@@ -2006,15 +2056,28 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     // (gated on the acceptance) and has run: take its scalars from its mailbox
     c->kc_pending = false;
     swap_mailbox(c, c->grad_mb);
-    rc = fetch(c);
+    bool missed = false;
+    rc = fetch(c, &missed);
     double vals[MS_NSCAL];
     for (int sl = 0; sl < MS_NSCAL; ++sl) vals[sl] = c->h_scal[sl];
     swap_mailbox(c, c->grad_mb);
-    for (int sl = 0; sl < MS_NSCAL; ++sl)
-      if (MASK_DIR & (1u << sl)) put_mailbox(c, sl, vals[sl]);
-    c->last_g = c->buf[MS_BUF_G];
-    c->dir_implicit = false;
-    c->maxg2_valid = true;
+    if (rc == MS_OK && missed) {
+      // The queued pass found its gate closed although the host accepted the trial: host and device did not see the
+      // same reduced energies.  Never observed in plain runs; seen under rocprofv3 --pmc, whose dispatch
+      // serialisation let the first workgroups of the gated kernel start before the preceding fold's scalars were
+      // visible.  The pass only writes G / D of the accepted state from x, the factors and the CG history, all intact:
+      // redo it without the gate.
+      ++c->queue_fallbacks;
+      rc = queue_energy_and_gradient(c, sp->stepper, use_history, carried);
+      c->maxg2_valid = !constraint;
+    } else {
+      for (int sl = 0; sl < MS_NSCAL; ++sl)
+        if (MASK_DIR & (1u << sl)) put_mailbox(c, sl, vals[sl]);
+      c->last_g = c->buf[MS_BUF_G];
+      c->dir_implicit = false;
+      c->maxg2_valid = true;
+      kc_taken = true;
+    }
   } else {
     c->kc_pending = false;
     rc = queue_energy_and_gradient(c, sp->stepper, use_history, carried);
@@ -2025,6 +2088,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     rc = fetch(c);
     if (rc) return rc;
   }
+  (void)kc_taken;
   // factors, mailbox energies and G now describe x (until a trial pass overwrites them)
   c->carry_valid = carry_mode;
   c->grad_valid = carry_mode && !constraint;

@@ -932,6 +932,12 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? 4 : 1) MS_WPE_GRADIENT void k
       }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.gate_out) *a.gate_out = run ? 1 : 0;
+#if MS_STAMPS
+    if (threadIdx.x == 0) {  // what this workgroup's gate saw (queue diagnostics)
+      g_stamps[8 * (size_t)blockIdx.x + 6] = (unsigned long long)__double_as_longlong(E_last);
+      g_stamps[8 * (size_t)blockIdx.x + 7] = run ? 1ull : 0ull;
+    }
+#endif
     if (!run) return;
   }
 

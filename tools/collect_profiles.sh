@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): rocprofv3 kernel stats + PMC passes of the bench command.
 # Usage: tools/collect_profiles.sh <tag>      -> gpurun_out/<tag>_*
-set -e
+set +e
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
