@@ -22,6 +22,10 @@
 
 #include "ms_internal.h"
 
+#ifndef MS_RSQRT_NORM
+#define MS_RSQRT_NORM 1  // facet normal length and its reciprocal from one refined rsqrt (norm_and_inverse)
+#endif
+
 namespace ms {
 
 // ---------------------------------------------------------------------------
@@ -191,6 +195,21 @@ __device__ __forceinline__ double axpy1(double x, double alpha, double d) {
 #else
   return fma(alpha, d, x);
 #endif
+}
+
+// |n| and 1/|n| from ONE reciprocal square root refined twice (v_rsq_f64 + two Newton steps: ~9 instructions instead
+// of the ~24 of an fp64 sqrt followed by an fp64 division); both within an ulp or two of the correctly rounded values.
+// n2 <= 1e-30 (|n| <= 1e-15, below every clamp of the reference): both 0.
+__device__ __forceinline__ void norm_and_inverse(double n2, double& nrm, double& inv) {
+  double rs = 0.0;
+  if (n2 > 1.0e-30) {
+    rs = __builtin_amdgcn_rsq(n2);
+    const double hn = 0.5 * n2;
+    rs = rs * fma(-hn, rs * rs, 1.5);
+    rs = rs * fma(-hn, rs * rs, 1.5);
+  }
+  nrm = n2 * rs;
+  inv = rs;
 }
 
 __device__ __forceinline__ V3 lds_v3(const double* base, int cap, int slot) {
@@ -510,7 +529,12 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
         const V3 e0 = v2 - v1, e1 = v0 - v2, e2 = v1 - v0;
         const double l0 = dot(e0, e0), l1 = dot(e1, e1), l2 = dot(e2, e2);
         const V3 n = cross(e2, -e1);  // (v1-v0) x (v2-v0) == e1 x e2
+#if MS_RSQRT_NORM
+        double A2, inv_A2;
+        norm_and_inverse(dot(n, n), A2, inv_A2);
+#else
         const double A2 = norm(n);
+#endif
         if (owner) {
           if (want_surf && A2 >= 1.0e-12) e_surf += gam * (0.5 * A2);
           if (want_vol && (tf.flags & TF_BODY)) vol += dot(cross(v1, v2), v0);
@@ -533,7 +557,11 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
         if (BEND) {
           // tilt_kernels.f90:133-151 with area_doubled = max(|n|, 1e-12)
           const double ad = A2 < 1.0e-12 ? 1.0e-12 : A2;
+#if MS_RSQRT_NORM
+          const double inv_ad = A2 < 1.0e-12 ? 1.0e12 : inv_A2;
+#else
           const double inv_ad = 1.0 / ad;
+#endif
           const double tri_area = 0.5 * ad;
           const double c0 = dot(-e1, e2) * inv_ad, c1 = dot(-e2, e0) * inv_ad, c2 = dot(-e0, e1) * inv_ad;
           corner_areas(c0, c1, c2, l0, l1, l2, tri_area, va0, va1, va2);
@@ -1118,7 +1146,12 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? 4 : 1) MS_WPE_GRADIENT void k
       const V3 e1 = v0 - v2, e2 = v1 - v0;
       V3 G0 = mk(0, 0, 0), G1 = mk(0, 0, 0), G2 = mk(0, 0, 0);
       const V3 n = cross(e1, e2);
+#if MS_RSQRT_NORM
+      double S, rs;
+      norm_and_inverse(dot(n, n), S, rs);
+#else
       const double S = norm(n);
+#endif
       // Every geometric contribution of this facet has the form
       //     G_k = (a_k1 e1 + a_k2 e2) + R (e_k x n) [+ the -L fK difference vectors]:
       // surface: -(gamma/2S) (e_k x n); grad-cot corner k with weight w_k: +-(w_k/S) e_j and
@@ -1126,7 +1159,11 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? 4 : 1) MS_WPE_GRADIENT void k
       // scalar R for all three vertices (sum_k e_k = 0); obtuse area term: -(factor/2S) (e_k x n); the six edge
       // terms q_k e_k.  Collecting scalars first leaves 2 cross products and ~10 vector FMAs per facet instead
       // of 9 cross products; sum_k G_k = 0 (translation invariance) gives the third vertex for free.
+#if MS_RSQRT_NORM
+      const double invS = rs;
+#else
       const double invS = S > 1.0e-15 ? 1.0 / S : 0.0;
+#endif
       double R = 0.0;                       // coefficient of (e_k x n)
       double a01 = 0, a02 = 0, a11 = 0, a12 = 0;  // e-part of G0, G1 in the basis (e1, e2)
       V3 T0 = mk(0, 0, 0), T1 = mk(0, 0, 0);     // -L fK part of G0, G1
