@@ -2773,7 +2773,7 @@ constexpr uint32_t SH_ENERGY = (1u << MS_S_ESURF) | (1u << MS_S_VOL) | (1u << MS
 constexpr uint32_t SH_GRAD = (1u << MS_S_GGC) | (1u << MS_S_GCGC);
 constexpr uint32_t SH_DIR = (1u << MS_S_GNORM2) | (1u << MS_S_GDOTD) | (1u << MS_S_MAXD2) | (1u << MS_S_MAXG2);
 
-// One exchange: boundary rows of `ids` + the 16 scalars of every rank; `slots` of the
+// One exchange: boundary rows of `ids` + the MS_NSCAL scalars of every rank; `slots` of the
 // rank-ordered fold go to c->sh_scal (push: also to the device scalars).
 int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push, bool fold_alt = false) {
   double* p[4];

@@ -2612,7 +2612,7 @@ hipError_t launch_row_dot(int tile0, int tile1, int nv, int T, const double* g, 
 
 // ---------------------------------------------------------------------------
 // Shard boundary exchange (multi-GPU): a rank's BOUNDARY rows are the rows it owns that some
-// other rank's tiles list as halo.  pack: send = [16 reduction scalars | boundary rows of up
+// other rank's tiles list as halo.  pack: send = [MS_NSCAL reduction scalars | boundary rows of up
 // to 4 per-vertex buffers, interleaved per row]; after the all-gather, unpack scatters every
 // peer's rows into the local buffers and lifts the per-rank scalar headers into one array.
 // ---------------------------------------------------------------------------

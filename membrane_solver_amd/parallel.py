@@ -10,7 +10,7 @@ the HALO rows of its tiles (a thin band along the patch border: the patch order
 is a Hilbert curve, so a rank's rows form a compact surface patch).
 
 One exchange = one fixed-size all-gather per rank of
-    [16 reduction scalars | this rank's BOUNDARY rows of the listed buffers]
+    [MS_NSCAL reduction scalars | this rank's BOUNDARY rows of the listed buffers]
 (boundary rows = rows it owns that other ranks read as halo; a few thousand rows
 of a million).  Every rank scatters the peers' rows into its buffers and folds the
 scalar headers on the host in rank order, so all ranks take identical Armijo

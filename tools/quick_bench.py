@@ -57,12 +57,16 @@ for i in range(ap_warm):
     if i < 60 or i % 10 == 0:
         print(f"  warm {i}: ok={r.success} trials={r.trials} guard={r.guard_rejects} alpha={r.alpha:.3e} next={r.next_step:.3e} E={r.energy:.12f} |g|={r.grad_norm:.3e} gd={r.g_dot_d:.3e}", flush=True)
     step = r.next_step
+    if not r.success:  # what minimize() does after a failed search (minimizer.py:1414-1426)
+        dm.reset_stepper()
 t = time.time()
 acc = 0
 trials = 0
 for _ in range(args.steps):
     r = dm.step(stepper=stp, step_size=step)
     step = r.next_step
+    if not r.success:
+        dm.reset_stepper()
     acc += r.success
     trials += r.trials
 dt = (time.time() - t) / args.steps
