@@ -44,6 +44,12 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
   return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 __device__ __forceinline__ double norm(V3 a) { return sqrt(dot(a, a)); }
+// min of two values known not to be signalling NaNs: one v_min_f64 (fmin() canonicalises both operands first)
+__device__ __forceinline__ double min_plain(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 constexpr int BLOCK = 256;
 constexpr int NXCD = 8;
@@ -267,6 +273,12 @@ __device__ __forceinline__ TileCtx tile_ctx(const DeviceMesh& m, int tile) {
 #ifndef MS_WPE_GRADIENT
 #define MS_WPE_GRADIENT
 #endif
+#ifndef MS_KA_SLOTS
+#define MS_KA_SLOTS 5  // workgroups per CU the headline k_energy instances are compiled for
+#endif
+#ifndef MS_LEAN_SLOTS
+#define MS_LEAN_SLOTS 5  // workgroups per CU the lean k_gradient instance is compiled for (<= 96 VGPRs)
+#endif
 constexpr int CSR_REGS = 12;  // entries per thread held in registers (T=256: 3072 entries)
 struct CsrStage {
   uint16_t vo0, vo1;  // this vertex's entry range [vo0, vo1) (offset row of the tile)
@@ -340,7 +352,7 @@ __device__ unsigned long long g_stamps[8 * 16384];
 #define MS_STAMP_ID() do {} while (0)
 #endif
 template <bool BEND, bool GUARD, int TT, int CAPC, bool ATOMIC, int MULTI = 0>
-__global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyArgs a, int cap_rt, int max_ent) {
+__global__ __launch_bounds__(TT ? TT : 512, (TT == 256 && BEND && !GUARD && ATOMIC) ? MS_KA_SLOTS : 1) MS_WPE_ENERGY void k_energy(EnergyArgs a, int cap_rt, int max_ent) {
   extern __shared__ double lds[];
   int bid = blockIdx.x;
   if (MULTI) {
@@ -538,7 +550,7 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
         if (owner) {
           if (want_surf && A2 >= 1.0e-12) e_surf += gam * (0.5 * A2);
           if (want_vol && (tf.flags & TF_BODY)) vol += dot(cross(v1, v2), v0);
-          min_e2 = fmin(min_e2, fmin(l0, fmin(l1, l2)));
+          min_e2 = min_plain(min_e2, min_plain(l0, min_plain(l1, l2)));
           if (GUARD) {
             const V3 o0 = lds_row3(ox, tf.l0), o1 = lds_row3(ox, tf.l1), o2 = lds_row3(ox, tf.l2);
             const V3 no = cross(o1 - o0, o2 - o0);
@@ -572,26 +584,25 @@ __global__ __launch_bounds__(TT ? TT : 512) MS_WPE_ENERGY void k_energy(EnergyAr
           const double ta_eff = fmax(0.5 * A2, 1.0e-12);
           if (ta_eff != tri_area) corner_areas(c0, c1, c2, l0, l1, l2, ta_eff, ve0, ve1, ve2);
           // bending_utils.py:121-153 boundary -> interior redistribution
-          int b0 = 0, b1 = 0, b2 = 0;
-          if (a.m.has_boundary) {  // uniform: closed surfaces skip the flag reads entirely
-            b0 = (lfl[tf.l0] & VF_BOUNDARY) ? 1 : 0;
-            b1 = (lfl[tf.l1] & VF_BOUNDARY) ? 1 : 0;
-            b2 = (lfl[tf.l2] & VF_BOUNDARY) ? 1 : 0;
-          }
-          const int n_int = 3 - (b0 + b1 + b2);
-          if (n_int > 0 && n_int < 3) {
-            const double b_sum = ve0 * b0 + ve1 * b1 + ve2 * b2;
-            const double extra = b_sum / (double)n_int;
-            const double m0 = b0 ? 0.0 : 1.0, m1 = b1 ? 0.0 : 1.0, m2 = b2 ? 0.0 : 1.0;
-            ve0 = ve0 * m0 + m0 * extra;
-            ve1 = ve1 * m1 + m1 * extra;
-            ve2 = ve2 * m2 + m2 * extra;
+          if (a.m.has_boundary) {  // uniform: closed surfaces skip the whole block
+            const int b0 = (lfl[tf.l0] & VF_BOUNDARY) ? 1 : 0;
+            const int b1 = (lfl[tf.l1] & VF_BOUNDARY) ? 1 : 0;
+            const int b2 = (lfl[tf.l2] & VF_BOUNDARY) ? 1 : 0;
+            const int n_int = 3 - (b0 + b1 + b2);
+            if (n_int > 0 && n_int < 3) {
+              const double b_sum = ve0 * b0 + ve1 * b1 + ve2 * b2;
+              const double extra = b_sum / (double)n_int;
+              const double m0 = b0 ? 0.0 : 1.0, m1 = b1 ? 0.0 : 1.0, m2 = b2 ? 0.0 : 1.0;
+              ve0 = ve0 * m0 + m0 * extra;
+              ve1 = ve1 * m1 + m1 * extra;
+              ve2 = ve2 * m2 + m2 * extra;
+            }
           }
           // K0 + K1 + K2 = 0 for every facet (each edge term enters two corners with opposite sign)
           const double hc0 = 0.5 * c0, hc1 = 0.5 * c1, hc2 = 0.5 * c2;
           const V3 K0 = hc2 * e2 - hc1 * e1;
           const V3 K1 = hc0 * e0 - hc2 * e2;
-          const V3 K2 = -(K0 + K1);
+          const V3 K2 = mk(-K0.x - K1.x, -K0.y - K1.y, -K0.z - K1.z);
           if (ATOMIC) {
             const int no = t.n_owned;
             if (tf.l0 < no) {
@@ -818,7 +829,9 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
   // tile instead of twelve and half the LDS traffic, at the price of a summation order that
   // varies from run to run (ms_set_deterministic).  Without bending there are no vertex sums.
   const bool atomic = a.atomic != 0 && bend;
-  const size_t lds = energy_lds_bytes(a.m.T, cap, max_ent, bend, guard, a.m.has_boundary != 0, atomic);
+  // MS_KA_LDS_MIN=<bytes>: diagnostic -- request at least this much LDS per workgroup (caps the workgroups per CU)
+  static const size_t lds_min = getenv("MS_KA_LDS_MIN") ? (size_t)atol(getenv("MS_KA_LDS_MIN")) : 0;
+  const size_t lds = std::max(lds_min, energy_lds_bytes(a.m.T, cap, max_ent, bend, guard, a.m.has_boundary != 0, atomic));
   hipError_t e;
 #define MS_LAUNCH_E(B, G, TT, CC, AT)                                                              \
   do {                                                                                             \
@@ -920,7 +933,7 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
 // previous-direction rows (dir_mode != 2, or pd = -pg after an implicit steepest-descent step): 8 registers fewer live
 // through the facet loop, which is what lets the kernel fit 128 VGPRs = 4 resident workgroups per CU instead of 3.
 template <int BENDMODE, bool VOLROW, int TT, int CAPC, bool ATOMIC, bool LEAN = false>
-__global__ __launch_bounds__(TT ? TT : 512, LEAN ? 4 : 1) MS_WPE_GRADIENT void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
+__global__ __launch_bounds__(TT ? TT : 512, LEAN ? MS_LEAN_SLOTS : 1) MS_WPE_GRADIENT void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
   extern __shared__ double lds[];
   constexpr bool BEND = BENDMODE != 0;
   // BENDMODE 3: leaflet bending_tilt (bt_gradient.py:89-389): analytic back-propagation whose effective-area
@@ -1046,8 +1059,12 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? 4 : 1) MS_WPE_GRADIENT void k
       lds_put3(px, tid, x0, x1, x2);
       if (BEND) {
         lds_put3(fk, tid, k0, k1, k2);
-        fa[2 * tid] = ae;
-        fa[2 * tid + 1] = av;
+        if (LEAN) {
+          fa[tid] = ae + av;  // the lean instance needs only C = fA_eff + fA_vor (no boundary rows, no leaflet factor)
+        } else {
+          fa[2 * tid] = ae;
+          fa[2 * tid + 1] = av;
+        }
       }
       if (LEAF) {
         kp[tid] = okp;
@@ -1067,8 +1084,12 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? 4 : 1) MS_WPE_GRADIENT void k
       lds_put3(px, s, hx0, hx1, hx2);
       if (BEND) {
         lds_put3(fk, s, hk0, hk1, hk2);
-        fa[2 * s] = hae;
-        fa[2 * s + 1] = hav;
+        if (LEAN) {
+          fa[s] = hae + hav;
+        } else {
+          fa[2 * s] = hae;
+          fa[2 * s + 1] = hav;
+        }
       }
       if (LEAF) {
         kp[s] = hkp;
@@ -1087,7 +1108,9 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? 4 : 1) MS_WPE_GRADIENT void k
         if (BEND) fk[3 * s + c] = a.fK[3 * (size_t)v + c];
         if (LEAF) tl[c * cap + s] = a.tilts[3 * (size_t)v + c];
       }
-      if (BEND) {
+      if (BEND && LEAN) {
+        fa[s] = a.fA[2 * (size_t)v] + a.fA[2 * (size_t)v + 1];
+      } else if (BEND) {
         fa[2 * s] = LEAF ? a.bt_vert[4 * (size_t)v] : a.fA[2 * (size_t)v];
         fa[2 * s + 1] = a.fA[2 * (size_t)v + 1];
       }
@@ -1130,7 +1153,7 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? 4 : 1) MS_WPE_GRADIENT void k
   for (int c0f = t.f0; c0f < (MS_ABL_NOLOOP ? t.f0 : t.f1); c0f += T) {
     const int p = c0f + tid;
     const TileFacet tf = tf_nx;
-    const double gam = gam_nx;
+    const double gam = LEAN ? a.m.gamma_const : gam_nx;  // (lean: a kernel argument, no vector register)
     if (p + T < t.f1) {
       tf_nx = a.m.tile_facets[p + T];
       if (!LEAN) gam_nx = a.m.gamma_uniform ? a.m.gamma_const : a.m.tf_gamma[p + T];
@@ -1168,7 +1191,7 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? 4 : 1) MS_WPE_GRADIENT void k
       double a01 = 0, a02 = 0, a11 = 0, a12 = 0;  // e-part of G0, G1 in the basis (e1, e2)
       V3 T0 = mk(0, 0, 0), T1 = mk(0, 0, 0);     // -L fK part of G0, G1
       if (surf && S >= 1.0e-12) R = -(0.5 * gam) * invS;  // g_k = gamma/2 (v_{k+1}-v_{k+2}) x nhat
-      if ((VOLROW || volpen) && (tf.flags & TF_BODY)) {
+      if (!LEAN && (VOLROW || volpen) && (tf.flags & TF_BODY)) {
         const V3 w0 = cross(v1, v2), w1 = cross(v2, v0), w2 = cross(v0, v1);
         if (volpen) {
           G0 = G0 + pen_factor * w0;
@@ -1209,14 +1232,16 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? 4 : 1) MS_WPE_GRADIENT void k
         const double inv_ad = S < 1.0e-12 ? 1.0e12 : invS;  // 1 / max(S, 1e-12)
         const double l1 = dot(e1, e1), l2 = dot(e2, e2), d12 = dot(e1, e2);
         const double d20 = -(d12 + l2), d01 = -(l1 + d12);  // e2.e0, e0.e1
-        const double c0 = -d12 * inv_ad, c1 = -d20 * inv_ad, c2 = -d01 * inv_ad;
+        // half cotans (cot_k = -d / max(S, 1e-12)); the powers of two of the formulas below are folded into as few
+        // factors as possible -- exact scalings, so the values are those of the formulas as written in the reference
+        const double h_inv = 0.5 * inv_ad;
+        const double hc0 = -d12 * h_inv, hc1 = -d20 * h_inv, hc2 = -d01 * h_inv;
         // term 1: -L fK  (bending_kernels.f90:118-129): G0 -= b + c, G1 -= a - c, G2 += a + b, and the term-2
         // weights (bending_gradient.py:37-42; (v1-v2) == -e0 etc.), one component of fK at a time so that the
         // nine factor values are never all live
         double w0 = 0.0, w1 = 0.0, w2 = 0.0;
         MS_SCHED_FENCE();
         {
-          const double hc0 = 0.5 * c0, hc1 = 0.5 * c1, hc2 = 0.5 * c2;
 #if MS_ABL_NOGATHER
           const double kk[9] = {gam, tf.l0 * 1e-3, 2.0, tf.l1 * 1e-3, 1.5, gam, 0.75, gam, tf.l2 * 1e-3};
           const double *r0 = kk, *r1 = kk + 3, *r2 = kk + 6;
@@ -1232,7 +1257,7 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? 4 : 1) MS_WPE_GRADIENT void k
             t0[c] = -(hc1 * f02 + hc2 * f01);
             t1[c] = hc2 * f01 - hc0 * f12;
             w0 -= f12 * (e1c[c] + e2c[c]);  // f12 . e0
-            w1 += f02 * e1c[c];
+            w1 -= f02 * e1c[c];
             w2 += f01 * e2c[c];
           }
           T0 = mk(t0[0], t0[1], t0[2]);
@@ -1240,12 +1265,10 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? 4 : 1) MS_WPE_GRADIENT void k
         }
         MS_SCHED_FENCE();
         if (ANALYTIC) {
-          w0 = 0.5 * w0;
-          w1 = -0.5 * w1;
-          w2 = 0.5 * w2;
+          // from here on w_k stands for TWICE the weight of grad cot_k (the halves go into hS below)
           // term 3 coefficients (bending_gradient.py:80-95)
           int t0 = 1, t1 = 1, t2 = 1;
-          if (a.m.has_boundary) {
+          if (!LEAN && a.m.has_boundary) {
             t0 = (lfl[tf.l0] & VF_BOUNDARY) ? 0 : 1;
             t1 = (lfl[tf.l1] & VF_BOUNDARY) ? 0 : 1;
             t2 = (lfl[tf.l2] & VF_BOUNDARY) ? 0 : 1;
@@ -1255,10 +1278,17 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? 4 : 1) MS_WPE_GRADIENT void k
           double fe0 = gam, fe1 = 2 * gam, fe2 = 3 * gam;
           const double fv0 = gam, fv1 = gam, fv2 = gam;
 #else
-          // (fA_eff, fA_vor) of a corner is one 16-byte row
-          const double2 fa0 = *reinterpret_cast<const double2*>(fa + 2 * tf.l0);
-          const double2 fa1 = *reinterpret_cast<const double2*>(fa + 2 * tf.l1);
-          const double2 fa2 = *reinterpret_cast<const double2*>(fa + 2 * tf.l2);
+          // (fA_eff, fA_vor) of a corner is one 16-byte row; the lean instance staged their sum
+          double2 fa0, fa1, fa2;
+          if (LEAN) {
+            fa0 = make_double2(fa[tf.l0], 0.0);
+            fa1 = make_double2(fa[tf.l1], 0.0);
+            fa2 = make_double2(fa[tf.l2], 0.0);
+          } else {
+            fa0 = *reinterpret_cast<const double2*>(fa + 2 * tf.l0);
+            fa1 = *reinterpret_cast<const double2*>(fa + 2 * tf.l1);
+            fa2 = *reinterpret_cast<const double2*>(fa + 2 * tf.l2);
+          }
           double fe0 = fa0.x, fe1 = fa1.x, fe2 = fa2.x;
           const double fv0 = fa0.y, fv1 = fa1.y, fv2 = fa2.y;
 #endif
@@ -1279,36 +1309,40 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? 4 : 1) MS_WPE_GRADIENT void k
             fe1 = 0.5 * kp[tf.l1] * (u1 * u1);
             fe2 = 0.5 * kp[tf.l2] * (u2 * u2);
           }
-          const double avg = cnt > 0 ? (fe0 * t0 + fe1 * t1 + fe2 * t2) / (double)cnt : 0.0;
-          const double C0 = (t0 ? fe0 : avg) + fv0;
-          const double C1 = (t1 ? fe1 : avg) + fv1;
-          const double C2 = (t2 ? fe2 : avg) + fv2;
-          const bool obtuse = (c0 < 0.0) || (c1 < 0.0) || (c2 < 0.0);
+          double C0 = LEAN ? fe0 : fe0 + fv0, C1 = LEAN ? fe1 : fe1 + fv1, C2 = LEAN ? fe2 : fe2 + fv2;
+          if (!LEAN && cnt < 3) {  // some corner on the boundary: it takes the interior corners' mean
+            const double avg = cnt > 0 ? (fe0 * t0 + fe1 * t1 + fe2 * t2) / (double)cnt : 0.0;
+            C0 = (t0 ? fe0 : avg) + fv0;
+            C1 = (t1 ? fe1 : avg) + fv1;
+            C2 = (t2 ? fe2 : avg) + fv2;
+          }
+          const bool obtuse = (hc0 < 0.0) || (hc1 < 0.0) || (hc2 < 0.0);
           double q0 = 0.0, q1 = 0.0, q2 = 0.0;
           if (!obtuse) {
             // six edge terms (:107-124): G0 += q1 e1 - q2 e2, G1 += q2 e2 - q0 e0, G2 += q0 e0 - q1 e1;
             // the second grad_cotan family (bending_math.py:244-249) has the same arguments as the
             // first, so its weights (:126-152) fold into w_k.
-            q0 = 0.25 * c0 * (C1 + C2);
-            q1 = 0.25 * c1 * (C0 + C2);
-            q2 = 0.25 * c2 * (C0 + C1);
-            w0 += 0.125 * ((l1 + l2) + 2.0 * d12) * (C1 + C2);  // |e0|^2
-            w1 += 0.125 * l1 * (C0 + C2);
-            w2 += 0.125 * l2 * (C0 + C1);
+            const double s0 = 0.5 * (C1 + C2), s1 = 0.5 * (C0 + C2), s2 = 0.5 * (C0 + C1);
+            q0 = hc0 * s0;  // 1/4 cot_0 (C1 + C2)
+            q1 = hc1 * s1;
+            q2 = hc2 * s2;
+            w0 += (0.5 * ((l1 + l2) + 2.0 * d12)) * s0;  // 2 * 1/8 |e0|^2 (C1 + C2)
+            w1 += (0.5 * l1) * s1;
+            w2 += (0.5 * l2) * s2;
           } else {
             // (:154-173) grad T with u = v1-v0, v = v2-v0: +factor/(2S) (n x e_k) at vertex k
             double factor = 0.0;
-            if (c0 < 0.0) factor += 0.5 * C0 + 0.25 * C1 + 0.25 * C2;
-            if (c1 < 0.0) factor += 0.5 * C1 + 0.25 * C0 + 0.25 * C2;
-            if (c2 < 0.0) factor += 0.5 * C2 + 0.25 * C0 + 0.25 * C1;
+            if (hc0 < 0.0) factor += 0.5 * C0 + 0.25 * C1 + 0.25 * C2;
+            if (hc1 < 0.0) factor += 0.5 * C1 + 0.25 * C0 + 0.25 * C2;
+            if (hc2 < 0.0) factor += 0.5 * C2 + 0.25 * C0 + 0.25 * C1;
             R -= (0.5 * factor) * invS;
           }
           // grad cot at corner k (bending_kernels.f90:32-74 with w = n for every corner):
           //   corner 0 -> G1 += w0 gu, G2 += w0 gv, G0 -= w0 (gu + gv), gu = -e1/S + kk0 (e1 x n), gv = e2/S + kk0 (e2 x n)
           //   (cyclic); kk_k = cot_k / S^2
-          const double invS2 = invS * invS;
-          const double p0 = w0 * invS, p1 = w1 * invS, p2 = w2 * invS;
-          R += ((w0 * (-d12) + w1 * (-d20)) + w2 * (-d01)) * (invS2 * invS);
+          const double invS2 = invS * invS, hS = 0.5 * invS;
+          const double p0 = w0 * hS, p1 = w1 * hS, p2 = w2 * hS;
+          R += ((w0 * (-d12) + w1 * (-d20)) + w2 * (-d01)) * (invS2 * hS);
           a01 = ((p0 + q1) - p1) + p2;
           a02 = ((-p0 - q2) - p1) + p2;
           a11 = ((p2 - p0) + p1) + q0;
@@ -1321,9 +1355,15 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? 4 : 1) MS_WPE_GRADIENT void k
         const V3 X1 = cross(e1, Rn), X2 = cross(e2, Rn);
         const V3 H0 = (T0 + (a01 * e1 + a02 * e2)) - (X1 + X2);  // e0 x n = -(e1 + e2) x n
         const V3 H1 = (T1 + (a11 * e1 + a12 * e2)) + X1;
-        G0 = G0 + H0;
-        G1 = G1 + H1;
-        G2 = G2 - (H0 + H1);
+        if (LEAN) {  // nothing was accumulated before (no volume terms in the lean instance)
+          G0 = H0;
+          G1 = H1;
+          G2 = mk(-H0.x - H1.x, -H0.y - H1.y, -H0.z - H1.z);
+        } else {
+          G0 = G0 + H0;
+          G1 = G1 + H1;
+          G2 = G2 - (H0 + H1);
+        }
       }
 #if MS_ABL_NOATOM
       if (ATOMIC) {
@@ -1477,7 +1517,8 @@ bool gradient_lean_instance(const GradientArgs& a) {
   const bool volrow = a.gC != nullptr && (a.modules & MS_CON_VOLUME);
   const bool leaf = bend && a.bt_vert != nullptr;
   return a.m.T == FAST_T && a.atomic != 0 && !volrow && !leaf && bend && a.bending_grad_mode != MS_GRAD_APPROX &&
-         a.m.gamma_uniform && (a.dir_mode != 2 || a.pd_neg_pg) && !no_lean();
+         a.m.gamma_uniform && !a.m.has_boundary && !(a.modules & MS_MOD_VOLUME_PENALTY) &&
+         (a.dir_mode != 2 || a.pd_neg_pg) && !no_lean();
 }
 
 hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStream_t s) {
