@@ -93,8 +93,49 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
   }
   out.perm.resize(nv);
   std::iota(out.perm.begin(), out.perm.end(), 0);
-  std::stable_sort(out.perm.begin(), out.perm.end(),
-                   [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+  static const int tile_order = getenv("MS_TILE_ORDER") ? atoi(getenv("MS_TILE_ORDER")) : 1;
+  if (tile_order == 0) {
+    std::stable_sort(out.perm.begin(), out.perm.end(),
+                     [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+  } else {
+    // Recursive coordinate bisection down to single tiles: a range of whole tiles is split, at a tile boundary
+    // nearest its middle, by the median along the longest axis of its bounding box.  The leaves are compact patches
+    // (fewer facets shared with other tiles than runs of a 3-D Hilbert curve, which crosses a 2-D surface
+    // irregularly), and the left-to-right leaf order keeps neighbouring tiles close in the tile sequence (the XCD
+    // and shard ranges are contiguous tile ranges).  Inside a tile the vertices keep their Hilbert order.
+    struct Range { int lo, hi; };
+    std::vector<Range> stack;
+    stack.push_back({0, nv});
+    while (!stack.empty()) {
+      const Range r = stack.back();
+      stack.pop_back();
+      const int n = r.hi - r.lo;
+      const int tiles = (n + T - 1) / T;
+      if (tiles <= 1) {
+        std::sort(out.perm.begin() + r.lo, out.perm.begin() + r.hi,
+                  [&](int32_t a, int32_t b) { return key[a] < key[b] || (key[a] == key[b] && a < b); });
+        continue;
+      }
+      double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+      for (int i = r.lo; i < r.hi; ++i)
+        for (int d = 0; d < 3; ++d) {
+          const double p = positions[3 * (size_t)out.perm[i] + d];
+          blo[d] = std::min(blo[d], p);
+          bhi[d] = std::max(bhi[d], p);
+        }
+      int ax = 0;
+      for (int d = 1; d < 3; ++d)
+        if (bhi[d] - blo[d] > bhi[ax] - blo[ax]) ax = d;
+      const int mid = r.lo + (tiles / 2) * T;
+      std::nth_element(out.perm.begin() + r.lo, out.perm.begin() + mid, out.perm.begin() + r.hi,
+                       [&](int32_t a, int32_t b) {
+                         const double pa = positions[3 * (size_t)a + ax], pb = positions[3 * (size_t)b + ax];
+                         return pa < pb || (pa == pb && a < b);
+                       });
+      stack.push_back({mid, r.hi});
+      stack.push_back({r.lo, mid});
+    }
+  }
   out.iperm.resize(nv);
   for (int i = 0; i < nv; ++i) out.iperm[out.perm[i]] = i;
 
