@@ -581,7 +581,10 @@ def main_sharded(args, rank, world, local_rank):
                                    + (f"; WEAK scaling: ~2 048 000 facets per GPU, {nf} in all" if args.weak else ""),
                        "parallelism": f"tiles (facet blocks) sharded over {world} GPUs; per exchange one RCCL "
                                       f"all-gather of [{L.MS_NSCAL} scalars | <= {be.boundary['max_rows']} boundary rows] "
-                                      f"per rank; driver: {driver}",
+                                      f"per rank" + ("" if be.exchange_mode == "halo" else
+                                                     " -- MS_SHARD_EXCHANGE=dense: scalars only, and a dense RCCL "
+                                                     "all-reduce of every exchanged per-vertex vector (the simple "
+                                                     "mode kept for comparison)") + f"; driver: {driver}",
                        "tile_vertices": args.tile or 256, "initial_step_size": args.step_size,
                        "deterministic": bool(args.deterministic)},
             "steps_accepted": acc, "line_search_trials": trials,

@@ -34,6 +34,7 @@ struct ms_ctx {
   int32_t* d_perm = nullptr;
   int32_t* d_tile_facet_off = nullptr;
   TileFacet* d_tile_facets = nullptr;
+  uint32_t* d_tile_facets32 = nullptr;  // packed copy (DeviceMesh::tile_facets32), or nullptr
   double* d_tf_gamma = nullptr;
   // Body's cached volume gradient (geometry/body.py:386-407): what the last fresh evaluation inside
   // ms_project_volume computed, and its squared norm
@@ -239,6 +240,7 @@ DeviceMesh device_mesh(const ms_ctx* c) {
   m.has_boundary = c->has_boundary ? 1 : 0;
   m.tile_facet_off = c->d_tile_facet_off;
   m.tile_facets = c->d_tile_facets;
+  m.tile_facets32 = c->d_tile_facets32;
   m.tf_gamma = c->d_tf_gamma;
   m.gamma_uniform = c->gamma_uniform ? 1 : 0;
   m.gamma_const = c->gamma_const;
@@ -1038,6 +1040,14 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
   CREATE_CHK(upload(c, &c->d_perm, t.perm));
   CREATE_CHK(upload(c, &c->d_tile_facet_off, t.tile_facet_off));
   CREATE_CHK(upload(c, &c->d_tile_facets, t.tile_facets));
+  if (t.T + t.max_halo <= 1024) {
+    std::vector<uint32_t> packed(t.tile_facets.size());
+    for (size_t i = 0; i < packed.size(); ++i) {
+      const TileFacet& f = t.tile_facets[i];
+      packed[i] = (uint32_t)f.l0 | ((uint32_t)f.l1 << 10) | ((uint32_t)f.l2 << 20) | ((uint32_t)(f.flags & 3u) << 30);
+    }
+    CREATE_CHK(upload(c, &c->d_tile_facets32, packed));
+  }
   CREATE_CHK(upload(c, &c->d_tile_halo_off, t.tile_halo_off));
   CREATE_CHK(upload(c, &c->d_halo_ids, t.halo_ids));
   CREATE_CHK(upload(c, &c->d_tile_ent_off, t.tile_ent_off));
@@ -1161,7 +1171,7 @@ void ms_destroy(ms_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (!c->own_state) c->state = nullptr;
-  void* ptrs[] = {c->d_perm, c->d_tile_facet_off, c->d_tile_facets, c->d_tf_gamma, c->d_volgrad_cache,
+  void* ptrs[] = {c->d_perm, c->d_tile_facet_off, c->d_tile_facets, c->d_tile_facets32, c->d_tf_gamma, c->d_volgrad_cache,
                   c->d_tile_halo_off, c->d_halo_ids, c->d_tile_ent_off, c->d_tile_voff, c->d_vent,
                   c->d_vflags, c->d_kappa, c->d_c0, c->tf[0].tilts, c->tf[0].grad, c->tf[0].trial, c->d_bt_vert, c->d_tn, c->tf[0].dir, c->tf[0].minv,
                   c->tf[1].tilts, c->tf[1].grad, c->tf[1].trial, c->tf[1].dir, c->tf[1].minv,

@@ -246,6 +246,44 @@ __device__ __forceinline__ void lds_put3(double* rows, int slot, double x, doubl
 // No atomics: the summation order per vertex is fixed by the CSR, so results
 // are bitwise reproducible run to run.
 // ---------------------------------------------------------------------------
+// A tile's facet record as it travels from HBM to the loop that uses it: the 8-byte TileFacet, or (T = 256
+// instances) its 4-byte packed form, unpacked with three bit-field extracts where the slots are needed.
+template <bool PACKED>
+struct FacetRec {
+  TileFacet v;
+};
+template <>
+struct FacetRec<true> {
+  uint32_t v;
+};
+template <bool PACKED>
+__device__ __forceinline__ FacetRec<PACKED> facet_load(const DeviceMesh& m, size_t i) {
+  FacetRec<PACKED> r;
+  if constexpr (PACKED) r.v = m.tile_facets32[i];
+  else r.v = m.tile_facets[i];
+  return r;
+}
+template <bool PACKED>
+__device__ __forceinline__ FacetRec<PACKED> facet_null() {
+  FacetRec<PACKED> r;
+  if constexpr (PACKED) r.v = 0u;
+  else r.v = TileFacet{0, 0, 0, 0};
+  return r;
+}
+template <bool PACKED>
+__device__ __forceinline__ TileFacet facet_unpack(const FacetRec<PACKED>& r) {
+  if constexpr (PACKED) {
+    TileFacet f;
+    f.l0 = (uint16_t)(r.v & 1023u);
+    f.l1 = (uint16_t)((r.v >> 10) & 1023u);
+    f.l2 = (uint16_t)((r.v >> 20) & 1023u);
+    f.flags = (uint16_t)(r.v >> 30);
+    return f;
+  } else {
+    return r.v;
+  }
+}
+
 struct TileCtx {
   int tile, v_lo, n_owned, h0, nh, f0, f1, e0, n_ent;
 };
@@ -409,10 +447,11 @@ __global__ __launch_bounds__(TT ? TT : 512, (TT == 256 && BEND && !GUARD && ATOM
 
   // facet records are fetched one chunk ahead so their HBM latency overlaps the
   // staging / the previous chunk's arithmetic
-  TileFacet tf_nx = {0, 0, 0, 0};
+  constexpr bool PACKED = TT == 256;
+  FacetRec<PACKED> tf_nx = facet_null<PACKED>();
   double gam_nx = 0.0;
   if (t.f0 + tid < t.f1) {
-    tf_nx = a.m.tile_facets[t.f0 + tid];
+    tf_nx = facet_load<PACKED>(a.m, (size_t)(t.f0 + tid));
     gam_nx = a.m.gamma_uniform ? a.m.gamma_const : a.m.tf_gamma[t.f0 + tid];
   }
 
@@ -527,10 +566,10 @@ __global__ __launch_bounds__(TT ? TT : 512, (TT == 256 && BEND && !GUARD && ATOM
 
   for (int c0 = t.f0; c0 < t.f1; c0 += T) {
     const int p = c0 + tid;
-    const TileFacet tf = tf_nx;
+    const TileFacet tf = facet_unpack<PACKED>(tf_nx);
     const double gam = gam_nx;
     if (p + T < t.f1) {
-      tf_nx = a.m.tile_facets[p + T];
+      tf_nx = facet_load<PACKED>(a.m, (size_t)(p + T));
       gam_nx = a.m.gamma_uniform ? a.m.gamma_const : a.m.tf_gamma[p + T];
     }
     double va0 = 0, va1 = 0, va2 = 0, ve0 = 0, ve1 = 0, ve2 = 0;
@@ -683,7 +722,9 @@ __global__ __launch_bounds__(TT ? TT : 512, (TT == 256 && BEND && !GUARD && ATOM
     const double kappa = kappa_v, c0 = c0_v;
     const bool interior = !(own_fl & VF_BOUNDARY);
     const double safe = fmax(aAv, 1.0e-12);
-    const double k_mag = norm(K);
+    // |K| and 1/|K| from one refined rsqrt (as for the facet normals); |K| <= 1e-15 gives (0, 0) and the rare path
+    double k_mag, inv_k_mag;
+    norm_and_inverse(dot(K, K), k_mag, inv_k_mag);
     // one reciprocal serves H and the area ratio (each fp64 division is ~14 VALU instructions)
     const double inv_safe = 1.0 / safe;
     double H = k_mag * (0.5 * inv_safe);
@@ -731,7 +772,7 @@ __global__ __launch_bounds__(TT ? TT : 512, (TT == 256 && BEND && !GUARD && ATOM
       if (signed_h) {
         Kd = nh;
       } else if ((MS_ABL_KA & 2) || k_mag > 1.0e-15) {
-        const double inv_k = 1.0 / k_mag;
+        const double inv_k = (MS_ABL_KA & 2) ? 1.0 / k_mag : inv_k_mag;
         Kd = mk(K.x * inv_k, K.y * inv_k, K.z * inv_k);
       } else {
         // bending.py:154-158 falls back to the vertex normal (bending_utils.py:13-34)
@@ -824,7 +865,7 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
   const int nb = a.tile1 - a.tile0;
   if (nb <= 0) return hipSuccess;
   const bool bend = (a.modules & (MS_MOD_BENDING | MS_MOD_BENDING_TILT)) != 0;
-  const bool fast = a.m.T == FAST_T;
+  const bool fast = a.m.T == FAST_T && a.m.tile_facets32 != nullptr;  // (the T = 256 instances read packed records)
   // atomic: per-vertex sums by LDS ds_add_f64 instead of the staged CSR gather -- one barrier per
   // tile instead of twelve and half the LDS traffic, at the price of a summation order that
   // varies from run to run (ms_set_deterministic).  Without bending there are no vertex sums.
@@ -989,10 +1030,11 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? MS_LEAN_SLOTS : 1) MS_WPE_GRA
   const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
   const int tid = threadIdx.x;
 
-  TileFacet tf_nx = {0, 0, 0, 0};
+  constexpr bool PACKED = TT == 256;
+  FacetRec<PACKED> tf_nx = facet_null<PACKED>();
   double gam_nx = 0.0;
   if (t.f0 + tid < t.f1) {
-    tf_nx = a.m.tile_facets[t.f0 + tid];
+    tf_nx = facet_load<PACKED>(a.m, (size_t)(t.f0 + tid));
     gam_nx = (LEAN || a.m.gamma_uniform) ? a.m.gamma_const : a.m.tf_gamma[t.f0 + tid];
   }
 
@@ -1152,10 +1194,10 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? MS_LEAN_SLOTS : 1) MS_WPE_GRA
 #endif
   for (int c0f = t.f0; c0f < (MS_ABL_NOLOOP ? t.f0 : t.f1); c0f += T) {
     const int p = c0f + tid;
-    const TileFacet tf = tf_nx;
+    const TileFacet tf = facet_unpack<PACKED>(tf_nx);
     const double gam = LEAN ? a.m.gamma_const : gam_nx;  // (lean: a kernel argument, no vector register)
     if (p + T < t.f1) {
-      tf_nx = a.m.tile_facets[p + T];
+      tf_nx = facet_load<PACKED>(a.m, (size_t)(p + T));
       if (!LEAN) gam_nx = a.m.gamma_uniform ? a.m.gamma_const : a.m.tf_gamma[p + T];
     }
     if (p < t.f1) {
@@ -1516,7 +1558,7 @@ bool gradient_lean_instance(const GradientArgs& a) {
   const bool bend = (a.modules & MS_MOD_BENDING) != 0;
   const bool volrow = a.gC != nullptr && (a.modules & MS_CON_VOLUME);
   const bool leaf = bend && a.bt_vert != nullptr;
-  return a.m.T == FAST_T && a.atomic != 0 && !volrow && !leaf && bend && a.bending_grad_mode != MS_GRAD_APPROX &&
+  return a.m.T == FAST_T && a.m.tile_facets32 != nullptr && a.atomic != 0 && !volrow && !leaf && bend && a.bending_grad_mode != MS_GRAD_APPROX &&
          a.m.gamma_uniform && !a.m.has_boundary && !(a.modules & MS_MOD_VOLUME_PENALTY) &&
          (a.dir_mode != 2 || a.pd_neg_pg) && !no_lean();
 }
@@ -1526,7 +1568,7 @@ hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStrea
   if (nb <= 0) return hipSuccess;
   const bool bend = (a.modules & MS_MOD_BENDING) != 0;
   const bool volrow = a.gC != nullptr && (a.modules & MS_CON_VOLUME);
-  const bool fast = a.m.T == FAST_T;
+  const bool fast = a.m.T == FAST_T && a.m.tile_facets32 != nullptr;
   const bool atomic = a.atomic != 0;
   const bool leaf = bend && a.bt_vert != nullptr;
   const size_t lds = gradient_lds_bytes(a.m.T, cap, max_ent, bend, volrow, atomic, leaf);

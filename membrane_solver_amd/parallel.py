@@ -7,7 +7,7 @@ patch order, each listing every facet that touches it) are dealt to ranks in
 contiguous ranges, so every rank OWNS a contiguous row range of each per-vertex
 vector and evaluates only its own facet blocks.  A rank reads its own rows plus
 the HALO rows of its tiles (a thin band along the patch border: the patch order
-is a Hilbert curve, so a rank's rows form a compact surface patch).
+is a recursive coordinate bisection, so a rank's rows form a compact surface patch).
 
 One exchange = one fixed-size all-gather per rank of
     [MS_NSCAL reduction scalars | this rank's BOUNDARY rows of the listed buffers]
@@ -22,6 +22,13 @@ and nothing else: the per-vertex gradient itself never travels (fixed-row zeroin
 volume-row projection and the per-row Polak-Ribiere beta are row-local), accepting
 a trial is x += alpha*d on the rows a rank reads, and the accepted trial's factors
 and energies are the next step's (same reuse as ms_step, include/membrane_hip.h).
+
+"Simple mode" (BASELINE.json's north star names it: a dense RCCL all-reduce of the per-vertex
+vector) is kept as the comparison point: ``HipShardBackend(exchange="dense")`` /
+``MS_SHARD_EXCHANGE=dense`` sends only the scalar header through the all-gather and
+all-reduces every listed buffer over ALL its rows (each row has exactly one non-zero
+contributor, its owner: the sum is the owner's value bit for bit) -- 24.6 MB per 3-vector at
+the headline size instead of ~100 KB of boundary rows, same trajectory.
 
 ``ShardedStepper`` holds the control flow (a restatement of ms_step, i.e. of
 runtime/minimizer.py:1314-1374 + line_search.py:267-426 of the reference) on
@@ -276,8 +283,12 @@ class HipShardBackend:
     """HIP kernels on this rank's tile range; collectives through torch.distributed."""
 
     def __init__(self, positions, tri_rows, *, rank: int, world: int, device: int, tile_vertices: int = 0,
-                 fixed=None, boundary=None, body_facets=None, group=None, debug_poison=False):
+                 fixed=None, boundary=None, body_facets=None, group=None, debug_poison=False, exchange=None):
         import torch
+
+        self.exchange_mode = exchange or os.environ.get("MS_SHARD_EXCHANGE", "halo")
+        if self.exchange_mode not in ("halo", "dense"):
+            raise ValueError(f"exchange mode {self.exchange_mode!r}: 'halo' or 'dense'")
 
         from .device import DeviceMesh
 
@@ -364,6 +375,11 @@ class HipShardBackend:
         self.dm.phase_set_factors_valid(valid)
 
     def enable_library_driver(self):
+        if self.exchange_mode != "halo":
+            raise L.MembraneHipError("the in-library shard driver exchanges boundary rows only (exchange='halo')")
+        return self._enable_library_driver()
+
+    def _enable_library_driver(self):
         """Give the context its own RCCL communicator (ncclUniqueId from rank 0, broadcast over
         the existing torch.distributed group) or, for an in-process group, an all-gather callback."""
         dist = self.dist
@@ -428,6 +444,19 @@ class HipShardBackend:
                 v = self._view(bid)
                 v[:r0] = float("nan")
                 v[r1:] = float("nan")
+        if self.exchange_mode == "dense":
+            # the north star's simple mode: scalar headers by all-gather, every listed buffer by a dense all-reduce
+            per_rank = self._exchange_message(())
+            r0, r1 = self.rank * self.rows, (self.rank + 1) * self.rows
+            for bid in buffers:
+                v = self._view(bid)
+                v[:r0].zero_()
+                v[r1:].zero_()
+                self.dist.all_reduce(v)
+            return per_rank
+        return self._exchange_message(buffers)
+
+    def _exchange_message(self, buffers):
         plan = self._plans.get(buffers)
         if plan is None:  # message size and tensor views per buffer set, resolved once
             n = self.dm.exchange_bytes(buffers) // 8

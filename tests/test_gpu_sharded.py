@@ -55,8 +55,34 @@ class ThreadGroup:
             self.done[k].synchronize()
         self.bar.wait()
 
+    def all_reduce(self, t):
+        """SUM over the ranks in rank order (the dense exchange mode): every rank reads every peer's tensor, and
+        overwrites its own only after all of them have finished reading."""
+        torch = self.torch
+        r = self.local.rank
+        cur = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        self.slots[r] = (t, ready)
+        self.bar.wait()
+        acc = torch.zeros_like(t)
+        for k in range(self.world):
+            src, ev = self.slots[k]
+            cur.wait_event(ev)
+            acc += src
+        done = torch.cuda.Event()
+        done.record(cur)
+        self.done[r] = done
+        self.bar.wait()
+        for k in range(self.world):
+            self.done[k].synchronize()
+        self.bar.wait()
+        t.copy_(acc)
+        cur.synchronize()
+        self.bar.wait()
 
-@pytest.mark.parametrize("driver,pair", [("python", "0"), ("library", "0"), ("library", "2")])
+
+@pytest.mark.parametrize("driver,pair", [("python", "0"), ("library", "0"), ("library", "2"), ("python-dense", "0")])
 @pytest.mark.parametrize("with_volume,world,level,freq,tile", [
     (False, 2, 2, 16, 64), (True, 2, 2, 16, 64), (False, 3, 2, 16, 64), (False, 2, 0, 16, 64), (True, 3, 0, 16, 64),
     (False, 4, 2, 160, 256),  # 512 000 facets, default tile size, 4 shards: sizes near the headline
@@ -112,7 +138,8 @@ def test_shards_match_single_context(with_volume, world, level, freq, tile, driv
         try:
             grp.bind(rank)
             be = HipShardBackend(P, T, rank=rank, world=world, device=0, tile_vertices=tile, fixed=fixed, group=grp,
-                                 debug_poison=(driver == "python"))
+                                 debug_poison=(driver != "library"),
+                                 exchange="dense" if driver == "python-dense" else "halo")
             be.configure(modules=mods, gamma=gamma, kappa=kappa, c0=c0, target_volume=V0)
             if driver == "library":
                 be.enable_library_driver()
