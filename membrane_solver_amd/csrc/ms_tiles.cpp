@@ -93,7 +93,7 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
   }
   out.perm.resize(nv);
   std::iota(out.perm.begin(), out.perm.end(), 0);
-  static const int tile_order = getenv("MS_TILE_ORDER") ? atoi(getenv("MS_TILE_ORDER")) : 1;
+  const int tile_order = getenv("MS_TILE_ORDER") ? atoi(getenv("MS_TILE_ORDER")) : 1;  // (A/B: 0 = Hilbert runs)
   if (tile_order == 0) {
     std::stable_sort(out.perm.begin(), out.perm.end(),
                      [&](int32_t a, int32_t b) { return key[a] < key[b]; });

@@ -147,6 +147,35 @@ def test_willmore_and_approx_on_open_noisy_mesh(L):
     dm.close()
 
 
+def test_high_valence_hub_takes_the_unpacked_record_path(L):
+    """A cone of 1500 facets around one apex: the apex's tile needs ~1750 LDS slots, more than the 10-bit corner
+    fields of the packed facet records address, so the T = 256 instances (and the lean gradient instance) must not
+    be picked -- the generic instances with 8-byte records run, and agree with the oracle."""
+    from membrane_solver_amd.device import DeviceMesh
+
+    n = 1500
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    rim = np.column_stack([np.cos(ang), np.sin(ang), 0.05 * np.sin(3 * ang)])
+    P = np.vstack([[0.0, 0.0, 0.6], rim])
+    T = np.column_stack([np.zeros(n, int), 1 + np.arange(n), 1 + (np.arange(n) + 1) % n]).astype(np.int32)
+    nv, nf = len(P), len(T)
+    B = np.ones(nv, bool)
+    B[0] = False
+    gamma, kappa, c0 = np.full(nf, 1.3), np.full(nv, 0.7), np.zeros(nv)
+    Es, Eb, gref = _oracle_eg(P, T, gamma, kappa, c0, B)
+    dm = DeviceMesh(P, T, boundary=B, tile_vertices=256)
+    assert dm.tile_stats()["max_halo"] + 256 > 1024
+    dm.set_surface_tension(gamma)
+    dm.set_bending_params(kappa, c0)
+    dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING)
+    e, g = dm.energy_and_gradient()
+    assert abs(e[0] - Es) <= 1e-12 * abs(Es) and abs(e[1] - Eb) <= 1e-11 * abs(Eb)
+    assert relerr(g, gref) < 1e-10
+    r = dm.step(stepper=L.MS_STEPPER_GD, step_size=1e-4)
+    assert r.trials >= 1
+    dm.close()
+
+
 def test_oversized_valence_and_bad_arguments_are_errors_not_crashes(L):
     from membrane_solver_amd.device import DeviceMesh
 
