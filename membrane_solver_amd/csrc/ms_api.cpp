@@ -134,6 +134,7 @@ struct ms_ctx {
   double ls_acc[LS_HIST] = {0};
   double ls_rej[LS_HIST] = {0};
   int ls_n = 0;
+  bool ls_reset = true;          // MS_LS_RESET=0: never forget the history on a regime change
   bool speculate = true;         // MS_SPECULATE=0 switches the ladder off
   bool relax_va_valid = false;  // a leaflet relaxation is running: tf[l].va describes the current x
   int factors_leaflet = 0;  // which leaflet's back-prop factors fK/fA hold (1 in, 2 out; 0: not a leaflet's)
@@ -1152,6 +1153,7 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
     c->pair_force = atoi(pe) >= 2 ? std::min(atoi(pe), 4) : 0;  // 4: triple launches whenever possible
   }
   c->speculate = !(getenv("MS_SPECULATE") != nullptr && atoi(getenv("MS_SPECULATE")) == 0);
+  c->ls_reset = !(getenv("MS_LS_RESET") != nullptr && atoi(getenv("MS_LS_RESET")) == 0);
   c->deterministic = getenv("MS_DETERMINISTIC") != nullptr && atoi(getenv("MS_DETERMINISTIC")) != 0;
   c->params.modules = MS_MOD_SURFACE;
   c->params.bending_model = MS_BEND_HELFRICH;
@@ -2180,6 +2182,8 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     out->volume = c->h_scal[MS_S_VOL];
     out->next_step = std::min(alpha_acc * sp->gamma, alpha_max);
     c->pred_trials = std::max(1, out->trials);
+    // an alpha far below everything accepted lately: the step-size regime has changed, the history predicts nothing
+    if (c->ls_reset && c->ls_n > 0 && alpha_acc < 0.5 * a_hi) c->ls_n = 0;
     c->ls_acc[c->ls_n % ms_ctx::LS_HIST] = alpha_acc;
     c->ls_rej[c->ls_n % ms_ctx::LS_HIST] = min_rejected;
     ++c->ls_n;
@@ -2429,6 +2433,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   }
   const double reduced = std::max(alpha * sp->beta, 0.0);  // :425-426
   out->next_step = std::max(reduced, step_size * sp->beta);
+  if (c->ls_reset) c->ls_n = 0;  // a search that ran out of trials: same
   return MS_OK;
 }
 
