@@ -602,6 +602,73 @@ def test_full_size_energy_and_gradient_match_oracle(freq):
     assert abs(e_t.sum() - e.sum()) <= 1e-11 * abs(e.sum()), report
 
 
+@pytest.mark.parametrize("freq,kind,n_steps", [(81, "gd", 10), (320, "cg", 5)])
+def test_full_size_trajectory_matches_oracle_port(freq, kind, n_steps):
+    """BASELINE configs 2 and 3 at their full sizes, as trajectories: icosphere f = 81 (131 220 facets), surface +
+    Lagrange volume constraint, gradient descent; f = 320 (2 048 000 facets), surface + Helfrich bending, CG.  The
+    oracle's minimizer port (C energy / gradient kernels under the restated control flow, itself pinned by the
+    reference's trajectories at small sizes) runs the same steps on the CPU: same accept / reject sequence, same
+    trial counts, same step sizes, energies to 1e-10.  Default (LDS-atomic) vertex sums, default line-search queue."""
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.geometry.mesh import ArrayMesh
+    from membrane_solver_amd.runtime.constraint_manager import ConstraintModuleManager
+    from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
+    from membrane_solver_amd.runtime.minimizer import Minimizer
+    from membrane_solver_amd.runtime.steppers import ConjugateGradient, GradientDescent
+    from oracle import minimizer_port as mp
+    from oracle import ms_oracle as orc
+
+    orc.use_openmp(True)  # (the checker may use the host's cores; the serial build gives the same trajectory)
+    P, T = meshgen.icosphere(freq)
+    P = meshgen.smooth_displace(P, 0.05)
+    if kind == "gd":
+        mods, cons = ["surface"], ["volume"]
+        gp = {"surface_tension": 1.0, "volume_constraint_mode": "lagrange",
+              "volume_projection_during_minimization": False}
+        V0 = 0.97 * orc.volume(P, T, None)
+    else:
+        mods, cons = ["surface", "bending"], []
+        gp = {"surface_tension": 1.0, "bending_modulus": 1.0}
+        V0 = None
+    # step sizes that make the searches backtrack (and, for config 2, run into the normal-rotation guard)
+    step0 = 3.0 if kind == "gd" else 4e-6
+    p = mp.Problem(positions=P, tri=T, energy_modules=list(mods), constraint_modules=list(cons), gp=dict(gp),
+                   target_volume=V0)
+    ref = mp.minimize(p, mp.GradientDescent() if kind == "gd" else mp.ConjugateGradient(), n_steps, step_size=step0)
+    orc.use_openmp(False)
+    from membrane_solver_amd.geometry.mesh import ArrayBody
+
+    bodies = [ArrayBody(0, None, float(V0))] if V0 is not None else []
+    mesh = ArrayMesh(P, T, bodies=bodies, global_parameters=dict(gp), energy_modules=list(mods),
+                     constraint_modules=list(cons))
+    stepper = GradientDescent() if kind == "gd" else ConjugateGradient()
+    log = []
+    orig = stepper.device_step
+
+    def logged(dm, m, step_size, tol=0.0):
+        r = orig(dm, m, step_size, tol=tol)
+        log.append((float(r.success), r.next_step, r.energy, r.trials))
+        return r
+
+    stepper.device_step = logged
+    mz = Minimizer(mesh, mesh.global_parameters, stepper, EnergyModuleManager(mods), ConstraintModuleManager(cons),
+                   quiet=True, step_size=step0)
+    res = mz.minimize(n_steps)
+    got = np.array(log)
+    want = np.array([[float(t["success"]), t["next_step"], t["E_accepted"], t["trials"]] for t in ref["trace"]])
+    assert got.shape == want.shape
+    assert want[:, 0].sum() >= 2 and want[:, 3].max() >= 2, "the case is expected to accept steps after backtracking"
+    assert np.array_equal(got[:, 0], want[:, 0]), (got, want)
+    assert np.array_equal(got[:, 3], want[:, 3]), (got, want)
+    assert np.allclose(got[:, 1], want[:, 1], rtol=1e-12)
+    assert np.allclose(got[:, 2], want[:, 2], rtol=1e-10)
+    assert abs(res["energy"] - ref["energy"]) <= 1e-10 * abs(ref["energy"])
+    # positions: the displacement of the run, not the positions themselves, is what the steps produced
+    moved = np.linalg.norm(p.positions - P)
+    assert moved > 0.0
+    assert np.linalg.norm(mesh.positions_view() - p.positions) <= (1e-8 if kind == "gd" else 1e-5) * moved
+
+
 def test_default_mode_ladder_at_full_size(monkeypatch):
     """The speculative line-search ladder (queued trials, pair / triple launches, gated gradient pass) where it is
     actually used: the headline workload at FULL size (2 048 000 facets) in the DEFAULT LDS-atomic mode.  Against the
