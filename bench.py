@@ -192,6 +192,12 @@ def roofline_block(kernels, n_prof):
            "share_of_kernel_time": d["share_of_profiled_ms"],
            "selection": "the instantiation with the largest share of the profiled kernel time",
            "measured": f"HIP events around every launch over {n_prof} steps after the timed region"}
+    if traffic is not None and traffic < d["algorithmic_bytes"]:
+        out["traffic_note"] = ("traffic below the algorithmic bytes: the algorithmic figure counts the connectivity as "
+                               "SURVEY 8(d) does, 12 B per facet (three int32 vertex ids); the kernels read it as 4-byte "
+                               "tile-local facet records (1.13 instances per facet) plus the halo id lists")
+    if out["avg_launch_us"] > 0:
+        out["traffic_GBps"] = (traffic / (d["avg_us"] * 1e-6) / 1e9) if traffic is not None else None
     fam = [k for k in ("energy", "energy_pair", "energy_triple") if k in kernels and "GBps" in kernels[k]]
     if fam:
         b = sum(kernels[k]["algorithmic_bytes"] * kernels[k]["launches"] for k in fam)
