@@ -296,6 +296,9 @@ __device__ __forceinline__ TileCtx tile_ctx(const DeviceMesh& m, int tile) {
   t.nh = m.tile_halo_off[tile + 1] - t.h0;
   t.f0 = m.tile_facet_off[tile];
   t.f1 = m.tile_facet_off[tile + 1];
+#ifdef MS_ABL_CLAMP  // timing experiment only (wrong results): at most this many facets per tile
+  t.f1 = min(t.f1, t.f0 + MS_ABL_CLAMP);
+#endif
   t.e0 = m.tile_ent_off[tile];
   t.n_ent = m.tile_ent_off[tile + 1] - t.e0;
   return t;
