@@ -75,7 +75,7 @@ def weak_frequency(gpus: int, base: int = 320) -> int:
     return int(round(base * gpus ** 0.5))
 
 
-def algorithmic_bytes(nv, nf, *, uniform=True, volume=False):
+def algorithmic_bytes(nv, nf, *, uniform=True, volume=False, lean_pairs=True):
     """Compulsory HBM bytes per launch (DESIGN.md 'Kernels'); each array touched once.  `uniform`: every facet has
     the same surface tension and every vertex the same kappa / c0 -- then those arrays are kernel constants and are
     neither read nor counted (ms_set_surface_tension / ms_set_bending_params decide; the bench's case)."""
@@ -87,9 +87,11 @@ def algorithmic_bytes(nv, nf, *, uniform=True, volume=False):
         "energy_trial": fac + (48 + vp) * nv + 24 * nv,               # x, d in; xt out
         "energy_trial_factors": fac + (48 + vp) * nv + 24 * nv + 40 * nv,
         # pair / triple launch: the inputs are compulsory ONCE (the other evaluations' reads are meant to hit L2),
-        # the outputs once per evaluation
-        "energy_pair": fac + (48 + vp) * nv + 2 * (24 + 40) * nv,
-        "energy_triple": fac + (48 + vp) * nv + 3 * (24 + 40) * nv,
+        # the outputs once per evaluation that writes any -- in ms_step only the LAST trial of the launch does (the
+        # early ones, expected to fail, are evaluated for their energies: `lean_pairs`; MS_PAIR_LEAN=0 and the sharded
+        # driver write every trial's outputs)
+        "energy_pair": fac + (48 + vp) * nv + (1 if lean_pairs else 2) * (24 + 40) * nv,
+        "energy_triple": fac + (48 + vp) * nv + (1 if lean_pairs else 3) * (24 + 40) * nv,
         # gradient with the fused direction pass: x 24 + fK,fA 40 + flags 1 in; g 24 and d 24 out; CG history in:
         # the previous gradient (24) and, unless it is minus that (after an implicit steepest-descent step: the lean
         # instance), the previous direction (24).  With a constraint row the direction is not fused: g and gC out.
@@ -428,7 +430,8 @@ def main_single(args):
         trial_passes = mz.last_run["trials"] + mz.last_run["guard_rejects"]
         prof = dm.profile_read()
         dm.profile_enable(False)
-        ab = algorithmic_bytes(nv, nf, uniform=True, volume=args.volume)
+        ab = algorithmic_bytes(nv, nf, uniform=True, volume=args.volume,
+                               lean_pairs=os.environ.get("MS_PAIR_LEAN", "1") != "0")
         kernels = kernel_table(prof, ab, trial_passes=trial_passes, level=int(stepper.reuse_energy0), nv=nv,
                                deterministic=bool(args.deterministic))
         out["roofline"] = roofline_block(kernels, n_prof)
@@ -551,7 +554,7 @@ def main_sharded(args, rank, world, local_rank):
             info = be.dm.shard_info()
             nv_l = int(info["row1"] - info["row0"])
             nf_l = int(round(nf * nv_l / max(nv, 1)))
-            ab = algorithmic_bytes(nv_l, nf_l, uniform=True)
+            ab = algorithmic_bytes(nv_l, nf_l, uniform=True, lean_pairs=False)
             # the sharded trial passes write no trial positions (the accepted step is committed in place)
             for key in ("energy_trial", "energy_trial_factors"):
                 ab[key] -= 24 * nv_l

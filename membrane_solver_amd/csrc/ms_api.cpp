@@ -111,6 +111,10 @@ struct ms_ctx {
   int pair_force = 0;            // MS_PAIR=2 / 3: pair (/ pair + a gated third trial) whenever possible, whatever
                                  // the history predicts (tests)
   int pair_on = 0;               // phase_energy / reduce_slots: queue a pair (2: second evaluation at pair_alpha2)
+  // the early trials of a pair / triple launch (the ones expected to fail) are evaluated for their energies only:
+  // no trial positions, no bending factors written for them (ms_step; the sharded driver needs the factor rows)
+  bool pair_lean = false;
+  bool pair_lean_enable = true;  // MS_PAIR_LEAN=0: write every trial's outputs (copied back if an early one is accepted)
                                  // or a triple (3: a third one at pair_alpha3)
   double pair_alpha2 = 0.0, pair_alpha3 = 0.0;
   double* xt3 = nullptr;
@@ -548,15 +552,15 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
     if (c->pair_on == 3) {
       if (!c->fK3) return fail(c, MS_ERR_STATE, "triple launch: buffers not allocated");
       a.alpha3 = trial_alpha(c, c->pair_alpha3);
-      a.xt3 = write_trial ? c->xt3 : nullptr;
-      a.fK3 = c->fK3;
-      a.fA3 = c->fA3;
+      a.xt3 = (write_trial && !c->pair_lean) ? c->xt3 : nullptr;
+      a.fK3 = c->pair_lean ? nullptr : c->fK3;
+      a.fA3 = c->pair_lean ? nullptr : c->fA3;
       a.partials3 = c->d_partials3;
     }
     a.alpha2 = trial_alpha(c, c->pair_alpha2);
-    a.xt2 = write_trial ? c->xt2 : nullptr;
-    a.fK2 = c->fK2;
-    a.fA2 = c->fA2;
+    a.xt2 = (write_trial && !c->pair_lean) ? c->xt2 : nullptr;
+    a.fK2 = c->pair_lean ? nullptr : c->fK2;
+    a.fA2 = c->pair_lean ? nullptr : c->fA2;
     a.partials2 = c->d_partials2;
   }
   if (bt && !c->d_bt_vert) return fail(c, MS_ERR_STATE, "bending_tilt: ms_set_params did not allocate its buffers");
@@ -1154,6 +1158,7 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
   }
   c->speculate = !(getenv("MS_SPECULATE") != nullptr && atoi(getenv("MS_SPECULATE")) == 0);
   c->ls_reset = !(getenv("MS_LS_RESET") != nullptr && atoi(getenv("MS_LS_RESET")) == 0);
+  c->pair_lean_enable = !(getenv("MS_PAIR_LEAN") != nullptr && atoi(getenv("MS_PAIR_LEAN")) == 0);
   c->deterministic = getenv("MS_DETERMINISTIC") != nullptr && atoi(getenv("MS_DETERMINISTIC")) != 0;
   c->params.modules = MS_MOD_SURFACE;
   c->params.bending_model = MS_BEND_HELFRICH;
@@ -2276,10 +2281,12 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       rhs[1] = energy0 + sp->c * alphas[1] * g_dot_d;
       if (triple) rhs[2] = energy0 + sp->c * alphas[2] * g_dot_d;
       c->pair_on = triple ? 3 : 2;
+      c->pair_lean = c->pair_lean_enable;
       c->pair_alpha2 = alphas[0];
       c->pair_alpha3 = alphas[1];
       rc = phase_energy(c, c->params.modules, true, alphas[triple ? 2 : 1], true, false, carry_mode);
       c->pair_on = 0;
+      c->pair_lean = false;
       if (rc) return rc;
       if (depth == 3 && !triple) {
         // a third trial, expected to be needed as well: gated on trial 1's rejection like any ladder stage (if it
@@ -2369,9 +2376,18 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
           min_rejected = alphas[j];
           continue;
         }
-        if (j + 1 < n_multi) {
-          // the unexpected case: this trial's positions and factors are in a side set, and the queued gradient
-          // pass vetoed itself
+        if (j + 1 < n_multi && c->pair_lean_enable) {
+          // the unexpected case: an early trial was accepted, and it was evaluated for its energies only -- evaluate it
+          // again, alone and with every output (the queued gradient pass vetoed itself).  With fixed-order sums the
+          // energies come out bit for bit as before; with LDS atomics in their last bits, like any re-evaluation.
+          rc = phase_energy(c, c->params.modules, true, alphas[j], true, false, carry_mode);
+          if (rc) return rc;
+          rc = fetch(c);
+          if (rc) return rc;
+          kc_queued = false;
+        } else if (j + 1 < n_multi) {
+          // (MS_PAIR_LEAN=0) this trial's positions and factors are in a side set, and the queued gradient pass
+          // vetoed itself
           const size_t nvp = (size_t)c->til.nvp;
           const double* sx = j == 0 ? c->xt2 : c->xt3;
           const double* sk = j == 0 ? c->fK2 : c->fK3;

@@ -214,7 +214,9 @@ def test_bench_launcher_command_and_schema_helpers(monkeypatch):
     ab = bench.algorithmic_bytes(nv, nf)
     assert ab["gradient_lean"] == 12 * nf + (65 + 24 + 48) * nv          # tri rows; x, fK, fA, flags; pg; g, d
     assert ab["gradient"] == ab["gradient_lean"] + 24 * nv               # + previous direction rows
-    assert ab["energy_pair"] == ab["energy_trial_factors"] + 64 * nv     # inputs once, outputs twice
+    assert ab["energy_pair"] == ab["energy_triple"] == ab["energy_trial_factors"]  # only the last trial writes outputs
+    full = bench.algorithmic_bytes(nv, nf, lean_pairs=False)             # MS_PAIR_LEAN=0 / sharded driver
+    assert full["energy_pair"] == ab["energy_trial_factors"] + 64 * nv   # inputs once, outputs twice
     assert bench.algorithmic_bytes(nv, nf, uniform=False)["energy_only"] == ab["energy_only"] + 8 * nf + 16 * nv
     prof = {"energy": (0.36, 10), "gradient": (0.0, 0), "gradient_lean": (0.50, 10), "reduce": (0.06, 10),
             "energy_pair": (0.30, 5), "energy_triple": (0.0, 0), "direction": (0.0, 0)}
