@@ -204,8 +204,14 @@ def roofline_block(kernels, n_prof):
     if fam:
         b = sum(kernels[k]["algorithmic_bytes"] * kernels[k]["launches"] for k in fam)
         t = sum(kernels[k]["avg_us"] * kernels[k]["launches"] for k in fam)
-        out["energy_family_time_weighted"] = {"GBps": b / (t * 1e-6) / 1e9, "frac": b / (t * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                              "share_of_kernel_time": sum(kernels[k]["share_of_profiled_ms"] for k in fam)}
+        ev = sum(kernels[k].get("evaluations_per_launch", 1) * kernels[k]["launches"] for k in fam)
+        out["energy_family_time_weighted"] = {
+            "GBps": b / (t * 1e-6) / 1e9, "frac": b / (t * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "share_of_kernel_time": sum(kernels[k]["share_of_profiled_ms"] for k in fam),
+            "us_per_evaluation": t / max(ev, 1),
+            "note": ("a pair / triple launch evaluates two / three trial energies on ONE set of compulsory bytes (inputs "
+                     "once, only the last trial writes outputs), so bytes per time understates it: compare "
+                     "us_per_evaluation with the single launch's avg_us")}
     gfam = [k for k in ("gradient", "gradient_lean") if k in kernels and "GBps" in kernels[k]]
     if gfam:
         b = sum(kernels[k]["algorithmic_bytes"] * kernels[k]["launches"] for k in gfam)
