@@ -987,7 +987,7 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
 // previous-direction rows (dir_mode != 2, or pd = -pg after an implicit steepest-descent step): 8 registers fewer live
 // through the facet loop, which is what lets the kernel fit 128 VGPRs = 4 resident workgroups per CU instead of 3.
 template <int BENDMODE, bool VOLROW, int TT, int CAPC, bool ATOMIC, bool LEAN = false>
-__global__ __launch_bounds__(TT ? TT : 512, LEAN ? MS_LEAN_SLOTS : 1) MS_WPE_GRADIENT void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
+__global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? MS_LEAN_SLOTS : 3) : 1) MS_WPE_GRADIENT void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
   extern __shared__ double lds[];
   constexpr bool BEND = BENDMODE != 0;
   // BENDMODE 3: leaflet bending_tilt (bt_gradient.py:89-389): analytic back-propagation whose effective-area
@@ -1571,7 +1571,7 @@ bool gradient_lean_instance(const GradientArgs& a) {
   const bool bend = (a.modules & MS_MOD_BENDING) != 0;
   const bool volrow = a.gC != nullptr && (a.modules & MS_CON_VOLUME);
   const bool leaf = bend && a.bt_vert != nullptr;
-  return a.m.T == FAST_T && a.m.tile_facets32 != nullptr && a.atomic != 0 && !volrow && !leaf && bend && a.bending_grad_mode != MS_GRAD_APPROX &&
+  return a.m.T == FAST_T && a.m.tile_facets32 != nullptr && !volrow && !leaf && bend && a.bending_grad_mode != MS_GRAD_APPROX &&
          a.m.gamma_uniform && !a.m.has_boundary && !(a.modules & MS_MOD_VOLUME_PENALTY) &&
          (a.dir_mode != 2 || a.pd_neg_pg) && !no_lean() && !no_fast();
 }
@@ -1593,9 +1593,15 @@ hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStrea
     hipLaunchKernelGGL((k_gradient<M, V, TT, CC, AT>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent); \
   } while (0)
   if (gradient_lean_instance(a)) {
-    e = ensure_lds(k_gradient<1, false, FAST_T, FAST_CAP, true, true>, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_gradient<1, false, FAST_T, FAST_CAP, true, true>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);
+    if (atomic) {
+      e = ensure_lds(k_gradient<1, false, FAST_T, FAST_CAP, true, true>, lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL((k_gradient<1, false, FAST_T, FAST_CAP, true, true>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);
+    } else {  // fixed-order vertex sums (ms_set_deterministic): the same diet, the CSR gather instead of LDS atomics
+      e = ensure_lds(k_gradient<1, false, FAST_T, FAST_CAP, false, true>, lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL((k_gradient<1, false, FAST_T, FAST_CAP, false, true>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);
+    }
     return hipGetLastError();
   }
 #define MS_PICK_G(M, V)                                           \
