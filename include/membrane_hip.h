@@ -176,7 +176,7 @@ int ms_device_count(void);
 const char *ms_last_error(const ms_ctx *ctx); /* ctx may be NULL */
 
 /*
- * Build a context: vertices are put in patch (Hilbert) order, cut into tiles
+ * Build a context: vertices are put in patch order (recursive coordinate bisection down to single tiles), cut into tiles
  * of `tile_vertices` owned vertices (0 = 256), and the tile->facet /
  * tile->halo-vertex CSR is pushed to HBM once.  Replaces the per-step reads of
  * Mesh.triangle_row_cache / fixed_mask / boundary_vertex_ids

@@ -1,4 +1,4 @@
-// Host-side tiling: patch (Hilbert) ordering of the vertices and the
+// Host-side tiling: patch ordering of the vertices (recursive coordinate bisection; Hilbert order inside a tile) and the
 // tile -> facet / tile -> halo-vertex CSR that the gfx950 kernels consume.
 //
 // The reference keeps vertices in Mesh.vertex_ids row order and facets in
