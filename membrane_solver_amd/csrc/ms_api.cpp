@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <string>
 #include <new>
@@ -264,6 +265,23 @@ DeviceMesh device_mesh(const ms_ctx* c) {
 }
 
 // RAII-free event bracket: begin() before a launch, end() after it.
+// MS_HOST_TIMING=1 (diagnostic): host time from "a fetch found its mailbox complete" to "the next k_energy launch call
+// returned" (what the GPU idles through, minus its own dispatch latency), and the launch call alone; printed by
+// ms_destroy
+struct HostTiming {
+  bool on = getenv("MS_HOST_TIMING") != nullptr && atoi(getenv("MS_HOST_TIMING")) != 0;
+  double t_fetch = 0.0;
+  bool armed = false;
+  double sum_gap = 0.0, sum_launch = 0.0, max_gap = 0.0;
+  long n = 0;
+  static double now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+  }
+};
+static HostTiming g_host_timing;
+
 struct ProfScope {
   ms_ctx* c;
   hipEvent_t a = nullptr, b = nullptr;
@@ -569,7 +587,16 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   a.modules = modules;
   if (!lbt) {
     ProfScope ps(c, a.pair == 3 ? 8 : (a.pair ? 7 : 0), c->cur_gate != nullptr);
+    const double t_l0 = g_host_timing.on ? HostTiming::now() : 0.0;
     HIPCHK(c, launch_energy(a, guard && use_dir, c->cap, c->til.max_ent, c->stream));
+    if (g_host_timing.on && g_host_timing.armed) {
+      const double t1 = HostTiming::now();
+      g_host_timing.armed = false;
+      g_host_timing.sum_gap += t1 - g_host_timing.t_fetch;
+      g_host_timing.max_gap = std::max(g_host_timing.max_gap, t1 - g_host_timing.t_fetch);
+      g_host_timing.sum_launch += t1 - t_l0;
+      ++g_host_timing.n;
+    }
   } else {
     // leaflet bending_tilt: the tilt projections and the unit vertex normals of the evaluated positions come
     // first, then per leaflet an energy pass with that leaflet's (kappa, c0) (signed curvature, K_dir = n)
@@ -847,7 +874,15 @@ int fetch(ms_ctx* c, bool* soft_miss = nullptr) {
           done = false;
           break;
         }
-      if (done) return take_mailbox(c);
+      if (done) {
+        if (g_host_timing.on) {
+          if (spin > 0) {  // (only when the host really waited: the GPU was the one ahead)
+            g_host_timing.t_fetch = HostTiming::now();
+            g_host_timing.armed = true;
+          }
+        }
+        return take_mailbox(c);
+      }
       __builtin_ia32_pause();
     }
   }
@@ -1174,6 +1209,14 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
 }
 
 void ms_destroy(ms_ctx* c) {
+  if (g_host_timing.on && g_host_timing.n > 0) {
+    fprintf(stderr, "[ms host timing] %ld waits followed by an energy launch: mailbox seen -> launch call returned %.2f us "
+                    "on average (max %.1f), of which the launch call itself %.2f us\n",
+            g_host_timing.n, g_host_timing.sum_gap / g_host_timing.n, g_host_timing.max_gap,
+            g_host_timing.sum_launch / g_host_timing.n);
+    g_host_timing.n = 0;
+    g_host_timing.sum_gap = g_host_timing.sum_launch = g_host_timing.max_gap = 0.0;
+  }
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
