@@ -114,6 +114,7 @@ struct ms_ctx {
   int pair_on = 0;               // phase_energy / reduce_slots: queue a pair (2: second evaluation at pair_alpha2)
   // the early trials of a pair / triple launch (the ones expected to fail) are evaluated for their energies only:
   // no trial positions, no bending factors written for them (ms_step; the sharded driver needs the factor rows)
+  bool no_fast = false;          // MS_NO_FAST=1
   bool pair_lean = false;
   bool pair_lean_enable = true;  // MS_PAIR_LEAN=0: write every trial's outputs (copied back if an early one is accepted)
                                  // or a triple (3: a third one at pair_alpha3)
@@ -247,6 +248,7 @@ DeviceMesh device_mesh(const ms_ctx* c) {
   m.tile_facet_off = c->d_tile_facet_off;
   m.tile_facets = c->d_tile_facets;
   m.tile_facets32 = c->d_tile_facets32;
+  m.no_fast = c->no_fast ? 1 : 0;
   m.tf_gamma = c->d_tf_gamma;
   m.gamma_uniform = c->gamma_uniform ? 1 : 0;
   m.gamma_const = c->gamma_const;
@@ -1193,6 +1195,7 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
   }
   c->speculate = !(getenv("MS_SPECULATE") != nullptr && atoi(getenv("MS_SPECULATE")) == 0);
   c->ls_reset = !(getenv("MS_LS_RESET") != nullptr && atoi(getenv("MS_LS_RESET")) == 0);
+  c->no_fast = getenv("MS_NO_FAST") != nullptr && atoi(getenv("MS_NO_FAST")) != 0;
   c->pair_lean_enable = !(getenv("MS_PAIR_LEAN") != nullptr && atoi(getenv("MS_PAIR_LEAN")) == 0);
   c->deterministic = getenv("MS_DETERMINISTIC") != nullptr && atoi(getenv("MS_DETERMINISTIC")) != 0;
   c->params.modules = MS_MOD_SURFACE;

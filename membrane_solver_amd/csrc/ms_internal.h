@@ -70,6 +70,7 @@ struct DeviceMesh {
   // the same records in 4 bytes (10 bits per corner slot | 2 flag bits) for the T = 256 instances of the two tile
   // kernels; nullptr when some tile needs more than 1024 LDS slots (those instances are not used then)
   const uint32_t* tile_facets32;
+  int no_fast;            // MS_NO_FAST at ms_create: never pick the T = 256 instances (A/B switch)
   const double* tf_gamma;  // surface tension per facet instance
   // uniform-parameter shortcuts: when every facet carries the same surface tension (every vertex the same kappa and
   // c0) the kernels take the value from here and the per-facet / per-vertex arrays are not read at all

@@ -844,15 +844,6 @@ size_t energy_lds_bytes(int T, int cap, int max_ent, bool bend, bool guard, bool
          ((flags || guard) ? (((size_t)cap + 15) / 16) * 16 : 0);
 }
 
-static bool no_fast() {  // MS_NO_FAST=1: A/B switch -- never pick the T = 256 instances (nor the lean one)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MS_NO_FAST");
-    v = (e && atoi(e) != 0) ? 1 : 0;
-  }
-  return v != 0;
-}
-
 static bool no_lean() {  // MS_NO_LEAN=1: A/B switch for the lean gradient instance
   static int v = -1;
   if (v < 0) {
@@ -869,7 +860,6 @@ static hipError_t ensure_lds(K kernel, size_t lds) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-static bool no_fast();
 constexpr int FAST_T = 256;  // specialised tile size (LDS staging offsets become immediates)
 constexpr int FAST_CAP = 0;  // patch capacity stays a runtime value: a fixed 512 slots would push
                              // the gradient kernel from 3 to 2 workgroups per CU (LDS)
@@ -878,7 +868,7 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
   const int nb = a.tile1 - a.tile0;
   if (nb <= 0) return hipSuccess;
   const bool bend = (a.modules & (MS_MOD_BENDING | MS_MOD_BENDING_TILT)) != 0;
-  const bool fast = a.m.T == FAST_T && a.m.tile_facets32 != nullptr && !no_fast();  // (T = 256 instances: packed records)
+  const bool fast = a.m.T == FAST_T && a.m.tile_facets32 != nullptr && !a.m.no_fast;  // (T = 256 instances: packed records)
   // atomic: per-vertex sums by LDS ds_add_f64 instead of the staged CSR gather -- one barrier per
   // tile instead of twelve and half the LDS traffic, at the price of a summation order that
   // varies from run to run (ms_set_deterministic).  Without bending there are no vertex sums.
@@ -1573,7 +1563,7 @@ bool gradient_lean_instance(const GradientArgs& a) {
   const bool leaf = bend && a.bt_vert != nullptr;
   return a.m.T == FAST_T && a.m.tile_facets32 != nullptr && !volrow && !leaf && bend && a.bending_grad_mode != MS_GRAD_APPROX &&
          a.m.gamma_uniform && !a.m.has_boundary && !(a.modules & MS_MOD_VOLUME_PENALTY) &&
-         (a.dir_mode != 2 || a.pd_neg_pg) && !no_lean() && !no_fast();
+         (a.dir_mode != 2 || a.pd_neg_pg) && !no_lean() && !a.m.no_fast;
 }
 
 hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStream_t s) {
@@ -1581,7 +1571,7 @@ hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStrea
   if (nb <= 0) return hipSuccess;
   const bool bend = (a.modules & MS_MOD_BENDING) != 0;
   const bool volrow = a.gC != nullptr && (a.modules & MS_CON_VOLUME);
-  const bool fast = a.m.T == FAST_T && a.m.tile_facets32 != nullptr && !no_fast();
+  const bool fast = a.m.T == FAST_T && a.m.tile_facets32 != nullptr && !a.m.no_fast;
   const bool atomic = a.atomic != 0;
   const bool leaf = bend && a.bt_vert != nullptr;
   const size_t lds = gradient_lds_bytes(a.m.T, cap, max_ent, bend, volrow, atomic, leaf);

@@ -147,6 +147,36 @@ def test_willmore_and_approx_on_open_noisy_mesh(L):
     dm.close()
 
 
+def test_tile_order_and_record_format_do_not_change_the_results(L, monkeypatch):
+    """The patch order (coordinate bisection / runs of the Hilbert order, MS_TILE_ORDER) and the instances that go with
+    the tile size (T = 256 with packed facet records and the lean gradient instance / runtime-size instances,
+    MS_NO_FAST) decide which workgroup sums what, never what is summed: energies and gradients agree to rounding."""
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+
+    P, T = meshgen.icosphere(40)  # 32 000 facets, 63 tiles of 256 vertices
+    P = meshgen.smooth_displace(P, 0.08)
+    nv, nf = len(P), len(T)
+    res = {}
+    for order, nofast in (("1", "0"), ("0", "0"), ("1", "1")):
+        monkeypatch.setenv("MS_TILE_ORDER", order)
+        monkeypatch.setenv("MS_NO_FAST", nofast)
+        dm = DeviceMesh(P, T)
+        dm.set_surface_tension(np.ones(nf))
+        dm.set_bending_params(np.ones(nv), np.full(nv, 0.15))
+        dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING)
+        e, g = dm.energy_and_gradient()
+        r = dm.step(stepper=L.MS_STEPPER_CG, step_size=1e-5)
+        res[(order, nofast)] = (e.copy(), g.copy(), r.energy, r.trials, dm.tile_stats()["facet_instances"])
+        dm.close()
+    e0, g0, E0, tr0, inst0 = res[("1", "0")]
+    for key, (e, g, E, tr, inst) in res.items():
+        assert np.allclose(e, e0, rtol=1e-13, atol=0), key
+        assert relerr(g, g0) < 1e-11, key
+        assert abs(E - E0) <= 1e-13 * abs(E0) and tr == tr0, key
+    assert res[("0", "0")][4] > inst0  # the Hilbert runs list more facet instances than the bisection tiles
+
+
 def test_high_valence_hub_takes_the_unpacked_record_path(L):
     """A cone of 1500 facets around one apex: the apex's tile needs ~1750 LDS slots, more than the 10-bit corner
     fields of the packed facet records address, so the T = 256 instances (and the lean gradient instance) must not

@@ -445,12 +445,14 @@ def test_topology_change_rebuilds_the_device_mirror(deterministic):
     assert res["energy"] == res_b["energy"] and mz.step_size == mz_b.step_size
 
 
-@pytest.mark.parametrize("mode", ["1", "2", "3", "4"])
-def test_pair_launch_does_not_change_the_trajectory(mode, monkeypatch):
+@pytest.mark.parametrize("mode,lean", [("1", "1"), ("2", "1"), ("3", "1"), ("4", "1"), ("2", "0"), ("4", "0")])
+def test_pair_launch_does_not_change_the_trajectory(mode, lean, monkeypatch):
     """Two trial evaluations in one launch (k_energy<PAIR>, ms_step): MS_PAIR=1 lets the line-search history decide,
-    MS_PAIR=2 pairs whenever it can (so trial 0 is accepted inside a pair now and then: the copy-back path), MS_PAIR=3
-    also queues a gated third trial behind every pair, MS_PAIR=4 evaluates three trials per launch whenever it can --
-    both must give the doubles of the one-trial-per-launch search, bit for bit with fixed-order sums."""
+    MS_PAIR=2 pairs whenever it can (so trial 0 is accepted inside a pair now and then: the re-evaluation path, or with
+    MS_PAIR_LEAN=0 the copy-back path), MS_PAIR=3 also queues a gated third trial behind every pair, MS_PAIR=4 evaluates
+    three trials per launch whenever it can -- all must give the doubles of the one-trial-per-launch search, bit for
+    bit with fixed-order sums.  `lean`: the early trials of a launch are evaluated for their energies only (default)
+    or write their positions and factors into side sets."""
     from membrane_solver_amd import _lib as L
     from membrane_solver_amd import meshgen
     from membrane_solver_amd.device import DeviceMesh
@@ -463,6 +465,7 @@ def test_pair_launch_does_not_change_the_trajectory(mode, monkeypatch):
     def run(pair, speculate="1"):
         monkeypatch.setenv("MS_PAIR", pair)
         monkeypatch.setenv("MS_SPECULATE", speculate)
+        monkeypatch.setenv("MS_PAIR_LEAN", lean)
         dm = DeviceMesh(pos, tri)
         dm.set_deterministic(True)
         dm.set_surface_tension(np.full(tri.shape[0], 1.0))
