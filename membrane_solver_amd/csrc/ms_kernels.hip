@@ -864,7 +864,15 @@ constexpr int FAST_T = 256;  // specialised tile size (LDS staging offsets becom
 constexpr int FAST_CAP = 0;  // patch capacity stays a runtime value: a fixed 512 slots would push
                              // the gradient kernel from 3 to 2 workgroups per CU (LDS)
 
-hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, hipStream_t s) {
+// MS_ABL_NTILES=<n>: timing experiment only (wrong results) -- the tile kernels process at most n tiles
+static int abl_ntiles() {
+  static const int v = getenv("MS_ABL_NTILES") ? atoi(getenv("MS_ABL_NTILES")) : 0;
+  return v;
+}
+
+hipError_t launch_energy(const EnergyArgs& a_in, bool guard, int cap, int max_ent, hipStream_t s) {
+  EnergyArgs a = a_in;
+  if (abl_ntiles() > 0) a.tile1 = std::min(a.tile1, a.tile0 + abl_ntiles());
   const int nb = a.tile1 - a.tile0;
   if (nb <= 0) return hipSuccess;
   const bool bend = (a.modules & (MS_MOD_BENDING | MS_MOD_BENDING_TILT)) != 0;
@@ -1566,7 +1574,9 @@ bool gradient_lean_instance(const GradientArgs& a) {
          (a.dir_mode != 2 || a.pd_neg_pg) && !no_lean() && !a.m.no_fast;
 }
 
-hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStream_t s) {
+hipError_t launch_gradient(const GradientArgs& a_in, int cap, int max_ent, hipStream_t s) {
+  GradientArgs a = a_in;
+  if (abl_ntiles() > 0) a.tile1 = std::min(a.tile1, a.tile0 + abl_ntiles());
   const int nb = a.tile1 - a.tile0;
   if (nb <= 0) return hipSuccess;
   const bool bend = (a.modules & MS_MOD_BENDING) != 0;
