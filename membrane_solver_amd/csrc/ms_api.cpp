@@ -109,6 +109,7 @@ struct ms_ctx {
   // pair launch: when the last search needed two or more trials, the first two are evaluated in ONE energy launch
   // (k_energy<PAIR>); the second trial uses the ordinary outputs, the first one the "2" set below
   bool pair_enable = true;       // MS_PAIR=0 switches it off
+  bool escalate = true;          // MS_ESCALATE=0: a search that keeps rejecting stays with what the history suggests
   int pair_force = 0;            // MS_PAIR=2 / 3: pair (/ pair + a gated third trial) whenever possible, whatever
                                  // the history predicts (tests)
   int pair_on = 0;               // phase_energy / reduce_slots: queue a pair (2: second evaluation at pair_alpha2)
@@ -1194,6 +1195,7 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
     c->pair_force = atoi(pe) >= 2 ? std::min(atoi(pe), 4) : 0;  // 4: triple launches whenever possible
   }
   c->speculate = !(getenv("MS_SPECULATE") != nullptr && atoi(getenv("MS_SPECULATE")) == 0);
+  c->escalate = !(getenv("MS_ESCALATE") != nullptr && atoi(getenv("MS_ESCALATE")) == 0);
   c->ls_reset = !(getenv("MS_LS_RESET") != nullptr && atoi(getenv("MS_LS_RESET")) == 0);
   c->no_fast = getenv("MS_NO_FAST") != nullptr && atoi(getenv("MS_NO_FAST")) != 0;
   c->pair_lean_enable = !(getenv("MS_PAIR_LEAN") != nullptr && atoi(getenv("MS_PAIR_LEAN")) == 0);
@@ -2243,7 +2245,6 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   // the ladder needs: carry mode (a trial is a complete energy pass), energies the device can add up the way the
   // host does (surface + bending only), no tilt projections between trials
   const bool can_chain = c->speculate && carry_mode && !tilt && !(c->params.modules & MS_MOD_VOLUME_PENALTY);
-  const bool can_spec = can_chain && (c->pair_force || (ls_warm ? r_lo < INFINITY : c->pred_trials > 1));
   // ... and the fused gradient + direction pass of the accepted point can follow in the same queue (no
   // constraint row to reduce first), gated on "some stage accepted"
   const bool can_spec_kc = can_chain && !constraint;
@@ -2251,6 +2252,11 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   while (it < max_iter) {
     const bool safe_small = alpha * max_dir < safe_step_limit;
     kc_queued = false;  // (a gradient pass queued behind an earlier, fully rejected round found its gate closed)
+    // A search that has rejected three alphas already will most likely reject more: from there on its trials go three
+    // to a launch (the early ones of a launch cost an energy-only evaluation each), whatever the history of the
+    // earlier searches says.  Prediction only -- the same alphas are tested in the same order.
+    const int force = c->pair_force ? c->pair_force : ((c->escalate && out->trials >= 3) ? 4 : 0);
+    const bool can_spec = can_chain && (force || (ls_warm ? r_lo < INFINITY : c->pred_trials > 1));
     int depth = 1;
     double alphas[1 + ms_ctx::SPEC_STAGES];
     alphas[0] = alpha;
@@ -2259,10 +2265,10 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       // how many trials to queue: as many as the last search needed (cold), or -- once there is a history --
       // one per alpha that still lies above (most of) the range where alphas were accepted lately
       const int room = std::min(1 + ms_ctx::SPEC_STAGES, max_iter - it);
-      const int want = c->pair_force ? std::min(std::min(c->pair_force, 3), room)
+      const int want = force ? std::min(std::min(force, 3), room)
                                      : (ls_warm ? room : std::min(c->pred_trials - out->trials, room));
       while (depth < want) {
-        if (!c->pair_force && ls_warm && !(alphas[depth - 1] > 0.9 * a_hi)) break;
+        if (!force && ls_warm && !(alphas[depth - 1] > 0.9 * a_hi)) break;
         const double a_next = alphas[depth - 1] * sp->beta;
         if (a_next < 1e-8) break;
         alphas[depth++] = a_next;
@@ -2278,15 +2284,15 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     // were rejected lately (a wasted evaluation costs more than a saved round trip gains)
     const bool pair = chain && depth > 1 && c->pair_enable && c->xt2 != nullptr &&
                       (c->params.modules & MS_MOD_BENDING) != 0 &&
-                      (c->pair_force || (ls_warm && alpha > 1.05 * a_hi && r_lo < INFINITY));
+                      (force || (ls_warm && alpha > 1.05 * a_hi && r_lo < INFINITY));
     // triple launch: trial 1 is expected to fail as well -- its alpha is not below one that was rejected lately
     bool triple = false;
     if (pair) {
       depth = std::min(depth, 3);
-      triple = depth == 3 && c->fK3 != nullptr && (c->pair_force ? c->pair_force == 4 : alphas[1] > r_lo);
+      triple = depth == 3 && c->fK3 != nullptr && (force ? force == 4 : alphas[1] > r_lo);
       // otherwise the pair, and one gated trial behind it when trial 1 is as sure to fail as trial 0 (an empty gated
       // stage costs about what the host round trip it saves does, so "probably" is not enough)
-      if (depth == 3 && !triple && !c->pair_force && !(alphas[1] > a_hi)) depth = 2;
+      if (depth == 3 && !triple && !force && !(alphas[1] > a_hi)) depth = 2;
     }
     if (!chain) {
       rc = phase_energy(c, c->params.modules, true, alpha, true, !safe_small, carry_mode);
