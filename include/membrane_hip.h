@@ -472,10 +472,18 @@ int ms_tile_stats(ms_ctx *ctx, int64_t *n_tiles, int64_t *facet_instances,
  * (three), 9 gradient, lean instantiation (k_gradient<1,false,256,0,true,true>: analytic
  * bending, uniform surface tension, no separate previous-direction rows)} and resets the
  * counters.  Used by bench.py for the roofline figure. */
-#define MS_PROF_KINDS 10
+#define MS_PROF_KINDS 11 /* 10: energy launch with four to eight trial evaluations (k_energy<...,8>) */
 int ms_profile_enable(ms_ctx *ctx, int on);
 int ms_profile_read(ms_ctx *ctx, double total_ms[MS_PROF_KINDS],
                     int64_t launches[MS_PROF_KINDS]);
+
+/* Line-search queue statistics since ms_create (ms_step): stats[0] rounds queued, [1] multi-trial energy
+ * launches among them, [2] trial evaluations of those launches that lay behind the accepted trial (wasted),
+ * [3] searches whose accepted trial was an energy-only early trial of a multi-trial launch (re-evaluated alone),
+ * [4] decisions on which host and device differed (each one also fails the call with MS_ERR_STATE: the device takes
+ * every Armijo decision once, in the fold that closes the stage -- runtime/steppers/line_search.py:386-392 -- and the
+ * host replays it from the same doubles), [5..7] reserved. */
+int ms_queue_stats(ms_ctx *ctx, int64_t stats[8]);
 
 /* Host-only planning pass (no GPU needed): runs the same tiling ms_create
  * uses and reports stats[0..7] = {n_tiles, facet_instances, max_halo,

@@ -191,6 +191,7 @@ SIGNATURES = {
     "ms_tile_stats": (ctypes.c_int, [_P, _I64, _I64, _I64, _I64, _I64]),
     "ms_profile_enable": (ctypes.c_int, [_P, ctypes.c_int]),
     "ms_profile_read": (ctypes.c_int, [_P, _D, _I64]),
+    "ms_queue_stats": (ctypes.c_int, [_P, _I64]),
     "ms_plan_tiling": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _D, _I32, ctypes.c_int, ctypes.c_int,
                                       _I64, _I32]),
     "ms_plan_tiling_conflicts": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _D, _I32, ctypes.c_int, _D]),

@@ -94,46 +94,54 @@ struct ms_ctx {
   static constexpr int SPEC_STAGES = 3;  // extra mailboxes (stage 0 uses the main one)
   struct Mailbox {
     double* h_scal = nullptr;              // host copy of the values (filled by fetch)
-    unsigned long long* h_seq = nullptr;   // pinned, mapped: 2*MS_NSCAL words, {value bits, sequence word} per slot
+    unsigned long long* h_seq = nullptr;   // pinned, mapped: 2*MS_MB_WORDS words, {value bits, sequence word} per entry
     unsigned long long* d_h_seq = nullptr;
-    unsigned long long expected[MS_NSCAL] = {0};
+    unsigned long long expected[MS_MB_WORDS] = {0};
   } spec[SPEC_STAGES];
   Mailbox grad_mb;               // mailbox of the gradient pass queued behind a ladder
   bool kc_pending = false;       // that pass ran for the accepted x: the next ms_step takes its result
-  long queue_fallbacks = 0;      // queued gradient passes redone without the gate (see ms_step)
   int kc_stepper = 0;
   bool kc_use_history = false;
-  int* d_gate = nullptr;         // SPEC_STAGES + 1 gate words + the "accepted" word
-  const int* cur_gate = nullptr; // gate word of the k_reduce launches being queued (nullptr: unconditional)
-  double cur_gate_rhs = 0.0;     // Armijo right-hand side the gated tile kernel tests the device scalars against
-  // pair launch: when the last search needed two or more trials, the first two are evaluated in ONE energy launch
-  // (k_energy<PAIR>); the second trial uses the ordinary outputs, the first one the "2" set below
+  // Decision records (ms_internal.h DEC_*): one 128-byte line each, written by the head workgroup of the fold that
+  // closes a line-search stage, read by every kernel queued behind that stage.  Record k belongs to stage k of the
+  // round being queued; the stream orders a record's readers between its writers.
+  uint32_t* d_dec = nullptr;
+  static constexpr int N_DEC = 16;
+  const uint32_t* cur_gate = nullptr;  // decision word the launches being queued test (nullptr: unconditional)
+  uint32_t cur_gate_want = 0;
+  uint32_t* cur_dec = nullptr;         // the fold being queued closes a stage: its decision goes here
+  double cur_rhs[MS_MAX_TRIALS] = {0}; // ... taken against these Armijo right-hand sides (trial order)
+  bool cur_check_ran = false;          // the tile kernel in front of the fold being queued is gated by cur_gate
+  unsigned long long* h_err = nullptr; // pinned word a fold sets when a gated launch ran on part of its workgroups
+  unsigned long long* d_h_err = nullptr;
+  long queue_mismatches = 0;           // host and device decisions that differed (every one is also a hard error)
+  long q_rounds = 0, q_multi = 0, q_wasted = 0, q_side_accepts = 0;  // queue statistics (ms_queue_stats)
+  int escalate_after = 3;              // rejections after which a search goes to multi-trial launches (MS_ESCALATE=n)
+  // multi-trial launch: trials 0 .. n-2 of a ladder are evaluated in the same energy launch as trial n-1
+  // (k_energy<MULTI>); the last trial uses the ordinary outputs, early trial j the side set j
   bool pair_enable = true;       // MS_PAIR=0 switches it off
   bool escalate = true;          // MS_ESCALATE=0: a search that keeps rejecting stays with what the history suggests
   int pair_force = 0;            // MS_PAIR=2 / 3: pair (/ pair + a gated third trial) whenever possible, whatever
                                  // the history predicts (tests)
-  int pair_on = 0;               // phase_energy / reduce_slots: queue a pair (2: second evaluation at pair_alpha2)
-  // the early trials of a pair / triple launch (the ones expected to fail) are evaluated for their energies only:
+  int pair_on = 0;               // phase_energy / reduce_slots: the launch being queued evaluates this many trials
+  // the early trials of a multi-trial launch (the ones expected to fail) are evaluated for their energies only:
   // no trial positions, no bending factors written for them (ms_step; the sharded driver needs the factor rows)
   bool no_fast = false;          // MS_NO_FAST=1
   bool pair_lean = false;
-  bool pair_lean_enable = true;  // MS_PAIR_LEAN=0: write every trial's outputs (copied back if an early one is accepted)
-                                 // or a triple (3: a third one at pair_alpha3)
-  double pair_alpha2 = 0.0, pair_alpha3 = 0.0;
-  double* xt3 = nullptr;
+  bool pair_lean_enable = true;  // MS_PAIR_LEAN=0: write the first two early trials' outputs (copied back if one is accepted)
+  double pair_alpha[MS_MAX_TRIALS] = {0};  // alphas of the early trials
+  static constexpr int N_SIDE = MS_MAX_TRIALS - 1;
+  struct SideSet {
+    double* partials = nullptr;
+    double* scal = nullptr;
+    Mailbox mb;
+  } side[N_SIDE];
+  double* xt3 = nullptr;         // full outputs of early trial 1 (MS_PAIR_LEAN=0)
   double* fK3 = nullptr;
   double* fA3 = nullptr;
-  double* d_partials3 = nullptr;
-  double* d_scal3 = nullptr;
-  const double* cur_veto3 = nullptr;
-  double cur_veto_rhs3 = 0.0;
-  double* xt2 = nullptr;
+  double* xt2 = nullptr;         // ... of early trial 0 (MS_PAIR_LEAN=0, the sharded pair)
   double* fK2 = nullptr;
   double* fA2 = nullptr;
-  double* d_partials2 = nullptr;
-  double* d_scal2 = nullptr;
-  const double* cur_veto = nullptr;  // gradient pass behind a pair: do not run if these energies pass cur_veto_rhs
-  double cur_veto_rhs = 0.0;
   int pred_trials = 1;           // trials the last successful search needed
   // line-search history of the last LS_HIST accepted steps (prediction only -- never changes a result):
   // the accepted alpha and the smallest alpha rejected on the way to it (INFINITY: accepted at once)
@@ -162,7 +170,7 @@ struct ms_ctx {
   unsigned long long* h_seq = nullptr;
   unsigned long long* d_h_seq = nullptr;
   unsigned long long ticket = 0;          // ticket of the latest reduce launch
-  unsigned long long expected[MS_NSCAL] = {0};  // latest ticket that folds each slot
+  unsigned long long expected[MS_MB_WORDS] = {0};  // latest ticket that folds each slot (+ the decision entry)
   bool has_boundary = false;
   double* d_stage = nullptr;  // nv*3 staging in external row order
   double* last_g = nullptr;   // buffer holding the most recent finalized gradient
@@ -501,39 +509,68 @@ const char* box_name(ms_ctx* c, const void* h_seq) {
   return it->second.c_str();
 }
 
+// energy slots whose sum is the energy the Armijo test compares (the ladder only runs for module sets whose energy
+// is surface + bending: ms_step's can_chain)
+uint32_t armijo_slots(const ms_ctx* c) {
+  return ((c->params.modules & MS_MOD_SURFACE) ? (1u << MS_S_ESURF) : 0u) |
+         ((c->params.modules & MS_MOD_BENDING) ? (1u << MS_S_EBEND) : 0u);
+}
+
 int reduce_slots(ms_ctx* c, uint32_t mask) {
   ProfScope ps(c, 3, c->cur_gate != nullptr);
   ++c->ticket;
   if (trace_queue())
-    fprintf(stderr, "[msq] fold ticket %llu mask %#x -> %s gate %p pair_on %d\n", (unsigned long long)(c->ticket), mask,
-            box_name(c, c->h_seq), (const void*)c->cur_gate, (int)c->pair_on);
-  // a pair launch has no tilt module: only the core slots carry anything (and the sharded driver parks the other
+    fprintf(stderr, "[msq] fold ticket %llu mask %#x -> %s gate %p want %u dec %p trials %d\n",
+            (unsigned long long)(c->ticket), mask, box_name(c, c->h_seq), (const void*)c->cur_gate, c->cur_gate_want,
+            (const void*)c->cur_dec, (int)c->pair_on);
+  // a multi-trial launch has no tilt module: only the core slots carry anything (and the sharded driver parks the other
   // trial's fold in the tilt slots of the device scalars, which the full mask would overwrite)
-  if (c->pair_on) {
+  const int n_multi = c->pair_on > 1 ? c->pair_on : 1;
+  if (n_multi > 1) {
     const uint32_t core = (1u << MS_S_ESURF) | (1u << MS_S_VOL) | (1u << MS_S_EBEND) | (1u << MS_S_MINEDGE2) |
                           (1u << MS_S_GUARD);
     // (nobody is to wait for the dropped slots: an older, gated-out launch may have left a ticket there)
     for (int sl = 0; sl < MS_NSCAL; ++sl)
-      if (mask & ~core & (1u << sl)) c->expected[sl] = c->spec[0].expected[sl] = c->spec[1].expected[sl] = 0;
+      if (mask & ~core & (1u << sl)) {
+        c->expected[sl] = 0;
+        for (int k = 0; k + 1 < n_multi; ++k) c->side[k].mb.expected[sl] = 0;
+      }
     mask &= core;
   }
+  FoldArgs f;
+  memset(&f, 0, sizeof(f));
+  f.n_tiles = c->til.n_tiles;
+  f.tile0 = c->tile0;
+  f.tile1 = c->tile1;
+  f.slot_mask = mask;
+  f.ticket = c->ticket;
+  f.n_sets = n_multi;
+  f.gate = c->cur_gate;
+  f.gate_want = c->cur_gate_want;
+  f.check_ran = (c->cur_gate != nullptr && c->cur_check_ran) ? 1 : 0;
+  f.dec_out = c->cur_dec;
+  f.e_mask = armijo_slots(c);
+  f.host_err = c->d_h_err;
+  for (int j = 0; j < MS_MAX_TRIALS; ++j) f.rhs[j] = c->cur_rhs[j];
+  // an energy-only early trial needs nothing but its energy slots (the head workgroup folds those); an early trial
+  // with outputs of its own (MS_PAIR_LEAN=0, the sharded pair) can be accepted as it is and needs every slot
+  f.side_full = (n_multi > 1 && (!c->pair_lean || !f.dec_out)) ? 1 : 0;
+  for (int j = 0; j + 1 < n_multi; ++j) {
+    ms_ctx::SideSet& sd = c->side[j];
+    f.set[j].partials = sd.partials;
+    f.set[j].scal = (j == 0 && c->pair_scal2) ? c->pair_scal2 : sd.scal;
+    f.set[j].host_box = sd.mb.d_h_seq;
+    const uint32_t posted = (f.side_full || !f.dec_out) ? mask : (mask & f.e_mask);
+    for (int sl = 0; sl < MS_NSCAL; ++sl)
+      if (posted & (1u << sl)) sd.mb.expected[sl] = c->ticket;
+  }
+  f.set[n_multi - 1].partials = c->d_partials;
+  f.set[n_multi - 1].scal = c->d_scal;
+  f.set[n_multi - 1].host_box = c->d_h_seq;
   for (int sl = 0; sl < MS_NSCAL; ++sl)
     if (mask & (1u << sl)) c->expected[sl] = c->ticket;
-  if (c->pair_on) {
-    const bool three = c->pair_on == 3;
-    for (int sl = 0; sl < MS_NSCAL; ++sl)
-      if (mask & (1u << sl)) {
-        c->spec[0].expected[sl] = c->ticket;
-        if (three) c->spec[1].expected[sl] = c->ticket;
-      }
-    HIPCHK(c, launch_reduce(c->d_partials, c->til.n_tiles, c->tile0, c->tile1, mask, c->d_scal, c->d_h_seq,
-                            c->ticket, c->stream, nullptr, c->d_partials2,
-                            c->pair_scal2 ? c->pair_scal2 : c->d_scal2, c->spec[0].d_h_seq,
-                            three ? c->d_partials3 : nullptr, c->d_scal3, c->spec[1].d_h_seq));
-    return MS_OK;
-  }
-  HIPCHK(c, launch_reduce(c->d_partials, c->til.n_tiles, c->tile0, c->tile1, mask, c->d_scal,
-                          c->d_h_seq, c->ticket, c->stream, c->cur_gate));
+  if (f.dec_out) c->expected[MS_MB_DEC] = c->ticket;
+  HIPCHK(c, launch_reduce(f, c->stream));
   return MS_OK;
 }
 
@@ -556,40 +593,44 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   a.fA = (bend && write_factors) ? c->buf[MS_BUF_FA] : nullptr;
   a.bt_vert = bt ? c->d_bt_vert : nullptr;
   a.bt_normals = nullptr;
-  a.gate_scal = c->cur_gate ? c->d_scal : nullptr;
-  a.gate_rhs = c->cur_gate_rhs;
-  a.gate_mods = c->params.modules;
-  a.gate_out = const_cast<int*>(c->cur_gate);
+  a.gate = c->cur_gate;
+  a.gate_want = c->cur_gate_want;
   a.atomic = c->deterministic ? 0 : 1;
   a.pair = 0;
-  a.alpha2 = 0.0;
-  a.xt2 = a.fK2 = a.fA2 = a.partials2 = nullptr;
-  a.alpha3 = 0.0;
-  a.xt3 = a.fK3 = a.fA3 = a.partials3 = nullptr;
-  if (c->pair_on) {
-    if (!use_dir || guard || !write_factors || !(modules & MS_MOD_BENDING) || bt || lbt || !c->fK2)
-      return fail(c, MS_ERR_STATE, "pair launch: not an ordinary bending trial");
+  for (int j = 0; j < MS_MAX_TRIALS - 1; ++j) {
+    a.alpha_side[j] = 0.0;
+    a.partials_side[j] = nullptr;
+  }
+  for (int j = 0; j < 2; ++j) a.xt_side[j] = a.fK_side[j] = a.fA_side[j] = nullptr;
+  if (c->pair_on > 1) {
+    if (!use_dir || guard || !write_factors || !(modules & MS_MOD_BENDING) || bt || lbt || !c->side[0].partials)
+      return fail(c, MS_ERR_STATE, "multi-trial launch: not an ordinary bending trial");
+    if (c->pair_on > MS_MAX_TRIALS || !c->side[c->pair_on - 2].partials)
+      return fail(c, MS_ERR_STATE, "multi-trial launch: side sets not allocated");
     a.pair = c->pair_on;
-    if (c->pair_on == 3) {
-      if (!c->fK3) return fail(c, MS_ERR_STATE, "triple launch: buffers not allocated");
-      a.alpha3 = trial_alpha(c, c->pair_alpha3);
-      a.xt3 = (write_trial && !c->pair_lean) ? c->xt3 : nullptr;
-      a.fK3 = c->pair_lean ? nullptr : c->fK3;
-      a.fA3 = c->pair_lean ? nullptr : c->fA3;
-      a.partials3 = c->d_partials3;
+    for (int j = 0; j + 1 < c->pair_on; ++j) {
+      a.alpha_side[j] = trial_alpha(c, c->pair_alpha[j]);
+      a.partials_side[j] = c->side[j].partials;
     }
-    a.alpha2 = trial_alpha(c, c->pair_alpha2);
-    a.xt2 = (write_trial && !c->pair_lean) ? c->xt2 : nullptr;
-    a.fK2 = c->pair_lean ? nullptr : c->fK2;
-    a.fA2 = c->pair_lean ? nullptr : c->fA2;
-    a.partials2 = c->d_partials2;
+    if (!c->pair_lean) {  // the first two early trials write their own positions / factors
+      double* const sx[2] = {c->xt2, c->xt3};
+      double* const sk[2] = {c->fK2, c->fK3};
+      double* const sa[2] = {c->fA2, c->fA3};
+      for (int j = 0; j < 2 && j + 1 < c->pair_on; ++j) {
+        if (!sk[j]) return fail(c, MS_ERR_STATE, "multi-trial launch: output side set not allocated");
+        a.xt_side[j] = write_trial ? sx[j] : nullptr;
+        a.fK_side[j] = sk[j];
+        a.fA_side[j] = sa[j];
+      }
+      if (c->pair_on > 3) return fail(c, MS_ERR_STATE, "multi-trial launch: only two early trials can write outputs");
+    }
   }
   if (bt && !c->d_bt_vert) return fail(c, MS_ERR_STATE, "bending_tilt: ms_set_params did not allocate its buffers");
   a.partials = c->d_partials;
   a.bending_model = c->params.bending_model;
   a.modules = modules;
   if (!lbt) {
-    ProfScope ps(c, a.pair == 3 ? 8 : (a.pair ? 7 : 0), c->cur_gate != nullptr);
+    ProfScope ps(c, a.pair > 3 ? 10 : (a.pair == 3 ? 8 : (a.pair ? 7 : 0)), c->cur_gate != nullptr);
     const double t_l0 = g_host_timing.on ? HostTiming::now() : 0.0;
     HIPCHK(c, launch_energy(a, guard && use_dir, c->cap, c->til.max_ent, c->stream));
     if (g_host_timing.on && g_host_timing.armed) {
@@ -747,14 +788,8 @@ int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulat
   a.pg = c->buf[MS_BUF_PG];
   a.pd = c->buf[MS_BUF_PD];
   a.pd_neg_pg = (dir_mode == 2 && c->pd_neg_pg) ? 1 : 0;
-  a.gate_scal = c->cur_gate ? c->d_scal : nullptr;
-  a.gate_rhs = c->cur_gate_rhs;
-  a.gate_mods = c->params.modules;
-  a.gate_out = const_cast<int*>(c->cur_gate);
-  a.veto_scal = c->cur_gate ? c->cur_veto : nullptr;
-  a.veto_rhs = c->cur_veto_rhs;
-  a.veto_scal3 = (c->cur_gate && c->cur_veto) ? c->cur_veto3 : nullptr;
-  a.veto_rhs3 = c->cur_veto_rhs3;
+  a.gate = c->cur_gate;
+  a.gate_want = c->cur_gate_want;
   a.atomic = c->deterministic ? 0 : 1;
   a.bt_vert = nullptr;
   a.tilts = nullptr;
@@ -821,7 +856,7 @@ int phase_direction(ms_ctx* c, int stepper, bool use_history, bool g_finalized =
     // the previous direction was an implicit -PG: write it out for the unfused direction kernel
     HIPCHK(c, launch_direction(c->tile0, c->tile1, c->til.nv, c->til.T, c->d_vflags, c->buf[MS_BUF_PG],
                                c->buf[MS_BUF_GC], c->buf[MS_BUF_PD], c->buf[MS_BUF_PG], c->buf[MS_BUF_PD], c->d_scal,
-                               0, 0, c->d_partials, c->til.n_tiles, 0, c->stream));
+                               0, 0, c->d_partials, c->til.n_tiles, 0, c->stream, c->cur_gate, c->cur_gate_want));
     c->pd_neg_pg = false;
   }
   {
@@ -830,23 +865,11 @@ int phase_direction(ms_ctx* c, int stepper, bool use_history, bool g_finalized =
                              c->buf[MS_BUF_GC], c->buf[MS_BUF_D], c->buf[MS_BUF_PG],
                              c->buf[MS_BUF_PD], c->d_scal, use_con ? 1 : 0,
                              (stepper == MS_STEPPER_CG && use_history) ? 1 : 0, c->d_partials,
-                             c->til.n_tiles, (g_finalized && !use_con) ? 0 : 1, c->stream));
+                             c->til.n_tiles, (g_finalized && !use_con) ? 0 : 1, c->stream, c->cur_gate,
+                             c->cur_gate_want));
   }
   c->last_g = c->buf[MS_BUF_G];
   return reduce_slots(c, MASK_DIR);
-}
-
-// k_reduce mirrors every slot it folds into the pinned mailbox and then bumps that slot's
-// sequence word; fetching = spinning on those words (a few microseconds less than waking up
-// from hipStreamSynchronize).  Falls back to a stream sync after ~50 ms of spinning.
-// value and sequence word of a slot arrive in one 16-byte write; the acquire load of the sequence word in fetch()
-// orders these reads after it
-int take_mailbox(ms_ctx* c) {
-  for (int sl = 0; sl < MS_NSCAL; ++sl) {
-    const unsigned long long bits = __atomic_load_n(&c->h_seq[2 * sl], __ATOMIC_RELAXED);
-    memcpy(&c->h_scal[sl], &bits, sizeof(double));
-  }
-  return MS_OK;
 }
 
 // host-side write of a slot (a stage mailbox's result moved into the main one): both the host copy and the value
@@ -860,57 +883,91 @@ void put_mailbox(ms_ctx* c, int sl, double v) {
 
 const char* box_name(ms_ctx* c, const void* h_seq);
 bool trace_queue();
-// soft_miss != nullptr: a post that is still missing after everything queued has run is reported through *soft_miss
-// (MS_OK is returned) instead of as an error -- for callers that can redo the launch without the queue
-int fetch(ms_ctx* c, bool* soft_miss = nullptr) {
-  if (soft_miss) *soft_miss = false;
-  if (trace_queue()) {
-    unsigned long long mx = 0;
-    for (int sl = 0; sl < MS_NSCAL; ++sl) mx = std::max<unsigned long long>(mx, c->expected[sl]);
-    fprintf(stderr, "[msq] fetch %s (latest expected ticket %llu)\n", box_name(c, c->h_seq), mx);
-  }
-  if (c->tile1 > c->tile0) {
-    for (long spin = 0; spin < 20000000L; ++spin) {
-      bool done = true;
-      for (int sl = 0; sl < MS_NSCAL; ++sl)
-        if (__atomic_load_n(&c->h_seq[2 * sl + 1], __ATOMIC_ACQUIRE) < c->expected[sl]) {
-          done = false;
-          break;
-        }
-      if (done) {
-        if (g_host_timing.on) {
-          if (spin > 0) {  // (only when the host really waited: the GPU was the one ahead)
-            g_host_timing.t_fetch = HostTiming::now();
-            g_host_timing.armed = true;
-          }
-        }
-        return take_mailbox(c);
+
+// a fold found that a gated launch had run on part of its workgroups only (FoldArgs::check_ran): never continue
+int check_queue_error(ms_ctx* c) {
+  if (!c->h_err) return MS_OK;
+  const unsigned long long e = __atomic_load_n(c->h_err, __ATOMIC_ACQUIRE);
+  if (e == 0) return MS_OK;
+  char msg[256];
+  snprintf(msg, sizeof(msg),
+           "line-search queue: a gated launch ran on %llu of its %d workgroups (fold ticket %llu): the workgroups of one "
+           "launch did not read the same decision word",
+           e & 0xffffffull, c->tile1 - c->tile0, (e >> 24) & 0xffffffffull);
+  return fail(c, MS_ERR_STATE, msg);
+}
+
+// wait until every entry of a mailbox carries the ticket of the latest fold queued for it; *vals (optional) receives
+// the MS_NSCAL slot values, *code the decision entry
+int wait_mailbox(ms_ctx* c, unsigned long long* h_seq, const unsigned long long* expected, double* vals,
+                 uint32_t* code) {
+  auto arrived = [&]() {
+    for (int sl = 0; sl < MS_MB_WORDS; ++sl)
+      if (__atomic_load_n(&h_seq[2 * sl + 1], __ATOMIC_ACQUIRE) < expected[sl]) return false;
+    return true;
+  };
+  bool done = c->tile1 <= c->tile0;
+  for (long spin = 0; !done && spin < 20000000L; ++spin) {
+    done = arrived();
+    if (done) {
+      if (g_host_timing.on && spin > 0) {  // (only when the host really waited: the GPU was the one ahead)
+        g_host_timing.t_fetch = HostTiming::now();
+        g_host_timing.armed = true;
       }
-      __builtin_ia32_pause();
+      break;
     }
+    __builtin_ia32_pause();
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  // everything queued has run: a slot that is still behind belongs to a gated launch that found its gate closed
-  // although the host expected it to run -- host and device disagreed on an Armijo test.  Never continue on that.
-  for (int sl = 0; sl < MS_NSCAL; ++sl)
-    if (c->tile1 > c->tile0 && __atomic_load_n(&c->h_seq[2 * sl + 1], __ATOMIC_ACQUIRE) < c->expected[sl]) {
-      if (soft_miss) {
-        *soft_miss = true;
-        for (int k = 0; k < MS_NSCAL; ++k) c->expected[k] = 0;  // nobody waits for that ticket any more
-        return MS_OK;
-      }
-      char msg[512];
-      const char* box = c->h_seq == c->spec[0].h_seq ? "stage-1" : (c->h_seq == c->spec[1].h_seq ? "stage-2"
-                        : (c->h_seq == c->grad_mb.h_seq ? "gradient" : "main"));
+  if (!done) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // everything queued has run: an entry that is still behind belongs to a gated fold that found its gate closed
+    // although the host expected it to run -- host and device disagreed on an Armijo test.  Never continue on that.
+    if (!arrived()) {
+      int rc = check_queue_error(c);
+      if (rc) return rc;
+      int sl = 0;
+      while (sl < MS_MB_WORDS && __atomic_load_n(&h_seq[2 * sl + 1], __ATOMIC_ACQUIRE) >= expected[sl]) ++sl;
+      char msg[384];
       snprintf(msg, sizeof(msg),
-               "line-search queue: a gated launch the host waited for did not run (mailbox %s, slot %d: sequence %llu "
-               "< expected %llu; ticket %llu, pair_on %d, gate %s; E_surf %.17g E_bend %.17g in this mailbox)",
-               box, sl, (unsigned long long)__atomic_load_n(&c->h_seq[2 * sl + 1], __ATOMIC_ACQUIRE),
-               (unsigned long long)c->expected[sl], (unsigned long long)c->ticket, (int)c->pair_on,
-               c->cur_gate ? "set" : "none", c->h_scal[MS_S_ESURF], c->h_scal[MS_S_EBEND]);
+               "line-search queue: a gated launch the host waited for did not run (mailbox %s, entry %d: sequence %llu "
+               "< expected %llu; ticket %llu)",
+               box_name(c, h_seq), sl, (unsigned long long)__atomic_load_n(&h_seq[2 * sl + 1], __ATOMIC_ACQUIRE),
+               (unsigned long long)expected[sl], (unsigned long long)c->ticket);
+      ++c->queue_mismatches;
       return fail(c, MS_ERR_STATE, msg);
     }
-  return take_mailbox(c);
+  }
+  int rc = check_queue_error(c);
+  if (rc) return rc;
+  if (vals)
+    for (int sl = 0; sl < MS_NSCAL; ++sl) {
+      const unsigned long long bits = __atomic_load_n(&h_seq[2 * sl], __ATOMIC_RELAXED);
+      memcpy(&vals[sl], &bits, sizeof(double));
+    }
+  if (code) *code = (uint32_t)__atomic_load_n(&h_seq[2 * MS_MB_DEC], __ATOMIC_RELAXED);
+  return MS_OK;
+}
+
+// k_reduce mirrors every slot it folds into the pinned mailbox and then bumps that slot's
+// sequence word; fetching = spinning on those words (a few microseconds less than waking up
+// from hipStreamSynchronize).  Falls back to a stream sync after ~50 ms of spinning.
+int fetch(ms_ctx* c, uint32_t* code = nullptr) {
+  if (trace_queue()) {
+    unsigned long long mx = 0;
+    for (int sl = 0; sl < MS_MB_WORDS; ++sl) mx = std::max<unsigned long long>(mx, c->expected[sl]);
+    fprintf(stderr, "[msq] fetch %s (latest expected ticket %llu)\n", box_name(c, c->h_seq), mx);
+  }
+  return wait_mailbox(c, c->h_seq, c->expected, c->h_scal, code);
+}
+
+// the host's decision against the device's (the code the fold posted next to the energies it decided on)
+int verify_decision(ms_ctx* c, uint32_t host_code, uint32_t dev_code, const char* where) {
+  if (host_code == dev_code) return MS_OK;
+  ++c->queue_mismatches;
+  char msg[256];
+  snprintf(msg, sizeof(msg), "line-search queue: host and device took different decisions at %s (host %u, device %#x)",
+           where, host_code, dev_code);
+  return fail(c, MS_ERR_STATE, msg);
 }
 
 double penalty_energy(const ms_ctx* c, double V) {
@@ -1128,16 +1185,19 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
     c->buf[MS_BUF_FA] = c->state + 8 * n3;
   }
   CREATE_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_partials),
-                       sizeof(double) * MS_NSCAL * (size_t)std::max(1, t.n_tiles)));
-  CREATE_HIP(hipMemset(c->d_partials, 0, sizeof(double) * MS_NSCAL * (size_t)std::max(1, t.n_tiles)));
+                       sizeof(double) * MS_NPART * (size_t)std::max(1, t.n_tiles)));
+  CREATE_HIP(hipMemset(c->d_partials, 0, sizeof(double) * MS_NPART * (size_t)std::max(1, t.n_tiles)));
   CREATE_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_scal), sizeof(double) * MS_NSCAL));
   CREATE_HIP(hipMemset(c->d_scal, 0, sizeof(double) * MS_NSCAL));
   c->buf[MS_BUF_SCAL] = c->d_scal;
   c->h_scal = static_cast<double*>(calloc(MS_NSCAL, sizeof(double)));
-  CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_seq), sizeof(unsigned long long) * 2 * MS_NSCAL,
+  CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_seq), sizeof(unsigned long long) * 2 * MS_MB_WORDS,
                            hipHostMallocMapped));
-  memset(c->h_seq, 0, sizeof(unsigned long long) * 2 * MS_NSCAL);
+  memset(c->h_seq, 0, sizeof(unsigned long long) * 2 * MS_MB_WORDS);
   CREATE_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_seq), c->h_seq, 0));
+  CREATE_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_err), sizeof(unsigned long long) * 8, hipHostMallocMapped));
+  memset(c->h_err, 0, sizeof(unsigned long long) * 8);
+  CREATE_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_err), c->h_err, 0));
   CREATE_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_stage), sizeof(double) * 3 * (size_t)nv));
   {
     // boundary lists of every rank (each rank derives all of them from the shared tiling)
@@ -1196,6 +1256,7 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
   }
   c->speculate = !(getenv("MS_SPECULATE") != nullptr && atoi(getenv("MS_SPECULATE")) == 0);
   c->escalate = !(getenv("MS_ESCALATE") != nullptr && atoi(getenv("MS_ESCALATE")) == 0);
+  if (getenv("MS_ESCALATE") != nullptr && atoi(getenv("MS_ESCALATE")) > 0) c->escalate_after = atoi(getenv("MS_ESCALATE"));
   c->ls_reset = !(getenv("MS_LS_RESET") != nullptr && atoi(getenv("MS_LS_RESET")) == 0);
   c->no_fast = getenv("MS_NO_FAST") != nullptr && atoi(getenv("MS_NO_FAST")) != 0;
   c->pair_lean_enable = !(getenv("MS_PAIR_LEAN") != nullptr && atoi(getenv("MS_PAIR_LEAN")) == 0);
@@ -1248,9 +1309,15 @@ void ms_destroy(ms_ctx* c) {
   }
   free(c->grad_mb.h_scal);
   if (c->grad_mb.h_seq) (void)hipHostFree(c->grad_mb.h_seq);
-  if (c->d_gate) (void)hipFree(c->d_gate);
-  for (double* q : {c->xt2, c->fK2, c->fA2, c->d_partials2, c->d_scal2, c->xt3, c->fK3, c->fA3, c->d_partials3,
-                    c->d_scal3})
+  if (c->d_dec) (void)hipFree(c->d_dec);
+  if (c->h_err) (void)hipHostFree(c->h_err);
+  for (auto& sd : c->side) {
+    if (sd.partials) (void)hipFree(sd.partials);
+    if (sd.scal) (void)hipFree(sd.scal);
+    free(sd.mb.h_scal);
+    if (sd.mb.h_seq) (void)hipHostFree(sd.mb.h_seq);
+  }
+  for (double* q : {c->xt2, c->fK2, c->fA2, c->xt3, c->fK3, c->fA3})
     if (q) (void)hipFree(q);
   free(c->h_scal);
   if (c->h_seq) (void)hipHostFree(c->h_seq);
@@ -2033,41 +2100,54 @@ int ms_reset_stepper(ms_ctx* c) {
 
 namespace {
 int spec_prepare(ms_ctx* c) {
-  if (c->d_gate) return MS_OK;
+  if (c->d_dec) return MS_OK;
+  auto make_box = [&](ms_ctx::Mailbox& m) -> int {
+    m.h_scal = static_cast<double*>(calloc(MS_NSCAL, sizeof(double)));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&m.h_seq), sizeof(unsigned long long) * 2 * MS_MB_WORDS,
+                            hipHostMallocMapped));
+    memset(m.h_seq, 0, sizeof(unsigned long long) * 2 * MS_MB_WORDS);
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&m.d_h_seq), m.h_seq, 0));
+    return MS_OK;
+  };
   if (c->pair_enable) {
     const size_t nvp = (size_t)std::max<int64_t>(1, c->til.nvp);
-    const size_t pb = sizeof(double) * MS_NSCAL * (size_t)std::max(1, c->til.n_tiles);
+    const size_t pb = sizeof(double) * MS_NPART * (size_t)std::max(1, c->til.n_tiles);
+    // early trial 0 may write outputs of its own (the sharded pair, MS_PAIR_LEAN=0), early trial 1 only in ms_step
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->xt2), sizeof(double) * 3 * nvp));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->fK2), sizeof(double) * 3 * nvp));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->fA2), sizeof(double) * 2 * nvp));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_partials2), pb));
-    HIPCHK(c, hipMemset(c->d_partials2, 0, pb));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_scal2), sizeof(double) * MS_NSCAL));
-    HIPCHK(c, hipMemset(c->d_scal2, 0, sizeof(double) * MS_NSCAL));
-    if (c->shard_count == 1) {  // (the sharded driver pairs, it does not triple)
+    if (c->shard_count == 1 && !c->pair_lean_enable) {
       HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->xt3), sizeof(double) * 3 * nvp));
       HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->fK3), sizeof(double) * 3 * nvp));
       HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->fA3), sizeof(double) * 2 * nvp));
-      HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_partials3), pb));
-      HIPCHK(c, hipMemset(c->d_partials3, 0, pb));
-      HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_scal3), sizeof(double) * MS_NSCAL));
-      HIPCHK(c, hipMemset(c->d_scal3, 0, sizeof(double) * MS_NSCAL));
+    }
+    const int n_side = c->shard_count == 1 ? ms_ctx::N_SIDE : 1;  // (the sharded driver pairs, no more)
+    for (int k = 0; k < n_side; ++k) {
+      ms_ctx::SideSet& sd = c->side[k];
+      HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&sd.partials), pb));
+      HIPCHK(c, hipMemset(sd.partials, 0, pb));
+      HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&sd.scal), sizeof(double) * MS_NSCAL));
+      HIPCHK(c, hipMemset(sd.scal, 0, sizeof(double) * MS_NSCAL));
+      int rc = make_box(sd.mb);
+      if (rc) return rc;
     }
   }
-  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_gate), sizeof(int) * (ms_ctx::SPEC_STAGES + 3)));
-  HIPCHK(c, hipMemset(c->d_gate, 0, sizeof(int) * (ms_ctx::SPEC_STAGES + 3)));
-  ms_ctx::Mailbox* boxes[ms_ctx::SPEC_STAGES + 1];
-  for (int k = 0; k < ms_ctx::SPEC_STAGES; ++k) boxes[k] = &c->spec[k];
-  boxes[ms_ctx::SPEC_STAGES] = &c->grad_mb;
-  for (ms_ctx::Mailbox* mp : boxes) {
-    ms_ctx::Mailbox& m = *mp;
-    m.h_scal = static_cast<double*>(calloc(MS_NSCAL, sizeof(double)));
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&m.h_seq), sizeof(unsigned long long) * 2 * MS_NSCAL,
-                            hipHostMallocMapped));
-    memset(m.h_seq, 0, sizeof(unsigned long long) * 2 * MS_NSCAL);
-    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&m.d_h_seq), m.h_seq, 0));
+  for (int k = 0; k < ms_ctx::SPEC_STAGES; ++k) {
+    int rc = make_box(c->spec[k]);
+    if (rc) return rc;
   }
+  {
+    int rc = make_box(c->grad_mb);
+    if (rc) return rc;
+  }
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_dec), sizeof(uint32_t) * MS_DEC_STRIDE * ms_ctx::N_DEC));
+  HIPCHK(c, hipMemset(c->d_dec, 0, sizeof(uint32_t) * MS_DEC_STRIDE * ms_ctx::N_DEC));
   return MS_OK;
+}
+inline uint32_t* dec_word(ms_ctx* c, int k) { return c->d_dec + (size_t)MS_DEC_STRIDE * k; }
+// the host knows a gated fold stayed out (an earlier stage was accepted, or nothing was): nobody waits for its ticket
+inline void forget(ms_ctx::Mailbox& m) {
+  for (int sl = 0; sl < MS_MB_WORDS; ++sl) m.expected[sl] = 0;
 }
 // make stage mailbox `m` the context's mailbox (and back: the swap is its own inverse)
 void swap_mailbox(ms_ctx* c, ms_ctx::Mailbox& m) {
@@ -2075,7 +2155,7 @@ void swap_mailbox(ms_ctx* c, ms_ctx::Mailbox& m) {
   std::swap(c->h_scal, m.h_scal);
   std::swap(c->h_seq, m.h_seq);
   std::swap(c->d_h_seq, m.d_h_seq);
-  for (int sl = 0; sl < MS_NSCAL; ++sl) std::swap(c->expected[sl], m.expected[sl]);
+  for (int sl = 0; sl < MS_MB_WORDS; ++sl) std::swap(c->expected[sl], m.expected[sl]);
 }
 }  // namespace
 
@@ -2095,9 +2175,12 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   const bool carry_mode = sp->reuse_energy0 >= 2 && !tilt;
   const bool carried = carry_mode && c->carry_valid &&
                        (c->factors_valid || !(c->params.modules & (MS_MOD_BENDING | MS_MOD_BENDING_TILT)));
+  // the direction cannot ride in the gradient kernel's epilogue when a constraint row has to be projected out first
+  // (lambda needs a global reduction) or when a tilt module adds its shape gradient behind K_C
+  const bool volrow = (c->params.modules & MS_CON_VOLUME) != 0;
   const bool constraint = (c->params.modules & (MS_CON_VOLUME | MS_TILT_SHAPE_MODS)) != 0;
   int rc;
-  bool restart_sd = false, kc_taken = false;
+  bool restart_sd = false;
   if (carried && c->grad_valid && !constraint && c->til.T <= 256) {
     // x has not moved since the last gradient pass (failed search, stepper reset): only the
     // direction changes.  k_direction on the finalized g repeats the fused epilogue's
@@ -2115,34 +2198,19 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     } else {
       rc = phase_direction(c, sp->stepper, use_history, /*g_finalized=*/true);
     }
-  } else if (c->kc_pending && carried && !constraint && c->kc_stepper == sp->stepper &&
+  } else if (c->kc_pending && carried && !(c->params.modules & MS_TILT_SHAPE_MODS) && c->kc_stepper == sp->stepper &&
              c->kc_use_history == use_history) {
-    // the fused gradient + direction pass of this x was queued behind the line search that accepted it
-    // (gated on the acceptance) and has run: take its scalars from its mailbox
+    // the gradient + direction pass of this x was queued behind the line search that accepted it (gated on the
+    // acceptance) and has run: take its scalars from its mailbox
     c->kc_pending = false;
-    swap_mailbox(c, c->grad_mb);
-    bool missed = false;
-    rc = fetch(c, &missed);
     double vals[MS_NSCAL];
-    for (int sl = 0; sl < MS_NSCAL; ++sl) vals[sl] = c->h_scal[sl];
-    swap_mailbox(c, c->grad_mb);
-    if (rc == MS_OK && missed) {
-      // The queued pass found its gate closed although the host accepted the trial: host and device did not see the
-      // same reduced energies.  Never observed in plain runs; seen under rocprofv3 --pmc, whose dispatch
-      // serialisation let the first workgroups of the gated kernel start before the preceding fold's scalars were
-      // visible.  The pass only writes G / D of the accepted state from x, the factors and the CG history, all intact:
-      // redo it without the gate.
-      ++c->queue_fallbacks;
-      rc = queue_energy_and_gradient(c, sp->stepper, use_history, carried);
-      c->maxg2_valid = !constraint;
-    } else {
-      for (int sl = 0; sl < MS_NSCAL; ++sl)
-        if (MASK_DIR & (1u << sl)) put_mailbox(c, sl, vals[sl]);
-      c->last_g = c->buf[MS_BUF_G];
-      c->dir_implicit = false;
-      c->maxg2_valid = true;
-      kc_taken = true;
-    }
+    rc = wait_mailbox(c, c->grad_mb.h_seq, c->grad_mb.expected, vals, nullptr);
+    if (rc) return rc;
+    for (int sl = 0; sl < MS_NSCAL; ++sl)
+      if (MASK_DIR & (1u << sl)) put_mailbox(c, sl, vals[sl]);
+    c->last_g = c->buf[MS_BUF_G];
+    c->dir_implicit = false;
+    c->maxg2_valid = !volrow;  // (the unfused direction kernel does not reduce max|g_i|^2)
   } else {
     c->kc_pending = false;
     rc = queue_energy_and_gradient(c, sp->stepper, use_history, carried);
@@ -2153,7 +2221,6 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     rc = fetch(c);
     if (rc) return rc;
   }
-  (void)kc_taken;
   // factors, mailbox energies and G now describe x (until a trial pass overwrites them)
   c->carry_valid = carry_mode;
   c->grad_valid = carry_mode && !constraint;
@@ -2242,59 +2309,16 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     ++c->ls_n;
     c->kc_pending = kc_queued;
   };
-  // the ladder needs: carry mode (a trial is a complete energy pass), energies the device can add up the way the
-  // host does (surface + bending only), no tilt projections between trials
+  // the queue needs: carry mode (a trial is a complete energy pass), energies the device can add up the way the
+  // host does (surface + bending only), no tilt projections between trials.  The gradient + direction pass of the
+  // accepted point follows in the same queue, gated on the acceptance (with a constraint row: K_C, the fold of
+  // <g,gC> / <gC,gC>, the direction kernel and its fold, all four behind the same decision word).
   const bool can_chain = c->speculate && carry_mode && !tilt && !(c->params.modules & MS_MOD_VOLUME_PENALTY);
-  // ... and the fused gradient + direction pass of the accepted point can follow in the same queue (no
-  // constraint row to reduce first), gated on "some stage accepted"
-  const bool can_spec_kc = can_chain && !constraint;
   int it = 0;
   while (it < max_iter) {
     const bool safe_small = alpha * max_dir < safe_step_limit;
     kc_queued = false;  // (a gradient pass queued behind an earlier, fully rejected round found its gate closed)
-    // A search that has rejected three alphas already will most likely reject more: from there on its trials go three
-    // to a launch (the early ones of a launch cost an energy-only evaluation each), whatever the history of the
-    // earlier searches says.  Prediction only -- the same alphas are tested in the same order.
-    const int force = c->pair_force ? c->pair_force : ((c->escalate && out->trials >= 3) ? 4 : 0);
-    const bool can_spec = can_chain && (force || (ls_warm ? r_lo < INFINITY : c->pred_trials > 1));
-    int depth = 1;
-    double alphas[1 + ms_ctx::SPEC_STAGES];
-    alphas[0] = alpha;
-    if (can_spec && safe_small) {
-      // queue the trials the last search needed; each further stage must be an ordinary (unguarded) trial
-      // how many trials to queue: as many as the last search needed (cold), or -- once there is a history --
-      // one per alpha that still lies above (most of) the range where alphas were accepted lately
-      const int room = std::min(1 + ms_ctx::SPEC_STAGES, max_iter - it);
-      const int want = force ? std::min(std::min(force, 3), room)
-                                     : (ls_warm ? room : std::min(c->pred_trials - out->trials, room));
-      while (depth < want) {
-        if (!force && ls_warm && !(alphas[depth - 1] > 0.9 * a_hi)) break;
-        const double a_next = alphas[depth - 1] * sp->beta;
-        if (a_next < 1e-8) break;
-        alphas[depth++] = a_next;
-      }
-    }
-    const bool chain = safe_small && (depth > 1 || can_spec_kc);
-    if (chain) {
-      rc = spec_prepare(c);
-      if (rc) return rc;
-    }
-    // two or more trials expected: the first two share one launch (and the ladder stops there for this round)
-    // ... and only when the first one is expected to fail: it lies above every alpha accepted lately, and alphas
-    // were rejected lately (a wasted evaluation costs more than a saved round trip gains)
-    const bool pair = chain && depth > 1 && c->pair_enable && c->xt2 != nullptr &&
-                      (c->params.modules & MS_MOD_BENDING) != 0 &&
-                      (force || (ls_warm && alpha > 1.05 * a_hi && r_lo < INFINITY));
-    // triple launch: trial 1 is expected to fail as well -- its alpha is not below one that was rejected lately
-    bool triple = false;
-    if (pair) {
-      depth = std::min(depth, 3);
-      triple = depth == 3 && c->fK3 != nullptr && (force ? force == 4 : alphas[1] > r_lo);
-      // otherwise the pair, and one gated trial behind it when trial 1 is as sure to fail as trial 0 (an empty gated
-      // stage costs about what the host round trip it saves does, so "probably" is not enough)
-      if (depth == 3 && !triple && !force && !(alphas[1] > a_hi)) depth = 2;
-    }
-    if (!chain) {
+    if (!(can_chain && safe_small)) {
       rc = phase_energy(c, c->params.modules, true, alpha, true, !safe_small, carry_mode);
       if (rc) return rc;
       rc = fetch(c);
@@ -2323,51 +2347,101 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       if (alpha < 1e-8) break;
       continue;
     }
-    // ---- speculative ladder: queue `depth` trials, stage j > 0 gated on the rejection of stage j-1 ----
-    double rhs[1 + ms_ctx::SPEC_STAGES];
-    int* const d_acc = c->d_gate + ms_ctx::SPEC_STAGES + 2;
-    if (pair) {
-      // trial 0 -> the "2" outputs and spec[0]'s mailbox, trial 1 -> the ordinary outputs and the main mailbox
-      // (triple: trial 0 -> "2" / spec[0], trial 1 -> "3" / spec[1], trial 2 -> the ordinary ones)
-      rhs[0] = energy0 + sp->c * alphas[0] * g_dot_d;
-      rhs[1] = energy0 + sp->c * alphas[1] * g_dot_d;
-      if (triple) rhs[2] = energy0 + sp->c * alphas[2] * g_dot_d;
-      c->pair_on = triple ? 3 : 2;
-      c->pair_lean = c->pair_lean_enable;
-      c->pair_alpha2 = alphas[0];
-      c->pair_alpha3 = alphas[1];
-      rc = phase_energy(c, c->params.modules, true, alphas[triple ? 2 : 1], true, false, carry_mode);
-      c->pair_on = 0;
-      c->pair_lean = false;
-      if (rc) return rc;
-      if (depth == 3 && !triple) {
-        // a third trial, expected to be needed as well: gated on trial 1's rejection like any ladder stage (if it
-        // is trial 0 that gets accepted, this stage may run for nothing; the copy-back below comes after it)
-        rhs[2] = energy0 + sp->c * alphas[2] * g_dot_d;
-        swap_mailbox(c, c->spec[1]);
-        c->cur_gate = c->d_gate + 2;
-        c->cur_gate_rhs = rhs[1];
-        rc = phase_energy(c, c->params.modules, true, alphas[2], true, false, carry_mode);
-        c->cur_gate = nullptr;
-        swap_mailbox(c, c->spec[1]);
-        if (rc) return rc;
+    rc = spec_prepare(c);
+    if (rc) return rc;
+    // ---- plan the round: n0 trials in one ungated launch, n_st single-trial stages gated behind it -------------
+    // (prediction only: the same alphas are tested in the same order whatever is chosen here)
+    const int room = max_iter - it;
+    const bool multi_ok = c->pair_enable && c->side[0].partials != nullptr && (c->params.modules & MS_MOD_BENDING) != 0;
+    const int n0_cap = !multi_ok ? 1 : (c->pair_lean_enable ? MS_MAX_TRIALS : (c->fK3 ? 3 : 2));
+    double alphas[MS_MAX_TRIALS + ms_ctx::SPEC_STAGES];
+    int n_alpha = 1;  // alphas of the ladder from here that are still >= 1e-8
+    alphas[0] = alpha;
+    while (n_alpha < room && n_alpha < MS_MAX_TRIALS + ms_ctx::SPEC_STAGES && alphas[n_alpha - 1] * sp->beta >= 1e-8) {
+      alphas[n_alpha] = alphas[n_alpha - 1] * sp->beta;
+      ++n_alpha;
+    }
+    int n0 = 1, n_st = 0;
+    // A search that has rejected `escalate_after` alphas already will most likely reject more: from there on a round
+    // evaluates as many trials as the search has rejected so far in ONE launch (the early ones of a launch cost an
+    // energy-only evaluation each), whatever the history of the earlier searches says.
+    const int rejected_here = out->trials + out->guard_rejects;
+    const int force = c->pair_force;
+    if (!force && c->escalate && multi_ok && rejected_here >= c->escalate_after) {
+      n0 = std::max(1, std::min(std::min(n_alpha, n0_cap), rejected_here));
+    } else {
+      const bool can_spec = force || (ls_warm ? r_lo < INFINITY : c->pred_trials > 1);
+      int depth = 1;
+      if (can_spec) {
+        // how many trials to queue: as many as the last search needed (cold), or -- once there is a history --
+        // one per alpha that still lies above (most of) the range where alphas were accepted lately
+        const int room4 = std::min(1 + ms_ctx::SPEC_STAGES, n_alpha);
+        const int want = force ? std::min(std::min(force, 3), room4)
+                               : (ls_warm ? room4 : std::min(c->pred_trials - out->trials, room4));
+        while (depth < want) {
+          if (!force && ls_warm && !(alphas[depth - 1] > 0.9 * a_hi)) break;
+          ++depth;
+        }
+      }
+      // two or more trials expected: the first two share one launch (and the ladder stops there for this round)
+      // ... and only when the first one is expected to fail: it lies above every alpha accepted lately, and alphas
+      // were rejected lately (a wasted evaluation costs more than a saved round trip gains)
+      const bool pair = depth > 1 && multi_ok && (force || (ls_warm && alpha > 1.05 * a_hi && r_lo < INFINITY));
+      if (pair) {
+        depth = std::min(depth, 3);
+        // triple launch: trial 1 is expected to fail as well -- its alpha is not below one that was rejected lately
+        const bool triple = depth == 3 && n0_cap >= 3 && (force ? force == 4 : alphas[1] > r_lo);
+        // otherwise the pair, and one gated trial behind it when trial 1 is as sure to fail as trial 0 (an empty gated
+        // stage costs about what the host round trip it saves does, so "probably" is not enough)
+        if (depth == 3 && !triple && !force && !(alphas[1] > a_hi)) depth = 2;
+        n0 = triple ? 3 : 2;
+        n_st = depth - n0;
+      } else {
+        n0 = 1;
+        n_st = depth - 1;
       }
     }
-    for (int j = 0; j < depth && !pair; ++j) {
-      rhs[j] = energy0 + sp->c * alphas[j] * g_dot_d;
-      if (j > 0) swap_mailbox(c, c->spec[j - 1]);
-      c->cur_gate = j > 0 ? c->d_gate + j : nullptr;  // stage j > 0 runs iff stage j-1 failed its Armijo test
-      c->cur_gate_rhs = j > 0 ? rhs[j - 1] : 0.0;
-      rc = phase_energy(c, c->params.modules, true, alphas[j], true, false, carry_mode);
+    const int n_round = n0 + n_st;
+    double rhs[MS_MAX_TRIALS + ms_ctx::SPEC_STAGES];
+    for (int j = 0; j < n_round; ++j) rhs[j] = energy0 + sp->c * alphas[j] * g_dot_d;
+    // ---- queue it ----------------------------------------------------------------------------------------------
+    // first launch: trials 0 .. n0-1, the early ones into the side sets, the last one into the ordinary outputs;
+    // its fold decides all of them and writes decision record 0
+    {
+      c->pair_on = n0 > 1 ? n0 : 0;
+      c->pair_lean = n0 > 1 && c->pair_lean_enable;
+      for (int j = 0; j + 1 < n0; ++j) c->pair_alpha[j] = alphas[j];
       c->cur_gate = nullptr;
-      if (j > 0) swap_mailbox(c, c->spec[j - 1]);
+      c->cur_dec = dec_word(c, 0);
+      for (int j = 0; j < n0; ++j) c->cur_rhs[j] = rhs[j];
+      rc = phase_energy(c, c->params.modules, true, alphas[n0 - 1], true, false, carry_mode);
+      c->pair_on = 0;
+      c->pair_lean = false;
+      c->cur_dec = nullptr;
       if (rc) return rc;
     }
-    if (can_spec_kc) {
-      // queue the next step's gradient pass in the state an acceptance produces (x <-> xt, CG history swapped,
-      // factors of the accepted trial), gated on d_acc; every change of the context is undone afterwards
+    // gated stages: stage s runs iff record s-1 says DEC_CONTINUE
+    for (int s2 = 1; s2 <= n_st; ++s2) {
+      swap_mailbox(c, c->spec[s2 - 1]);
+      c->cur_gate = dec_word(c, s2 - 1);
+      c->cur_gate_want = DEC_CONTINUE;
+      c->cur_check_ran = true;
+      c->cur_dec = dec_word(c, s2);
+      c->cur_rhs[0] = rhs[n0 + s2 - 1];
+      rc = phase_energy(c, c->params.modules, true, alphas[n0 + s2 - 1], true, false, carry_mode);
+      c->cur_gate = nullptr;
+      c->cur_check_ran = false;
+      c->cur_dec = nullptr;
+      swap_mailbox(c, c->spec[s2 - 1]);
+      if (rc) return rc;
+    }
+    {
+      // the next step's gradient pass in the state an acceptance produces (x <-> xt, CG history swapped, factors of
+      // the accepted trial), gated on "the accepted trial is the one in the ordinary buffers"; every change of the
+      // context is undone afterwards
       const bool next_hist = cg && ((c->cg_iter_count + 1) % restart != 0);
       const bool s_factors = c->factors_valid, s_implicit = c->dir_implicit, s_pdneg = c->pd_neg_pg;
+      const bool s_grad_valid = c->grad_valid, s_carry = c->carry_valid, s_maxg2 = c->maxg2_valid;
       double* const s_last_g = c->last_g;
       std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
       if (cg) {
@@ -2377,17 +2451,12 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       }
       c->factors_valid = true;
       swap_mailbox(c, c->grad_mb);
-      c->cur_gate = d_acc;  // runs iff the energies left in device memory pass the last stage's test
-      c->cur_gate_rhs = rhs[depth - 1];
-      // behind a pair the pass evaluates trial 1's point: it must also stay out when trial 0 was accepted
-      c->cur_veto = pair ? c->d_scal2 : nullptr;
-      c->cur_veto_rhs = rhs[0];
-      c->cur_veto3 = triple ? c->d_scal3 : nullptr;
-      c->cur_veto_rhs3 = rhs[1];
-      rc = phase_gradient(c, c->params.modules, c->buf[MS_BUF_G], false, next_hist ? 2 : 1, /*reduce_now=*/true);
+      c->cur_gate = dec_word(c, n_st);
+      c->cur_gate_want = DEC_ACCEPT_MAIN;
+      c->cur_check_ran = true;
+      rc = queue_energy_and_gradient(c, sp->stepper, next_hist, /*skip_energy=*/true);
       c->cur_gate = nullptr;
-      c->cur_veto = nullptr;
-      c->cur_veto3 = nullptr;
+      c->cur_check_ran = false;
       swap_mailbox(c, c->grad_mb);
       if (cg) {
         std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
@@ -2398,105 +2467,107 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       c->dir_implicit = s_implicit;
       c->pd_neg_pg = s_pdneg;
       c->last_g = s_last_g;
+      c->grad_valid = s_grad_valid;
+      c->carry_valid = s_carry;
+      c->maxg2_valid = s_maxg2;
       if (rc) return rc;
       kc_queued = true;
       c->kc_stepper = sp->stepper;
       c->kc_use_history = next_hist;
     }
-    if (pair) {
-      // trial 0 reported to spec[0]'s mailbox, (triple: trial 1 to spec[1]'s,) the last one to the main mailbox --
-      // one fold, so they have landed together
-      const int n_multi = triple ? 3 : 2;
-      double v[3][MS_NSCAL];
-      for (int j = 0; j + 1 < n_multi; ++j) {
-        swap_mailbox(c, c->spec[j]);
-        rc = fetch(c);
-        memcpy(v[j], c->h_scal, sizeof(v[j]));
-        swap_mailbox(c, c->spec[j]);
-        if (rc) return rc;
-      }
-      rc = fetch(c);
+    ++c->q_rounds;
+    // ---- take the results in order, replaying the device's decisions from the same doubles --------------------
+    // first launch: every set was folded by ONE k_reduce, so they land together
+    double v[MS_MAX_TRIALS][MS_NSCAL];
+    uint32_t dev_code = DEC_NONE;
+    for (int j = 0; j + 1 < n0; ++j) {
+      rc = wait_mailbox(c, c->side[j].mb.h_seq, c->side[j].mb.expected, v[j], nullptr);
       if (rc) return rc;
-      memcpy(v[n_multi - 1], c->h_scal, sizeof(v[0]));
-      for (int j = 0; j < n_multi; ++j) {
-        for (int sl = 0; sl < MS_NSCAL; ++sl)
-          if (MASK_ENERGY & (1u << sl)) put_mailbox(c, sl, v[j][sl]);
-        ++out->trials;
-        energies_from_mailbox(c, e);
-        const double E_t = e[0] + e[1] + e[2] + e[3];
-        if (!(E_t <= rhs[j])) {
-          min_rejected = alphas[j];
-          continue;
-        }
-        if (j + 1 < n_multi && c->pair_lean_enable) {
-          // the unexpected case: an early trial was accepted, and it was evaluated for its energies only -- evaluate it
-          // again, alone and with every output (the queued gradient pass vetoed itself).  With fixed-order sums the
-          // energies come out bit for bit as before; with LDS atomics in their last bits, like any re-evaluation.
-          rc = phase_energy(c, c->params.modules, true, alphas[j], true, false, carry_mode);
-          if (rc) return rc;
-          rc = fetch(c);
-          if (rc) return rc;
-          kc_queued = false;
-        } else if (j + 1 < n_multi) {
-          // (MS_PAIR_LEAN=0) this trial's positions and factors are in a side set, and the queued gradient pass
-          // vetoed itself
-          const size_t nvp = (size_t)c->til.nvp;
-          const double* sx = j == 0 ? c->xt2 : c->xt3;
-          const double* sk = j == 0 ? c->fK2 : c->fK3;
-          const double* sa = j == 0 ? c->fA2 : c->fA3;
-          HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_XT], sx, sizeof(double) * 3 * nvp, hipMemcpyDeviceToDevice, c->stream));
-          HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FK], sk, sizeof(double) * 3 * nvp, hipMemcpyDeviceToDevice, c->stream));
-          HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FA], sa, sizeof(double) * 2 * nvp, hipMemcpyDeviceToDevice, c->stream));
-          kc_queued = false;
-        }
-        accept(alphas[j], E_t);
-        return MS_OK;
-      }
-      if (depth == 3 && !triple) {
-        swap_mailbox(c, c->spec[1]);
-        rc = fetch(c);
-        memcpy(v[0], c->h_scal, sizeof(v[0]));
-        swap_mailbox(c, c->spec[1]);
-        if (rc) return rc;
-        for (int sl = 0; sl < MS_NSCAL; ++sl)
-          if (MASK_ENERGY & (1u << sl)) put_mailbox(c, sl, v[0][sl]);
-        ++out->trials;
-        energies_from_mailbox(c, e);
-        const double E_t = e[0] + e[1] + e[2] + e[3];
-        if (E_t <= rhs[2]) {
-          accept(alphas[2], E_t);
-          return MS_OK;
-        }
-        min_rejected = alphas[2];
-      }
-      alpha = alphas[depth - 1] * sp->beta;
-      it += depth;
-      if (alpha < 1e-8) break;
-      continue;
     }
+    rc = fetch(c, &dev_code);
+    if (rc) return rc;
+    memcpy(v[n0 - 1], c->h_scal, sizeof(v[0]));
+    int acc = -1;
+    double E_acc = 0.0;
+    for (int j = 0; j < n0 && acc < 0; ++j) {
+      ++out->trials;
+      const double E_t = ((c->params.modules & MS_MOD_SURFACE) ? v[j][MS_S_ESURF] : 0.0) +
+                         ((c->params.modules & MS_MOD_BENDING) ? v[j][MS_S_EBEND] : 0.0);
+      if (E_t <= rhs[j]) {
+        acc = j;
+        E_acc = E_t;
+      } else {
+        min_rejected = alphas[j];
+      }
+    }
+    rc = verify_decision(c, acc < 0 ? DEC_CONTINUE : (acc == n0 - 1 ? DEC_ACCEPT_MAIN : DEC_ACCEPT_SIDE), dev_code,
+                         "the first launch of a round");
+    if (rc) return rc;
+    if (n0 > 1) {
+      ++c->q_multi;
+      c->q_wasted += acc < 0 ? 0 : n0 - 1 - acc;
+    }
+    if (acc >= 0)
+      for (int s2 = 0; s2 < n_st; ++s2) forget(c->spec[s2]);  // (the gated stages stay out)
+    if (acc >= 0 && acc < n0 - 1) {
+      // the unexpected case: an early trial was accepted.  The gradient pass queued behind stays out (DEC_ACCEPT_SIDE).
+      ++c->q_side_accepts;
+      kc_queued = false;
+      forget(c->grad_mb);
+      if (c->pair_lean_enable) {
+        // it was evaluated for its energies only -- evaluate it again, alone and with every output.  With fixed-order
+        // sums the energies come out bit for bit as before; with LDS atomics in their last bits, like any
+        // re-evaluation.
+        rc = phase_energy(c, c->params.modules, true, alphas[acc], true, false, carry_mode);
+        if (rc) return rc;
+        rc = fetch(c);
+        if (rc) return rc;
+      } else {
+        // (MS_PAIR_LEAN=0) this trial's positions and factors are in a side set
+        const size_t nvp = (size_t)c->til.nvp;
+        const double* sx = acc == 0 ? c->xt2 : c->xt3;
+        const double* sk = acc == 0 ? c->fK2 : c->fK3;
+        const double* sa = acc == 0 ? c->fA2 : c->fA3;
+        HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_XT], sx, sizeof(double) * 3 * nvp, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FK], sk, sizeof(double) * 3 * nvp, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FA], sa, sizeof(double) * 2 * nvp, hipMemcpyDeviceToDevice, c->stream));
+        for (int sl = 0; sl < MS_NSCAL; ++sl)
+          if (MASK_ENERGY & (1u << sl)) put_mailbox(c, sl, v[acc][sl]);
+      }
+      accept(alphas[acc], E_acc);
+      return MS_OK;
+    }
+    if (acc == n0 - 1) {
+      accept(alphas[acc], E_acc);
+      return MS_OK;
+    }
+    // gated stages, in order
     bool accepted = false;
-    for (int j = 0; j < depth; ++j) {
-      if (j > 0) swap_mailbox(c, c->spec[j - 1]);
-      rc = fetch(c);
+    for (int s2 = 1; s2 <= n_st && !accepted; ++s2) {
       double vals[MS_NSCAL];
-      for (int sl = 0; sl < MS_NSCAL; ++sl) vals[sl] = c->h_scal[sl];
-      if (j > 0) swap_mailbox(c, c->spec[j - 1]);
+      uint32_t code = DEC_NONE;
+      rc = wait_mailbox(c, c->spec[s2 - 1].h_seq, c->spec[s2 - 1].expected, vals, &code);
       if (rc) return rc;
       for (int sl = 0; sl < MS_NSCAL; ++sl)
         if (MASK_ENERGY & (1u << sl)) put_mailbox(c, sl, vals[sl]);
       ++out->trials;
       energies_from_mailbox(c, e);
       const double E_t = e[0] + e[1] + e[2] + e[3];
-      if (E_t <= rhs[j]) {  // the device took the same decision from the same doubles: later stages skip
-        accept(alphas[j], E_t);
+      const bool ok = E_t <= rhs[n0 + s2 - 1];
+      rc = verify_decision(c, ok ? DEC_ACCEPT_MAIN : DEC_CONTINUE, code, "a gated stage");
+      if (rc) return rc;
+      if (ok) {  // the device took the same decision from the same doubles: later stages stay out
+        for (int s3 = s2; s3 < n_st; ++s3) forget(c->spec[s3]);
+        accept(alphas[n0 + s2 - 1], E_t);
         accepted = true;
-        break;
+      } else {
+        min_rejected = alphas[n0 + s2 - 1];
       }
-      min_rejected = alphas[j];
     }
     if (accepted) return MS_OK;
-    alpha = alphas[depth - 1] * sp->beta;
-    it += depth;
+    forget(c->grad_mb);  // every trial of the round was rejected: the gradient pass behind it stayed out
+    it += n_round;
+    alpha = alphas[n_round - 1] * sp->beta;
     if (alpha < 1e-8) break;
   }
   const double reduced = std::max(alpha * sp->beta, 0.0);  // :425-426
@@ -3116,7 +3187,7 @@ int ms_shard_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, doub
     if (rc) return rc;
     const double alpha0 = alpha, alpha1 = alpha * sp->beta;
     c->pair_on = 2;
-    c->pair_alpha2 = alpha0;
+    c->pair_alpha[0] = alpha0;
     c->pair_scal2 = c->d_scal + SH_ALT;
     rc = phase_energy(c, mods, true, alpha1, false, false, true);
     c->pair_on = 0;
@@ -3243,6 +3314,17 @@ int ms_tile_stats(ms_ctx* c, int64_t* n_tiles, int64_t* facet_instances, int64_t
   if (lds_bytes_gradient)
     *lds_bytes_gradient = (int64_t)gradient_lds_bytes(t.T, c->cap, t.max_ent, bend,
                                                       (c->params.modules & MS_CON_VOLUME) != 0, !c->deterministic);
+  return MS_OK;
+}
+
+int ms_queue_stats(ms_ctx* c, int64_t stats[8]) {
+  if (!c || !stats) return MS_ERR_INVALID;
+  for (int k = 0; k < 8; ++k) stats[k] = 0;
+  stats[0] = c->q_rounds;
+  stats[1] = c->q_multi;
+  stats[2] = c->q_wasted;
+  stats[3] = c->q_side_accepts;
+  stats[4] = c->queue_mismatches;
   return MS_OK;
 }
 

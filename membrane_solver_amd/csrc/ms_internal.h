@@ -24,6 +24,28 @@ static_assert(sizeof(TileFacet) == 8, "TileFacet must be 8 bytes");
 constexpr uint16_t TF_OWNER = 1;
 constexpr uint16_t TF_BODY = 2;
 
+// ---- device-side line-search decisions (ms_step's queue) -----------------------------------------------------------
+// A fold (k_reduce) that closes a line-search stage takes the Armijo decision itself -- ONE workgroup, from the energies
+// it has just folded and the right-hand sides the host supplied -- and publishes it as one word with an agent-scope
+// (write-through) store.  Every kernel queued behind the stage reads that word with an agent-scope load and runs iff it
+// holds the code the host queued it for; no workgroup re-derives a decision from doubles, so the workgroups of one
+// launch cannot disagree.  The host replays the decision from the same doubles (mailbox) and compares codes.
+constexpr int MS_MAX_TRIALS = 8;        // trials one energy launch can evaluate (alphas of one Armijo ladder)
+constexpr int MS_P_RAN = MS_NSCAL;      // partial row: 1.0 from every workgroup of a GATED launch that ran, 0.0 from one that did not
+constexpr int MS_NPART = MS_NSCAL + 1;  // rows of a partials array
+constexpr int MS_MB_DEC = MS_NSCAL;     // mailbox entry of the fold's decision code
+constexpr int MS_MB_WORDS = MS_NSCAL + 1;  // {value, sequence} entries of a mailbox
+constexpr int MS_DEC_STRIDE = 32;       // uint32 words between two decision records (one 128-byte line each)
+enum : uint32_t {
+  DEC_NONE = 0,         // never written
+  DEC_CONTINUE = 1,     // every trial so far was rejected: the next stage of the ladder runs
+  DEC_ACCEPT_MAIN = 2,  // accepted, and the accepted trial's outputs are the ordinary ones (xt, fK, fA): the gradient pass runs
+  DEC_ACCEPT_SIDE = 3,  // an EARLY trial of a multi-trial launch was accepted (energy-only evaluation): nothing queued runs
+  DEC_GO = 4,           // direction fold: the search the host queued behind it may run (Phase: next search)
+  DEC_STOP = 5,         // direction fold: it may not (converged, non-descent, guard range, ...)
+  DEC_ERR_RAN = 0x100   // flag: a gated launch ran on some of its workgroups only
+};
+
 constexpr uint8_t VF_FIXED = 1;
 constexpr uint8_t VF_BOUNDARY = 2;
 constexpr uint8_t VF_TILT_FIXED = 4;  // vertex.tilt_fixed (runtime/minimizer_helpers.py:49-75)
@@ -101,27 +123,20 @@ struct EnergyArgs {
   // bending_tilt: per-vertex record {base = 2H - c0 (0 on boundary), A_eff, kappa*ratio*H, 0}
   // written instead of the final factors; fK then holds K_dir * kappa * ratio (k_bt finishes)
   double* bt_vert;
-  // speculative stage (nullptr: unconditional): run only if the reduced energies in gate_scal FAIL the Armijo
-  // test against gate_rhs; the decision is published in *gate_out for the stage's k_reduce
-  const double* gate_scal;
-  double gate_rhs;
-  uint32_t gate_mods;
-  int* gate_out;
+  // queued stage (nullptr: unconditional): run only if the decision word holds `gate_want` (see DEC_*)
+  const uint32_t* gate;
+  uint32_t gate_want;
   const double* bt_normals;  // leaflet bending_tilt: unit vertex normals of the evaluated positions (signed H, K_dir = n)
   int atomic;             // accumulate per-vertex sums with LDS atomics (not bitwise reproducible)
-  // pair / triple launch (pair = 2 / 3): more evaluations at alpha2 (alpha3) in the same launch, with their own
-  // outputs
+  // multi-trial launch (pair = n >= 2): trials 0 .. n-2 of the ladder are evaluated in the same launch at alpha_side[j]
+  // into partials_side[j] (energy only unless xt/fK/fA_side[j] are given: j < 2), trial n-1 at `alpha` with the
+  // ordinary outputs
   int pair;
-  double alpha2;
-  double* xt2;
-  double* fK2;
-  double* fA2;
-  double* partials2;
-  double alpha3;
-  double* xt3;
-  double* fK3;
-  double* fA3;
-  double* partials3;
+  double alpha_side[MS_MAX_TRIALS - 1];
+  double* partials_side[MS_MAX_TRIALS - 1];
+  double* xt_side[2];
+  double* fK_side[2];
+  double* fA_side[2];
 };
 
 struct GradientArgs {
@@ -143,16 +158,9 @@ struct GradientArgs {
   double* d;
   const double* pg;
   const double* pd;
-  // speculative launch (nullptr: unconditional): run only if the reduced energies in gate_scal PASS the Armijo
-  // test against gate_rhs
-  const double* gate_scal;
-  double gate_rhs;
-  uint32_t gate_mods;
-  int* gate_out;
-  const double* veto_scal;  // pair launch: do NOT run if these energies (the first trial's) pass veto_rhs
-  double veto_rhs;
-  const double* veto_scal3; // triple launch: ... nor if these (the second trial's) pass veto_rhs3
-  double veto_rhs3;
+  // queued behind a line search (nullptr: unconditional): run only if the decision word holds `gate_want`
+  const uint32_t* gate;
+  uint32_t gate_want;
   int pd_neg_pg;           // the previous direction is -pg (an implicit steepest-descent step): derive, do not load
   int atomic;
   // leaflet bending_tilt (BENDMODE 3): per-corner fA_eff = 1/2 kappa_k (base_k + s div_f t)^2
@@ -252,12 +260,31 @@ hipError_t launch_tvec(int mode, int tile0, int tile1, int nv, int T, const uint
                        const double* normals, double* out, double coef, int flag, double* partials,
                        int n_tiles, hipStream_t s, uint8_t fixed_bit = VF_TILT_FIXED,
                        int s_gn2 = MS_S_TGNORM2, int s_rz = MS_S_TRZ);
-hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
-                         uint32_t slot_mask, double* scal, unsigned long long* host_box,
-                         unsigned long long ticket, hipStream_t s,
-                         const int* gate = nullptr, const double* partials2 = nullptr, double* scal2 = nullptr,
-                         unsigned long long* host_box2 = nullptr, const double* partials3 = nullptr,
-                         double* scal3 = nullptr, unsigned long long* host_box3 = nullptr);
+// One fold launch.  set[]: the trials of a multi-trial launch in TRIAL order (the last one = the ordinary outputs); a
+// plain fold has one set.
+struct FoldSet {
+  const double* partials;
+  double* scal;
+  unsigned long long* host_box;  // pinned mailbox {value, sequence} entries or nullptr
+};
+struct FoldArgs {
+  int n_tiles, tile0, tile1;
+  uint32_t slot_mask;
+  unsigned long long ticket;
+  int n_sets;
+  FoldSet set[MS_MAX_TRIALS];
+  const uint32_t* gate;   // fold only if *gate == gate_want (nullptr: always)
+  uint32_t gate_want;
+  int check_ran;          // the tile kernel feeding this fold was gated by the same word: its MS_P_RAN partials must add
+                          // up to every tile (gate open) or to none (closed)
+  uint32_t* dec_out;      // Armijo decision of this stage (nullptr: none)
+  uint32_t e_mask;        // slots whose sum is a trial's energy (ESURF | EBEND as the module set has them)
+  double rhs[MS_MAX_TRIALS];  // energy0 + c alpha_j <g,d>, trial order
+  unsigned long long* host_err;  // pinned word: set non-zero when check_ran fails
+  int side_full;          // fold every slot of the early trials' sets too (they have outputs of their own and can be
+                          // accepted as they are); otherwise only their energy slots, by the head workgroup
+};
+hipError_t launch_reduce(const FoldArgs& a, hipStream_t s);
 
 hipError_t launch_pack_boundary(const int32_t* rows, int n_rows, const double* const* bufs,
                                 const int* ncomp, int n_bufs, const double* scal, double* send,
@@ -275,7 +302,8 @@ hipError_t launch_row_dot(int tile0, int tile1, int nv, int T, const double* g, 
 hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* g,
                             const double* gC, double* d, const double* pg, const double* pd,
                             const double* scal, int use_constraint, int cg_history,
-                            double* partials, int n_tiles, int write_g, hipStream_t s);
+                            double* partials, int n_tiles, int write_g, hipStream_t s,
+                            const uint32_t* gate = nullptr, uint32_t gate_want = 0);
 hipError_t launch_axpy_masked(int64_t n_rows, const uint8_t* vflags, double* x, const double* y,
                               double coef, hipStream_t s);
 hipError_t launch_permute_in(int nv, const int32_t* perm, const double* src_ext, double* dst_int,

@@ -203,6 +203,33 @@ __device__ __forceinline__ double axpy1(double x, double alpha, double d) {
 #endif
 }
 
+// Cross-kernel scalars (the folded reductions and the decision words k_reduce derives from them) travel with
+// agent-scope accesses on BOTH sides: write-through `sc1` stores, `sc1` vector loads that bypass the CU's L1 and never
+// go through the scalar data cache.  They are the only data in the library that one kernel writes and the next one
+// branches on per workgroup; with these forms their visibility does not hang on what a kernel boundary does to the
+// per-XCD L2s and the scalar caches (MI355X_MICROARCH.md, "inter-workgroup visibility").
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Gate of a queued launch: open iff the decision word holds the code the host queued the launch for.  The word was
+// written by ONE lane of an earlier kernel of the stream and does not change while this launch runs, so every workgroup
+// takes the same branch.  Thread 0 records what the workgroup did in the MS_P_RAN row of the partials: the fold that
+// follows checks that the launch ran everywhere or nowhere.
+__device__ __forceinline__ bool gate_open(const uint32_t* word, uint32_t want, double* ran_cell) {
+  const bool run = ld_agent(word) == want;
+  if (threadIdx.x == 0 && ran_cell) *ran_cell = run ? 1.0 : 0.0;
+  return run;
+}
+
 // |n| and 1/|n| from ONE reciprocal square root refined twice (v_rsq_f64 + two Newton steps: ~9 instructions instead
 // of the ~24 of an fp64 sqrt followed by an fp64 division); both within an ulp or two of the correctly rounded values.
 // n2 <= 1e-30 (|n| <= 1e-15, below every clamp of the reference): both 0.
@@ -396,23 +423,29 @@ template <bool BEND, bool GUARD, int TT, int CAPC, bool ATOMIC, int MULTI = 0>
 __global__ __launch_bounds__(TT ? TT : 512, (TT == 256 && BEND && !GUARD && ATOMIC) ? MS_KA_SLOTS : 1) MS_WPE_ENERGY void k_energy(EnergyArgs a, int cap_rt, int max_ent) {
   extern __shared__ double lds[];
   int bid = blockIdx.x;
+  double* const ran_row = a.partials + (size_t)MS_P_RAN * a.m.n_tiles;  // (of the ordinary partials)
+  bool last_trial = true;  // this workgroup evaluates the launch's last trial (ordinary outputs)
   if (MULTI) {
+    const int nm = MULTI == 8 ? a.pair : MULTI;  // (8: the trial count is a launch argument)
     const int k = bid % NXCD, j2 = bid / NXCD;
-    const int st = j2 % MULTI;
-    bid = (j2 / MULTI) * NXCD + k;
+    const int st = j2 % nm;
+    bid = (j2 / nm) * NXCD + k;
     if (bid >= a.tile1 - a.tile0) return;
-    if (st == 1) {
-      a.alpha = a.alpha2;
-      a.xt = a.xt2;
-      a.fK = a.fK2;
-      a.fA = a.fA2;
-      a.partials = a.partials2;
-    } else if (MULTI == 3 && st == 2) {
-      a.alpha = a.alpha3;
-      a.xt = a.xt3;
-      a.fK = a.fK3;
-      a.fA = a.fA3;
-      a.partials = a.partials3;
+    if (st != 0) {  // trial st-1 of the ladder: its own alpha and partials; outputs only where the caller gave some
+      last_trial = false;
+      a.xt = a.fK = a.fA = nullptr;
+      // (selected with constant indices: a dynamically indexed kernel argument would move the whole struct to scratch)
+#pragma unroll
+      for (int j = 0; j < MS_MAX_TRIALS - 1; ++j)
+        if (j < (MULTI == 8 ? MS_MAX_TRIALS - 1 : MULTI - 1) && st - 1 == j) {
+          a.alpha = a.alpha_side[j];
+          a.partials = a.partials_side[j];
+          if (j < 2) {
+            a.xt = a.xt_side[j];
+            a.fK = a.fK_side[j];
+            a.fA = a.fA_side[j];
+          }
+        }
     }
   }
   const int T = TT ? TT : a.m.T;  // == blockDim.x
@@ -428,23 +461,15 @@ __global__ __launch_bounds__(TT ? TT : 512, (TT == 256 && BEND && !GUARD && ATOM
   uint16_t* vent = reinterpret_cast<uint16_t*>(stg + (BEND ? (ATOMIC ? 5 : 9) * T : 5 * 16));
   uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + ((BEND && !ATOMIC) ? ((max_ent + 3) & ~3) : 0));
   const bool stage_flags = a.m.has_boundary || GUARD;
-  // speculative line-search stage: runs only if the trial before it was rejected.  Every workgroup repeats the
-  // host's Armijo test on the reduced energies in device memory (line_search.py:386-392; `gate_rhs` is the host's
-  // energy0 + c alpha <g,d> of the PREVIOUS stage).  The right-hand sides grow along the ladder (alpha shrinks,
-  // <g,d> < 0), so after an acceptance every later stage sees "accepted" too and returns.
-  if (a.gate_scal != nullptr) {
-    const double E_prev = ((a.gate_mods & MS_MOD_SURFACE) ? a.gate_scal[MS_S_ESURF] : 0.0) +
-                          ((a.gate_mods & MS_MOD_BENDING) ? a.gate_scal[MS_S_EBEND] : 0.0);
-    const bool run = !(E_prev <= a.gate_rhs);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.gate_out) *a.gate_out = run ? 1 : 0;  // for this stage's k_reduce
-    if (!run) return;
-  }
+  // queued line-search stage: runs only if the decision word says so (DEC_CONTINUE: every trial before it was rejected)
+  const int my_tile = a.tile0 + xcd_tile(bid, a.tile1 - a.tile0);
+  if (a.gate != nullptr && !gate_open(a.gate, a.gate_want, last_trial ? ran_row + my_tile : nullptr)) return;
 
   const int blk = bid;
   (void)blk;
   MS_STAMP(0);
   MS_STAMP_ID();
-  const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(bid, a.tile1 - a.tile0));
+  const TileCtx t = tile_ctx(a.m, my_tile);
   const int tid = threadIdx.x;
   const bool have_d = a.d != nullptr;
 
@@ -864,10 +889,15 @@ constexpr int FAST_T = 256;  // specialised tile size (LDS staging offsets becom
 constexpr int FAST_CAP = 0;  // patch capacity stays a runtime value: a fixed 512 slots would push
                              // the gradient kernel from 3 to 2 workgroups per CU (LDS)
 
-// MS_ABL_NTILES=<n>: timing experiment only (wrong results) -- the tile kernels process at most n tiles
+// Variant builds only (-DMS_ABL_NTILES_ENV, tools/build_variant.sh): MS_ABL_NTILES=<n> makes the tile kernels process
+// at most n tiles -- a timing experiment with wrong results, so the shipped library does not read the variable at all
 static int abl_ntiles() {
+#ifdef MS_ABL_NTILES_ENV
   static const int v = getenv("MS_ABL_NTILES") ? atoi(getenv("MS_ABL_NTILES")) : 0;
   return v;
+#else
+  return 0;
+#endif
 }
 
 hipError_t launch_energy(const EnergyArgs& a_in, bool guard, int cap, int max_ent, hipStream_t s) {
@@ -899,7 +929,7 @@ hipError_t launch_energy(const EnergyArgs& a_in, bool guard, int cap, int max_en
   if (a.pair) {
     // pair launch: bending factors on, no guard (the caller checked both)
     if (!bend || guard) return hipErrorInvalidValue;
-    if (a.pair != 2 && a.pair != 3) return hipErrorInvalidValue;
+    if (a.pair < 2 || a.pair > MS_MAX_TRIALS) return hipErrorInvalidValue;
     const int nb2 = a.pair * NXCD * ((nb + NXCD - 1) / NXCD);
 #define MS_LAUNCH_P(TT, CC, AT, NM)                                                                          \
   do {                                                                                                       \
@@ -915,7 +945,7 @@ hipError_t launch_energy(const EnergyArgs& a_in, bool guard, int cap, int max_en
       if (fast) MS_LAUNCH_P(FAST_T, FAST_CAP, false, NM); else MS_LAUNCH_P(0, 0, false, NM); \
     }                                                                                  \
   } while (0)
-    if (a.pair == 2) MS_PICK_P(2); else MS_PICK_P(3);
+    if (a.pair == 2) MS_PICK_P(2); else if (a.pair == 3) MS_PICK_P(3); else MS_PICK_P(8);
 #undef MS_PICK_P
 #undef MS_LAUNCH_P
     return hipGetLastError();
@@ -1006,39 +1036,16 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? MS_LEAN_SLOTS : 3) 
   double* red = stg + (ATOMIC ? NACC : (VOLROW ? 18 : 9)) * T;
   uint16_t* vent = reinterpret_cast<uint16_t*>(red + 4 * 16);
   uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + (ATOMIC ? 0 : ((max_ent + 3) & ~3)));
-  // queued behind a line-search ladder: runs only if one of its stages was accepted, i.e. if the energies now in
-  // device memory pass the Armijo test of the LAST stage (the right-hand sides grow along the ladder)
-  if (a.gate_scal != nullptr) {
-    const double E_last = ((a.gate_mods & MS_MOD_SURFACE) ? a.gate_scal[MS_S_ESURF] : 0.0) +
-                          ((a.gate_mods & MS_MOD_BENDING) ? a.gate_scal[MS_S_EBEND] : 0.0);
-    bool run = E_last <= a.gate_rhs;
-    if (a.veto_scal != nullptr) {
-      // pair launch: gate_scal holds the SECOND trial's energies; the pass belongs to it only if the first trial
-      // (energies in veto_scal) was rejected -- otherwise the accepted point is the first trial's
-      const double E_first = ((a.gate_mods & MS_MOD_SURFACE) ? a.veto_scal[MS_S_ESURF] : 0.0) +
-                             ((a.gate_mods & MS_MOD_BENDING) ? a.veto_scal[MS_S_EBEND] : 0.0);
-      run = run && !(E_first <= a.veto_rhs);
-      if (a.veto_scal3 != nullptr) {  // triple launch: neither may trial 1 have been accepted
-        const double E_second = ((a.gate_mods & MS_MOD_SURFACE) ? a.veto_scal3[MS_S_ESURF] : 0.0) +
-                                ((a.gate_mods & MS_MOD_BENDING) ? a.veto_scal3[MS_S_EBEND] : 0.0);
-        run = run && !(E_second <= a.veto_rhs3);
-      }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.gate_out) *a.gate_out = run ? 1 : 0;
-#if MS_STAMPS
-    if (threadIdx.x == 0) {  // what this workgroup's gate saw (queue diagnostics)
-      g_stamps[8 * (size_t)blockIdx.x + 6] = (unsigned long long)__double_as_longlong(E_last);
-      g_stamps[8 * (size_t)blockIdx.x + 7] = run ? 1ull : 0ull;
-    }
-#endif
-    if (!run) return;
-  }
+  // queued behind a line search: runs only if the decision word says the accepted point is the one in the ordinary
+  // buffers (DEC_ACCEPT_MAIN)
+  const int my_tile = a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0);
+  if (a.gate != nullptr && !gate_open(a.gate, a.gate_want, a.partials + (size_t)MS_P_RAN * a.m.n_tiles + my_tile)) return;
 
   const int blk = blockIdx.x;
   (void)blk;
   MS_STAMP(0);
   MS_STAMP_ID();
-  const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
+  const TileCtx t = tile_ctx(a.m, my_tile);
   const int tid = threadIdx.x;
 
   constexpr bool PACKED = TT == 256;
@@ -1176,7 +1183,7 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? MS_LEAN_SLOTS : 3) 
   const bool surf = a.modules & MS_MOD_SURFACE;
   const bool volpen = a.modules & MS_MOD_VOLUME_PENALTY;
   double pen_factor = 0.0;
-  if (volpen) pen_factor = a.volume_stiffness * (a.scal[MS_S_VOL] - a.target_volume) / 6.0;
+  if (volpen) pen_factor = a.volume_stiffness * (ld_agent(a.scal + MS_S_VOL) - a.target_volume) / 6.0;
 
   double gx = 0, gy = 0, gz = 0, cx = 0, cy = 0, cz = 0;
   if (tid >= t.n_owned) cur = end = 0;
@@ -2463,7 +2470,7 @@ __global__ __launch_bounds__(BLOCK) void k_disk_target(DiskTargetArgs a, int mod
   double R = a.radius, den = 1.0;
   bool off = false;
   if (mode == 1) {
-    if (!(R > 0.0)) R = a.scal[a.r_slot];
+    if (!(R > 0.0)) R = ld_agent(a.scal + a.r_slot);
     off = !(R > 0.0);                         // :219-220
     if (!off && !(fabs(a.lambda) < 1.0e-12)) {
       den = bessel_i1_series30(a.lambda * R);
@@ -2514,50 +2521,16 @@ hipError_t launch_disk_target(const DiskTargetArgs& a, int mode, hipStream_t s) 
 }
 
 constexpr int RBLOCK = 512;  // 512 threads x 8 loads in flight cover 4096 tiles in one round trip
-__global__ __launch_bounds__(RBLOCK) void k_reduce(const double* partials, int n_tiles, int tile0,
-                                                  int tile1, uint32_t slot_mask, double* scal,
-                                                  unsigned long long* host_box,
-                                                  unsigned long long ticket, const int* gate,
-                                                  const double* partials2, double* scal2,
-                                                  unsigned long long* host_box2, const double* partials3,
-                                                  double* scal3, unsigned long long* host_box3) {
-  __shared__ double red[16];
-  if (gate != nullptr && *gate == 0) return;
-  int rb = blockIdx.x;
-  if (partials2 != nullptr && rb >= __popc(slot_mask)) {  // second / third set of a pair / triple launch
-    rb -= __popc(slot_mask);
-    partials = partials2;
-    scal = scal2;
-    host_box = host_box2;
-    if (partials3 != nullptr && rb >= __popc(slot_mask)) {
-      rb -= __popc(slot_mask);
-      partials = partials3;
-      scal = scal3;
-      host_box = host_box3;
-    }
-  }
-  // one workgroup per requested slot; partials are slot-major so lanes read
-  // consecutive doubles.
-  int slot = -1;
-  {
-    int k = rb;
-    for (int s = 0; s < MS_NSCAL; ++s)
-      if (slot_mask & (1u << s)) {
-        if (k == 0) {
-          slot = s;
-          break;
-        }
-        --k;
-      }
-  }
-  if (slot < 0) return;
+// ordered fold of one slot over the tiles [tile0, tile1) by the whole workgroup; the result is valid in thread 0
+__device__ __forceinline__ double fold_slot(const double* partials, int n_tiles, int tile0, int tile1, int slot,
+                                            double* red) {
   const int op = (slot == MS_S_MINEDGE2) ? 1 : ((slot == MS_S_GUARD || slot == MS_S_MAXD2 || slot == MS_S_MAXG2 ||
                                                  slot == MS_S_DTR_IN || slot == MS_S_DTR_OUT) ? 2 : 0);
   const double* p = partials + (size_t)slot * n_tiles;
-  double v = op == 1 ? 1.0e300 : 0.0;
+  const double neutral = op == 1 ? 1.0e300 : 0.0;
+  double v = neutral;
   // RU loads in flight per thread (the order of the additions is unchanged)
   constexpr int RU = 8;
-  const double neutral = op == 1 ? 1.0e300 : 0.0;
   for (int t = tile0 + threadIdx.x; t < tile1; t += RU * RBLOCK) {
     double q[RU];
 #pragma unroll
@@ -2574,32 +2547,113 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(const double* partials, int n
     }
   }
   v = block_reduce(v, op, red);
-  if (threadIdx.x == 0) {
-    const double r = (slot == MS_S_VOL) ? v / 6.0 : v;
-    scal[slot] = r;
-    if (host_box) {
-      // pinned, device-mapped mailbox entry {value, sequence word}: the value first, a system-scope release, then the
-      // sequence word the host polls with acquire loads.  (One 16-byte store of both was observed untorn on gfx950 and
-      // ~neutral in time, but it is no architectural guarantee: a torn entry would hand the host a stale energy next to
-      // a fresh sequence word, i.e. host and device deciding an Armijo test on different doubles.)
-      volatile unsigned long long* e = host_box + 2 * slot;
-      e[0] = (unsigned long long)__double_as_longlong(r);
-      __threadfence_system();
-      e[1] = ticket;
-    }
+  return (slot == MS_S_VOL) ? v / 6.0 : v;
+}
+// thread 0: a folded slot goes to the device scalars (agent scope: later kernels read it with ld_agent) and to the
+// pinned, device-mapped mailbox entry {value, sequence word}: the value first, a system-scope release, then the sequence
+// word the host polls with acquire loads.  (One 16-byte store of both was observed untorn on gfx950 and ~neutral in
+// time, but it is no architectural guarantee: a torn entry would hand the host a stale energy next to a fresh sequence
+// word, i.e. host and device deciding an Armijo test on different doubles.)
+__device__ __forceinline__ void post_slot(double* scal, unsigned long long* host_box, int entry, double r,
+                                          unsigned long long ticket) {
+  if (entry < MS_NSCAL) st_agent(scal + entry, r);
+  if (host_box) {
+    volatile unsigned long long* e = host_box + 2 * entry;
+    e[0] = (unsigned long long)__double_as_longlong(r);
+    __threadfence_system();
+    e[1] = ticket;
   }
 }
+// Grid: [head workgroup] + one workgroup per (set, slot).  The head workgroup exists when the fold closes a line-search
+// stage (dec_out) or checks a gated launch (check_ran): it folds the energy slots of EVERY set itself, one after the
+// other, takes the Armijo decision from exactly those doubles -- the first trial j whose energy passes rhs[j] is the
+// accepted one, as in line_search.py:386-392 -- and publishes the code.  With the gate closed only the head workgroup
+// does anything: it hands the earlier decision on (later stages and the gradient pass test THIS stage's word) and checks
+// that no workgroup of the gated tile kernel ran.
+__global__ __launch_bounds__(RBLOCK) void k_reduce(FoldArgs a) {
+  __shared__ double red[16];
+  const bool has_head = a.dec_out != nullptr || a.check_ran;
+  const uint32_t head_mask = a.dec_out != nullptr ? (a.slot_mask & a.e_mask) : 0u;
+  bool open = true;
+  uint32_t prev = DEC_NONE;
+  if (a.gate != nullptr) {
+    prev = ld_agent(a.gate);
+    open = prev == a.gate_want;
+  }
+  int rb = blockIdx.x;
+  if (has_head && rb == 0) {
+    uint32_t code = DEC_CONTINUE;
+    if (open) {
+      bool decided = false;
+      for (int j = 0; j < a.n_sets; ++j) {
+        double E = 0.0;
+        for (int s = 0; s < MS_NSCAL; ++s)
+          if (head_mask & (1u << s)) {
+            const double r = fold_slot(a.set[j].partials, a.n_tiles, a.tile0, a.tile1, s, red);
+            if (threadIdx.x == 0) post_slot(a.set[j].scal, a.set[j].host_box, s, r, a.ticket);
+            E = E + r;  // (slot order: the host adds surface + bending in the same order)
+          }
+        if (a.dec_out != nullptr && !decided && E <= a.rhs[j]) {
+          decided = true;
+          code = j == a.n_sets - 1 ? DEC_ACCEPT_MAIN : DEC_ACCEPT_SIDE;
+        }
+      }
+    } else {
+      code = prev;  // an earlier stage has decided (or failed): later readers see the same
+    }
+    if (a.check_ran) {
+      const double ran = fold_slot(a.set[a.n_sets - 1].partials, a.n_tiles, a.tile0, a.tile1, MS_P_RAN, red);
+      const double want = open ? (double)(a.tile1 - a.tile0) : 0.0;
+      if (ran != want) {
+        code |= DEC_ERR_RAN;
+        if (threadIdx.x == 0 && a.host_err) {
+          *reinterpret_cast<volatile unsigned long long*>(a.host_err) =
+              ((unsigned long long)a.ticket << 24) | (unsigned long long)(unsigned int)ran | (1ull << 63);
+          __threadfence_system();
+        }
+      }
+    }
+    if (threadIdx.x == 0) {
+      if (a.dec_out != nullptr) st_agent(a.dec_out, code);
+      if (open && a.dec_out != nullptr && a.set[a.n_sets - 1].host_box)
+        post_slot(nullptr, a.set[a.n_sets - 1].host_box, MS_MB_DEC, __longlong_as_double((long long)code), a.ticket);
+    }
+    return;
+  }
+  if (!open) return;
+  if (has_head) --rb;
+  const uint32_t rest = a.slot_mask & ~head_mask;
+  const int per_set = __popc(rest);
+  if (per_set == 0) return;
+  const int n_reg = a.side_full ? a.n_sets : 1;  // sets with slots of their own to fold: all, or the last trial's only
+  if (rb / per_set >= n_reg) return;
+  const int j = a.n_sets - n_reg + rb / per_set;
+  // one workgroup per remaining slot of a set; partials are slot-major so lanes read consecutive doubles
+  int slot = -1;
+  {
+    int k = rb % per_set;
+    for (int s = 0; s < MS_NSCAL; ++s)
+      if (rest & (1u << s)) {
+        if (k == 0) {
+          slot = s;
+          break;
+        }
+        --k;
+      }
+  }
+  if (slot < 0) return;
+  const double r = fold_slot(a.set[j].partials, a.n_tiles, a.tile0, a.tile1, slot, red);
+  if (threadIdx.x == 0) post_slot(a.set[j].scal, a.set[j].host_box, slot, r, a.ticket);
+}
 
-hipError_t launch_reduce(const double* partials, int n_tiles, int tile0, int tile1,
-                         uint32_t slot_mask, double* scal, unsigned long long* host_box,
-                         unsigned long long ticket, hipStream_t s, const int* gate, const double* partials2,
-                         double* scal2, unsigned long long* host_box2, const double* partials3, double* scal3,
-                         unsigned long long* host_box3) {
-  const int nslots = __builtin_popcount(slot_mask);
-  if (nslots == 0) return hipSuccess;
-  const int sets = partials2 ? (partials3 ? 3 : 2) : 1;
-  hipLaunchKernelGGL(k_reduce, dim3(sets * nslots), dim3(RBLOCK), 0, s, partials, n_tiles, tile0, tile1, slot_mask,
-                     scal, host_box, ticket, gate, partials2, scal2, host_box2, partials3, scal3, host_box3);
+hipError_t launch_reduce(const FoldArgs& a, hipStream_t s) {
+  const bool has_head = a.dec_out != nullptr || a.check_ran;
+  const uint32_t head_mask = a.dec_out != nullptr ? (a.slot_mask & a.e_mask) : 0u;
+  const int per_set = __builtin_popcount(a.slot_mask & ~head_mask);
+  const int nb = (has_head ? 1 : 0) + (a.side_full ? a.n_sets : 1) * per_set;
+  if (nb == 0) return hipSuccess;
+  if (a.n_sets < 1 || a.n_sets > MS_MAX_TRIALS) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(RBLOCK), 0, s, a);
   return hipGetLastError();
 }
 
@@ -2621,15 +2675,17 @@ __global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, c
                                                      const double* pg, const double* pd,
                                                      const double* scal, int use_constraint,
                                                      int cg_history, double* partials,
-                                                     int n_tiles, int write_g) {
+                                                     int n_tiles, int write_g, const uint32_t* gate,
+                                                     uint32_t gate_want) {
   __shared__ double red[16];
   const int tile = tile0 + blockIdx.x;
+  if (gate != nullptr && !gate_open(gate, gate_want, partials + (size_t)MS_P_RAN * n_tiles + tile)) return;
   double lam = 0.0;
   bool project = false;
   if (use_constraint) {
-    const double nsq = scal[MS_S_GCGC];
+    const double nsq = ld_agent(scal + MS_S_GCGC);
     if (nsq > 1.0e-18) {
-      lam = scal[MS_S_GGC] / nsq;
+      lam = ld_agent(scal + MS_S_GGC) / nsq;
       project = true;
     }
   }
@@ -2680,10 +2736,11 @@ __global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, c
 hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* g,
                             const double* gC, double* d, const double* pg, const double* pd,
                             const double* scal, int use_constraint, int cg_history,
-                            double* partials, int n_tiles, int write_g, hipStream_t s) {
+                            double* partials, int n_tiles, int write_g, hipStream_t s, const uint32_t* gate,
+                            uint32_t gate_want) {
   if (tile1 <= tile0) return hipSuccess;
   hipLaunchKernelGGL(k_direction, dim3(tile1 - tile0), dim3(BLOCK), 0, s, tile0, nv, T, vflags, g,
-                     gC, d, pg, pd, scal, use_constraint, cg_history, partials, n_tiles, write_g);
+                     gC, d, pg, pd, scal, use_constraint, cg_history, partials, n_tiles, write_g, gate, gate_want);
   return hipGetLastError();
 }
 
@@ -2727,7 +2784,7 @@ struct RowBufs {
 __global__ void k_pack_boundary(const int32_t* rows, int n_rows, RowBufs b, const double* scal,
                                 double* send) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < MS_NSCAL) send[j] = scal[j];
+  if (j < MS_NSCAL) send[j] = ld_agent(scal + j);
   if (j >= n_rows) return;
   const size_t v = (size_t)rows[j];
   double* o = send + MS_NSCAL + (size_t)j * b.comps;

@@ -465,12 +465,19 @@ class DeviceMesh:
 
     def profile_read(self):
         """-> {kind: (total_ms, launches)} per kernel kind (include/membrane_hip.h, ms_profile_read)."""
-        ms = np.zeros(10)
-        n = np.zeros(10, dtype=np.int64)
+        ms = np.zeros(11)
+        n = np.zeros(11, dtype=np.int64)
         self._chk(L.lib().ms_profile_read(self._h, _pd(ms), n.ctypes.data_as(L._I64)), "ms_profile_read")
         names = ("energy", "gradient", "direction", "reduce", "tilt", "bending_tilt", "tilt_vec", "energy_pair", "energy_triple",
-                 "gradient_lean")
+                 "gradient_lean", "energy_multi")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
+
+    def queue_stats(self):
+        """Line-search queue statistics (include/membrane_hip.h, ms_queue_stats)."""
+        v = np.zeros(8, dtype=np.int64)
+        self._chk(L.lib().ms_queue_stats(self._h, v.ctypes.data_as(L._I64)), "ms_queue_stats")
+        return {"rounds": int(v[0]), "multi_launches": int(v[1]), "wasted_evaluations": int(v[2]),
+                "side_accepts": int(v[3]), "mismatches": int(v[4])}
 
     def shard_info(self):
         v = [ctypes.c_int64(0) for _ in range(4)]
