@@ -396,6 +396,10 @@ def main_single(args):
                 int(stepper.reuse_energy0), dt),
         "energy_start": E_start, "energy_end": res["energy"],
     }
+    q0 = mesh._hip_mirror.dm.queue_stats()
+    out["line_search_queue"] = dict(q0, note="since ms_create (warm-up included): rounds = energy launches queued with their "
+                                            "gated followers; every decision is taken once on the device and replayed by "
+                                            "the host from the same doubles -- mismatches must be 0")
 
     # -- the same K steps with every pass the reference repeats (reuse level 0): energy0
     #    re-evaluated, a fresh energy/factor pass after every accepted step, a full gradient

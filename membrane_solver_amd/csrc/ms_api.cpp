@@ -516,6 +516,13 @@ uint32_t armijo_slots(const ms_ctx* c) {
          ((c->params.modules & MS_MOD_BENDING) ? (1u << MS_S_EBEND) : 0u);
 }
 
+// slots an energy pass of `modules` leaves partials in: the core five, and the tilt families' only when one of them is on
+uint32_t energy_mask(uint32_t modules) {
+  constexpr uint32_t core = (1u << MS_S_ESURF) | (1u << MS_S_VOL) | (1u << MS_S_EBEND) | (1u << MS_S_MINEDGE2) |
+                            (1u << MS_S_GUARD);
+  return (modules & MS_ANY_TILT_MODS) ? MASK_ENERGY : core;
+}
+
 int reduce_slots(ms_ctx* c, uint32_t mask) {
   ProfScope ps(c, 3, c->cur_gate != nullptr);
   ++c->ticket;
@@ -549,6 +556,7 @@ int reduce_slots(ms_ctx* c, uint32_t mask) {
   f.gate_want = c->cur_gate_want;
   f.check_ran = (c->cur_gate != nullptr && c->cur_check_ran) ? 1 : 0;
   f.dec_out = c->cur_dec;
+  f.counter = c->d_dec ? c->d_dec + (size_t)MS_DEC_STRIDE * (ms_ctx::N_DEC - 1) : nullptr;  // (the last record's line)
   f.e_mask = armijo_slots(c);
   f.host_err = c->d_h_err;
   for (int j = 0; j < MS_MAX_TRIALS; ++j) f.rhs[j] = c->cur_rhs[j];
@@ -737,7 +745,7 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
     if (rc) return rc;
   }
   if (reduce_now) {
-    int rc = reduce_slots(c, MASK_ENERGY);
+    int rc = reduce_slots(c, energy_mask(modules));
     if (rc) return rc;
   }
   if (bend && write_factors) c->factors_valid = !use_dir;
@@ -879,6 +887,8 @@ void put_mailbox(ms_ctx* c, int sl, double v) {
   unsigned long long bits;
   memcpy(&bits, &v, sizeof(double));
   __atomic_store_n(&c->h_seq[2 * sl], bits, __ATOMIC_RELAXED);
+  // (the entry keeps validating against the ticket it carried: tag = value XOR ticket, see wait_mailbox)
+  __atomic_store_n(&c->h_seq[2 * sl + 1], bits ^ c->expected[sl], __ATOMIC_RELAXED);
 }
 
 const char* box_name(ms_ctx* c, const void* h_seq);
@@ -901,9 +911,16 @@ int check_queue_error(ms_ctx* c) {
 // the MS_NSCAL slot values, *code the decision entry
 int wait_mailbox(ms_ctx* c, unsigned long long* h_seq, const unsigned long long* expected, double* vals,
                  uint32_t* code) {
+  // an entry has arrived when value XOR tag is the ticket waited for (k_reduce: post_entry); the value word read for
+  // that test is the one handed out
+  unsigned long long bits[MS_MB_WORDS];
   auto arrived = [&]() {
-    for (int sl = 0; sl < MS_MB_WORDS; ++sl)
-      if (__atomic_load_n(&h_seq[2 * sl + 1], __ATOMIC_ACQUIRE) < expected[sl]) return false;
+    for (int sl = 0; sl < MS_MB_WORDS; ++sl) {
+      if (expected[sl] == 0) continue;
+      const unsigned long long tag = __atomic_load_n(&h_seq[2 * sl + 1], __ATOMIC_ACQUIRE);
+      bits[sl] = __atomic_load_n(&h_seq[2 * sl], __ATOMIC_ACQUIRE);
+      if ((bits[sl] ^ tag) != expected[sl]) return false;
+    }
     return true;
   };
   bool done = c->tile1 <= c->tile0;
@@ -926,12 +943,15 @@ int wait_mailbox(ms_ctx* c, unsigned long long* h_seq, const unsigned long long*
       int rc = check_queue_error(c);
       if (rc) return rc;
       int sl = 0;
-      while (sl < MS_MB_WORDS && __atomic_load_n(&h_seq[2 * sl + 1], __ATOMIC_ACQUIRE) >= expected[sl]) ++sl;
+      while (sl < MS_MB_WORDS - 1 && (expected[sl] == 0 || ((__atomic_load_n(&h_seq[2 * sl], __ATOMIC_ACQUIRE) ^
+                                                              __atomic_load_n(&h_seq[2 * sl + 1], __ATOMIC_ACQUIRE)) == expected[sl])))
+        ++sl;
       char msg[384];
       snprintf(msg, sizeof(msg),
-               "line-search queue: a gated launch the host waited for did not run (mailbox %s, entry %d: sequence %llu "
-               "< expected %llu; ticket %llu)",
-               box_name(c, h_seq), sl, (unsigned long long)__atomic_load_n(&h_seq[2 * sl + 1], __ATOMIC_ACQUIRE),
+               "line-search queue: a gated launch the host waited for did not run (mailbox %s, entry %d: ticket %llu "
+               "found, %llu expected; latest ticket %llu)",
+               box_name(c, h_seq), sl,
+               (unsigned long long)(__atomic_load_n(&h_seq[2 * sl], __ATOMIC_ACQUIRE) ^ __atomic_load_n(&h_seq[2 * sl + 1], __ATOMIC_ACQUIRE)),
                (unsigned long long)expected[sl], (unsigned long long)c->ticket);
       ++c->queue_mismatches;
       return fail(c, MS_ERR_STATE, msg);
@@ -941,10 +961,11 @@ int wait_mailbox(ms_ctx* c, unsigned long long* h_seq, const unsigned long long*
   if (rc) return rc;
   if (vals)
     for (int sl = 0; sl < MS_NSCAL; ++sl) {
-      const unsigned long long bits = __atomic_load_n(&h_seq[2 * sl], __ATOMIC_RELAXED);
-      memcpy(&vals[sl], &bits, sizeof(double));
+      // (entries nobody waited for keep whatever an earlier fold or put_mailbox left in their value word)
+      const unsigned long long b = expected[sl] ? bits[sl] : __atomic_load_n(&h_seq[2 * sl], __ATOMIC_RELAXED);
+      memcpy(&vals[sl], &b, sizeof(double));
     }
-  if (code) *code = (uint32_t)__atomic_load_n(&h_seq[2 * MS_MB_DEC], __ATOMIC_RELAXED);
+  if (code) *code = expected[MS_MB_DEC] ? (uint32_t)bits[MS_MB_DEC] : (uint32_t)__atomic_load_n(&h_seq[2 * MS_MB_DEC], __ATOMIC_RELAXED);
   return MS_OK;
 }
 
@@ -1011,11 +1032,11 @@ int queue_energy_and_gradient(ms_ctx* c, int stepper, bool use_history, bool ski
     const int dir_mode = (stepper == MS_STEPPER_CG && use_history) ? 2 : 1;
     rc = phase_gradient(c, mods, c->buf[MS_BUF_G], false, dir_mode, /*reduce_now=*/false);
     if (rc) return rc;
-    return reduce_slots(c, (penalty ? 0u : MASK_ENERGY) | MASK_DIR);
+    return reduce_slots(c, (penalty ? 0u : energy_mask(mods)) | MASK_DIR);
   }
   rc = phase_gradient(c, mods, c->buf[MS_BUF_G], false, 0, /*reduce_now=*/false);
   if (rc) return rc;
-  rc = reduce_slots(c, (penalty ? 0u : MASK_ENERGY) | MASK_GRAD);
+  rc = reduce_slots(c, (penalty ? 0u : energy_mask(mods)) | MASK_GRAD);
   if (rc) return rc;
   return phase_direction(c, stepper, use_history);
 }
@@ -2064,7 +2085,7 @@ int ms_energy_and_raw_gradient(ms_ctx* c, double energies[4], double* grad) {
   c->grad_valid = false;  // G receives the raw gradient: no fixed-row zeroing, no KKT projection
   rc = phase_gradient(c, mods, c->buf[MS_BUF_G], false, 0, /*reduce_now=*/false);
   if (rc) return rc;
-  rc = reduce_slots(c, (penalty ? 0u : MASK_ENERGY) | MASK_GRAD);
+  rc = reduce_slots(c, (penalty ? 0u : energy_mask(mods)) | MASK_GRAD);
   if (rc) return rc;
   rc = fetch(c);
   if (rc) return rc;

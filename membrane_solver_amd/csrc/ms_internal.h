@@ -278,6 +278,7 @@ struct FoldArgs {
   int check_ran;          // the tile kernel feeding this fold was gated by the same word: its MS_P_RAN partials must add
                           // up to every tile (gate open) or to none (closed)
   uint32_t* dec_out;      // Armijo decision of this stage (nullptr: none)
+  uint32_t* counter;      // arrival counter of the stage's energy workgroups (zero between launches)
   uint32_t e_mask;        // slots whose sum is a trial's energy (ESURF | EBEND as the module set has them)
   double rhs[MS_MAX_TRIALS];  // energy0 + c alpha_j <g,d>, trial order
   unsigned long long* host_err;  // pinned word: set non-zero when check_ran fails

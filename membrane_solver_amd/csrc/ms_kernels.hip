@@ -220,6 +220,19 @@ __device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) {
 __device__ __forceinline__ void st_agent(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Diagnostic build (-DMS_GATE_PROBE=1, tools/gate_probe.sh): how do the three read paths of a scalar that the PREVIOUS
+// kernel of the stream folded compare?  k_reduce stores every folded slot of the ordinary set once more, the round-2 way
+// (a plain store from one lane), into g_shadow; every workgroup of a gated gradient pass reads the bending energy from
+// there through the scalar data cache (s_load of a uniform address: what the round-2 gates did) and through the vector
+// L1/L2 (plain global_load), and compares both with the agent-scope load of the device scalars.  Counters only.
+#ifndef MS_GATE_PROBE
+#define MS_GATE_PROBE 0
+#endif
+#if MS_GATE_PROBE
+__device__ unsigned long long g_probe[32];
+__device__ double g_shadow[MS_NSCAL];
+#endif
+
 // Gate of a queued launch: open iff the decision word holds the code the host queued the launch for.  The word was
 // written by ONE lane of an earlier kernel of the stream and does not change while this launch runs, so every workgroup
 // takes the same branch.  Thread 0 records what the workgroup did in the MS_P_RAN row of the partials: the fold that
@@ -1039,6 +1052,26 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? MS_LEAN_SLOTS : 3) 
   // queued behind a line search: runs only if the decision word says the accepted point is the one in the ordinary
   // buffers (DEC_ACCEPT_MAIN)
   const int my_tile = a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0);
+#if MS_GATE_PROBE
+  if (a.gate != nullptr) {
+    const double truth = ld_agent(a.scal + MS_S_EBEND);
+    const double via_scalar = g_shadow[MS_S_EBEND];
+    const double via_vector = *reinterpret_cast<const volatile double*>(g_shadow + MS_S_EBEND + (threadIdx.x >> 12));
+    if (threadIdx.x == 0) {
+      const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u;  // XCC_ID
+      atomicAdd(&g_probe[0], 1ull);
+      if (via_scalar != truth) {
+        atomicAdd(&g_probe[1], 1ull);
+        atomicAdd(&g_probe[8 + xcc], 1ull);
+      }
+      if (via_vector != truth) {
+        atomicAdd(&g_probe[2], 1ull);
+        atomicAdd(&g_probe[16 + xcc], 1ull);
+      }
+      if (blockIdx.x == 0) atomicAdd(&g_probe[3], 1ull);  // gated launches probed
+    }
+  }
+#endif
   if (a.gate != nullptr && !gate_open(a.gate, a.gate_want, a.partials + (size_t)MS_P_RAN * a.m.n_tiles + my_tile)) return;
 
   const int blk = blockIdx.x;
@@ -2521,20 +2554,38 @@ hipError_t launch_disk_target(const DiskTargetArgs& a, int mode, hipStream_t s) 
 }
 
 constexpr int RBLOCK = 512;  // 512 threads x 8 loads in flight cover 4096 tiles in one round trip
-// ordered fold of one slot over the tiles [tile0, tile1) by the whole workgroup; the result is valid in thread 0
-__device__ __forceinline__ double fold_slot(const double* partials, int n_tiles, int tile0, int tile1, int slot,
-                                            double* red) {
-  const int op = (slot == MS_S_MINEDGE2) ? 1 : ((slot == MS_S_GUARD || slot == MS_S_MAXD2 || slot == MS_S_MAXG2 ||
-                                                 slot == MS_S_DTR_IN || slot == MS_S_DTR_OUT) ? 2 : 0);
+constexpr int RU = 8;
+__device__ __forceinline__ int fold_op(int slot) {  // 0 sum, 1 min, 2 max
+  return (slot == MS_S_MINEDGE2) ? 1 : ((slot == MS_S_GUARD || slot == MS_S_MAXD2 || slot == MS_S_MAXG2 ||
+                                         slot == MS_S_DTR_IN || slot == MS_S_DTR_OUT) ? 2 : 0);
+}
+// The ordered fold of one slot over the tiles [tile0, tile1), by the whole workgroup, in two halves so that the loads
+// of the NEXT slot can be in flight while this one is reduced: fold_issue requests the first 4096 tiles' partials (8 per
+// thread: thread i takes tiles tile0 + i, + 512, ...), fold_finish adds them up in that order, walks on if the range is
+// longer, and combines the threads (wave DPP tree, then the eight waves in order).  The result is valid in thread 0.
+// Partials are slot-major: the lanes of a wave read consecutive doubles.
+__device__ __forceinline__ void fold_issue(double (&q)[RU], const double* partials, int n_tiles, int tile0, int tile1,
+                                           int slot) {
+  const double* p = partials + (size_t)slot * n_tiles;
+  const double neutral = fold_op(slot) == 1 ? 1.0e300 : 0.0;
+  const int t = tile0 + (int)threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < RU; ++k) q[k] = t + k * RBLOCK < tile1 ? p[t + k * RBLOCK] : neutral;
+}
+__device__ __forceinline__ double fold_finish(const double (&q0)[RU], const double* partials, int n_tiles, int tile0,
+                                              int tile1, int slot, double* red) {
+  const int op = fold_op(slot);
   const double* p = partials + (size_t)slot * n_tiles;
   const double neutral = op == 1 ? 1.0e300 : 0.0;
   double v = neutral;
-  // RU loads in flight per thread (the order of the additions is unchanged)
-  constexpr int RU = 8;
-  for (int t = tile0 + threadIdx.x; t < tile1; t += RU * RBLOCK) {
-    double q[RU];
+  double q[RU];
 #pragma unroll
-    for (int k = 0; k < RU; ++k) q[k] = t + k * RBLOCK < tile1 ? p[t + k * RBLOCK] : neutral;
+  for (int k = 0; k < RU; ++k) q[k] = q0[k];
+  for (int t = tile0 + (int)threadIdx.x; t < tile1; t += RU * RBLOCK) {
+    if (t >= tile0 + RU * RBLOCK) {
+#pragma unroll
+      for (int k = 0; k < RU; ++k) q[k] = t + k * RBLOCK < tile1 ? p[t + k * RBLOCK] : neutral;
+    }
 #pragma unroll
     for (int k = 0; k < RU; ++k) {
       if (op == 0) {
@@ -2549,110 +2600,122 @@ __device__ __forceinline__ double fold_slot(const double* partials, int n_tiles,
   v = block_reduce(v, op, red);
   return (slot == MS_S_VOL) ? v / 6.0 : v;
 }
-// thread 0: a folded slot goes to the device scalars (agent scope: later kernels read it with ld_agent) and to the
-// pinned, device-mapped mailbox entry {value, sequence word}: the value first, a system-scope release, then the sequence
-// word the host polls with acquire loads.  (One 16-byte store of both was observed untorn on gfx950 and ~neutral in
-// time, but it is no architectural guarantee: a torn entry would hand the host a stale energy next to a fresh sequence
-// word, i.e. host and device deciding an Armijo test on different doubles.)
-__device__ __forceinline__ void post_slot(double* scal, unsigned long long* host_box, int entry, double r,
-                                          unsigned long long ticket) {
-  if (entry < MS_NSCAL) st_agent(scal + entry, r);
-  if (host_box) {
-    volatile unsigned long long* e = host_box + 2 * entry;
-    e[0] = (unsigned long long)__double_as_longlong(r);
-    __threadfence_system();
-    e[1] = ticket;
-  }
+// Mailbox entries live in pinned, device-mapped host memory: {value bits, tag} with tag = ticket XOR value bits, both
+// written with system-scope write-through stores (`sc0 sc1`, no cache holds them) and NO ordering between them.  The host
+// accepts an entry when value XOR tag equals the ticket it waits for: of the four (value, tag) combinations a reader can
+// see while the two stores land in either order, the test passes only for pairs whose value word IS the new value (old
+// value with new tag passes only if old == new; new value with old tag only if it completes the same ticket; old with
+// old never).  So neither a 16-byte store (observed untorn on gfx950, no architectural guarantee) nor a fence between
+// value and sequence word is needed -- the `__threadfence_system` per posted slot was most of this kernel's time, and a
+// wait for the value's PCIe acknowledgement before the sequence word the next largest part.
+__device__ __forceinline__ void st_sys(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// Grid: [head workgroup] + one workgroup per (set, slot).  The head workgroup exists when the fold closes a line-search
-// stage (dec_out) or checks a gated launch (check_ran): it folds the energy slots of EVERY set itself, one after the
-// other, takes the Armijo decision from exactly those doubles -- the first trial j whose energy passes rhs[j] is the
-// accepted one, as in line_search.py:386-392 -- and publishes the code.  With the gate closed only the head workgroup
-// does anything: it hands the earlier decision on (later stages and the gradient pass test THIS stage's word) and checks
-// that no workgroup of the gated tile kernel ran.
+__device__ __forceinline__ void post_entry(unsigned long long* box, int entry, unsigned long long bits,
+                                           unsigned long long ticket) {
+  st_sys(box + 2 * entry, bits);
+  st_sys(box + 2 * entry + 1, bits ^ ticket);
+}
+// One workgroup per (set, slot) task -- the MS_P_RAN count of a gated producer, the energy slots of every set, then the
+// remaining slots -- each on a CU of its own: ONE CU cannot keep enough cache lines in flight to read several 32 KB
+// partial rows at HBM/Infinity-Cache latency (a single-workgroup fold of five slots measured 9-13 us against 4.6 us
+// for five workgroups).  Thread 0 of a workgroup stores its result to the device scalars (agent scope: later kernels
+// read them with ld_agent) and posts it to its mailbox entry.
+// When the fold closes a line-search stage (dec_out) the energy workgroups count themselves in on an agent-scope
+// counter once their scalar store has completed; the one whose add comes last reads all the stage's energies back with
+// agent-scope loads and takes the Armijo decision ONCE from exactly the doubles that were posted -- the first trial j
+// whose energy passes rhs[j] is the accepted one, as in line_search.py:386-392 -- and publishes the code.
+// Every workgroup reads the gate word (one word, written by an earlier kernel); with the gate closed nothing is stored
+// or posted, workgroup 0 only hands the earlier decision on (later stages and the gradient pass test THIS stage's
+// word) and checks that no workgroup of the gated producer ran.
 __global__ __launch_bounds__(RBLOCK) void k_reduce(FoldArgs a) {
   __shared__ double red[16];
-  const bool has_head = a.dec_out != nullptr || a.check_ran;
-  const uint32_t head_mask = a.dec_out != nullptr ? (a.slot_mask & a.e_mask) : 0u;
-  bool open = true;
-  uint32_t prev = DEC_NONE;
-  if (a.gate != nullptr) {
-    prev = ld_agent(a.gate);
-    open = prev == a.gate_want;
-  }
-  int rb = blockIdx.x;
-  if (has_head && rb == 0) {
-    uint32_t code = DEC_CONTINUE;
-    if (open) {
-      bool decided = false;
-      for (int j = 0; j < a.n_sets; ++j) {
-        double E = 0.0;
-        for (int s = 0; s < MS_NSCAL; ++s)
-          if (head_mask & (1u << s)) {
-            const double r = fold_slot(a.set[j].partials, a.n_tiles, a.tile0, a.tile1, s, red);
-            if (threadIdx.x == 0) post_slot(a.set[j].scal, a.set[j].host_box, s, r, a.ticket);
-            E = E + r;  // (slot order: the host adds surface + bending in the same order)
-          }
-        if (a.dec_out != nullptr && !decided && E <= a.rhs[j]) {
-          decided = true;
-          code = j == a.n_sets - 1 ? DEC_ACCEPT_MAIN : DEC_ACCEPT_SIDE;
-        }
-      }
-    } else {
-      code = prev;  // an earlier stage has decided (or failed): later readers see the same
-    }
-    if (a.check_ran) {
-      const double ran = fold_slot(a.set[a.n_sets - 1].partials, a.n_tiles, a.tile0, a.tile1, MS_P_RAN, red);
-      const double want = open ? (double)(a.tile1 - a.tile0) : 0.0;
-      if (ran != want) {
-        code |= DEC_ERR_RAN;
-        if (threadIdx.x == 0 && a.host_err) {
-          *reinterpret_cast<volatile unsigned long long*>(a.host_err) =
-              ((unsigned long long)a.ticket << 24) | (unsigned long long)(unsigned int)ran | (1ull << 63);
-          __threadfence_system();
-        }
-      }
-    }
-    if (threadIdx.x == 0) {
-      if (a.dec_out != nullptr) st_agent(a.dec_out, code);
-      if (open && a.dec_out != nullptr && a.set[a.n_sets - 1].host_box)
-        post_slot(nullptr, a.set[a.n_sets - 1].host_box, MS_MB_DEC, __longlong_as_double((long long)code), a.ticket);
-    }
-    return;
-  }
-  if (!open) return;
-  if (has_head) --rb;
-  const uint32_t rest = a.slot_mask & ~head_mask;
-  const int per_set = __popc(rest);
-  if (per_set == 0) return;
-  const int n_reg = a.side_full ? a.n_sets : 1;  // sets with slots of their own to fold: all, or the last trial's only
-  if (rb / per_set >= n_reg) return;
-  const int j = a.n_sets - n_reg + rb / per_set;
-  // one workgroup per remaining slot of a set; partials are slot-major so lanes read consecutive doubles
-  int slot = -1;
+  const uint32_t e_mask = a.slot_mask & a.e_mask;
+  const uint32_t rest_mask = a.slot_mask & ~e_mask;
+  const uint32_t prev = a.gate != nullptr ? ld_agent(a.gate) : a.gate_want;  // (consumed after the fold's loads)
+  const int n_e = __popc(e_mask);                       // energy slots per set (<= 2)
+  const int n_rest = __popc(rest_mask);                 // other slots per set
+  const int n_reg = a.side_full ? a.n_sets : 1;         // sets whose other slots are folded too: all, or the last trial's
+  const int t_e = a.check_ran ? 1 : 0;                  // first energy task (task 0: the ran count)
+  const int t_rest = t_e + a.n_sets * n_e;
+  const int task = blockIdx.x;
+  int set, slot = -1;
   {
-    int k = rb % per_set;
-    for (int s = 0; s < MS_NSCAL; ++s)
-      if (rest & (1u << s)) {
-        if (k == 0) {
-          slot = s;
-          break;
-        }
+    uint32_t m = 0;
+    int k = 0;
+    if (task < t_e) {
+      set = a.n_sets - 1;
+      slot = MS_P_RAN;
+    } else if (task < t_rest) {  // energy slot k of set `set`
+      set = (task - t_e) / n_e;
+      k = (task - t_e) % n_e;
+      m = e_mask;
+    } else {
+      const int r = task - t_rest;
+      set = a.n_sets - n_reg + r / n_rest;
+      k = r % n_rest;
+      m = rest_mask;
+    }
+    for (int s = 0; s < MS_NSCAL && slot < 0; ++s)
+      if (m & (1u << s)) {
+        if (k == 0) slot = s;
         --k;
       }
   }
   if (slot < 0) return;
-  const double r = fold_slot(a.set[j].partials, a.n_tiles, a.tile0, a.tile1, slot, red);
-  if (threadIdx.x == 0) post_slot(a.set[j].scal, a.set[j].host_box, slot, r, a.ticket);
+  double q[RU];
+  fold_issue(q, a.set[set].partials, a.n_tiles, a.tile0, a.tile1, slot);
+  const bool open = prev == a.gate_want;
+  if (!open && task != 0) return;
+  const double r = fold_finish(q, a.set[set].partials, a.n_tiles, a.tile0, a.tile1, slot, red);
+  if (threadIdx.x != 0) return;
+  if (slot == MS_P_RAN) {
+    const double want = open ? (double)(a.tile1 - a.tile0) : 0.0;
+    if (r != want && a.host_err)
+      st_sys(a.host_err, ((unsigned long long)a.ticket << 24) | (unsigned long long)(unsigned int)r | (1ull << 63));
+  }
+  if (!open) {  // (task 0) an earlier stage has decided (or failed): later readers of THIS stage's word see the same
+    if (a.dec_out != nullptr) st_agent(a.dec_out, prev);
+    return;
+  }
+  if (slot == MS_P_RAN) return;
+  if (a.set[set].scal) st_agent(a.set[set].scal + slot, r);
+  if (a.set[set].host_box) post_entry(a.set[set].host_box, slot, (unsigned long long)__double_as_longlong(r), a.ticket);
+#if MS_GATE_PROBE
+  if (set == a.n_sets - 1) g_shadow[slot] = r;
+#endif
+  if (a.dec_out == nullptr || task >= t_rest) return;
+  // an energy of a stage that is decided here: count in once the scalar store has completed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint32_t arrived = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (arrived != (uint32_t)(a.n_sets * n_e - 1)) return;
+  st_agent(a.counter, 0u);  // (the next fold of the stream starts from zero)
+  uint32_t code = DEC_CONTINUE;
+  for (int j = 0; j < a.n_sets; ++j) {
+    double E = 0.0;
+    bool first = true;
+    for (int s = 0; s < MS_NSCAL; ++s)
+      if (e_mask & (1u << s)) {  // (slot order: the host adds surface + bending in this order)
+        const double v = ld_agent(a.set[j].scal + s);
+        E = first ? v : E + v;
+        first = false;
+      }
+    if (E <= a.rhs[j]) {
+      code = j == a.n_sets - 1 ? DEC_ACCEPT_MAIN : DEC_ACCEPT_SIDE;
+      break;
+    }
+  }
+  st_agent(a.dec_out, code);
+  if (a.set[a.n_sets - 1].host_box) post_entry(a.set[a.n_sets - 1].host_box, MS_MB_DEC, (unsigned long long)code, a.ticket);
 }
 
 hipError_t launch_reduce(const FoldArgs& a, hipStream_t s) {
-  const bool has_head = a.dec_out != nullptr || a.check_ran;
-  const uint32_t head_mask = a.dec_out != nullptr ? (a.slot_mask & a.e_mask) : 0u;
-  const int per_set = __builtin_popcount(a.slot_mask & ~head_mask);
-  const int nb = (has_head ? 1 : 0) + (a.side_full ? a.n_sets : 1) * per_set;
-  if (nb == 0) return hipSuccess;
   if (a.n_sets < 1 || a.n_sets > MS_MAX_TRIALS) return hipErrorInvalidValue;
+  const uint32_t em = a.slot_mask & a.e_mask;
+  const int nb = (a.check_ran ? 1 : 0) + a.n_sets * __builtin_popcount(em) +
+                 (a.side_full ? a.n_sets : 1) * __builtin_popcount(a.slot_mask & ~em);
+  if (nb == 0) return hipSuccess;
+  if (a.dec_out != nullptr && (a.counter == nullptr || em == 0)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(RBLOCK), 0, s, a);
   return hipGetLastError();
 }
@@ -3064,6 +3127,11 @@ hipError_t launch_curvature_raw(int nv, int nf, const double* pos, const int32_t
 }
 
 }  // namespace ms
+#if MS_GATE_PROBE
+extern "C" int ms_debug_read_probe(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ms::g_probe), sizeof(unsigned long long) * 32);
+}
+#endif
 #if MS_STAMPS
 extern "C" int ms_debug_read_stamps(unsigned long long* out, int n_blocks) {
   if (n_blocks < 0) {  // the rare-path counter

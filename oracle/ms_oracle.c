@@ -24,6 +24,16 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
+/* Third build, libms_oracle_ld.so (-DORC_LD): every `double` of this file -- arguments, locals, accumulators, scratch
+ * arrays -- is the x87 80-bit long double (64-bit mantissa: 2^-11 of fp64's rounding unit), sqrt is sqrtl.  The literal
+ * constants are exact in both types (0.5, 0.25, 2, 6, 8, 1e-12 thresholds as their fp64 values).  Callers pass
+ * numpy.longdouble arrays (oracle/truth.py).  It serves ONE purpose: a reference gradient against which the fp64
+ * oracle's and the HIP path's rounding errors at full size can both be measured (tests/test_gpu_minimizer.py). */
+#ifdef ORC_LD
+#define double long double
+#define sqrt sqrtl
+#endif
+
 /* The same source builds twice: libms_oracle.so (serial, strict order of operations: the
  * CHECKER) and libms_oracle_omp.so (-fopenmp -DORC_OMP: facet loops split over the host
  * cores, vertex scatter-adds by `omp atomic`; sums arrive in a different order, so this

@@ -33,6 +33,8 @@ def build(force: bool = False) -> str:
         or not os.path.exists(_LIB_PATH)
         or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)
         or not os.path.exists(os.path.join(_HERE, "libms_oracle_omp.so"))
+        or not os.path.exists(os.path.join(_HERE, "libms_oracle_ld.so"))
+        or os.path.getmtime(os.path.join(_HERE, "libms_oracle_ld.so")) < os.path.getmtime(src)
     ):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _LIB_PATH
