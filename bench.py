@@ -41,6 +41,7 @@ KERNEL_NAMES = {
     "energy_triple": "ms::k_energy<true, false, 256, 0, true, 3>",
     "gradient": "ms::k_gradient<1, false, 256, 0, true, false>",
     "gradient_lean": "ms::k_gradient<1, false, 256, 0, true, true>",
+    "energy_multi": "ms::k_energy<true, false, 256, 0, true, 8>",
 }
 
 
@@ -92,6 +93,7 @@ def algorithmic_bytes(nv, nf, *, uniform=True, volume=False, lean_pairs=True):
         # driver write every trial's outputs)
         "energy_pair": fac + (48 + vp) * nv + (1 if lean_pairs else 2) * (24 + 40) * nv,
         "energy_triple": fac + (48 + vp) * nv + (1 if lean_pairs else 3) * (24 + 40) * nv,
+        "energy_multi": fac + (48 + vp) * nv + (24 + 40) * nv,  # four to eight trials, only the last one writes outputs
         # gradient with the fused direction pass: x 24 + fK,fA 40 + flags 1 in; g 24 and d 24 out; CG history in:
         # the previous gradient (24) and, unless it is minus that (after an implicit steepest-descent step: the lean
         # instance), the previous direction (24).  With a constraint row the direction is not fused: g and gC out.
@@ -147,10 +149,12 @@ def kernel_table(prof, ab, *, trial_passes, level, nv, deterministic):
     n_p = prof.get("energy_pair", (0.0, 0))[1]
     n_t = prof.get("energy_triple", (0.0, 0))[1]
     n_g = prof.get("gradient", (0.0, 0))[1] + prof.get("gradient_lean", (0.0, 0))[1]
-    for kind, key, n_ev in (("energy_pair", "energy_pair", 2), ("energy_triple", "energy_triple", 3)):
+    for kind, key, n_ev in (("energy_pair", "energy_pair", 2), ("energy_triple", "energy_triple", 3),
+                            ("energy_multi", "energy_multi", None)):
         if kind in kernels:
             kernels[kind]["algorithmic_bytes"] = ab[key]
-            kernels[kind]["evaluations_per_launch"] = n_ev
+            if n_ev is not None:
+                kernels[kind]["evaluations_per_launch"] = n_ev
     if n_e:
         # single launches are a mix of passes at x (with or without the factor write) and trial passes: weight by
         # what was actually launched
@@ -200,7 +204,7 @@ def roofline_block(kernels, n_prof):
                                "tile-local facet records (1.13 instances per facet) plus the halo id lists")
     if out["avg_launch_us"] > 0:
         out["traffic_GBps"] = (traffic / (d["avg_us"] * 1e-6) / 1e9) if traffic is not None else None
-    fam = [k for k in ("energy", "energy_pair", "energy_triple") if k in kernels and "GBps" in kernels[k]]
+    fam = [k for k in ("energy", "energy_pair", "energy_triple", "energy_multi") if k in kernels and "GBps" in kernels[k]]
     if fam:
         b = sum(kernels[k]["algorithmic_bytes"] * kernels[k]["launches"] for k in fam)
         t = sum(kernels[k]["avg_us"] * kernels[k]["launches"] for k in fam)
@@ -341,6 +345,77 @@ def rates(steps, accepted, trials, guard_rejects, level, dt):
             "evaluations": {"line_search_energy_passes": e_evals, "energy_plus_gradient": g_evals}}
 
 
+def secondary_config(name, freq, mods, cons, stepper_name, *, volume_row, step_size, steps, warmup, device):
+    """One more configuration of BASELINE.json next to the headline, as an object of the same JSON line: steps/s,
+    accepted steps/s, what the line searches did, and the gradient kernel instance of that module set with its
+    fraction of the HBM peak (HIP events over a profiled pass of the same steps)."""
+    import torch
+
+    from membrane_solver_amd.geometry.mesh import ArrayBody, ArrayMesh
+    from membrane_solver_amd.runtime.constraint_manager import ConstraintModuleManager
+    from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
+    from membrane_solver_amd.runtime.minimizer import Minimizer
+    from membrane_solver_amd.runtime.steppers import ConjugateGradient, GradientDescent
+
+    P, T = bench_mesh(freq)
+    nv, nf = P.shape[0], T.shape[0]
+    gp = dict(GP)
+    bodies = []
+    if volume_row:
+        v0, v1, v2 = P[T[:, 0]], P[T[:, 1]], P[T[:, 2]]
+        bodies = [ArrayBody(0, None, float(np.einsum("ij,ij->i", np.cross(v1, v2), v0).sum() / 6.0))]
+    mesh = ArrayMesh(P, T, global_parameters=gp, energy_modules=list(mods), constraint_modules=list(cons), bodies=bodies)
+    stepper = ConjugateGradient() if stepper_name == "conjugate_gradient" else GradientDescent()
+    mz = Minimizer(mesh, mesh.global_parameters, stepper, EnergyModuleManager(list(mods)),
+                   ConstraintModuleManager(list(cons)), quiet=True, step_size=step_size, device=device)
+    mz.compute_energy()
+    mz.minimize(warmup, sync_mesh=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = mz.minimize(steps, sync_mesh=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    run = dict(mz.last_run)
+    dm = mesh._hip_mirror.dm
+    out = {"workload": f"class-I icosphere f={freq} (nv={nv}, nf={nf}), modules {'+'.join(mods)}"
+                       + (", volume Lagrange row (k = 1 KKT projection of the gradient)" if volume_row else "")
+                       + f", {stepper_name}, initial step {step_size:g}",
+           "value": steps / dt, "unit": "steps/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
+           "steps_accepted": res["steps_accepted"], "line_search_trials": res["line_search_trials"],
+           **rates(steps, res["steps_accepted"], res["line_search_trials"], run.get("guard_rejects", 0), 2, dt)}
+    n_prof = min(steps, 40)
+    dm.profile_enable(True)
+    dm.profile_read()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mz.minimize(n_prof, sync_mesh=False)
+    torch.cuda.synchronize()
+    dtp = time.perf_counter() - t0
+    prof = dm.profile_read()
+    dm.profile_enable(False)
+    ab = algorithmic_bytes(nv, nf, uniform=True, volume=volume_row)
+    bend = "bending" in mods
+    inst = {}
+    for kind in ("gradient", "gradient_lean"):
+        ms, n = prof.get(kind, (0.0, 0))
+        if n:
+            nbytes = ab[kind] if bend else 12 * nf + 25 * nv + (48 if volume_row else 48) * nv
+            name = (KERNEL_NAMES[kind] if bend else "ms::k_gradient<0, %s, 256, 0, true, false>" % ("true" if volume_row else "false"))
+            if bend and volume_row:
+                name = "ms::k_gradient<1, true, 256, 0, true, false>"
+            us = 1e3 * ms / n
+            inst[kind] = {"kernel": name, "avg_us": us, "launches": n, "algorithmic_bytes": nbytes,
+                          "GBps": nbytes / (us * 1e-6) / 1e9, "frac_of_hbm_peak": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    out["gradient_instance"] = inst
+    tot_ms = sum(ms for ms, _n in prof.values())
+    out["kernel_busy_share"] = tot_ms * 1e-3 / dtp
+    out["kernels_avg_us"] = {k: 1e3 * ms / n for k, (ms, n) in prof.items() if n}
+    out["line_search_queue"] = {k: v for k, v in dm.queue_stats().items()}
+    dm.close()
+    mesh._hip_mirror = None
+    return out
+
+
 def main_single(args):
     import torch  # device plumbing: synchronize bracket of the contract
 
@@ -399,7 +474,8 @@ def main_single(args):
     q0 = mesh._hip_mirror.dm.queue_stats()
     out["line_search_queue"] = dict(q0, note="since ms_create (warm-up included): rounds = energy launches queued with their "
                                             "gated followers; every decision is taken once on the device and replayed by "
-                                            "the host from the same doubles -- mismatches must be 0")
+                                            "the host from the same doubles -- mismatches must be 0; ahead = rounds queued for a step that had not "
+                                            "started yet (behind the running gradient pass), adopted = those the step took")
 
     # -- the same K steps with every pass the reference repeats (reuse level 0): energy0
     #    re-evaluated, a fresh energy/factor pass after every accepted step, a full gradient
@@ -436,10 +512,17 @@ def main_single(args):
         n_prof = min(args.steps, 40)
         dm.profile_enable(True)
         dm.profile_read()
+        torch.cuda.synchronize()
+        t0p = time.perf_counter()
         mz.minimize(n_prof, sync_mesh=False)
+        torch.cuda.synchronize()
+        dt_prof = time.perf_counter() - t0p
         trial_passes = mz.last_run["trials"] + mz.last_run["guard_rejects"]
         prof = dm.profile_read()
         dm.profile_enable(False)
+        out["kernel_busy_share"] = {"value": sum(ms for ms, _n in prof.values()) * 1e-3 / dt_prof,
+                                    "what": "sum of the kernels' HIP-event durations / wall time of the same profiled "
+                                            f"{n_prof} steps (the event brackets lengthen both a little)"}
         ab = algorithmic_bytes(nv, nf, uniform=True, volume=args.volume,
                                lean_pairs=os.environ.get("MS_PAIR_LEAN", "1") != "0")
         kernels = kernel_table(prof, ab, trial_passes=trial_passes, level=int(stepper.reuse_energy0), nv=nv,
@@ -463,6 +546,19 @@ def main_single(args):
         out["energy_plus_gradient_evaluation"] = eg
         if out["roofline"] is not None:
             out["roofline"]["energy_plus_gradient_evaluation_frac"] = eg["frac"] if eg else None
+
+    # -- the other single-GPU configurations of BASELINE.json, same line -------------------------
+    if not args.headline_only and not args.volume and args.freq == 320:
+        try:
+            out["config2"] = secondary_config("config2", 81, ["surface"], ["volume"], "gradient_descent", volume_row=True,
+                                              step_size=1e-3, steps=200, warmup=30, device=local_rank)
+            out["config3_volume_row"] = secondary_config("config3_volume_row", 320, ["surface", "bending"], ["volume"],
+                                                         "conjugate_gradient", volume_row=True, step_size=args.step_size,
+                                                         steps=min(args.steps, 100), warmup=min(args.warmup, 30),
+                                                         device=local_rank)
+            out["config3_volume_row"]["vs_no_row"] = out["config3_volume_row"]["value"] / out["value"]
+        except Exception as exc:  # secondary figures never cost the headline line
+            print(f"[bench] secondary configurations skipped: {exc!r}", file=sys.stderr)
 
     # -- CPU baseline: the oracle port on the host cores, bounded sample ---------
     n_cpu = 6 if args.cpu_steps < 0 else args.cpu_steps

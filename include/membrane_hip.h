@@ -482,7 +482,8 @@ int ms_profile_read(ms_ctx *ctx, double total_ms[MS_PROF_KINDS],
  * [3] searches whose accepted trial was an energy-only early trial of a multi-trial launch (re-evaluated alone),
  * [4] decisions on which host and device differed (each one also fails the call with MS_ERR_STATE: the device takes
  * every Armijo decision once, in the fold that closes the stage -- runtime/steppers/line_search.py:386-392 -- and the
- * host replays it from the same doubles), [5..7] reserved. */
+ * host replays it from the same doubles), [5] rounds queued for a step that had not started yet (behind the running
+ * gradient pass; ms_minimize only), [6] those the step adopted, [7] those dropped. */
 int ms_queue_stats(ms_ctx *ctx, int64_t stats[8]);
 
 /* Host-only planning pass (no GPU needed): runs the same tiling ms_create

@@ -97,9 +97,46 @@ struct ms_ctx {
     unsigned long long* h_seq = nullptr;   // pinned, mapped: 2*MS_MB_WORDS words, {value bits, sequence word} per entry
     unsigned long long* d_h_seq = nullptr;
     unsigned long long expected[MS_MB_WORDS] = {0};
-  } spec[SPEC_STAGES];
-  Mailbox grad_mb;               // mailbox of the gradient pass queued behind a ladder
+  } spec[2][SPEC_STAGES];        // (everything a round posts to exists twice: a round can be queued while the one
+                                 // before it has not been read yet -- see Ahead)
+  Mailbox first_mb[2];           // mailbox of a round's first launch
+  Mailbox grad_mb[2];            // mailbox of the gradient pass queued behind a round
   bool kc_pending = false;       // that pass ran for the accepted x: the next ms_step takes its result
+  int kc_parity = 0;
+  int next_parity = 0, cur_parity = 0;
+  // a round queued for a step that has not started yet (queue_ahead)
+  struct RoundPlanT {
+    int n0 = 1, n_st = 0;
+    double alphas[MS_MAX_TRIALS + SPEC_STAGES] = {0};
+  };
+  struct Ahead {
+    bool valid = false;
+    bool go_known = false, go = false;  // the device's answer (FoldArgs::go_out) has been read / was DEC_GO
+    int kind = 0, parity = 0, src = 0, stepper = 0, max_iter = 0;
+    bool implicit = false;
+    double alpha0 = 0, energy0 = 0, beta = 0, c1 = 0, tol2p = 0, lim = 0;
+    RoundPlanT plan;
+  } ahead;
+  bool ahead_enable = true;      // MS_AHEAD=0 switches the rounds queued ahead off
+  int steps_left = 0;            // ... steps that follow the current one in this ms_minimize call
+  bool ahead_allowed = false;    // set by ms_minimize: the caller is the library's own loop (nothing else touches the
+                                 // context between two steps), and another step follows
+  // The direction fold of a round's gradient pass can be left out when the round is queued (defer_dir) and merged
+  // into the first fold of the round after it: that round's energy launch then starts right behind the gradient pass
+  bool defer_dir = false;                 // reduce_slots: do not launch a direction fold, remember its mask
+  uint32_t dir_deferred_mask = 0;
+  bool dir_pending[2] = {false, false};   // the round's gradient pass has run (if its gate was open) without its fold
+  uint32_t dir_mask[2] = {0, 0};
+  uint32_t* kc_gate[2] = {nullptr, nullptr};  // decision word that pass was gated on
+  uint32_t cur_extra_mask = 0;            // reduce_slots: fold these slots of the ordinary partials as well
+  const unsigned long long* cur_go_par = nullptr;  // ... and take the GO decision with these parameters first
+  bool cur_gate_fold_only = false;        // the gate (and the ran check) belongs to the fold, not to the energy kernel
+  bool last_hist_descent = false;         // the last direction with CG history was a descent direction
+  unsigned long long* h_go_par[2] = {nullptr, nullptr};  // pinned: parameters for it (FoldArgs::go_par)
+  unsigned long long* d_h_go_par[2] = {nullptr, nullptr};
+  uint32_t* cur_go = nullptr;          // the direction fold being queued may open the next round: its GO word
+  const double* cur_rhs_dev = nullptr; // the fold being queued takes its right-hand sides from the device
+  long q_ahead = 0, q_adopted = 0, q_dropped = 0;
   int kc_stepper = 0;
   bool kc_use_history = false;
   // Decision records (ms_internal.h DEC_*): one 128-byte line each, written by the head workgroup of the fold that
@@ -126,7 +163,7 @@ struct ms_ctx {
   int pair_on = 0;               // phase_energy / reduce_slots: the launch being queued evaluates this many trials
   // the early trials of a multi-trial launch (the ones expected to fail) are evaluated for their energies only:
   // no trial positions, no bending factors written for them (ms_step; the sharded driver needs the factor rows)
-  bool no_fast = false;          // MS_NO_FAST=1
+  bool no_fast = false;          // MS_NO_FAST=1 (variant builds only)
   bool pair_lean = false;
   bool pair_lean_enable = true;  // MS_PAIR_LEAN=0: write the first two early trials' outputs (copied back if one is accepted)
   double pair_alpha[MS_MAX_TRIALS] = {0};  // alphas of the early trials
@@ -134,7 +171,7 @@ struct ms_ctx {
   struct SideSet {
     double* partials = nullptr;
     double* scal = nullptr;
-    Mailbox mb;
+    Mailbox mb[2];
   } side[N_SIDE];
   double* xt3 = nullptr;         // full outputs of early trial 1 (MS_PAIR_LEAN=0)
   double* fK3 = nullptr;
@@ -334,6 +371,7 @@ constexpr uint32_t MS_ANY_TILT_MODS = MS_TILT_MODS | MS_LEAFLET_MODS;
 // modules whose shape gradient is added into g by a pass after K_C (so the direction cannot be fused)
 constexpr uint32_t MS_TILT_SHAPE_MODS = MS_MOD_TILT | MS_MOD_TILT_IN | MS_MOD_TILT_OUT | MS_LEAFLET_BT | MS_LEAFLET_DT;
 using TiltField = ms_ctx::TiltField;
+using RoundPlan = ms_ctx::RoundPlanT;
 
 // the tilt fields the module set reads: [0] single field, [1] inner, [2] outer leaflet
 int active_fields(ms_ctx* c, uint32_t mods, TiltField* out[3]) {
@@ -509,6 +547,10 @@ const char* box_name(ms_ctx* c, const void* h_seq) {
   return it->second.c_str();
 }
 
+inline uint32_t* dec_word(ms_ctx* c, int parity, int k) { return c->d_dec + (size_t)MS_DEC_STRIDE * (parity * 4 + k); }
+inline uint32_t* go_word(ms_ctx* c, int parity) { return c->d_dec + (size_t)MS_DEC_STRIDE * (8 + parity); }
+inline const double* go_rhs(ms_ctx* c, int parity) { return reinterpret_cast<const double*>(go_word(c, parity) + 2); }
+
 // energy slots whose sum is the energy the Armijo test compares (the ladder only runs for module sets whose energy
 // is surface + bending: ms_step's can_chain)
 uint32_t armijo_slots(const ms_ctx* c) {
@@ -524,6 +566,11 @@ uint32_t energy_mask(uint32_t modules) {
 }
 
 int reduce_slots(ms_ctx* c, uint32_t mask) {
+  if (c->defer_dir && (mask & (1u << MS_S_GDOTD)) && c->cur_dec == nullptr) {
+    c->dir_deferred_mask = mask;  // (queue_round: the fold of the round after this one takes these slots along)
+    return MS_OK;
+  }
+  mask |= c->cur_extra_mask;
   ProfScope ps(c, 3, c->cur_gate != nullptr);
   ++c->ticket;
   if (trace_queue())
@@ -535,12 +582,12 @@ int reduce_slots(ms_ctx* c, uint32_t mask) {
   const int n_multi = c->pair_on > 1 ? c->pair_on : 1;
   if (n_multi > 1) {
     const uint32_t core = (1u << MS_S_ESURF) | (1u << MS_S_VOL) | (1u << MS_S_EBEND) | (1u << MS_S_MINEDGE2) |
-                          (1u << MS_S_GUARD);
+                          (1u << MS_S_GUARD) | c->cur_extra_mask;
     // (nobody is to wait for the dropped slots: an older, gated-out launch may have left a ticket there)
     for (int sl = 0; sl < MS_NSCAL; ++sl)
       if (mask & ~core & (1u << sl)) {
         c->expected[sl] = 0;
-        for (int k = 0; k + 1 < n_multi; ++k) c->side[k].mb.expected[sl] = 0;
+        for (int k = 0; k + 1 < n_multi; ++k) c->side[k].mb[c->cur_parity].expected[sl] = 0;
       }
     mask &= core;
   }
@@ -567,16 +614,22 @@ int reduce_slots(ms_ctx* c, uint32_t mask) {
     ms_ctx::SideSet& sd = c->side[j];
     f.set[j].partials = sd.partials;
     f.set[j].scal = (j == 0 && c->pair_scal2) ? c->pair_scal2 : sd.scal;
-    f.set[j].host_box = sd.mb.d_h_seq;
+    f.set[j].host_box = sd.mb[c->cur_parity].d_h_seq;
     const uint32_t posted = (f.side_full || !f.dec_out) ? mask : (mask & f.e_mask);
     for (int sl = 0; sl < MS_NSCAL; ++sl)
-      if (posted & (1u << sl)) sd.mb.expected[sl] = c->ticket;
+      if (posted & (1u << sl)) sd.mb[c->cur_parity].expected[sl] = c->ticket;
   }
   f.set[n_multi - 1].partials = c->d_partials;
   f.set[n_multi - 1].scal = c->d_scal;
   f.set[n_multi - 1].host_box = c->d_h_seq;
   for (int sl = 0; sl < MS_NSCAL; ++sl)
     if (mask & (1u << sl)) c->expected[sl] = c->ticket;
+  f.rhs_dev = c->cur_rhs_dev;
+  if (c->cur_go_par && f.dec_out && (mask & (1u << MS_S_GDOTD))) {  // merged: direction scalars + GO + Armijo decision
+    f.go_out = c->cur_go;
+    f.go_par = c->cur_go_par;
+    f.go_ticket = c->ticket;
+  }
   if (f.dec_out) c->expected[MS_MB_DEC] = c->ticket;
   HIPCHK(c, launch_reduce(f, c->stream));
   return MS_OK;
@@ -601,7 +654,7 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   a.fA = (bend && write_factors) ? c->buf[MS_BUF_FA] : nullptr;
   a.bt_vert = bt ? c->d_bt_vert : nullptr;
   a.bt_normals = nullptr;
-  a.gate = c->cur_gate;
+  a.gate = c->cur_gate_fold_only ? nullptr : c->cur_gate;
   a.gate_want = c->cur_gate_want;
   a.atomic = c->deterministic ? 0 : 1;
   a.pair = 0;
@@ -1276,10 +1329,11 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
     c->pair_force = atoi(pe) >= 2 ? std::min(atoi(pe), 4) : 0;  // 4: triple launches whenever possible
   }
   c->speculate = !(getenv("MS_SPECULATE") != nullptr && atoi(getenv("MS_SPECULATE")) == 0);
+  c->ahead_enable = !(getenv("MS_AHEAD") != nullptr && atoi(getenv("MS_AHEAD")) == 0);
   c->escalate = !(getenv("MS_ESCALATE") != nullptr && atoi(getenv("MS_ESCALATE")) == 0);
   if (getenv("MS_ESCALATE") != nullptr && atoi(getenv("MS_ESCALATE")) > 0) c->escalate_after = atoi(getenv("MS_ESCALATE"));
   c->ls_reset = !(getenv("MS_LS_RESET") != nullptr && atoi(getenv("MS_LS_RESET")) == 0);
-  c->no_fast = getenv("MS_NO_FAST") != nullptr && atoi(getenv("MS_NO_FAST")) != 0;
+  c->no_fast = variant_env("MS_NO_FAST") != nullptr && atoi(variant_env("MS_NO_FAST")) != 0;
   c->pair_lean_enable = !(getenv("MS_PAIR_LEAN") != nullptr && atoi(getenv("MS_PAIR_LEAN")) == 0);
   c->deterministic = getenv("MS_DETERMINISTIC") != nullptr && atoi(getenv("MS_DETERMINISTIC")) != 0;
   c->params.modules = MS_MOD_SURFACE;
@@ -1324,19 +1378,26 @@ void ms_destroy(ms_ctx* c) {
   if (c->d_xrecv) (void)hipFree(c->d_xrecv);
   if (c->h_scal_all) (void)hipHostFree(c->h_scal_all);
   if (c->h_xseq) (void)hipHostFree(c->h_xseq);
-  for (auto& m : c->spec) {
-    free(m.h_scal);
-    if (m.h_seq) (void)hipHostFree(m.h_seq);
+  for (int p = 0; p < 2; ++p) {
+    for (auto& m : c->spec[p]) {
+      free(m.h_scal);
+      if (m.h_seq) (void)hipHostFree(m.h_seq);
+    }
+    for (ms_ctx::Mailbox* m : {&c->grad_mb[p], &c->first_mb[p]}) {
+      free(m->h_scal);
+      if (m->h_seq) (void)hipHostFree(m->h_seq);
+    }
+    if (c->h_go_par[p]) (void)hipHostFree(c->h_go_par[p]);
   }
-  free(c->grad_mb.h_scal);
-  if (c->grad_mb.h_seq) (void)hipHostFree(c->grad_mb.h_seq);
   if (c->d_dec) (void)hipFree(c->d_dec);
   if (c->h_err) (void)hipHostFree(c->h_err);
   for (auto& sd : c->side) {
     if (sd.partials) (void)hipFree(sd.partials);
     if (sd.scal) (void)hipFree(sd.scal);
-    free(sd.mb.h_scal);
-    if (sd.mb.h_seq) (void)hipHostFree(sd.mb.h_seq);
+    for (auto& m : sd.mb) {
+      free(m.h_scal);
+      if (m.h_seq) (void)hipHostFree(m.h_seq);
+    }
   }
   for (double* q : {c->xt2, c->fK2, c->fA2, c->xt3, c->fK3, c->fA3})
     if (q) (void)hipFree(q);
@@ -2149,23 +2210,30 @@ int spec_prepare(ms_ctx* c) {
       HIPCHK(c, hipMemset(sd.partials, 0, pb));
       HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&sd.scal), sizeof(double) * MS_NSCAL));
       HIPCHK(c, hipMemset(sd.scal, 0, sizeof(double) * MS_NSCAL));
-      int rc = make_box(sd.mb);
-      if (rc) return rc;
+      for (auto& m : sd.mb) {
+        int rc = make_box(m);
+        if (rc) return rc;
+      }
     }
   }
-  for (int k = 0; k < ms_ctx::SPEC_STAGES; ++k) {
-    int rc = make_box(c->spec[k]);
+  for (int p = 0; p < 2; ++p) {
+    for (int k = 0; k < ms_ctx::SPEC_STAGES; ++k) {
+      int rc = make_box(c->spec[p][k]);
+      if (rc) return rc;
+    }
+    int rc = make_box(c->grad_mb[p]);
     if (rc) return rc;
-  }
-  {
-    int rc = make_box(c->grad_mb);
+    rc = make_box(c->first_mb[p]);
     if (rc) return rc;
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_go_par[p]), sizeof(unsigned long long) * 2 * 12,
+                            hipHostMallocMapped));
+    memset(c->h_go_par[p], 0, sizeof(unsigned long long) * 2 * 12);
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_go_par[p]), c->h_go_par[p], 0));
   }
   HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_dec), sizeof(uint32_t) * MS_DEC_STRIDE * ms_ctx::N_DEC));
   HIPCHK(c, hipMemset(c->d_dec, 0, sizeof(uint32_t) * MS_DEC_STRIDE * ms_ctx::N_DEC));
   return MS_OK;
 }
-inline uint32_t* dec_word(ms_ctx* c, int k) { return c->d_dec + (size_t)MS_DEC_STRIDE * k; }
 // the host knows a gated fold stayed out (an earlier stage was accepted, or nothing was): nobody waits for its ticket
 inline void forget(ms_ctx::Mailbox& m) {
   for (int sl = 0; sl < MS_MB_WORDS; ++sl) m.expected[sl] = 0;
@@ -2177,6 +2245,308 @@ void swap_mailbox(ms_ctx* c, ms_ctx::Mailbox& m) {
   std::swap(c->h_seq, m.h_seq);
   std::swap(c->d_h_seq, m.d_h_seq);
   for (int sl = 0; sl < MS_MB_WORDS; ++sl) std::swap(c->expected[sl], m.expected[sl]);
+}
+}  // namespace
+
+// ---- line-search rounds (ms_step) ------------------------------------------------------------------------------
+// A round = one ungated (or GO-gated) energy launch of n0 trials, n_st single-trial stages gated behind it, and the
+// gradient + direction pass of the accepted point gated behind those.
+namespace {
+// plan a round from `alpha` on (prediction only: the same alphas are tested in the same order whatever is chosen)
+void plan_round(ms_ctx* c, const ms_stepper_params* sp, double alpha, int room, int rejected_here, double a_hi,
+                double r_lo, bool ls_warm, int trials_so_far, RoundPlan& plan) {
+  const bool multi_ok = c->pair_enable && c->side[0].partials != nullptr && (c->params.modules & MS_MOD_BENDING) != 0;
+  const int n0_cap = !multi_ok ? 1 : (c->pair_lean_enable ? MS_MAX_TRIALS : (c->fK3 ? 3 : 2));
+  double* alphas = plan.alphas;
+  int n_alpha = 1;  // alphas of the ladder from here that are still >= 1e-8
+  alphas[0] = alpha;
+  while (n_alpha < room && n_alpha < MS_MAX_TRIALS + ms_ctx::SPEC_STAGES && alphas[n_alpha - 1] * sp->beta >= 1e-8) {
+    alphas[n_alpha] = alphas[n_alpha - 1] * sp->beta;
+    ++n_alpha;
+  }
+  int n0 = 1, n_st = 0;
+  // A search that has rejected `escalate_after` alphas already will most likely reject more: from there on a round
+  // evaluates as many trials as the search has rejected so far in ONE launch (the early ones of a launch cost an
+  // energy-only evaluation each), whatever the history of the earlier searches says.
+  const int force = c->pair_force;
+  if (!force && c->escalate && multi_ok && rejected_here >= c->escalate_after) {
+    n0 = std::max(1, std::min(std::min(n_alpha, n0_cap), rejected_here));
+  } else {
+    const bool can_spec = force || (ls_warm ? r_lo < INFINITY : c->pred_trials > 1);
+    int depth = 1;
+    if (can_spec) {
+      // how many trials to queue: as many as the last search needed (cold), or -- once there is a history --
+      // one per alpha that still lies above (most of) the range where alphas were accepted lately
+      const int room4 = std::min(1 + ms_ctx::SPEC_STAGES, n_alpha);
+      const int want = force ? std::min(std::min(force, 3), room4)
+                             : (ls_warm ? room4 : std::min(c->pred_trials - trials_so_far, room4));
+      while (depth < want) {
+        if (!force && ls_warm && !(alphas[depth - 1] > 0.9 * a_hi)) break;
+        ++depth;
+      }
+    }
+    // two or more trials expected: the first two share one launch (and the ladder stops there for this round)
+    // ... and only when the first one is expected to fail: it lies above every alpha accepted lately, and alphas
+    // were rejected lately (a wasted evaluation costs more than a saved round trip gains)
+    const bool pair = depth > 1 && multi_ok && (force || (ls_warm && alpha > 1.05 * a_hi && r_lo < INFINITY));
+    if (pair) {
+      depth = std::min(depth, 3);
+      // triple launch: trial 1 is expected to fail as well -- its alpha is not below one that was rejected lately
+      const bool triple = depth == 3 && n0_cap >= 3 && (force ? force == 4 : alphas[1] > r_lo);
+      // otherwise the pair, and one gated trial behind it when trial 1 is as sure to fail as trial 0 (an empty gated
+      // stage costs about what the host round trip it saves does, so "probably" is not enough)
+      if (depth == 3 && !triple && !force && !(alphas[1] > a_hi)) depth = 2;
+      n0 = triple ? 3 : 2;
+      n_st = depth - n0;
+    } else {
+      n0 = 1;
+      n_st = depth - 1;
+    }
+  }
+  plan.n0 = n0;
+  plan.n_st = n_st;
+}
+
+// queue a planned round into the mailboxes / decision records of `parity`.  merged: the round belongs to a step that
+// has not started -- its first launch runs right behind the gradient pass of round `go_src`, whose direction scalars
+// the round's first fold folds itself; that fold decides first whether the search happens at all (FoldArgs::go_par)
+// and forms the Armijo right-hand sides on the device.
+int queue_round(ms_ctx* c, const ms_stepper_params* sp, const RoundPlan& plan, int parity, double energy0,
+                double g_dot_d, bool merged, int go_src, bool carry_mode, bool cg, int restart) {
+  const bool go_gated = merged;
+  const int n0 = plan.n0, n_st = plan.n_st;
+  const double* alphas = plan.alphas;
+  c->cur_parity = parity;
+  int rc;
+  // first launch: trials 0 .. n0-1, the early ones into the side sets, the last one into the ordinary outputs;
+  // its fold decides all of them and writes decision record 0
+  {
+    c->pair_on = n0 > 1 ? n0 : 0;
+    c->pair_lean = n0 > 1 && c->pair_lean_enable;
+    for (int j = 0; j + 1 < n0; ++j) c->pair_alpha[j] = alphas[j];
+    swap_mailbox(c, c->first_mb[parity]);
+    // merged: the fold (not the energy kernel) is tied to the gradient pass in front: it checks that pass's ran count
+    c->cur_gate = merged ? c->kc_gate[go_src] : nullptr;
+    c->cur_gate_want = DEC_ACCEPT_MAIN;
+    c->cur_gate_fold_only = merged;
+    c->cur_check_ran = merged;
+    c->cur_dec = dec_word(c, parity, 0);
+    c->cur_extra_mask = merged ? c->dir_mask[go_src] : 0u;
+    c->cur_go_par = merged ? c->d_h_go_par[go_src] : nullptr;
+    c->cur_go = merged ? go_word(c, go_src) : nullptr;
+    for (int j = 0; j < n0; ++j) c->cur_rhs[j] = energy0 + sp->c * alphas[j] * g_dot_d;
+    rc = phase_energy(c, c->params.modules, true, alphas[n0 - 1], true, false, carry_mode);
+    c->pair_on = 0;
+    c->pair_lean = false;
+    c->cur_dec = nullptr;
+    c->cur_gate = nullptr;
+    c->cur_gate_fold_only = false;
+    c->cur_check_ran = false;
+    c->cur_extra_mask = 0;
+    c->cur_go_par = nullptr;
+    c->cur_go = nullptr;
+    if (merged) c->dir_pending[go_src] = false;
+    swap_mailbox(c, c->first_mb[parity]);
+    if (rc) return rc;
+  }
+  // gated stages: stage s runs iff record s-1 says DEC_CONTINUE
+  for (int s2 = 1; s2 <= n_st; ++s2) {
+    swap_mailbox(c, c->spec[parity][s2 - 1]);
+    c->cur_gate = dec_word(c, parity, s2 - 1);
+    c->cur_gate_want = DEC_CONTINUE;
+    c->cur_check_ran = true;
+    c->cur_dec = dec_word(c, parity, s2);
+    c->cur_rhs[0] = energy0 + sp->c * alphas[n0 + s2 - 1] * g_dot_d;
+    c->cur_rhs_dev = go_gated ? go_rhs(c, go_src) + (n0 + s2 - 1) : nullptr;
+    rc = phase_energy(c, c->params.modules, true, alphas[n0 + s2 - 1], true, false, carry_mode);
+    c->cur_gate = nullptr;
+    c->cur_check_ran = false;
+    c->cur_dec = nullptr;
+    c->cur_rhs_dev = nullptr;
+    swap_mailbox(c, c->spec[parity][s2 - 1]);
+    if (rc) return rc;
+  }
+  {
+    // the next step's gradient pass in the state an acceptance produces (x <-> xt, CG history swapped, factors of
+    // the accepted trial), gated on "the accepted trial is the one in the ordinary buffers"; every change of the
+    // context is undone afterwards.  Its direction fold can open the round after this one (queue_ahead).
+    const bool next_hist = cg && ((c->cg_iter_count + 1) % restart != 0);
+    const bool s_factors = c->factors_valid, s_implicit = c->dir_implicit, s_pdneg = c->pd_neg_pg;
+    const bool s_grad_valid = c->grad_valid, s_carry = c->carry_valid, s_maxg2 = c->maxg2_valid;
+    double* const s_last_g = c->last_g;
+    std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
+    if (cg) {
+      std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
+      std::swap(c->buf[MS_BUF_D], c->buf[MS_BUF_PD]);
+      c->pd_neg_pg = c->dir_implicit;
+    }
+    c->factors_valid = true;
+    swap_mailbox(c, c->grad_mb[parity]);
+    c->cur_gate = dec_word(c, parity, n_st);
+    c->cur_gate_want = DEC_ACCEPT_MAIN;
+    c->cur_check_ran = true;
+    // inside ms_minimize the direction fold of this pass is left to the first fold of the round after this one
+    c->defer_dir = c->ahead_allowed && sp->edge_fraction <= 0.0;
+    c->dir_deferred_mask = 0;
+    rc = queue_energy_and_gradient(c, sp->stepper, next_hist, /*skip_energy=*/true);
+    c->dir_pending[parity] = c->defer_dir && c->dir_deferred_mask != 0;
+    c->dir_mask[parity] = c->dir_deferred_mask;
+    c->kc_gate[parity] = dec_word(c, parity, n_st);
+    c->defer_dir = false;
+    c->cur_gate = nullptr;
+    c->cur_check_ran = false;
+    swap_mailbox(c, c->grad_mb[parity]);
+    if (cg) {
+      std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
+      std::swap(c->buf[MS_BUF_D], c->buf[MS_BUF_PD]);
+    }
+    std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
+    c->factors_valid = s_factors;
+    c->dir_implicit = s_implicit;
+    c->pd_neg_pg = s_pdneg;
+    c->last_g = s_last_g;
+    c->grad_valid = s_grad_valid;
+    c->carry_valid = s_carry;
+    c->maxg2_valid = s_maxg2;
+    if (rc) return rc;
+  }
+  return MS_OK;
+}
+
+// the direction fold of round `parity`'s gradient pass was left out and nobody merged it: launch it on its own
+int flush_dir_fold(ms_ctx* c, int parity) {
+  if (!c->dir_pending[parity]) return MS_OK;
+  c->dir_pending[parity] = false;
+  swap_mailbox(c, c->grad_mb[parity]);
+  c->cur_gate = c->kc_gate[parity];
+  c->cur_gate_want = DEC_ACCEPT_MAIN;
+  c->cur_check_ran = true;
+  const int rc = reduce_slots(c, c->dir_mask[parity]);
+  c->cur_gate = nullptr;
+  c->cur_check_ran = false;
+  swap_mailbox(c, c->grad_mb[parity]);
+  return rc;
+}
+
+// nobody will take the results of the round queued ahead.  ran 0: none of its kernels ran; 1: its first energy launch
+// ran and everything behind it stayed out (the fold said DEC_STOP): the bending factors, the trial positions and the
+// device scalars are that launch's now, the host's scalars and G still describe x; 2: any of it may have run (the
+// gradient pass behind an acceptance writes the CG history buffers)
+void drop_ahead(ms_ctx* c, int ran) {
+  if (!c->ahead.valid) return;
+  const int p = c->ahead.parity;
+  forget(c->first_mb[p]);
+  forget(c->grad_mb[p]);
+  for (auto& m : c->spec[p]) forget(m);
+  for (auto& sd : c->side) forget(sd.mb[p]);
+  c->dir_pending[p] = false;
+  c->ahead.valid = false;
+  ++c->q_dropped;
+  if (ran >= 1) c->factors_valid = false;
+  if (ran >= 2) {
+    c->carry_valid = c->grad_valid = c->maxg2_valid = false;
+    c->kc_pending = false;
+    c->cg_have_history = false;
+    c->cg_iter_count = 0;
+    c->pd_neg_pg = false;
+  }
+}
+
+// The step has accepted a trial and the gradient pass of the new x is running (queued with the round, gated on the
+// acceptance).  Queue the first round of the NEXT search behind it now: what the host does not know yet -- <g,d> of
+// the new gradient, whether the iteration converges, whether the trials need the normal-rotation guard -- the
+// direction fold of that pass decides from its own scalars (FoldArgs::go_out) with the parameters handed to it here.
+//   kind 1: the pass computes a direction with CG history; in the steady state of the headline workload that is no
+//           descent direction, the step fails without a trial, the stepper is reset and the step after it searches
+//           along d = -g with the same step size: that search's first round is queued;
+//   kind 2: the pass computes d = -g itself (gradient descent, CG restart steps): the next step's own first round.
+int queue_ahead(ms_ctx* c, const ms_stepper_params* sp, const ms_step_result* out, double tol, bool carry_mode,
+                bool cg, int restart, double a_hi_old, double r_lo_old) {
+  (void)a_hi_old;
+  (void)r_lo_old;
+  if (!c->kc_pending || c->ahead.valid) return MS_OK;
+  const int src = c->kc_parity;
+  if (!c->dir_pending[src]) return MS_OK;  // (the pass was queued with its own direction fold)
+  // kind 1: CG history, and the last direction with history was no descent direction; 3: it was one -- the next step
+  // searches along the direction this pass writes; 2: the pass writes d = -g itself
+  const int kind = c->kc_use_history ? (c->last_hist_descent ? 3 : 1) : 2;
+  const double alpha0 = out->next_step;
+  const double me2 = c->h_scal[MS_S_MINEDGE2];
+  if (c->steps_left < (kind == 1 ? 2 : 1) || !(alpha0 >= 1e-8) || sp->edge_fraction > 0.0)
+    return flush_dir_fold(c, src);  // (the step it would belong to is not part of this call)
+  // line-search history as the consuming step will see it (accept() has just added this search)
+  double a_hi = 0.0, r_lo = INFINITY;
+  for (int k = 0; k < std::min(c->ls_n, (int)ms_ctx::LS_HIST); ++k) {
+    a_hi = std::max(a_hi, c->ls_acc[k]);
+    r_lo = std::min(r_lo, c->ls_rej[k]);
+  }
+  const int max_iter = sp->max_iter > 0 ? sp->max_iter : 10;
+  ms_ctx::Ahead& ah = c->ahead;
+  plan_round(c, sp, alpha0, max_iter, 0, a_hi, r_lo, c->ls_n >= 2, 0, ah.plan);
+  if (ah.plan.n0 + ah.plan.n_st > 8) return flush_dir_fold(c, src);  // (the fold forms eight right-hand sides)
+  ah.kind = kind;
+  ah.stepper = sp->stepper;
+  ah.implicit = kind == 1;
+  ah.alpha0 = alpha0;
+  ah.energy0 = out->energy;
+  ah.beta = sp->beta;
+  ah.c1 = sp->c;
+  ah.max_iter = max_iter;
+  ah.tol2p = tol * tol * (1.0 + 1e-9);
+  ah.lim = (c->til.nf > 0 && me2 > 0.0) ? (0.09 * me2 / (1.0 + 1e-9)) / (alpha0 * alpha0) : INFINITY;
+  ah.src = src;
+  ah.go = false;
+  ah.go_known = false;
+  // parameters for the direction fold that is about to run (tagged entries: ms_internal.h FoldArgs::go_par)
+  {
+    const double par[7] = {kind == 1 ? 1.0 : 2.0, ah.tol2p, ah.lim, ah.energy0, sp->c, alpha0, sp->beta};
+    unsigned long long* box = c->h_go_par[src];
+    const unsigned long long t = c->ticket + 1;  // the first fold queued from here on: the round's first launch's
+    for (int k = 0; k < 7; ++k) {
+      unsigned long long b;
+      memcpy(&b, &par[k], sizeof(b));
+      __atomic_store_n(box + 2 * k, b, __ATOMIC_RELAXED);
+      __atomic_store_n(box + 2 * k + 1, b ^ t, __ATOMIC_RELEASE);
+    }
+  }
+  // the round itself, in the state the consuming step will be in
+  const bool s_hist = c->cg_have_history, s_implicit = c->dir_implicit, s_pdneg = c->pd_neg_pg;
+  const int s_iter = c->cg_iter_count;
+  double* const s_last_g = c->last_g;
+  const bool s_kcp = c->kc_pending;
+  const int s_kcpar = c->kc_parity;
+  // (queueing a trial pass marks the carried state as gone; for a round that belongs to a later step it is not)
+  const bool s_carry = c->carry_valid, s_grad = c->grad_valid, s_maxg2 = c->maxg2_valid, s_fac = c->factors_valid,
+             s_bt = c->bt_valid;
+  if (kind == 1) {  // (after the failed step: ms_reset_stepper, then the steepest-descent restart reads G with -alpha)
+    c->cg_have_history = false;
+    c->cg_iter_count = 0;
+    c->pd_neg_pg = false;
+    c->dir_implicit = true;
+  } else {
+    c->dir_implicit = false;
+  }
+  const int parity = c->next_parity;
+  c->next_parity ^= 1;
+  ah.parity = parity;
+  // (host-side right-hand sides are not known yet: the device forms them; the consuming step replays them)
+  int rc = queue_round(c, sp, ah.plan, parity, 0.0, 0.0, /*merged=*/true, src, carry_mode, cg, restart);
+  c->cg_have_history = s_hist;
+  c->cg_iter_count = s_iter;
+  c->dir_implicit = s_implicit;
+  c->pd_neg_pg = s_pdneg;
+  c->last_g = s_last_g;
+  c->kc_pending = s_kcp;
+  c->kc_parity = s_kcpar;
+  c->carry_valid = s_carry;
+  c->grad_valid = s_grad;
+  c->maxg2_valid = s_maxg2;
+  c->factors_valid = s_fac;
+  c->bt_valid = s_bt;
+  if (rc) return rc;
+  ah.valid = true;
+  ++c->q_ahead;
+  return MS_OK;
 }
 }  // namespace
 
@@ -2194,7 +2564,15 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   const int n_tf = active_fields(c, c->params.modules, tfl);
   // reuse_energy0 == 2: an accepted trial doubles as the next step's energy/factor pass
   const bool carry_mode = sp->reuse_energy0 >= 2 && !tilt;
-  const bool carried = carry_mode && c->carry_valid &&
+  if (c->ahead.valid && !c->ahead.go_known && !(c->kc_pending && carry_mode && c->carry_valid)) {
+    // a round was queued ahead, and this step will not read the direction fold that decides about it (something
+    // touched the context in between): whatever it did, none of it is used
+    drop_ahead(c, /*ran=*/2);
+  }
+  // the mailbox energies (and G, when grad_valid) describe x ...
+  const bool carried_x = carry_mode && c->carry_valid;
+  // ... and so do the bending factors in fK / fA (what a gradient pass at x needs)
+  const bool carried = carried_x &&
                        (c->factors_valid || !(c->params.modules & (MS_MOD_BENDING | MS_MOD_BENDING_TILT)));
   // the direction cannot ride in the gradient kernel's epilogue when a constraint row has to be projected out first
   // (lambda needs a global reduction) or when a tilt module adds its shape gradient behind K_C
@@ -2202,7 +2580,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   const bool constraint = (c->params.modules & (MS_CON_VOLUME | MS_TILT_SHAPE_MODS)) != 0;
   int rc;
   bool restart_sd = false;
-  if (carried && c->grad_valid && !constraint && c->til.T <= 256) {
+  if (carried_x && c->grad_valid && !constraint && c->til.T <= 256) {
     // x has not moved since the last gradient pass (failed search, stepper reset): only the
     // direction changes.  k_direction on the finalized g repeats the fused epilogue's
     // arithmetic and reduction order exactly.
@@ -2219,14 +2597,42 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     } else {
       rc = phase_direction(c, sp->stepper, use_history, /*g_finalized=*/true);
     }
-  } else if (c->kc_pending && carried && !(c->params.modules & MS_TILT_SHAPE_MODS) && c->kc_stepper == sp->stepper &&
+  } else if (c->kc_pending && carried_x && !(c->params.modules & MS_TILT_SHAPE_MODS) && c->kc_stepper == sp->stepper &&
              c->kc_use_history == use_history) {
     // the gradient + direction pass of this x was queued behind the line search that accepted it (gated on the
     // acceptance) and has run: take its scalars from its mailbox
     c->kc_pending = false;
     double vals[MS_NSCAL];
-    rc = wait_mailbox(c, c->grad_mb.h_seq, c->grad_mb.expected, vals, nullptr);
-    if (rc) return rc;
+    if (c->ahead.valid && !c->ahead.go_known && c->ahead.src == c->kc_parity) {
+      // The direction scalars of this pass arrive with the first fold of the round that was queued behind it (its
+      // energy launch did not wait for them).  That fold decided first whether the round's search happens at all:
+      // replay that from the scalars it was taken on (comparisons only -- the host's outcome is the device's, or
+      // the queue is broken).
+      ms_ctx::Ahead& ah = c->ahead;
+      uint32_t code = DEC_NONE;
+      rc = wait_mailbox(c, c->first_mb[ah.parity].h_seq, c->first_mb[ah.parity].expected, vals, &code);
+      if (rc) return rc;
+      ah.go_known = true;
+      if (code == DEC_STOP_LATE) {
+        ah.go = false;  // (the parameters reached the device too late)
+      } else {
+        const double gn2 = vals[MS_S_GNORM2], gdd = vals[MS_S_GDOTD];
+        const bool kind_ok = ah.kind == 1 ? gdd >= 0.0 : gdd < 0.0;
+        const bool go = kind_ok && gn2 > ah.tol2p && (ah.kind == 1 ? vals[MS_S_MAXG2] : vals[MS_S_MAXD2]) < ah.lim;
+        if (go != (code != DEC_STOP)) {
+          rc = verify_decision(c, go ? DEC_GO : DEC_STOP, code, "the fold that opens a round queued ahead");
+          if (rc) return rc;
+        }
+        ah.go = go;
+      }
+      // its energy launch has run in any case: without the search, the factors and the trial positions are scrap
+      if (!ah.go) drop_ahead(c, /*ran=*/1);
+    } else {
+      rc = flush_dir_fold(c, c->kc_parity);  // (nobody merged the direction fold: launch it now)
+      if (rc) return rc;
+      rc = wait_mailbox(c, c->grad_mb[c->kc_parity].h_seq, c->grad_mb[c->kc_parity].expected, vals, nullptr);
+      if (rc) return rc;
+    }
     for (int sl = 0; sl < MS_NSCAL; ++sl)
       if (MASK_DIR & (1u << sl)) put_mailbox(c, sl, vals[sl]);
     c->last_g = c->buf[MS_BUF_G];
@@ -2257,6 +2663,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   out->volume = c->h_scal[MS_S_VOL];
   out->next_step = step_size;
   out->energy = E_eval;
+  if (use_history) c->last_hist_descent = g_dot_d < 0.0;  // (what queue_ahead expects of the next direction with history)
   if (grad_norm < tol) {  // minimizer.py:1324
     out->converged = 1;
     out->success = 1;
@@ -2335,11 +2742,31 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   // accepted point follows in the same queue, gated on the acceptance (with a constraint row: K_C, the fold of
   // <g,gC> / <gC,gC>, the direction kernel and its fold, all four behind the same decision word).
   const bool can_chain = c->speculate && carry_mode && !tilt && !(c->params.modules & MS_MOD_VOLUME_PENALTY);
+  // a round queued by the step before (while its gradient pass was running): the round of THIS search's first
+  // iteration if it was queued for exactly what this step has computed by itself
+  bool adopted = false;
+  if (c->ahead.valid) {
+    const ms_ctx::Ahead& ah = c->ahead;
+    const bool same = ah.go && can_chain && ah.stepper == sp->stepper && ah.implicit == c->dir_implicit &&
+                      ah.alpha0 == alpha && ah.energy0 == energy0 && ah.beta == sp->beta && ah.c1 == sp->c &&
+                      ah.max_iter == max_iter && alpha * max_dir < safe_step_limit;
+    if (same) {
+      adopted = true;
+    } else {
+      // its kernels ran for a search that is not this one: the factors, trial positions and device scalars of x are
+      // theirs now -- once more from x, without it
+      drop_ahead(c, /*ran=*/2);
+      return ms_step(c, sp, step_size, tol, out);
+    }
+  }
   int it = 0;
+  bool unchained_ran = false;  // a trial went through the context's own mailbox (its scalars replaced x's there)
+  const bool s_maxg2_x = c->maxg2_valid;
   while (it < max_iter) {
     const bool safe_small = alpha * max_dir < safe_step_limit;
     kc_queued = false;  // (a gradient pass queued behind an earlier, fully rejected round found its gate closed)
     if (!(can_chain && safe_small)) {
+      unchained_ran = true;
       rc = phase_energy(c, c->params.modules, true, alpha, true, !safe_small, carry_mode);
       if (rc) return rc;
       rc = fetch(c);
@@ -2370,144 +2797,43 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     }
     rc = spec_prepare(c);
     if (rc) return rc;
-    // ---- plan the round: n0 trials in one ungated launch, n_st single-trial stages gated behind it -------------
-    // (prediction only: the same alphas are tested in the same order whatever is chosen here)
-    const int room = max_iter - it;
-    const bool multi_ok = c->pair_enable && c->side[0].partials != nullptr && (c->params.modules & MS_MOD_BENDING) != 0;
-    const int n0_cap = !multi_ok ? 1 : (c->pair_lean_enable ? MS_MAX_TRIALS : (c->fK3 ? 3 : 2));
-    double alphas[MS_MAX_TRIALS + ms_ctx::SPEC_STAGES];
-    int n_alpha = 1;  // alphas of the ladder from here that are still >= 1e-8
-    alphas[0] = alpha;
-    while (n_alpha < room && n_alpha < MS_MAX_TRIALS + ms_ctx::SPEC_STAGES && alphas[n_alpha - 1] * sp->beta >= 1e-8) {
-      alphas[n_alpha] = alphas[n_alpha - 1] * sp->beta;
-      ++n_alpha;
-    }
-    int n0 = 1, n_st = 0;
-    // A search that has rejected `escalate_after` alphas already will most likely reject more: from there on a round
-    // evaluates as many trials as the search has rejected so far in ONE launch (the early ones of a launch cost an
-    // energy-only evaluation each), whatever the history of the earlier searches says.
-    const int rejected_here = out->trials + out->guard_rejects;
-    const int force = c->pair_force;
-    if (!force && c->escalate && multi_ok && rejected_here >= c->escalate_after) {
-      n0 = std::max(1, std::min(std::min(n_alpha, n0_cap), rejected_here));
+    RoundPlan plan;
+    int parity;
+    if (adopted) {
+      plan = c->ahead.plan;
+      parity = c->ahead.parity;
+      c->ahead.valid = false;
+      adopted = false;
+      kc_queued = true;  // (queue_round queued it with the round)
+      c->kc_stepper = sp->stepper;
+      c->kc_use_history = cg && ((c->cg_iter_count + 1) % restart != 0);
+      ++c->q_adopted;
     } else {
-      const bool can_spec = force || (ls_warm ? r_lo < INFINITY : c->pred_trials > 1);
-      int depth = 1;
-      if (can_spec) {
-        // how many trials to queue: as many as the last search needed (cold), or -- once there is a history --
-        // one per alpha that still lies above (most of) the range where alphas were accepted lately
-        const int room4 = std::min(1 + ms_ctx::SPEC_STAGES, n_alpha);
-        const int want = force ? std::min(std::min(force, 3), room4)
-                               : (ls_warm ? room4 : std::min(c->pred_trials - out->trials, room4));
-        while (depth < want) {
-          if (!force && ls_warm && !(alphas[depth - 1] > 0.9 * a_hi)) break;
-          ++depth;
-        }
-      }
-      // two or more trials expected: the first two share one launch (and the ladder stops there for this round)
-      // ... and only when the first one is expected to fail: it lies above every alpha accepted lately, and alphas
-      // were rejected lately (a wasted evaluation costs more than a saved round trip gains)
-      const bool pair = depth > 1 && multi_ok && (force || (ls_warm && alpha > 1.05 * a_hi && r_lo < INFINITY));
-      if (pair) {
-        depth = std::min(depth, 3);
-        // triple launch: trial 1 is expected to fail as well -- its alpha is not below one that was rejected lately
-        const bool triple = depth == 3 && n0_cap >= 3 && (force ? force == 4 : alphas[1] > r_lo);
-        // otherwise the pair, and one gated trial behind it when trial 1 is as sure to fail as trial 0 (an empty gated
-        // stage costs about what the host round trip it saves does, so "probably" is not enough)
-        if (depth == 3 && !triple && !force && !(alphas[1] > a_hi)) depth = 2;
-        n0 = triple ? 3 : 2;
-        n_st = depth - n0;
-      } else {
-        n0 = 1;
-        n_st = depth - 1;
-      }
-    }
-    const int n_round = n0 + n_st;
-    double rhs[MS_MAX_TRIALS + ms_ctx::SPEC_STAGES];
-    for (int j = 0; j < n_round; ++j) rhs[j] = energy0 + sp->c * alphas[j] * g_dot_d;
-    // ---- queue it ----------------------------------------------------------------------------------------------
-    // first launch: trials 0 .. n0-1, the early ones into the side sets, the last one into the ordinary outputs;
-    // its fold decides all of them and writes decision record 0
-    {
-      c->pair_on = n0 > 1 ? n0 : 0;
-      c->pair_lean = n0 > 1 && c->pair_lean_enable;
-      for (int j = 0; j + 1 < n0; ++j) c->pair_alpha[j] = alphas[j];
-      c->cur_gate = nullptr;
-      c->cur_dec = dec_word(c, 0);
-      for (int j = 0; j < n0; ++j) c->cur_rhs[j] = rhs[j];
-      rc = phase_energy(c, c->params.modules, true, alphas[n0 - 1], true, false, carry_mode);
-      c->pair_on = 0;
-      c->pair_lean = false;
-      c->cur_dec = nullptr;
-      if (rc) return rc;
-    }
-    // gated stages: stage s runs iff record s-1 says DEC_CONTINUE
-    for (int s2 = 1; s2 <= n_st; ++s2) {
-      swap_mailbox(c, c->spec[s2 - 1]);
-      c->cur_gate = dec_word(c, s2 - 1);
-      c->cur_gate_want = DEC_CONTINUE;
-      c->cur_check_ran = true;
-      c->cur_dec = dec_word(c, s2);
-      c->cur_rhs[0] = rhs[n0 + s2 - 1];
-      rc = phase_energy(c, c->params.modules, true, alphas[n0 + s2 - 1], true, false, carry_mode);
-      c->cur_gate = nullptr;
-      c->cur_check_ran = false;
-      c->cur_dec = nullptr;
-      swap_mailbox(c, c->spec[s2 - 1]);
-      if (rc) return rc;
-    }
-    {
-      // the next step's gradient pass in the state an acceptance produces (x <-> xt, CG history swapped, factors of
-      // the accepted trial), gated on "the accepted trial is the one in the ordinary buffers"; every change of the
-      // context is undone afterwards
-      const bool next_hist = cg && ((c->cg_iter_count + 1) % restart != 0);
-      const bool s_factors = c->factors_valid, s_implicit = c->dir_implicit, s_pdneg = c->pd_neg_pg;
-      const bool s_grad_valid = c->grad_valid, s_carry = c->carry_valid, s_maxg2 = c->maxg2_valid;
-      double* const s_last_g = c->last_g;
-      std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
-      if (cg) {
-        std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
-        std::swap(c->buf[MS_BUF_D], c->buf[MS_BUF_PD]);
-        c->pd_neg_pg = c->dir_implicit;
-      }
-      c->factors_valid = true;
-      swap_mailbox(c, c->grad_mb);
-      c->cur_gate = dec_word(c, n_st);
-      c->cur_gate_want = DEC_ACCEPT_MAIN;
-      c->cur_check_ran = true;
-      rc = queue_energy_and_gradient(c, sp->stepper, next_hist, /*skip_energy=*/true);
-      c->cur_gate = nullptr;
-      c->cur_check_ran = false;
-      swap_mailbox(c, c->grad_mb);
-      if (cg) {
-        std::swap(c->buf[MS_BUF_G], c->buf[MS_BUF_PG]);
-        std::swap(c->buf[MS_BUF_D], c->buf[MS_BUF_PD]);
-      }
-      std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
-      c->factors_valid = s_factors;
-      c->dir_implicit = s_implicit;
-      c->pd_neg_pg = s_pdneg;
-      c->last_g = s_last_g;
-      c->grad_valid = s_grad_valid;
-      c->carry_valid = s_carry;
-      c->maxg2_valid = s_maxg2;
+      plan_round(c, sp, alpha, max_iter - it, out->trials + out->guard_rejects, a_hi, r_lo, ls_warm, out->trials, plan);
+      parity = c->next_parity;
+      c->next_parity ^= 1;
+      rc = queue_round(c, sp, plan, parity, energy0, g_dot_d, /*merged=*/false, 0, carry_mode, cg, restart);
       if (rc) return rc;
       kc_queued = true;
       c->kc_stepper = sp->stepper;
-      c->kc_use_history = next_hist;
+      c->kc_use_history = cg && ((c->cg_iter_count + 1) % restart != 0);
     }
+    c->kc_parity = parity;
+    const int n0 = plan.n0, n_st = plan.n_st, n_round = n0 + n_st;
+    const double* const alphas = plan.alphas;
+    double rhs[MS_MAX_TRIALS + ms_ctx::SPEC_STAGES];
+    for (int j = 0; j < n_round; ++j) rhs[j] = energy0 + sp->c * alphas[j] * g_dot_d;
     ++c->q_rounds;
     // ---- take the results in order, replaying the device's decisions from the same doubles --------------------
-    // first launch: every set was folded by ONE k_reduce, so they land together
+    // first launch: every set was folded by ONE k_reduce launch, so they land together
     double v[MS_MAX_TRIALS][MS_NSCAL];
     uint32_t dev_code = DEC_NONE;
     for (int j = 0; j + 1 < n0; ++j) {
-      rc = wait_mailbox(c, c->side[j].mb.h_seq, c->side[j].mb.expected, v[j], nullptr);
+      rc = wait_mailbox(c, c->side[j].mb[parity].h_seq, c->side[j].mb[parity].expected, v[j], nullptr);
       if (rc) return rc;
     }
-    rc = fetch(c, &dev_code);
+    rc = wait_mailbox(c, c->first_mb[parity].h_seq, c->first_mb[parity].expected, v[n0 - 1], &dev_code);
     if (rc) return rc;
-    memcpy(v[n0 - 1], c->h_scal, sizeof(v[0]));
     int acc = -1;
     double E_acc = 0.0;
     for (int j = 0; j < n0 && acc < 0; ++j) {
@@ -2529,12 +2855,13 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       c->q_wasted += acc < 0 ? 0 : n0 - 1 - acc;
     }
     if (acc >= 0)
-      for (int s2 = 0; s2 < n_st; ++s2) forget(c->spec[s2]);  // (the gated stages stay out)
+      for (int s2 = 0; s2 < n_st; ++s2) forget(c->spec[parity][s2]);  // (the gated stages stay out)
     if (acc >= 0 && acc < n0 - 1) {
       // the unexpected case: an early trial was accepted.  The gradient pass queued behind stays out (DEC_ACCEPT_SIDE).
       ++c->q_side_accepts;
       kc_queued = false;
-      forget(c->grad_mb);
+      forget(c->grad_mb[parity]);
+      c->dir_pending[parity] = false;
       if (c->pair_lean_enable) {
         // it was evaluated for its energies only -- evaluate it again, alone and with every output.  With fixed-order
         // sums the energies come out bit for bit as before; with LDS atomics in their last bits, like any
@@ -2553,13 +2880,19 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
         HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FK], sk, sizeof(double) * 3 * nvp, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FA], sa, sizeof(double) * 2 * nvp, hipMemcpyDeviceToDevice, c->stream));
         for (int sl = 0; sl < MS_NSCAL; ++sl)
-          if (MASK_ENERGY & (1u << sl)) put_mailbox(c, sl, v[acc][sl]);
+          if (energy_mask(c->params.modules) & (1u << sl)) put_mailbox(c, sl, v[acc][sl]);
       }
       accept(alphas[acc], E_acc);
       return MS_OK;
     }
     if (acc == n0 - 1) {
+      for (int sl = 0; sl < MS_NSCAL; ++sl)
+        if (energy_mask(c->params.modules) & (1u << sl)) put_mailbox(c, sl, v[acc][sl]);
       accept(alphas[acc], E_acc);
+      if (c->ahead_allowed) {
+        rc = queue_ahead(c, sp, out, tol, carry_mode, cg, restart, a_hi, r_lo);
+        if (rc) return rc;
+      }
       return MS_OK;
     }
     // gated stages, in order
@@ -2567,26 +2900,33 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     for (int s2 = 1; s2 <= n_st && !accepted; ++s2) {
       double vals[MS_NSCAL];
       uint32_t code = DEC_NONE;
-      rc = wait_mailbox(c, c->spec[s2 - 1].h_seq, c->spec[s2 - 1].expected, vals, &code);
+      rc = wait_mailbox(c, c->spec[parity][s2 - 1].h_seq, c->spec[parity][s2 - 1].expected, vals, &code);
       if (rc) return rc;
-      for (int sl = 0; sl < MS_NSCAL; ++sl)
-        if (MASK_ENERGY & (1u << sl)) put_mailbox(c, sl, vals[sl]);
       ++out->trials;
-      energies_from_mailbox(c, e);
-      const double E_t = e[0] + e[1] + e[2] + e[3];
+      const double E_t = ((c->params.modules & MS_MOD_SURFACE) ? vals[MS_S_ESURF] : 0.0) +
+                         ((c->params.modules & MS_MOD_BENDING) ? vals[MS_S_EBEND] : 0.0);
       const bool ok = E_t <= rhs[n0 + s2 - 1];
       rc = verify_decision(c, ok ? DEC_ACCEPT_MAIN : DEC_CONTINUE, code, "a gated stage");
       if (rc) return rc;
       if (ok) {  // the device took the same decision from the same doubles: later stages stay out
-        for (int s3 = s2; s3 < n_st; ++s3) forget(c->spec[s3]);
+        for (int s3 = s2; s3 < n_st; ++s3) forget(c->spec[parity][s3]);
+        for (int sl = 0; sl < MS_NSCAL; ++sl)
+          if (energy_mask(c->params.modules) & (1u << sl)) put_mailbox(c, sl, vals[sl]);
         accept(alphas[n0 + s2 - 1], E_t);
         accepted = true;
       } else {
         min_rejected = alphas[n0 + s2 - 1];
       }
     }
-    if (accepted) return MS_OK;
-    forget(c->grad_mb);  // every trial of the round was rejected: the gradient pass behind it stayed out
+    if (accepted) {
+      if (c->ahead_allowed) {
+        rc = queue_ahead(c, sp, out, tol, carry_mode, cg, restart, a_hi, r_lo);
+        if (rc) return rc;
+      }
+      return MS_OK;
+    }
+    forget(c->grad_mb[parity]);  // every trial of the round was rejected: the gradient pass behind it stayed out
+    c->dir_pending[parity] = false;
     it += n_round;
     alpha = alphas[n_round - 1] * sp->beta;
     if (alpha < 1e-8) break;
@@ -2594,6 +2934,14 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   const double reduced = std::max(alpha * sp->beta, 0.0);  // :425-426
   out->next_step = std::max(reduced, step_size * sp->beta);
   if (c->ls_reset) c->ls_n = 0;  // a search that ran out of trials: same
+  if (carry_mode && !unchained_ran) {
+    // every trial was rejected and x has not moved: G and the host's scalars still describe x (the queued rounds post
+    // to mailboxes of their own); only the bending factors in fK / fA and the device scalars are the last trial's
+    c->carry_valid = true;
+    c->grad_valid = !constraint;
+    c->maxg2_valid = s_maxg2_x;
+    c->factors_valid = false;
+  }
   return MS_OK;
 }
 
@@ -2665,8 +3013,13 @@ int ms_minimize(ms_ctx* c, const ms_minimize_params* mp, int n_steps, ms_minimiz
     }
     const double step_in = mp->fixed_step_mode ? mp->fixed_step : step_size;
     ms_step_result r;
+    // rounds may be queued ahead of the step they belong to while this loop is the only thing touching the context
+    c->steps_left = n_steps - 1 - i;
+    c->ahead_allowed = c->ahead_enable && i + 1 < n_steps && !mp->relax_tilts && !mp->fixed_step_mode &&
+                       c->shard_count == 1 && !c->comm && !c->allgather_cb;
     rc = (c->shard_count > 1 || c->comm || c->allgather_cb) ? ms_shard_step(c, &mp->stepper, step_in, mp->tol, &r)
                                                             : ms_step(c, &mp->stepper, step_in, mp->tol, &r);
+    c->ahead_allowed = false;
     if (rc) return rc;
     out->iterations = i + 1;
     out->energy_eval = r.energy_eval;
@@ -2686,6 +3039,7 @@ int ms_minimize(ms_ctx* c, const ms_minimize_params* mp, int n_steps, ms_minimiz
       out->converged = 1;
       out->step_success = 1;
       out->step_size = step_size;
+      drop_ahead(c, /*ran=*/2);
       return MS_OK;
     }
     out->step_success = r.success;
@@ -2703,6 +3057,7 @@ int ms_minimize(ms_ctx* c, const ms_minimize_params* mp, int n_steps, ms_minimiz
       if (step_size <= mp->step_size_floor) {
         if (++zero_steps >= mp->max_zero_steps) {
           out->zero_step_exit = 1;
+          drop_ahead(c, /*ran=*/2);
           return MS_OK;
         }
       } else {
@@ -2717,6 +3072,7 @@ int ms_minimize(ms_ctx* c, const ms_minimize_params* mp, int n_steps, ms_minimiz
         if (std::fabs(r.volume - mp->target_volume) / denom > mp->volume_tolerance) {
           if (mp->project_on_drift) {
             int iters = 0;
+            drop_ahead(c, /*ran=*/2);  // (the projection moves x: a round queued for the next step is void)
             rc = ms_project_volume_cached(c, mp->target_volume, 1e-12, 12, 1, &iters, nullptr);
             if (rc) return rc;
             out->volume_cache_current = 0;  // enforce_constraints_after_mesh_ops bumps the mesh version
@@ -2731,6 +3087,7 @@ int ms_minimize(ms_ctx* c, const ms_minimize_params* mp, int n_steps, ms_minimiz
       }
     }
   }
+  drop_ahead(c, /*ran=*/2);
   return MS_OK;
 }
 
@@ -3346,6 +3703,9 @@ int ms_queue_stats(ms_ctx* c, int64_t stats[8]) {
   stats[2] = c->q_wasted;
   stats[3] = c->q_side_accepts;
   stats[4] = c->queue_mismatches;
+  stats[5] = c->q_ahead;
+  stats[6] = c->q_adopted;
+  stats[7] = c->q_dropped;
   return MS_OK;
 }
 

@@ -5,12 +5,24 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
 #include "membrane_hip.h"
 
 namespace ms {
+
+// Switches of finished experiments (MS_NO_FAST, MS_TILE_ORDER, MS_FACET_ORDER, MS_KA_LDS_MIN) exist only in variant
+// builds (tools/build_variant.sh passes -DMS_VARIANT_ENV): the shipped library does not read them.
+inline const char* variant_env(const char* name) {
+#ifdef MS_VARIANT_ENV
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 // One tile-facet instance: local vertex slots inside the tile's LDS patch
 // ([0,n_owned) owned, then halo) + flags.
@@ -35,14 +47,15 @@ constexpr int MS_P_RAN = MS_NSCAL;      // partial row: 1.0 from every workgroup
 constexpr int MS_NPART = MS_NSCAL + 1;  // rows of a partials array
 constexpr int MS_MB_DEC = MS_NSCAL;     // mailbox entry of the fold's decision code
 constexpr int MS_MB_WORDS = MS_NSCAL + 1;  // {value, sequence} entries of a mailbox
-constexpr int MS_DEC_STRIDE = 32;       // uint32 words between two decision records (one 128-byte line each)
+constexpr int MS_DEC_STRIDE = 64;       // uint32 words between two decision records (256 bytes: a GO record carries 8 right-hand sides and 8 handed-over parameters)
 enum : uint32_t {
   DEC_NONE = 0,         // never written
   DEC_CONTINUE = 1,     // every trial so far was rejected: the next stage of the ladder runs
   DEC_ACCEPT_MAIN = 2,  // accepted, and the accepted trial's outputs are the ordinary ones (xt, fK, fA): the gradient pass runs
   DEC_ACCEPT_SIDE = 3,  // an EARLY trial of a multi-trial launch was accepted (energy-only evaluation): nothing queued runs
-  DEC_GO = 4,           // direction fold: the search the host queued behind it may run (Phase: next search)
-  DEC_STOP = 5,         // direction fold: it may not (converged, non-descent, guard range, ...)
+  DEC_GO = 4,           // direction fold: the round the host queued behind the gradient pass may run
+  DEC_STOP = 5,         // direction fold: it may not (converged, the other kind of direction, guard range)
+  DEC_STOP_LATE = 6,    // ... it may not because the host's parameters were not there when the fold ran
   DEC_ERR_RAN = 0x100   // flag: a gated launch ran on some of its workgroups only
 };
 
@@ -281,6 +294,21 @@ struct FoldArgs {
   uint32_t* counter;      // arrival counter of the stage's energy workgroups (zero between launches)
   uint32_t e_mask;        // slots whose sum is a trial's energy (ESURF | EBEND as the module set has them)
   double rhs[MS_MAX_TRIALS];  // energy0 + c alpha_j <g,d>, trial order
+  // Armijo right-hand sides formed on the device (nullptr: the host's rhs[] above): rhs_dev[j], written by the direction
+  // fold that opened this round (go_out below)
+  const double* rhs_dev;
+  // A direction fold can open the NEXT round (ms_step queues it while the gradient pass runs): the workgroup of this
+  // fold that arrives last tests, from the direction scalars it reads back, whether the search the host expects will
+  // happen -- kind 1: the direction with history is no descent direction (<g,d> >= 0), so the stepper restarts with
+  // d = -g; kind 2: the direction just written is a descent direction -- is not converged (|g|^2 > go[1]) and stays in
+  // the unguarded range (max|d_i|^2 < go[2]), then writes DEC_GO and rhs_j = go[3] + go[4+j] <g,d> (the host's
+  // energy0 + (c alpha_j) <g,d>, alpha_j = alpha_{j-1} beta: the same roundings) to go_out, else DEC_STOP.  The
+  // parameters go[0..6] = {kind, tol^2 (1+1e-9), 0.09 min_edge^2 / ((1+1e-9) alpha_0^2), energy0, c, alpha_0, beta}
+  // arrive in pinned host memory AFTER this fold was queued (the host learns the accepted alpha later): entries
+  // {bits, bits XOR go_ticket}; a parameter that does not validate yet means DEC_STOP_LATE.
+  uint32_t* go_out;                 // {code, -, rhs[8], hand-over[8] as doubles from byte 8} or nullptr
+  const unsigned long long* go_par; // 7 tagged entries in pinned host memory
+  unsigned long long go_ticket;
   unsigned long long* host_err;  // pinned word: set non-zero when check_ran fails
   int side_full;          // fold every slot of the early trials' sets too (they have outputs of their own and can be
                           // accepted as they are); otherwise only their energy slots, by the head workgroup

@@ -924,8 +924,8 @@ hipError_t launch_energy(const EnergyArgs& a_in, bool guard, int cap, int max_en
   // tile instead of twelve and half the LDS traffic, at the price of a summation order that
   // varies from run to run (ms_set_deterministic).  Without bending there are no vertex sums.
   const bool atomic = a.atomic != 0 && bend;
-  // MS_KA_LDS_MIN=<bytes>: diagnostic -- request at least this much LDS per workgroup (caps the workgroups per CU)
-  static const size_t lds_min = getenv("MS_KA_LDS_MIN") ? (size_t)atol(getenv("MS_KA_LDS_MIN")) : 0;
+  // MS_KA_LDS_MIN=<bytes> (variant builds only): request at least this much LDS per workgroup (caps the workgroups per CU)
+  static const size_t lds_min = variant_env("MS_KA_LDS_MIN") ? (size_t)atol(variant_env("MS_KA_LDS_MIN")) : 0;
   const size_t lds = std::max(lds_min, energy_lds_bytes(a.m.T, cap, max_ent, bend, guard, a.m.has_boundary != 0, atomic));
   hipError_t e;
 #define MS_LAUNCH_E(B, G, TT, CC, AT)                                                              \
@@ -2663,6 +2663,26 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(FoldArgs a) {
       }
   }
   if (slot < 0) return;
+  // A direction fold that may open the next round needs the host's parameters (pinned host memory: every word is a
+  // PCIe read of ~0.2 us, and they do not overlap).  ONE lane of the launch -- thread 0 of the first slot's workgroup --
+  // requests them now, next to its partials, and hands them on in device memory before it counts in.
+  const bool par_reader = a.go_par != nullptr && a.go_out != nullptr && task == t_e && threadIdx.x == 0;
+  // merged: this launch folds the direction scalars of the gradient pass in front of the energy launch TOGETHER with
+  // that launch's energies (the energy launch did not wait for them: one fold and one kernel boundary per step less)
+  const bool merged = a.go_par != nullptr && a.dec_out != nullptr;
+  unsigned long long gp_b[7], gp_t[7];
+  if (par_reader) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      gp_b[k] = __hip_atomic_load(a.go_par + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      gp_t[k] = __hip_atomic_load(a.go_par + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  double rhs_d[MS_MAX_TRIALS];
+  if (a.rhs_dev != nullptr && a.dec_out != nullptr && task >= t_e && task < t_rest && threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < MS_MAX_TRIALS; ++j) rhs_d[j] = j < a.n_sets ? ld_agent(a.rhs_dev + j) : 0.0;
+  }
   double q[RU];
   fold_issue(q, a.set[set].partials, a.n_tiles, a.tile0, a.tile1, slot);
   const bool open = prev == a.gate_want;
@@ -2676,6 +2696,7 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(FoldArgs a) {
   }
   if (!open) {  // (task 0) an earlier stage has decided (or failed): later readers of THIS stage's word see the same
     if (a.dec_out != nullptr) st_agent(a.dec_out, prev);
+    if (a.go_out != nullptr) st_agent(a.go_out, DEC_STOP);  // (the gradient pass stayed out: nothing follows it)
     return;
   }
   if (slot == MS_P_RAN) return;
@@ -2684,14 +2705,96 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(FoldArgs a) {
 #if MS_GATE_PROBE
   if (set == a.n_sets - 1) g_shadow[slot] = r;
 #endif
-  if (a.dec_out == nullptr || task >= t_rest) return;
-  // an energy of a stage that is decided here: count in once the scalar store has completed
+  if (a.go_out != nullptr && a.dec_out == nullptr) {
+    // a direction fold that may open the next round: every slot's workgroup counts in, the last one decides
+    double* const hand = reinterpret_cast<double*>(a.go_out + 2) + 8;  // {valid, kind, tol2, lim, E0, c, alpha0, beta}
+    if (par_reader) {
+      bool have = true;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) have = have && ((gp_b[k] ^ gp_t[k]) == a.go_ticket);
+      st_agent(hand, have ? 1.0 : 0.0);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) st_agent(hand + 1 + k, __longlong_as_double((long long)gp_b[k]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t arrived = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (arrived != (uint32_t)(n_reg * n_rest + a.n_sets * n_e - 1)) return;
+    st_agent(a.counter, 0u);
+    double par[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) par[k] = ld_agent(hand + k);
+    double* const sc = a.set[a.n_sets - 1].scal;
+    const double gn2 = ld_agent(sc + MS_S_GNORM2), gdd = ld_agent(sc + MS_S_GDOTD);
+    const double md2 = ld_agent(sc + MS_S_MAXD2), mg2 = ld_agent(sc + MS_S_MAXG2);
+    uint32_t go = DEC_STOP_LATE;
+    if (par[0] == 1.0) {
+      const bool restart = par[1] == 1.0;
+      const double slope = restart ? -gn2 : gdd;  // <g,d> of the search that follows
+      const bool kind_ok = restart ? gdd >= 0.0 : gdd < 0.0;
+      go = (kind_ok && gn2 > par[2] && (restart ? mg2 : md2) < par[3]) ? DEC_GO : DEC_STOP;
+      if (go == DEC_GO) {
+        // rhs_j = energy0 + (c alpha_j) <g,d> with alpha_j = alpha_{j-1} beta: the host's expressions, rounding for
+        // rounding.  (Read by the NEXT kernels of the stream only: the kernel boundary orders them behind these stores.)
+        double* const rhs = reinterpret_cast<double*>(a.go_out + 2);
+        double al = par[6];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          st_agent(rhs + k, __dadd_rn(par[4], __dmul_rn(__dmul_rn(par[5], al), slope)));
+          al = __dmul_rn(al, par[7]);
+        }
+      }
+    }
+    st_agent(a.go_out, go);
+    if (a.set[a.n_sets - 1].host_box) post_entry(a.set[a.n_sets - 1].host_box, MS_MB_DEC, (unsigned long long)go, a.ticket);
+    return;
+  }
+  if (a.dec_out == nullptr || (!merged && task >= t_rest)) return;
+  // a stage that is decided here: its energies' workgroups (merged: every slot's) count in once their scalar store has
+  // completed; the one that comes last decides
+  double* const hand = merged ? reinterpret_cast<double*>(a.go_out + 2) + 8 : nullptr;
+  if (par_reader) {
+    bool have = true;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) have = have && ((gp_b[k] ^ gp_t[k]) == a.go_ticket);
+    st_agent(hand, have ? 1.0 : 0.0);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) st_agent(hand + 1 + k, __longlong_as_double((long long)gp_b[k]));
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const uint32_t arrived = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (arrived != (uint32_t)(a.n_sets * n_e - 1)) return;
+  if (arrived != (uint32_t)(a.n_sets * n_e + (merged ? n_reg * n_rest : 0) - 1)) return;
   st_agent(a.counter, 0u);  // (the next fold of the stream starts from zero)
   uint32_t code = DEC_CONTINUE;
-  for (int j = 0; j < a.n_sets; ++j) {
+  bool decide = true;
+  double m_e0 = 0.0, m_c = 0.0, m_al = 0.0, m_beta = 0.0, m_slope = 0.0;
+  if (merged) {
+    // first: does the search the host queued this launch for happen at all?  (FoldArgs::go_par: kind 1 -- the direction
+    // with history is no descent direction, the stepper restarts along -g; kind 2 -- the direction just written is one;
+    // not converged; unguarded range)
+    double par[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) par[k] = ld_agent(hand + k);
+    double* const sc = a.set[a.n_sets - 1].scal;
+    const double gn2 = ld_agent(sc + MS_S_GNORM2), gdd = ld_agent(sc + MS_S_GDOTD);
+    const double md2 = ld_agent(sc + MS_S_MAXD2), mg2 = ld_agent(sc + MS_S_MAXG2);
+    if (par[0] != 1.0) {
+      code = DEC_STOP_LATE;
+      decide = false;
+    } else {
+      const bool restart = par[1] == 1.0;
+      m_slope = restart ? -gn2 : gdd;  // <g,d> of the search
+      const bool kind_ok = restart ? gdd >= 0.0 : gdd < 0.0;
+      if (!(kind_ok && gn2 > par[2] && (restart ? mg2 : md2) < par[3])) {
+        code = DEC_STOP;
+        decide = false;
+      }
+      m_e0 = par[4];
+      m_c = par[5];
+      m_al = par[6];
+      m_beta = par[7];
+    }
+  }
+  for (int j = 0; j < a.n_sets && decide; ++j) {
     double E = 0.0;
     bool first = true;
     for (int s = 0; s < MS_NSCAL; ++s)
@@ -2700,9 +2803,27 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(FoldArgs a) {
         E = first ? v : E + v;
         first = false;
       }
-    if (E <= a.rhs[j]) {
+    double rhs = a.rhs[j];
+    if (merged) {
+      // energy0 + (c alpha_j) <g,d> with alpha_j = alpha_{j-1} beta: the host's expressions, rounding for rounding
+      rhs = __dadd_rn(m_e0, __dmul_rn(__dmul_rn(m_c, m_al), m_slope));
+      m_al = __dmul_rn(m_al, m_beta);
+    } else if (a.rhs_dev != nullptr) {
+#pragma unroll
+      for (int k = 0; k < MS_MAX_TRIALS; ++k)
+        if (k == j) rhs = rhs_d[k];
+    }
+    if (E <= rhs) {
       code = j == a.n_sets - 1 ? DEC_ACCEPT_MAIN : DEC_ACCEPT_SIDE;
       break;
+    }
+  }
+  if (merged && decide && a.go_out != nullptr) {
+    // the gated stages behind this launch test later alphas of the same ladder: leave them their right-hand sides
+    double* const rhs = reinterpret_cast<double*>(a.go_out + 2);
+    for (int k = 0; k < 8 - a.n_sets; ++k) {
+      st_agent(rhs + a.n_sets + k, __dadd_rn(m_e0, __dmul_rn(__dmul_rn(m_c, m_al), m_slope)));
+      m_al = __dmul_rn(m_al, m_beta);
     }
   }
   st_agent(a.dec_out, code);
@@ -2715,7 +2836,11 @@ hipError_t launch_reduce(const FoldArgs& a, hipStream_t s) {
   const int nb = (a.check_ran ? 1 : 0) + a.n_sets * __builtin_popcount(em) +
                  (a.side_full ? a.n_sets : 1) * __builtin_popcount(a.slot_mask & ~em);
   if (nb == 0) return hipSuccess;
-  if (a.dec_out != nullptr && (a.counter == nullptr || em == 0)) return hipErrorInvalidValue;
+  if ((a.dec_out != nullptr || a.go_out != nullptr) && a.counter == nullptr) return hipErrorInvalidValue;
+  if (a.dec_out != nullptr && em == 0) return hipErrorInvalidValue;
+  if (a.go_out != nullptr && a.go_par == nullptr) return hipErrorInvalidValue;
+  if (a.go_out != nullptr && a.dec_out == nullptr && a.n_sets != 1) return hipErrorInvalidValue;
+  if (a.go_par != nullptr && a.go_out == nullptr) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(RBLOCK), 0, s, a);
   return hipGetLastError();
 }

@@ -93,7 +93,7 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
   }
   out.perm.resize(nv);
   std::iota(out.perm.begin(), out.perm.end(), 0);
-  const int tile_order = getenv("MS_TILE_ORDER") ? atoi(getenv("MS_TILE_ORDER")) : 1;  // (A/B: 0 = Hilbert runs)
+  const int tile_order = variant_env("MS_TILE_ORDER") ? atoi(variant_env("MS_TILE_ORDER")) : 1;  // (variant builds: 0 = Hilbert runs)
   if (tile_order == 0) {
     std::stable_sort(out.perm.begin(), out.perm.end(),
                      [&](int32_t a, int32_t b) { return key[a] < key[b]; });
@@ -219,7 +219,7 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
   std::vector<int32_t> halo_tmp;
   std::vector<int32_t> vcnt(T + 1);
   // lane order inside a tile (MS_FACET_ORDER): 0 walk order, 1 stride permutation, 2 (default) bank-aware
-  const char* env_order = getenv("MS_FACET_ORDER");
+  const char* env_order = variant_env("MS_FACET_ORDER");  // (variant builds only)
   const int order_mode = env_order ? atoi(env_order) : 2;
   const char* env_stride = getenv("MS_FACET_STRIDE");
   const int stride_mode = env_stride ? atoi(env_stride) : 1;

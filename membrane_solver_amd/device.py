@@ -477,7 +477,8 @@ class DeviceMesh:
         v = np.zeros(8, dtype=np.int64)
         self._chk(L.lib().ms_queue_stats(self._h, v.ctypes.data_as(L._I64)), "ms_queue_stats")
         return {"rounds": int(v[0]), "multi_launches": int(v[1]), "wasted_evaluations": int(v[2]),
-                "side_accepts": int(v[3]), "mismatches": int(v[4])}
+                "side_accepts": int(v[3]), "mismatches": int(v[4]), "ahead": int(v[5]), "adopted": int(v[6]),
+                "dropped": int(v[7])}
 
     def shard_info(self):
         v = [ctypes.c_int64(0) for _ in range(4)]

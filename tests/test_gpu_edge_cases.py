@@ -147,36 +147,53 @@ def test_willmore_and_approx_on_open_noisy_mesh(L):
     dm.close()
 
 
-def test_tile_order_and_record_format_do_not_change_the_results(L, monkeypatch):
-    """The patch order (coordinate bisection / runs of the Hilbert order, MS_TILE_ORDER) and the instances that go with
-    the tile size (T = 256 with packed facet records and the lean gradient instance / runtime-size instances,
-    MS_NO_FAST) decide which workgroup sums what, never what is summed: energies and gradients agree to rounding."""
+def test_tile_size_and_instance_choice_do_not_change_the_results(L):
+    """The tile size decides which workgroup sums what and which kernel instances run (T = 256: packed facet records
+    and the lean gradient instance; 128 / 64: the runtime-size instances), never what is summed: energies agree to
+    1e-12 and gradients to a bound that is MEASURED here -- five times the larger of (a) the run-to-run difference of
+    the default LDS-atomic sums on one tiling and (b) the CPU oracle's own summation-order noise (serial against OpenMP
+    build of the same source).  The bending back-propagation amplifies last-bit differences of the vertex sums by
+    ~1/h^2, on the CPU exactly as on the GPU, which is what both measurements show."""
     from membrane_solver_amd import meshgen
     from membrane_solver_amd.device import DeviceMesh
+    from oracle import ms_oracle as orc
 
     P, T = meshgen.icosphere(40)  # 32 000 facets, 63 tiles of 256 vertices
     P = meshgen.smooth_displace(P, 0.08)
     nv, nf = len(P), len(T)
-    res = {}
-    for order, nofast in (("1", "0"), ("0", "0"), ("1", "1")):
-        monkeypatch.setenv("MS_TILE_ORDER", order)
-        monkeypatch.setenv("MS_NO_FAST", nofast)
-        dm = DeviceMesh(P, T)
+    kappa, c0 = np.ones(nv), np.full(nv, 0.15)
+    res, repeat = {}, 0.0
+    for tile in (256, 128, 64):
+        dm = DeviceMesh(P, T, tile_vertices=tile)
         dm.set_surface_tension(np.ones(nf))
-        dm.set_bending_params(np.ones(nv), np.full(nv, 0.15))
+        dm.set_bending_params(kappa, c0)
         dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING)
         e, g = dm.energy_and_gradient()
+        for _ in range(3):
+            _e2, g2 = dm.energy_and_gradient()
+            repeat = max(repeat, relerr(g2, g))
         r = dm.step(stepper=L.MS_STEPPER_CG, step_size=1e-5)
-        res[(order, nofast)] = (e.copy(), g.copy(), r.energy, r.trials, dm.tile_stats()["facet_instances"])
+        res[tile] = (e.copy(), g.copy(), r.energy, r.trials)
         dm.close()
-    e0, g0, E0, tr0, inst0 = res[("1", "0")]
-    for key, (e, g, E, tr, inst) in res.items():
+
+    def oracle(omp):
+        orc.use_openmp(omp)
+        try:
+            gr = np.zeros_like(P)
+            orc.surface_energy_and_gradient(P, T, np.ones(nf), gr)
+            orc.bending_energy_and_gradient(P, T, kappa, c0, np.zeros(nv, bool), grad=gr)
+        finally:
+            orc.use_openmp(False)
+        return gr
+
+    noise = relerr(oracle(True), oracle(False))
+    tol = 5.0 * max(repeat, noise)
+    assert 0.0 < tol < 1e-10, (repeat, noise)
+    e0, g0, E0, tr0 = res[256]
+    for key, (e, g, E, tr) in res.items():
         assert np.allclose(e, e0, rtol=1e-12, atol=0), key
-        # (the bending back-propagation amplifies last-bit differences of the vertex sums by ~1/h^2: 1e-11 at this size,
-        # run to run with the LDS-atomic sums as well as between tilings)
-        assert relerr(g, g0) < 5e-10, key
+        assert relerr(g, g0) < tol, (key, relerr(g, g0), repeat, noise)
         assert abs(E - E0) <= 1e-12 * abs(E0) and tr == tr0, key
-    assert res[("0", "0")][4] > inst0  # the Hilbert runs list more facet instances than the bisection tiles
 
 
 def test_high_valence_hub_takes_the_unpacked_record_path(L):

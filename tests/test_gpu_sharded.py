@@ -92,6 +92,17 @@ def test_shards_match_single_context(with_volume, world, level, freq, tile, driv
     flow inside the library (ms_shard_step) with the in-process all-gather plugged in where
     ncclAllGather goes.  pair "2": every search that can starts with a pair launch (trials 0 and 1 in one energy
     launch and ONE exchange; MS_PAIR) -- same trajectory, fewer exchanges."""
+    _run_shard_case(with_volume, world, level, freq, tile, driver, pair, monkeypatch)
+
+
+def test_config4_full_size_eight_shards(monkeypatch):
+    """BASELINE configs[3] at its own size: the 2 048 000-facet icosphere cut into 8 facet-block shards (8 contexts on
+    this one GPU, the library driver with the in-process all-gather where ncclAllGather goes), six CG steps with
+    fixed-order vertex sums, against the single-context run step for step."""
+    _run_shard_case(False, 8, 2, 320, 256, "library", "0", monkeypatch)
+
+
+def _run_shard_case(with_volume, world, level, freq, tile, driver, pair, monkeypatch):
     import torch
 
     from membrane_solver_amd import _lib as L
@@ -170,7 +181,7 @@ def test_shards_match_single_context(with_volume, world, level, freq, tile, driv
     for t in threads:
         t.start()
     for t in threads:
-        t.join(timeout=300)
+        t.join(timeout=600)
     assert not errors, errors[0]
     ref = np.array(ref_log)
     assert ref[:, 0].sum() >= 2

@@ -79,9 +79,10 @@ def test_tiling_invariants(tile):
     assert b"tile_vertices" in lib.ms_last_error(None)
 
 
-def test_bisection_tiles_list_fewer_facet_instances_than_hilbert_runs(monkeypatch):
-    """the default patch order (recursive coordinate bisection down to single tiles) gives
-    compacter tiles than runs of the 3-D Hilbert order (MS_TILE_ORDER=0): fewer facet instances, smaller halos."""
+def test_bisection_tiles_are_compact():
+    """the patch order (recursive coordinate bisection down to single tiles) gives compact tiles:
+    a facet is listed by 1.13-1.16 tiles on a refined icosphere (a perfect hexagonal patch of 256 lattice vertices:
+    1.10; the runs of a 3-D Hilbert curve that round 1 used: 1.21), and no halo is longer than half a tile."""
     from membrane_solver_amd import _lib as L
     from membrane_solver_amd import meshgen
 
@@ -89,20 +90,14 @@ def test_bisection_tiles_list_fewer_facet_instances_than_hilbert_runs(monkeypatc
     P, T = meshgen.icosphere(48)  # 46 080 facets, 91 tiles of 256 vertices
     P = meshgen.smooth_displace(P, 0.05)
     nv, nf = len(P), len(T)
-    stats = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("MS_TILE_ORDER", mode)
-        st = (ctypes.c_int64 * 8)()
-        perm = np.empty(nv, np.int32)
-        assert lib.ms_plan_tiling(nv, nf, P.ctypes.data_as(L._D), T.ctypes.data_as(L._I32), 256, 1, st,
-                                  perm.ctypes.data_as(L._I32)) == 0
-        assert sorted(perm.tolist()) == list(range(nv))
-        assert st[5] == nf and st[6] == 3 * nf
-        stats[mode] = (st[1], st[2], st[3])
-    (inst_h, halo_h, big_h), (inst_b, halo_b, big_b) = stats["0"], stats["1"]
-    assert inst_b < 0.97 * inst_h, stats
-    assert halo_b < halo_h and big_b <= big_h, stats
-    assert inst_b < 1.2 * nf, stats
+    st = (ctypes.c_int64 * 8)()
+    perm = np.empty(nv, np.int32)
+    assert lib.ms_plan_tiling(nv, nf, P.ctypes.data_as(L._D), T.ctypes.data_as(L._I32), 256, 1, st,
+                              perm.ctypes.data_as(L._I32)) == 0
+    assert sorted(perm.tolist()) == list(range(nv))
+    assert st[5] == nf and st[6] == 3 * nf
+    assert st[1] < 1.17 * nf, list(st)
+    assert st[2] <= 128, list(st)
 
 
 def test_array_mesh_accessors_and_managers():

@@ -10,7 +10,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/membrane_solver_amd/csrc
 obj=$root/build_variants/obj_$name
 mkdir -p "$obj"
-common="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -ffp-contract=fast -I$root/include -I$src"
+common="-DMS_VARIANT_ENV=1 -DMS_ABL_NTILES_ENV=1 --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -ffp-contract=fast -I$root/include -I$src"
 /opt/rocm/bin/hipcc $common $kflags -c "$src/ms_kernels.hip" -o "$obj/ms_kernels.o" &
 /opt/rocm/bin/hipcc $common $kflags $aflags -x hip -c "$src/ms_api.cpp" -o "$obj/ms_api.o" &
 /opt/rocm/bin/hipcc $common -x hip -c "$src/ms_tiles.cpp" -o "$obj/ms_tiles.o" &
