@@ -399,10 +399,15 @@ def secondary_config(name, freq, mods, cons, stepper_name, *, volume_row, step_s
     for kind in ("gradient", "gradient_lean"):
         ms, n = prof.get(kind, (0.0, 0))
         if n:
-            nbytes = ab[kind] if bend else 12 * nf + 25 * nv + (48 if volume_row else 48) * nv
-            name = (KERNEL_NAMES[kind] if bend else "ms::k_gradient<0, %s, 256, 0, true, false>" % ("true" if volume_row else "false"))
-            if bend and volume_row:
-                name = "ms::k_gradient<1, true, 256, 0, true, false>"
+            lean = "true" if kind == "gradient_lean" else "false"
+            row = "true" if volume_row else "false"
+            if bend:
+                # with a constraint row the direction is not fused: x, factors, flags in; g and gC out
+                nbytes = ab["gradient"] if volume_row else ab[kind]
+                name = f"ms::k_gradient<1, {row}, 256, 0, true, {lean}>"
+            else:
+                nbytes = 12 * nf + 25 * nv + 48 * nv
+                name = f"ms::k_gradient<0, {row}, 256, 0, true, false>"
             us = 1e3 * ms / n
             inst[kind] = {"kernel": name, "avg_us": us, "launches": n, "algorithmic_bytes": nbytes,
                           "GBps": nbytes / (us * 1e-6) / 1e9, "frac_of_hbm_peak": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}

@@ -2577,13 +2577,15 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   // the direction cannot ride in the gradient kernel's epilogue when a constraint row has to be projected out first
   // (lambda needs a global reduction) or when a tilt module adds its shape gradient behind K_C
   const bool volrow = (c->params.modules & MS_CON_VOLUME) != 0;
-  const bool constraint = (c->params.modules & (MS_CON_VOLUME | MS_TILT_SHAPE_MODS)) != 0;
   int rc;
   bool restart_sd = false;
-  if (carried_x && c->grad_valid && !constraint && c->til.T <= 256) {
+  const bool tilt_shape = (c->params.modules & MS_TILT_SHAPE_MODS) != 0;
+  if (carried_x && c->grad_valid && !tilt_shape && c->til.T <= 256 &&
+      (!volrow || (!use_history && c->maxg2_valid))) {
     // x has not moved since the last gradient pass (failed search, stepper reset): only the
     // direction changes.  k_direction on the finalized g repeats the fused epilogue's
-    // arithmetic and reduction order exactly.
+    // arithmetic and reduction order exactly.  (With a constraint row G is the projected gradient the direction
+    // kernel wrote back: a steepest-descent restart reads it as it is; projecting it a second time is not on.)
     restart_sd = !use_history && c->maxg2_valid;
     if (restart_sd) {
       // steepest-descent restart: d = -g, whose scalars the gradient pass already reduced
@@ -2637,11 +2639,11 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       if (MASK_DIR & (1u << sl)) put_mailbox(c, sl, vals[sl]);
     c->last_g = c->buf[MS_BUF_G];
     c->dir_implicit = false;
-    c->maxg2_valid = !volrow;  // (the unfused direction kernel does not reduce max|g_i|^2)
+    c->maxg2_valid = true;  // (the fused epilogue and the direction kernel both reduce max|g_i|^2)
   } else {
     c->kc_pending = false;
     rc = queue_energy_and_gradient(c, sp->stepper, use_history, carried);
-    c->maxg2_valid = !constraint;  // the fused epilogue reduced max|g_i|^2 as well
+    c->maxg2_valid = true;  // the fused epilogue / the direction kernel reduced max|g_i|^2 as well
   }
   if (rc) return rc;
   if (!restart_sd) {
@@ -2650,7 +2652,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   }
   // factors, mailbox energies and G now describe x (until a trial pass overwrites them)
   c->carry_valid = carry_mode;
-  c->grad_valid = carry_mode && !constraint;
+  c->grad_valid = carry_mode && !tilt_shape;
   double e[4];
   energies_from_mailbox(c, e);
   const double E_eval = e[0] + e[1] + e[2] + e[3];
@@ -2938,7 +2940,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     // every trial was rejected and x has not moved: G and the host's scalars still describe x (the queued rounds post
     // to mailboxes of their own); only the bending factors in fK / fA and the device scalars are the last trial's
     c->carry_valid = true;
-    c->grad_valid = !constraint;
+    c->grad_valid = !tilt_shape;
     c->maxg2_valid = s_maxg2_x;
     c->factors_valid = false;
   }

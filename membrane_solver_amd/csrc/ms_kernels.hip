@@ -1028,7 +1028,7 @@ hipError_t launch_energy(const EnergyArgs& a_in, bool guard, int cap, int max_en
 // previous-direction rows (dir_mode != 2, or pd = -pg after an implicit steepest-descent step): 8 registers fewer live
 // through the facet loop, which is what lets the kernel fit 128 VGPRs = 4 resident workgroups per CU instead of 3.
 template <int BENDMODE, bool VOLROW, int TT, int CAPC, bool ATOMIC, bool LEAN = false>
-__global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? MS_LEAN_SLOTS : 3) : 1) MS_WPE_GRADIENT void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
+__global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? (VOLROW ? 4 : MS_LEAN_SLOTS) : 3) : 1) MS_WPE_GRADIENT void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
   extern __shared__ double lds[];
   constexpr bool BEND = BENDMODE != 0;
   // BENDMODE 3: leaflet bending_tilt (bt_gradient.py:89-389): analytic back-propagation whose effective-area
@@ -1214,7 +1214,7 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? MS_LEAN_SLOTS : 3) 
   MS_STAMP(1);
 
   const bool surf = a.modules & MS_MOD_SURFACE;
-  const bool volpen = a.modules & MS_MOD_VOLUME_PENALTY;
+  const bool volpen = !LEAN && (a.modules & MS_MOD_VOLUME_PENALTY);  // (the lean instances have no penalty term)
   double pen_factor = 0.0;
   if (volpen) pen_factor = a.volume_stiffness * (ld_agent(a.scal + MS_S_VOL) - a.target_volume) / 6.0;
 
@@ -1284,7 +1284,7 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? MS_LEAN_SLOTS : 3) 
       double a01 = 0, a02 = 0, a11 = 0, a12 = 0;  // e-part of G0, G1 in the basis (e1, e2)
       V3 T0 = mk(0, 0, 0), T1 = mk(0, 0, 0);     // -L fK part of G0, G1
       if (surf && S >= 1.0e-12) R = -(0.5 * gam) * invS;  // g_k = gamma/2 (v_{k+1}-v_{k+2}) x nhat
-      if (!LEAN && (VOLROW || volpen) && (tf.flags & TF_BODY)) {
+      if ((VOLROW || volpen) && (tf.flags & TF_BODY)) {
         const V3 w0 = cross(v1, v2), w1 = cross(v2, v0), w2 = cross(v0, v1);
         if (volpen) {
           G0 = G0 + pen_factor * w0;
@@ -1604,12 +1604,13 @@ size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow, b
   return d * sizeof(double) + (atomic ? 0 : u16_bytes(T, max_ent)) + (((size_t)cap + 15) / 16) * 16;
 }
 
-// the lean instance (see k_gradient): analytic bending, no constraint row, uniform gamma, no pd rows to load
+// the lean instances (see k_gradient): analytic bending on a closed surface, uniform gamma, no penalty, no pd rows to
+// load -- without a constraint row (the headline's) or with one (no fused direction pass then: the KKT multiplier
+// needs a global reduction first)
 bool gradient_lean_instance(const GradientArgs& a) {
   const bool bend = (a.modules & MS_MOD_BENDING) != 0;
-  const bool volrow = a.gC != nullptr && (a.modules & MS_CON_VOLUME);
   const bool leaf = bend && a.bt_vert != nullptr;
-  return a.m.T == FAST_T && a.m.tile_facets32 != nullptr && !volrow && !leaf && bend && a.bending_grad_mode != MS_GRAD_APPROX &&
+  return a.m.T == FAST_T && a.m.tile_facets32 != nullptr && !leaf && bend && a.bending_grad_mode != MS_GRAD_APPROX &&
          a.m.gamma_uniform && !a.m.has_boundary && !(a.modules & MS_MOD_VOLUME_PENALTY) &&
          (a.dir_mode != 2 || a.pd_neg_pg) && !no_lean() && !a.m.no_fast;
 }
@@ -1633,15 +1634,19 @@ hipError_t launch_gradient(const GradientArgs& a_in, int cap, int max_ent, hipSt
     hipLaunchKernelGGL((k_gradient<M, V, TT, CC, AT>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent); \
   } while (0)
   if (gradient_lean_instance(a)) {
-    if (atomic) {
-      e = ensure_lds(k_gradient<1, false, FAST_T, FAST_CAP, true, true>, lds);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL((k_gradient<1, false, FAST_T, FAST_CAP, true, true>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);
-    } else {  // fixed-order vertex sums (ms_set_deterministic): the same diet, the CSR gather instead of LDS atomics
-      e = ensure_lds(k_gradient<1, false, FAST_T, FAST_CAP, false, true>, lds);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL((k_gradient<1, false, FAST_T, FAST_CAP, false, true>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent);
+#define MS_LAUNCH_LEAN(V, AT)                                                                               \
+  do {                                                                                                      \
+    e = ensure_lds(k_gradient<1, V, FAST_T, FAST_CAP, AT, true>, lds);                                      \
+    if (e != hipSuccess) return e;                                                                          \
+    hipLaunchKernelGGL((k_gradient<1, V, FAST_T, FAST_CAP, AT, true>), dim3(nb), dim3(a.m.T), lds, s, a, cap, max_ent); \
+  } while (0)
+    // (atomic: LDS ds_add_f64 vertex sums; otherwise the same diet with the fixed-order CSR gather, ms_set_deterministic)
+    if (volrow) {
+      if (atomic) MS_LAUNCH_LEAN(true, true); else MS_LAUNCH_LEAN(true, false);
+    } else {
+      if (atomic) MS_LAUNCH_LEAN(false, true); else MS_LAUNCH_LEAN(false, false);
     }
+#undef MS_LAUNCH_LEAN
     return hipGetLastError();
   }
 #define MS_PICK_G(M, V)                                           \
@@ -2877,7 +2882,7 @@ __global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, c
       project = true;
     }
   }
-  double gn2 = 0.0, gd = 0.0, md2 = 0.0;
+  double gn2 = 0.0, gd = 0.0, md2 = 0.0, mg2 = 0.0;
   for (int i = threadIdx.x; i < T; i += BLOCK) {
     const int v = tile * T + i;
     if (v >= nv) break;
@@ -2907,9 +2912,11 @@ __global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, c
     d[o] = di.x;
     d[o + 1] = di.y;
     d[o + 2] = di.z;
-    gn2 += dot_pinned(gi, gi);
+    const double g2 = dot_pinned(gi, gi);
+    gn2 += g2;
     gd += dot_pinned(gi, di);
     if (!fixed) md2 = fmax(md2, dot_pinned(di, di));
+    mg2 = fmax(mg2, g2);  // (gi is zero on fixed rows) max|d_i|^2 of a steepest-descent restart on this gradient
   }
   double* out = partials + tile;
   const size_t ps = (size_t)n_tiles;
@@ -2919,6 +2926,8 @@ __global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, c
   if (threadIdx.x == 0) out[MS_S_GDOTD * ps] = r;
   r = block_reduce(md2, 2, red);
   if (threadIdx.x == 0) out[MS_S_MAXD2 * ps] = r;
+  r = block_reduce(mg2, 2, red);
+  if (threadIdx.x == 0) out[MS_S_MAXG2 * ps] = r;
 }
 
 hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* g,
