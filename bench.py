@@ -60,6 +60,9 @@ def build_parser():
     ap.add_argument("--cpu-steps", type=int, default=-1,
                     help="CPU oracle steps per cpu_baseline leg (0 = skip; default 6 at N=1, 2 at N>1)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-large", action="store_true",
+                    help="skip the 16-million-facet legs (f = 905: the size at which strong scaling over 8 GPUs means "
+                         "something, and the weak-scaling size of 8 GPUs)")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the secondary sections (reuse level 0, deterministic mode): for kernel traces")
     ap.add_argument("--reuse-level", type=int, default=2, choices=(0, 1, 2),
@@ -565,12 +568,88 @@ def main_single(args):
         except Exception as exc:  # secondary figures never cost the headline line
             print(f"[bench] secondary configurations skipped: {exc!r}", file=sys.stderr)
 
+    # -- the N = 1 point of the 16-million-facet strong-scaling curve (bench.py --gpus N reports the others) --------
+    if not args.headline_only and not args.no_large and not args.volume and args.freq == 320:
+        try:
+            lg = secondary_config("strong_16M_facets", LARGE_FREQ, ["surface", "bending"], [], "conjugate_gradient",
+                                  volume_row=False, step_size=args.step_size * (320.0 / LARGE_FREQ) ** 2,
+                                  steps=40, warmup=10, device=local_rank)
+            lg["facets_per_gpu"] = 20 * LARGE_FREQ * LARGE_FREQ
+            out["strong_16M_facets"] = lg
+        except Exception as exc:
+            print(f"[bench] 16 M-facet leg skipped: {exc!r}", file=sys.stderr)
+
     # -- CPU baseline: the oracle port on the host cores, bounded sample ---------
     n_cpu = 6 if args.cpu_steps < 0 else args.cpu_steps
     if n_cpu > 0:
         out["cpu_baseline"] = cpu_baseline(dm.get_positions(), T, mods, cons, bodies, gp, mz.step_size, n_cpu)
         out["step_size_after_warmup"] = step_size_after_warmup
     print(json.dumps(out))
+
+
+LARGE_FREQ = 905  # 16 380 500 facets: 2 M facets per GPU at 8 GPUs (weak_frequency(8))
+
+
+def sharded_extra_leg(args, rank, world, local_rank, freq, steps, warmup):
+    """One more timed run of the sharded driver at another mesh size (same process group): -> dict or None."""
+    import torch
+    import torch.distributed as dist
+
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd.parallel import HipShardBackend, LibraryShardedStepper, ShardedStepper
+
+    P, T = bench_mesh(freq)
+    nv, nf = P.shape[0], T.shape[0]
+    be = HipShardBackend(P, T, rank=rank, world=world, device=local_rank, tile_vertices=args.tile)
+    be.configure(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING, gamma=np.ones(nf), kappa=np.ones(nv), c0=np.zeros(nv))
+    ok = 1
+    try:
+        if os.environ.get("MS_SHARD_PYTHON_DRIVER"):
+            raise RuntimeError("MS_SHARD_PYTHON_DRIVER set")
+        be.enable_library_driver()
+    except Exception:
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=be.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    lib = int(flag.item()) == 1
+    drv = LibraryShardedStepper(be, stepper=L.MS_STEPPER_CG) if lib else ShardedStepper(be, stepper=L.MS_STEPPER_CG)
+    step = args.step_size * (320.0 / freq) ** 2  # (the stable step scales with h^2)
+
+    def run(n):
+        nonlocal step
+        acc = trials = 0
+        if lib:
+            o = drv.run(n, step, tol=1e-6)
+            step = float(o.step_size)
+            return int(o.accepted), int(o.trials)
+        for _ in range(n):
+            r = drv.step(step, tol=1e-6)
+            step = r.next_step
+            acc += int(r.success)
+            trials += r.trials
+            if not r.success:
+                drv.reset()
+        return acc, trials
+
+    run(warmup)
+    ex0 = drv.exchanges
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    acc, trials = run(steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=be.device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    out = {"workload": f"class-I icosphere f={freq} (nv={nv}, nf={nf}), surface + Helfrich bending, CG, sharded over {world} GPU(s)",
+           "value": steps / dt, "unit": "steps/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
+           "steps_accepted": acc, "line_search_trials": trials, "facets_per_gpu": nf / world,
+           "exchanges_per_step": (drv.exchanges - ex0) / max(steps, 1),
+           "driver": "library" if lib else "python"}
+    be.dm.close()
+    return out
 
 
 def main_sharded(args, rank, world, local_rank):
@@ -689,11 +768,28 @@ def main_sharded(args, rank, world, local_rank):
         if rank == 0:
             cpu = cpu_baseline(x_full, T, ["surface", "bending"], [], [], dict(GP), step, n_cpu)
         dist.barrier()
+    # -- one SCALE invocation yields all three curves: the headline mesh (strong), 16 M facets (strong, the size at
+    #    which 8 GPUs have 2 M facets each) and 2 M facets per GPU (weak); the latter two coincide at 8 GPUs
+    extra = {}
+    if not args.no_large and not args.weak and args.freq == 320:
+        be.dm.close()
+        for key, f in (("strong_16M_facets", LARGE_FREQ), ("weak_2M_facets_per_gpu", weak_frequency(world, 320))):
+            try:
+                if key.startswith("weak") and f == LARGE_FREQ and "strong_16M_facets" in extra:
+                    extra[key] = dict(extra["strong_16M_facets"], note="same run as strong_16M_facets at 8 GPUs")
+                elif key.startswith("weak") and f == 320:
+                    extra[key] = {"note": "the headline run itself at 1 GPU"}
+                else:
+                    extra[key] = sharded_extra_leg(args, rank, world, local_rank, f, min(args.steps, 40), min(args.warmup, 10))
+            except Exception as exc:  # an extra leg never costs the headline line
+                print(f"[bench] rank {rank}: leg {key} skipped: {exc!r}", file=sys.stderr)
+                extra[key] = None
     sys.stdout.flush()
     os.dup2(stdout_fd, 1)
     os.close(stdout_fd)
     if rank == 0:
         print(json.dumps({
+            **extra,
             "metric": METRIC, "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",

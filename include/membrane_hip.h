@@ -155,6 +155,13 @@ typedef struct ms_stepper_params {
                                  bending factors) serves as the next step's energy
                                  pass.  Same kernel on the same doubles: all three
                                  modes give bitwise identical trajectories.       */
+  int enforce_volume;      /* line_search.py:428-487 with constraint_enforcer =
+                              Minimizer._enforce_constraints (minimizer.py:1379) and
+                              volume_projection_during_minimization on: every trial
+                              that passed the guard is projected onto the target
+                              volume (volume.enforce_constraint: 3 linearised steps,
+                              tol 1e-12) BEFORE its energy is taken; a rejected
+                              trial restores the positions.  Unqueued trials.      */
 } ms_stepper_params;
 
 typedef struct ms_step_result {

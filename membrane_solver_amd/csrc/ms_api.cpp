@@ -2743,7 +2743,10 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   // host does (surface + bending only), no tilt projections between trials.  The gradient + direction pass of the
   // accepted point follows in the same queue, gated on the acceptance (with a constraint row: K_C, the fold of
   // <g,gC> / <gC,gC>, the direction kernel and its fold, all four behind the same decision word).
-  const bool can_chain = c->speculate && carry_mode && !tilt && !(c->params.modules & MS_MOD_VOLUME_PENALTY);
+  // the enforcer lane (ms_stepper_params.enforce_volume): every trial is projected onto the target volume before its
+  // energy is taken -- three more passes per trial, one trial at a time
+  const bool enforce = sp->enforce_volume != 0 && volrow && !tilt;
+  const bool can_chain = c->speculate && carry_mode && !tilt && !(c->params.modules & MS_MOD_VOLUME_PENALTY) && !enforce;
   // a round queued by the step before (while its gradient pass was running): the round of THIS search's first
   // iteration if it was queued for exactly what this step has computed by itself
   bool adopted = false;
@@ -2769,7 +2772,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     kc_queued = false;  // (a gradient pass queued behind an earlier, fully rejected round found its gate closed)
     if (!(can_chain && safe_small)) {
       unchained_ran = true;
-      rc = phase_energy(c, c->params.modules, true, alpha, true, !safe_small, carry_mode);
+      rc = phase_energy(c, c->params.modules, true, alpha, true, !safe_small, carry_mode && !enforce);
       if (rc) return rc;
       rc = fetch(c);
       if (rc) return rc;
@@ -2780,6 +2783,17 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
         ++it;
         if (alpha < 1e-8) break;
         continue;
+      }
+      if (enforce) {
+        // line_search.py:448-452: constraint_enforcer(mesh) on the trial positions, then energy_fn() there.  The
+        // projection works on buffer X: the trial takes that place for its duration.
+        std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
+        rc = ms_project_volume_cached(c, c->params.target_volume, 1e-12, 3, 0, nullptr, nullptr);
+        if (rc == MS_OK) rc = phase_energy(c, c->params.modules, false, 0.0, false, false, carry_mode);
+        if (rc == MS_OK) rc = fetch(c);
+        std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);  // (the projected trial is the trial buffer again)
+        if (rc) return rc;
+        if (carry_mode) c->factors_valid = false;  // (they belong to the trial point until it is accepted)
       }
       ++out->trials;
       energies_from_mailbox(c, e);

@@ -84,10 +84,20 @@ def icosphere(freq: int, radius: float = 1.0) -> tuple[np.ndarray, np.ndarray]:
             local_tris + k * npts
         )
     pts /= np.linalg.norm(pts, axis=1)[:, None]
+    # rows in lexicographic (x, y, z) order of the rounded coordinates, duplicates merged: what
+    # np.unique(key, axis=0, return_index=True, return_inverse=True) returns, by a stable three-key sort (an order of
+    # magnitude faster on the 16-million-point lattices of the scaling runs)
     key = np.round(pts, 9)
-    _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
+    order = np.lexsort((key[:, 2], key[:, 1], key[:, 0]))
+    ks = key[order]
+    new = np.empty(ks.shape[0], dtype=bool)
+    new[0] = True
+    np.any(ks[1:] != ks[:-1], axis=1, out=new[1:])
+    first = order[new]  # (stable sort: the first row of a group is its earliest occurrence)
+    inv = np.empty(ks.shape[0], dtype=np.int64)
+    inv[order] = np.cumsum(new) - 1
     positions = np.ascontiguousarray(pts[first] * float(radius))
-    tri_rows = inv.reshape(-1)[tris].astype(np.int32)
+    tri_rows = inv[tris].astype(np.int32)
     # Orient outward (positive enclosed volume).
     v0 = positions[tri_rows[:, 0]]
     v1 = positions[tri_rows[:, 1]]

@@ -55,21 +55,20 @@ class ConstraintModuleManager:
             lam = float(np.sum(grad_arr * gC)) / norm_sq
             grad_arr -= lam * gC
 
-    def enforce_all(self, mesh, **kwargs):
-        """constraint_manager.py:843-905 for the volume module."""
-        context = kwargs.get("context", "minimize")
-        global_params = kwargs.get("global_params")
-        project_in_minimize = True
-        if global_params is not None:
-            project_in_minimize = global_params.get("volume_projection_during_minimization", True)
-        for name, module in self.modules.items():
-            if not hasattr(module, "enforce_constraint"):
-                continue
-            if name == "volume" and context == "minimize" and not project_in_minimize:
-                continue
-            call_kwargs = dict(kwargs)
-            call_kwargs.pop("force_projection", None)
-            if name == "volume":
-                module.enforce_constraint(mesh, force_projection=True, **call_kwargs)
-            else:
-                module.enforce_constraint(mesh, **kwargs)
+    def enforce_all(self, mesh, *, context="minimize", global_params=None, **options):
+        """Hard projection of every loaded constraint that has one -- here: ``volume`` -- onto its target
+        (interface of constraint_manager.py:843-905).
+
+        Inside a minimisation step (``context == "minimize"``) the volume projection only runs when
+        ``volume_projection_during_minimization`` is on; with it off the optimizer holds the volume through the
+        KKT projection of the gradient alone.  After mesh operations and at the end of ``minimize`` (the other
+        contexts) it always runs, with ``force_projection=True``."""
+        during_step = context == "minimize"
+        step_projection = True if global_params is None else bool(
+            global_params.get("volume_projection_during_minimization", True))
+        options.pop("force_projection", None)
+        volume = self.modules.get("volume")
+        if volume is None or (during_step and not step_projection):
+            return
+        volume.enforce_constraint(mesh, force_projection=True, context=context, global_params=global_params,
+                                  **options)

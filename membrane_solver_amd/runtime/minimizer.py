@@ -463,7 +463,7 @@ class Minimizer:
         mp.stepper = L.ms_stepper_params(int(st.stepper_id), int(st._max_iter_for(self.mesh)), float(st.beta),
                                          float(st.c), float(st.gamma), float(st.alpha_max_factor),
                                          int(extra.get("restart_interval", 10)), edge_fraction,
-                                         int(st.reuse_energy0))
+                                         int(st.reuse_energy0), int(getattr(st, "enforce_volume", 0)))
         step_mode = str(gp.get("step_size_mode", "adaptive") or "adaptive").lower()
         mp.step_size = float(self.step_size)
         mp.tol = float(self.tol)
@@ -498,12 +498,13 @@ class Minimizer:
         ``sync_mesh_from_device()``); benchmarks use it to keep PCIe out of the loop."""
         mir, dm = self._device()
         gp = self.global_params
-        if self._has_enforceable_constraints and gp.get("volume_projection_during_minimization", True) \
-                and gp.get("volume_constraint_mode", "lagrange") == "lagrange":
-            raise L.MembraneHipError(
-                "volume_projection_during_minimization=True re-projects the volume inside every "
-                "line-search trial (line_search.py:428-456); that host-side lane is not on the HIP "
-                "path -- set it to False (the reference parser's default for Lagrange decks)")
+        # minimizer.py:1379: the stepper gets Minimizer._enforce_constraints as its constraint enforcer; with
+        # volume_projection_during_minimization on (the programmatic default) that projects every trial onto the
+        # target volume before its energy is taken (line_search.py:428-487) -- on the device: ms_stepper_params.enforce_volume
+        self.stepper.enforce_volume = int(bool(
+            self._has_enforceable_constraints and gp.get("volume_projection_during_minimization", True)
+            and gp.get("volume_constraint_mode", "lagrange") == "lagrange" and self._target_volume() is not None
+            and (dm.modules & L.MS_CON_VOLUME)))
         if n_steps <= 0:
             E, g = self.compute_energy_and_gradient_array()
             moved = self._enforce(dm, "minimize")

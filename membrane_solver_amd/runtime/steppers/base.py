@@ -48,6 +48,9 @@ class BaseStepper(ABC):
         # 0 re-evaluates everything the reference re-evaluates; 2 skips the passes whose
         # result is already on the device bit for bit (tests assert identical trajectories)
         self.reuse_energy0 = 2
+        # set by the Minimizer: every trial is projected onto the target volume before its energy is taken
+        # (line_search.py:428-487 with the volume module's enforce_constraint as the enforcer)
+        self.enforce_volume = 0
         self._dm = None
 
     @abstractmethod
@@ -66,19 +69,18 @@ class BaseStepper(ABC):
         return dm.step(stepper=self.stepper_id, step_size=step_size, tol=tol,
                        max_iter=self._max_iter_for(mesh), beta=self.beta, c=self.c, gamma=self.gamma,
                        alpha_max_factor=self.alpha_max_factor, edge_fraction=edge_fraction,
-                       reuse_energy0=self.reuse_energy0, **self._extra())
+                       reuse_energy0=self.reuse_energy0, enforce_volume=int(self.enforce_volume), **self._extra())
 
     def step(self, mesh, grad, step_size, energy_fn=None, constraint_enforcer=None,
              trial_energy_fn=None):
         _ = (grad, energy_fn, trial_energy_fn)
         if constraint_enforcer is not None:
+            # the enforcer of the hot path is the volume module's projection (the only constraint in scope): with
+            # volume_projection_during_minimization on it runs on the device inside every trial
             gp = getattr(mesh, "global_parameters", None)
-            if gp is not None and gp.get("volume_projection_during_minimization", True) and \
-                    gp.get("volume_constraint_mode", "lagrange") == "lagrange":
-                raise L.MembraneHipError(
-                    "per-trial geometric volume projection inside the line search "
-                    "(volume_projection_during_minimization=True) is not on the HIP path; "
-                    "set it to False (Lagrange gradient projection) as the reference's parser does")
+            self.enforce_volume = int(bool(gp is not None and gp.get("volume_projection_during_minimization", True)
+                                           and gp.get("volume_constraint_mode", "lagrange") == "lagrange"
+                                           and getattr(mesh, "bodies", None)))
         mir = mirror_for(mesh)
         dm = mir.sync()
         r = self.device_step(dm, mesh, float(step_size))

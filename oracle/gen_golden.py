@@ -38,6 +38,7 @@ ap.add_argument("--only-disk", action="store_true", help="tilt_disk_target_in/ou
 ap.add_argument("--only-defects", action="store_true", help="angle-defect vectors only")
 ap.add_argument("--only-guard", action="store_true", help="guard / exhausted-search / volume-drift trajectories only")
 ap.add_argument("--only-config5", action="store_true", help="the caveolin deck of BASELINE config 5 only")
+ap.add_argument("--only-enforcer", action="store_true", help="line-search enforcer-lane trajectories only")
 args = ap.parse_args()
 
 sys.dont_write_bytecode = True
@@ -1143,6 +1144,47 @@ def gen_guard_and_enforce():
 
 
 # ---------------------------------------------------------------------------
+# (k2) the enforcer lane of the line search (line_search.py:428-487 with constraint_enforcer =
+#      Minimizer._enforce_constraints, minimizer.py:1379) with the PROGRAMMATIC defaults of the volume parameters:
+#      GlobalParameters() gives volume_constraint_mode = "lagrange" and volume_projection_during_minimization = True
+#      (core/parameters/global_parameters.py:18,24), so every trial is projected onto the target volume
+#      (volume.enforce_constraint, three linearised steps) before its energy is taken, next to the k = 1 KKT
+#      projection of the gradient.
+# ---------------------------------------------------------------------------
+def gen_enforcer_lane():
+    P8, T8 = meshgen.icosphere(8)
+    P8 = meshgen.smooth_displace(P8, 0.05)
+    cases = [
+        ("traj_ico8_gd_volume_enforcer.npz", ["surface"], GradientDescent, 6, 2e-2,
+         {"surface_tension": 1.0, "mesh_quality_auto_repair_enabled": False}),
+        ("traj_ico8_cg_bending_volume_enforcer.npz", ["surface", "bending"], ConjugateGradient, 8, 1e-3,
+         {"surface_tension": 1.0, "bending_modulus": 1.0, "bending_energy_model": "helfrich",
+          "spontaneous_curvature": 0.3, "mesh_quality_auto_repair_enabled": False}),
+    ]
+    for fname, mods, stepper_cls, n_steps, step0, gp in cases:
+        mm = build_mesh(P8, T8, dict(gp))
+        assert mm.global_parameters.get("volume_projection_during_minimization", True) is True
+        assert mm.global_parameters.get("volume_constraint_mode", "lagrange") == "lagrange"
+        add_body(mm)
+        mm.energy_modules = list(mods)
+        mm.constraint_modules = ["volume"]
+        stats, undo = _count_enforce()
+        try:
+            out = run_trajectory(fname, mm, stepper_cls(), n_steps, step_size=step0)
+        finally:
+            undo()
+        out["enforce_calls"] = np.array(stats["calls"])
+        out["volume_final"] = np.array(float(mm.bodies[0].compute_volume(mm)))
+        if "bending" in mods:
+            out["kappa"] = np.array(1.0)
+            out["c0"] = np.array(0.3)
+        # (start + one per line-search trial + finalize)
+        assert stats["calls"] >= n_steps + 2, stats
+        np.savez_compressed(os.path.join(OUT, fname), **out)
+        print("%s E_final=%.16g enforce calls %d" % (fname, out["E_final"], stats["calls"]), out["step_log"].tolist())
+
+
+# ---------------------------------------------------------------------------
 # (l) BASELINE config 5 on its own deck: meshes/caveolin/kozlov_1disk_3d_tensionless_bilayer_profile.yaml.
 #     Kept from the deck: positions, triangle rows, fixed / tilt_fixed_in / tilt_fixed_out flags, the "disk" group
 #     rows, every global parameter and the energy-module list.  NOT kept: its three constraint modules
@@ -1277,6 +1319,9 @@ if __name__ == "__main__":
     if "--only-config5" in sys.argv:
         gen_config5()
         sys.exit(0)
+    if "--only-enforcer" in sys.argv:
+        gen_enforcer_lane()
+        sys.exit(0)
     if "--only-disk" in sys.argv:
         gen_disk_target()
         sys.exit(0)
@@ -1302,4 +1347,5 @@ if __name__ == "__main__":
     gen_disk_target()
     gen_angle_defects()
     gen_guard_and_enforce()
+    gen_enforcer_lane()
     gen_config5()

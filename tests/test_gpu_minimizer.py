@@ -46,6 +46,13 @@ CASES = {
     "traj_ico8_gd_volume_drift.npz": (["surface"], ["volume"], "gd", dict(BASE, volume_tolerance=1.0e-11)),
     "traj_ico4_gd_tilt_volume_drift.npz": (["surface", "tilt"], ["volume"], "gd",
                                            dict(BASE, tilt_rigidity=2.5, volume_tolerance=1.0e-11)),
+    # the enforcer lane (ms_stepper_params.enforce_volume): GlobalParameters()'s own defaults -- Lagrange row and
+    # volume_projection_during_minimization on -- project every line-search trial onto the target volume
+    "traj_ico8_gd_volume_enforcer.npz": (["surface"], ["volume"], "gd",
+                                         dict(BASE, volume_projection_during_minimization=True)),
+    "traj_ico8_cg_bending_volume_enforcer.npz": (["surface", "bending"], ["volume"], "cg",
+                                                 dict(BASE, bending_modulus=1.0, spontaneous_curvature=0.3,
+                                                      volume_projection_during_minimization=True)),
 }
 # positions against the reference: the drift cases resolve the 1 % effect of the cached-gradient first projection
 # step on a 7e-7 displacement, so they are held to a tighter bound than the historical 1e-8

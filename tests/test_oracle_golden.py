@@ -173,6 +173,16 @@ TRAJ = {
                                            {"tilt_rigidity": 2.5, "volume_constraint_mode": "lagrange",
                                             "volume_tolerance": 1.0e-11,
                                             "volume_projection_during_minimization": False}),
+    # the enforcer lane of the line search with the programmatic defaults of GlobalParameters() (Lagrange row AND
+    # volume_projection_during_minimization on): every trial is projected onto the target volume before its energy is
+    # taken (line_search.py:428-487, minimizer.py:1379)
+    "traj_ico8_gd_volume_enforcer.npz": (["surface"], ["volume"], "gd",
+                                         {"volume_constraint_mode": "lagrange",
+                                          "volume_projection_during_minimization": True}),
+    "traj_ico8_cg_bending_volume_enforcer.npz": (["surface", "bending"], ["volume"], "cg",
+                                                 {"bending_modulus": 1.0, "spontaneous_curvature": 0.3,
+                                                  "volume_constraint_mode": "lagrange",
+                                                  "volume_projection_during_minimization": True}),
 }
 
 

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out; T=$1
 cd $R
 if [ "$2" = "tests" ]; then python -m pytest tests -m gpu -x -q > $O/${T}_tests.log 2>&1; tail -3 $O/${T}_tests.log; fi
-python3 bench.py --cpu-steps 0 > $O/${T}_full.json 2> $O/${T}_full.err
+python3 bench.py --cpu-steps 0 ${NOLARGE---no-large} > $O/${T}_full.json 2> $O/${T}_full.err
 python3 bench.py --steps 20 --warmup 5 --cpu-steps 0 --headline-only --no-roofline > $O/${T}_b20.json 2> $O/${T}_b20.err
 python3 - <<PY
 import json
