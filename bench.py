@@ -590,8 +590,9 @@ def main_single(args):
 LARGE_FREQ = 905  # 16 380 500 facets: 2 M facets per GPU at 8 GPUs (weak_frequency(8))
 
 
-def sharded_extra_leg(args, rank, world, local_rank, freq, steps, warmup):
-    """One more timed run of the sharded driver at another mesh size (same process group): -> dict or None."""
+def sharded_extra_leg(args, rank, world, local_rank, freq, steps, warmup, exchange="rccl"):
+    """One more timed run of the sharded driver at another mesh size or with the peer-to-peer exchange (same process
+    group): -> dict or None."""
     import torch
     import torch.distributed as dist
 
@@ -604,14 +605,21 @@ def sharded_extra_leg(args, rank, world, local_rank, freq, steps, warmup):
     be.configure(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING, gamma=np.ones(nf), kappa=np.ones(nv), c0=np.zeros(nv))
     ok = 1
     try:
-        if os.environ.get("MS_SHARD_PYTHON_DRIVER"):
-            raise RuntimeError("MS_SHARD_PYTHON_DRIVER set")
-        be.enable_library_driver()
-    except Exception:
+        if exchange == "peer":
+            be.enable_peer_exchange()  # pack kernels write into the peers' slabs; no collective in the step
+        else:
+            if os.environ.get("MS_SHARD_PYTHON_DRIVER"):
+                raise RuntimeError("MS_SHARD_PYTHON_DRIVER set")
+            be.enable_library_driver()
+    except Exception as exc:
         ok = 0
+        print(f"[bench] rank {rank}: {exchange} exchange not available: {exc!r}", file=sys.stderr)
     flag = torch.tensor([ok], dtype=torch.int32, device=be.device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     lib = int(flag.item()) == 1
+    if exchange == "peer" and not lib:
+        be.dm.close()
+        return {"note": "peer-to-peer exchange could not be set up on every rank"}
     drv = LibraryShardedStepper(be, stepper=L.MS_STEPPER_CG) if lib else ShardedStepper(be, stepper=L.MS_STEPPER_CG)
     step = args.step_size * (320.0 / freq) ** 2  # (the stable step scales with h^2)
 
@@ -647,7 +655,9 @@ def sharded_extra_leg(args, rank, world, local_rank, freq, steps, warmup):
            "value": steps / dt, "unit": "steps/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
            "steps_accepted": acc, "line_search_trials": trials, "facets_per_gpu": nf / world,
            "exchanges_per_step": (drv.exchanges - ex0) / max(steps, 1),
-           "driver": "library" if lib else "python"}
+           "driver": "library" if lib else "python",
+           "exchange": ("peer-to-peer: pack kernels store into the peers' IPC-mapped slabs, flag words, bounded wait"
+                        if exchange == "peer" else "RCCL all-gather")}
     be.dm.close()
     return out
 
@@ -773,9 +783,13 @@ def main_sharded(args, rank, world, local_rank):
     extra = {}
     if not args.no_large and not args.weak and args.freq == 320:
         be.dm.close()
-        for key, f in (("strong_16M_facets", LARGE_FREQ), ("weak_2M_facets_per_gpu", weak_frequency(world, 320))):
+        for key, f in (("peer_exchange", 320), ("strong_16M_facets", LARGE_FREQ), ("strong_16M_facets_peer_exchange", LARGE_FREQ),
+                       ("weak_2M_facets_per_gpu", weak_frequency(world, 320))):
             try:
-                if key.startswith("weak") and f == LARGE_FREQ and "strong_16M_facets" in extra:
+                if key.endswith("peer_exchange"):
+                    extra[key] = sharded_extra_leg(args, rank, world, local_rank, f, min(args.steps, 100 if f == 320 else 40),
+                                                   min(args.warmup, 10), exchange="peer")
+                elif key.startswith("weak") and f == LARGE_FREQ and "strong_16M_facets" in extra:
                     extra[key] = dict(extra["strong_16M_facets"], note="same run as strong_16M_facets at 8 GPUs")
                 elif key.startswith("weak") and f == 320:
                     extra[key] = {"note": "the headline run itself at 1 GPU"}

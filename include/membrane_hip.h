@@ -446,6 +446,25 @@ typedef int (*ms_allgather_fn)(void *user, const void *send_dev, void *recv_dev,
 int ms_shard_unique_id(void *id128);
 int ms_shard_comm_init(ms_ctx *ctx, const void *id128);
 int ms_shard_set_allgather(ms_ctx *ctx, ms_allgather_fn fn, void *user);
+/* Peer-to-peer exchange (no collective library in the step): every rank's pack kernel stores its scalar header and
+ * boundary rows straight into EVERY peer's receive slab (xGMI stores through IPC-mapped device memory), a one-wave
+ * kernel then raises this rank's flag word on every peer, and the unpack kernel starts behind a bounded wait on the
+ * rank's own flag words.  Two slabs alternate (a peer can be at most one exchange ahead).
+ *   ms_shard_peer_export: fills handles[0..127] with the hipIpcMemHandle_t of this rank's receive slab and of its flag
+ *                          words (64 bytes each); the caller all-gathers the 128-byte records in rank order;
+ *   ms_shard_peer_open:   opens every peer's two handles (world x 128 bytes, rank order; the own record is skipped);
+ *   ms_shard_peer_set_pointers: the same for shard contexts of ONE process (thread shards): raw device pointers of
+ *                          every rank's slab / flag words in rank order (ms_shard_peer_local gives a rank's own).
+ * With peers set, ms_shard_step uses this exchange instead of ncclAllGather / the all-gather callback. */
+int ms_shard_peer_export(ms_ctx *ctx, void *handles128);
+int ms_shard_peer_open(ms_ctx *ctx, const void *handles_all);
+int ms_shard_peer_local(ms_ctx *ctx, void **recv_slab, void **flag_words);
+int ms_shard_peer_set_pointers(ms_ctx *ctx, void *const *recv_slabs, void *const *flag_words);
+/* Shard contexts of ONE process share the device's few hardware queues: a rank's waiting wave can sit in front of the
+ * very kernels of another rank it waits for.  Such contexts (tests) wait on the host instead: after raising its flags a
+ * rank synchronises its stream and calls fn(user), which returns once every rank has done the same. */
+typedef int (*ms_barrier_fn)(void *user);
+int ms_shard_peer_set_barrier(ms_ctx *ctx, ms_barrier_fn fn, void *user);
 int ms_shard_step(ms_ctx *ctx, const ms_stepper_params *params, double step_size,
                   double tol, ms_step_result *out);
 /* number of exchanges done so far by ms_shard_step on this context */

@@ -55,6 +55,9 @@ class ms_params(ctypes.Structure):
                 ("target_volume", ctypes.c_double)]
 
 
+BARRIER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
+
+
 class ms_stepper_params(ctypes.Structure):
     _fields_ = [("stepper", ctypes.c_int), ("max_iter", ctypes.c_int), ("beta", ctypes.c_double),
                 ("c", ctypes.c_double), ("gamma", ctypes.c_double),
@@ -192,6 +195,11 @@ SIGNATURES = {
     "ms_profile_enable": (ctypes.c_int, [_P, ctypes.c_int]),
     "ms_profile_read": (ctypes.c_int, [_P, _D, _I64]),
     "ms_queue_stats": (ctypes.c_int, [_P, _I64]),
+    "ms_shard_peer_export": (ctypes.c_int, [_P, _P]),
+    "ms_shard_peer_open": (ctypes.c_int, [_P, _P]),
+    "ms_shard_peer_local": (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(_P)]),
+    "ms_shard_peer_set_pointers": (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(_P)]),
+    "ms_shard_peer_set_barrier": (ctypes.c_int, [_P, _P, _P]),
     "ms_plan_tiling": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _D, _I32, ctypes.c_int, ctypes.c_int,
                                       _I64, _I32]),
     "ms_plan_tiling_conflicts": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _D, _I32, ctypes.c_int, _D]),

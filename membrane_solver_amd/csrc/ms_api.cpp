@@ -238,6 +238,18 @@ struct ms_ctx {
   unsigned long long* h_xseq = nullptr;
   unsigned long long* d_h_xseq = nullptr;
   unsigned long long xticket = 0;
+  // peer-to-peer exchange (ms_shard_peer_*): two receive slabs (the exchanges alternate between them) and one flag
+  // word per (slab, peer) on this rank; the peers' slabs / flag words as this process sees them
+  double* d_peer_slab = nullptr;            // 2 x shard_count x stride doubles
+  unsigned long long* d_peer_flag = nullptr;  // 2 x 16 words
+  size_t peer_stride = 0;                   // doubles per (slab, rank) slot
+  std::vector<double*> peer_slabs;          // [rank]: base of that rank's slabs (own: d_peer_slab)
+  std::vector<unsigned long long*> peer_flags;
+  std::vector<void*> peer_opened;           // hipIpcOpenMemHandle results to close
+  bool peer_on = false;
+  unsigned long long peer_ticket = 0;
+  ms_barrier_fn peer_barrier = nullptr;     // contexts of one process: host-side wait instead of the waiting wave
+  void* peer_barrier_user = nullptr;
   double sh_scal[MS_NSCAL] = {0};  // rank-ordered fold of the last exchanges
   double sh_scal2[MS_NSCAL] = {0}; // ... of a pair launch's other trial (header slots SH_ALT + slot)
   double* pair_scal2 = nullptr;    // where a pair launch's second fold goes (nullptr: d_scal2)
@@ -1373,6 +1385,9 @@ void ms_destroy(ms_ctx* c) {
                   c->d_halo_rows, c->d_scal_all};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (void* q : c->peer_opened) (void)hipIpcCloseMemHandle(q);
+  if (c->d_peer_slab) (void)hipFree(c->d_peer_slab);
+  if (c->d_peer_flag) (void)hipFree(c->d_peer_flag);
   if (c->comm) shard_comm_destroy(c->comm);
   if (c->d_xsend) (void)hipFree(c->d_xsend);
   if (c->d_xrecv) (void)hipFree(c->d_xrecv);
@@ -3332,6 +3347,33 @@ int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push, 
   if (rc) return rc;
   const size_t count = (size_t)MS_NSCAL + (size_t)c->bnd_max * comps;
   const int me = c->shard_rank, W = c->shard_count;
+  ++c->xticket;
+  if (c->peer_on) {
+    // peer-to-peer: this rank's message goes straight into slot `me` of every peer's slab (slab = exchange parity),
+    // then its flag word there is raised; the unpack kernel runs behind a bounded wait for every peer's word here
+    ++c->peer_ticket;
+    const int par = (int)(c->peer_ticket & 1);
+    if (count > c->peer_stride) return fail(c, MS_ERR_STATE, "peer exchange: message longer than the slab slot");
+    double* dst[16];
+    unsigned long long* flg[16];
+    for (int r = 0; r < W; ++r) {
+      dst[r] = c->peer_slabs[(size_t)r] + ((size_t)par * W + (size_t)me) * c->peer_stride;
+      flg[r] = c->peer_flags[(size_t)r] + (size_t)par * 16;
+    }
+    HIPCHK(c, launch_pack_peers(c->d_bnd_rows + c->bnd_off[(size_t)me],
+                                c->bnd_off[(size_t)me + 1] - c->bnd_off[(size_t)me], p, nc, n, c->d_scal, dst, W,
+                                c->stream));
+    HIPCHK(c, launch_flag_peers(flg, me, W, c->peer_ticket, c->stream));
+    if (c->peer_barrier) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (c->peer_barrier(c->peer_barrier_user) != 0) return fail(c, MS_ERR_STATE, "peer exchange: the caller's barrier failed");
+    } else {
+      HIPCHK(c, launch_wait_flags(c->d_peer_flag + (size_t)par * 16, W, c->peer_ticket, c->d_h_err, c->stream));
+    }
+    HIPCHK(c, launch_unpack_boundary(c->d_bnd_rows, c->d_bnd_off, me, W, c->bnd_max, p, nc, n,
+                                     c->d_peer_slab + (size_t)par * W * c->peer_stride, c->peer_stride,
+                                     c->d_h_scal_all, c->stream, c->d_h_xseq, c->xticket, /*remote_written=*/true));
+  } else {
   HIPCHK(c, launch_pack_boundary(c->d_bnd_rows + c->bnd_off[(size_t)me],
                                  c->bnd_off[(size_t)me + 1] - c->bnd_off[(size_t)me], p, nc, n, c->d_scal,
                                  c->d_xsend, c->stream));
@@ -3346,12 +3388,12 @@ int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push, 
   } else if (W == 1) {
     HIPCHK(c, hipMemcpyAsync(c->d_xrecv, c->d_xsend, count * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   } else {
-    return fail(c, MS_ERR_STATE, "ms_shard_step: no communicator (ms_shard_comm_init / ms_shard_set_allgather)");
+    return fail(c, MS_ERR_STATE, "ms_shard_step: no communicator (ms_shard_comm_init / ms_shard_set_allgather / ms_shard_peer_*)");
   }
-  ++c->xticket;
   // the unpack kernel posts one sequence word per rank as soon as that rank's scalar header is in the mailbox
   HIPCHK(c, launch_unpack_boundary(c->d_bnd_rows, c->d_bnd_off, me, W, c->bnd_max, p, nc, n, c->d_xrecv, count,
                                    c->d_h_scal_all, c->stream, c->d_h_xseq, c->xticket));
+  }
   bool seen = false;
   for (long spin = 0; spin < 20000000L; ++spin) {
     seen = true;
@@ -3360,6 +3402,9 @@ int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push, 
     __builtin_ia32_pause();
   }
   if (!seen) HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->peer_on && c->h_err && (__atomic_load_n(c->h_err, __ATOMIC_ACQUIRE) >> 62) == 1)
+    return fail(c, MS_ERR_STATE, "peer exchange: a peer's flag did not arrive within the bounded wait (rank " +
+                                     std::to_string((int)((*c->h_err >> 32) & 0xff)) + ")");
   // fold in rank order: every rank adds the same doubles in the same order
   for (int sl : SH_SUM)
     if (slots & (1u << sl)) {
@@ -3440,6 +3485,95 @@ int ms_shard_set_allgather(ms_ctx* c, ms_allgather_fn fn, void* user) {
   c->allgather_cb = fn;
   c->allgather_user = user;
   return shard_buffers(c);
+}
+
+namespace {
+int peer_alloc(ms_ctx* c) {
+  if (c->d_peer_slab) return MS_OK;
+  if (c->shard_count > 16) return fail(c, MS_ERR_INVALID, "peer exchange: at most 16 ranks");
+  int rc = shard_buffers(c);
+  if (rc) return rc;
+  c->peer_stride = (size_t)MS_NSCAL + 10 * (size_t)c->bnd_max;
+  const size_t sb = sizeof(double) * 2 * (size_t)c->shard_count * c->peer_stride;
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_peer_slab), sb));
+  HIPCHK(c, hipMemset(c->d_peer_slab, 0, sb));
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_peer_flag), sizeof(unsigned long long) * 32));
+  HIPCHK(c, hipMemset(c->d_peer_flag, 0, sizeof(unsigned long long) * 32));
+  HIPCHK(c, hipDeviceSynchronize());
+  return MS_OK;
+}
+}  // namespace
+
+int ms_shard_peer_local(ms_ctx* c, void** recv_slab, void** flag_words) {
+  if (!c || !recv_slab || !flag_words) return MS_ERR_INVALID;
+  int rc = peer_alloc(c);
+  if (rc) return rc;
+  *recv_slab = c->d_peer_slab;
+  *flag_words = c->d_peer_flag;
+  return MS_OK;
+}
+
+int ms_shard_peer_export(ms_ctx* c, void* handles128) {
+  if (!c || !handles128) return MS_ERR_INVALID;
+  int rc = peer_alloc(c);
+  if (rc) return rc;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  hipIpcMemHandle_t h[2];
+  HIPCHK(c, hipIpcGetMemHandle(&h[0], c->d_peer_slab));
+  HIPCHK(c, hipIpcGetMemHandle(&h[1], c->d_peer_flag));
+  memcpy(handles128, h, 128);
+  return MS_OK;
+}
+
+int ms_shard_peer_open(ms_ctx* c, const void* handles_all) {
+  if (!c || !handles_all) return MS_ERR_INVALID;
+  int rc = peer_alloc(c);
+  if (rc) return rc;
+  const int W = c->shard_count;
+  c->peer_slabs.assign((size_t)W, nullptr);
+  c->peer_flags.assign((size_t)W, nullptr);
+  for (int r = 0; r < W; ++r) {
+    if (r == c->shard_rank) {
+      c->peer_slabs[(size_t)r] = c->d_peer_slab;
+      c->peer_flags[(size_t)r] = c->d_peer_flag;
+      continue;
+    }
+    hipIpcMemHandle_t h[2];
+    memcpy(h, static_cast<const char*>(handles_all) + 128 * (size_t)r, 128);
+    void *ps = nullptr, *pf = nullptr;
+    HIPCHK(c, hipIpcOpenMemHandle(&ps, h[0], hipIpcMemLazyEnablePeerAccess));
+    c->peer_opened.push_back(ps);
+    HIPCHK(c, hipIpcOpenMemHandle(&pf, h[1], hipIpcMemLazyEnablePeerAccess));
+    c->peer_opened.push_back(pf);
+    c->peer_slabs[(size_t)r] = static_cast<double*>(ps);
+    c->peer_flags[(size_t)r] = static_cast<unsigned long long*>(pf);
+  }
+  c->peer_on = true;
+  return MS_OK;
+}
+
+int ms_shard_peer_set_pointers(ms_ctx* c, void* const* recv_slabs, void* const* flag_words) {
+  if (!c || !recv_slabs || !flag_words) return MS_ERR_INVALID;
+  int rc = peer_alloc(c);
+  if (rc) return rc;
+  const int W = c->shard_count;
+  c->peer_slabs.assign((size_t)W, nullptr);
+  c->peer_flags.assign((size_t)W, nullptr);
+  for (int r = 0; r < W; ++r) {
+    c->peer_slabs[(size_t)r] = static_cast<double*>(recv_slabs[r]);
+    c->peer_flags[(size_t)r] = static_cast<unsigned long long*>(flag_words[r]);
+  }
+  if (c->peer_slabs[(size_t)c->shard_rank] != c->d_peer_slab)
+    return fail(c, MS_ERR_INVALID, "ms_shard_peer_set_pointers: the own entry must be ms_shard_peer_local's");
+  c->peer_on = true;
+  return MS_OK;
+}
+
+int ms_shard_peer_set_barrier(ms_ctx* c, ms_barrier_fn fn, void* user) {
+  if (!c) return MS_ERR_INVALID;
+  c->peer_barrier = fn;
+  c->peer_barrier_user = user;
+  return MS_OK;
 }
 
 int64_t ms_shard_exchange_count(const ms_ctx* c) { return c ? (int64_t)c->sh_exchanges : 0; }

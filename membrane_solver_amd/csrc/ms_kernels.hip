@@ -1227,12 +1227,15 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? (VOLROW ? 4 : MS_LE
     // spills exactly these six).  Instead one wave pulls the tile's pg rows into L2 now -- a 4-byte LDS-DMA per
     // 128-byte line into the (still unused) reduction scratch, no destination registers -- and the rows are loaded
     // after the loop, from L2.
-    if (!MS_ABL_NOHIST && a.dir_mode == 2 && tid < 64) {
+    if (!MS_ABL_NOHIST && a.dir_mode == 2 && tid < 128) {
+      // (wave 0: the previous gradient's rows; wave 1: the previous direction's, unless that is minus the gradient)
       const int n_lines = (t.n_owned * 24 + 127) >> 7;
-      if (tid < n_lines)
+      const int l = tid & 63;
+      const double* rows = tid < 64 ? a.pg : a.pd;
+      if (l < n_lines && (tid < 64 || !a.pd_neg_pg))
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)((const char*)a.pg + (size_t)t.v_lo * 24 + (size_t)tid * 128),
-            (__attribute__((address_space(3))) void*)red, 4, 0, 0);
+            (const __attribute__((address_space(1))) void*)((const char*)rows + (size_t)t.v_lo * 24 + (size_t)l * 128),
+            (__attribute__((address_space(3))) void*)(red + (tid < 64 ? 0 : 1)), 4, 0, 0);
     }
   } else if (!MS_ABL_NOHIST && a.dir_mode == 2 && tid < t.n_owned) {
     const size_t o = 3 * (size_t)(t.v_lo + tid);
@@ -1502,6 +1505,7 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? (VOLROW ? 4 : MS_LE
   if (LEAN && !MS_ABL_NOHIST && a.dir_mode == 2 && tid < t.n_owned) {
     const size_t o = 3 * (size_t)(t.v_lo + tid);
     h_pg = mk(a.pg[o], a.pg[o + 1], a.pg[o + 2]);
+    h_pd = a.pd_neg_pg ? -h_pg : mk(a.pd[o], a.pd[o + 1], a.pd[o + 2]);
   }
   if (ATOMIC) {
     __syncthreads();
@@ -1540,7 +1544,7 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? (VOLROW ? 4 : MS_LE
         const V3 pgv = h_pg;
         const double beta = dot_pinned(gi, gi - pgv) / (dot_pinned(pgv, pgv) + 1.0e-20);
         if (!(beta < 0.0)) {
-          const V3 q = LEAN ? -h_pg : h_pd;
+          const V3 q = h_pd;
           di = mk(fma(beta, q.x, -gi.x), fma(beta, q.y, -gi.y), fma(beta, q.z, -gi.z));
         }
       }
@@ -1611,8 +1615,7 @@ bool gradient_lean_instance(const GradientArgs& a) {
   const bool bend = (a.modules & MS_MOD_BENDING) != 0;
   const bool leaf = bend && a.bt_vert != nullptr;
   return a.m.T == FAST_T && a.m.tile_facets32 != nullptr && !leaf && bend && a.bending_grad_mode != MS_GRAD_APPROX &&
-         a.m.gamma_uniform && !a.m.has_boundary && !(a.modules & MS_MOD_VOLUME_PENALTY) &&
-         (a.dir_mode != 2 || a.pd_neg_pg) && !no_lean() && !a.m.no_fast;
+         a.m.gamma_uniform && !a.m.has_boundary && !(a.modules & MS_MOD_VOLUME_PENALTY) && !no_lean() && !a.m.no_fast;
 }
 
 hipError_t launch_gradient(const GradientArgs& a_in, int cap, int max_ent, hipStream_t s) {
@@ -2989,14 +2992,61 @@ __global__ void k_pack_boundary(const int32_t* rows, int n_rows, RowBufs b, cons
     for (int c = 0; c < b.ncomp[k]; ++c) *o++ = b.p[k][v * b.ncomp[k] + c];
 }
 
+// peer-to-peer form of the pack: block row y writes this rank's message into peer y's slab (dst.p[y] = the slot of THIS
+// rank there) with system-scope write-through stores -- the destination is another GPU's memory (or, for the own
+// slot, memory the unpack kernel reads with system-scope loads)
+struct PeerDst {
+  double* p[16];
+};
+__device__ __forceinline__ void st_sys_f64(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_pack_peers(const int32_t* rows, int n_rows, RowBufs b, const double* scal, PeerDst dst) {
+  double* send = dst.p[blockIdx.y];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < MS_NSCAL) st_sys_f64(send + j, ld_agent(scal + j));
+  if (j >= n_rows) return;
+  const size_t v = (size_t)rows[j];
+  double* o = send + MS_NSCAL + (size_t)j * b.comps;
+  for (int k = 0; k < b.n; ++k)
+    for (int c = 0; c < b.ncomp[k]; ++c) st_sys_f64(o++, b.p[k][v * b.ncomp[k] + c]);
+}
+struct PeerFlags {
+  unsigned long long* p[16];
+};
+// queued behind the pack kernel (whose stores have completed and been released by then): lane r raises this rank's
+// word on peer r
+__global__ void k_flag_peers(PeerFlags f, int me, int world, unsigned long long ticket) {
+  const int r = threadIdx.x;
+  if (r < world) __hip_atomic_store(f.p[r] + me, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// one wave: lane r waits until peer r's word here has reached `ticket`.  BOUNDED: a peer that never arrives ends the
+// wait after ~2 s with an error word for the host instead of a wave that never finishes
+__global__ void k_wait_flags(const unsigned long long* my_flags, int world, unsigned long long ticket,
+                             unsigned long long* host_err) {
+  const int r = threadIdx.x;
+  bool ok = r >= world;
+  for (long it = 0; it < (1L << 22) && !__all(ok); ++it) {
+    if (!ok) ok = __hip_atomic_load(my_flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= ticket;
+    if (!__all(ok)) __builtin_amdgcn_s_sleep(32);
+  }
+  if (!ok && host_err) st_sys(host_err, (1ull << 62) | ((unsigned long long)r << 32) | (ticket & 0xffffffffull));
+}
+
 // grid (ceil(max_rows/256), world); recv = world x stride doubles
+template <bool REMOTE>
 __global__ void k_unpack_boundary(const int32_t* rows_all, const int32_t* row_off, int me,
                                   RowBufs b, const double* recv, size_t stride, double* scal_all,
                                   unsigned long long* host_seq, unsigned long long ticket) {
   const int r = blockIdx.y;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const double* src = recv + (size_t)r * stride;
-  if (j < MS_NSCAL) scal_all[r * MS_NSCAL + j] = src[j];
+  // REMOTE: the slab was written by other GPUs (peer-to-peer exchange): read it with system-scope loads, past this
+  // GPU's caches
+  auto ld = [&](const double* q) {
+    return REMOTE ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : *q;
+  };
+  if (j < MS_NSCAL) scal_all[r * MS_NSCAL + j] = ld(src + j);
   if (host_seq != nullptr && blockIdx.x == 0) {
     // the host only waits for the scalars (the rows are consumed by later kernels of the same stream): rank r's
     // header is complete once this workgroup has written it -> post its sequence word, no extra kernel
@@ -3012,7 +3062,7 @@ __global__ void k_unpack_boundary(const int32_t* rows_all, const int32_t* row_of
   const size_t v = (size_t)rows_all[row_off[r] + j];
   const double* i = src + MS_NSCAL + (size_t)j * b.comps;
   for (int k = 0; k < b.n; ++k)
-    for (int c = 0; c < b.ncomp[k]; ++c) b.p[k][v * b.ncomp[k] + c] = *i++;
+    for (int c = 0; c < b.ncomp[k]; ++c) b.p[k][v * b.ncomp[k] + c] = ld(i++);
 }
 
 hipError_t launch_pack_boundary(const int32_t* rows, int n_rows, const double* const* bufs,
@@ -3033,7 +3083,7 @@ hipError_t launch_pack_boundary(const int32_t* rows, int n_rows, const double* c
 hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_off, int me, int world,
                                   int max_rows, double* const* bufs, const int* ncomp, int n_bufs,
                                   const double* recv, size_t stride, double* scal_all, hipStream_t s,
-                                  unsigned long long* host_seq, unsigned long long ticket) {
+                                  unsigned long long* host_seq, unsigned long long ticket, bool remote_written) {
   RowBufs b{};
   b.n = n_bufs;
   for (int k = 0; k < n_bufs; ++k) {
@@ -3042,8 +3092,44 @@ hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_of
     b.comps += ncomp[k];
   }
   const int n = max_rows > MS_NSCAL ? max_rows : MS_NSCAL;
-  hipLaunchKernelGGL(k_unpack_boundary, dim3((n + 255) / 256, world), dim3(256), 0, s, rows_all, row_off,
-                     me, b, recv, stride, scal_all, host_seq, ticket);
+  if (remote_written)
+    hipLaunchKernelGGL(k_unpack_boundary<true>, dim3((n + 255) / 256, world), dim3(256), 0, s, rows_all, row_off,
+                       me, b, recv, stride, scal_all, host_seq, ticket);
+  else
+    hipLaunchKernelGGL(k_unpack_boundary<false>, dim3((n + 255) / 256, world), dim3(256), 0, s, rows_all, row_off,
+                       me, b, recv, stride, scal_all, host_seq, ticket);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_peers(const int32_t* rows, int n_rows, const double* const* bufs, const int* ncomp, int n_bufs,
+                             const double* scal, double* const* dst, int world, hipStream_t s) {
+  if (world > 16) return hipErrorInvalidValue;
+  RowBufs b{};
+  b.n = n_bufs;
+  for (int k = 0; k < n_bufs; ++k) {
+    b.p[k] = const_cast<double*>(bufs[k]);
+    b.ncomp[k] = ncomp[k];
+    b.comps += ncomp[k];
+  }
+  PeerDst d{};
+  for (int r = 0; r < world; ++r) d.p[r] = dst[r];
+  const int n = n_rows > MS_NSCAL ? n_rows : MS_NSCAL;
+  hipLaunchKernelGGL(k_pack_peers, dim3((n + 255) / 256, world), dim3(256), 0, s, rows, n_rows, b, scal, d);
+  return hipGetLastError();
+}
+
+hipError_t launch_flag_peers(unsigned long long* const* peer_flags, int me, int world, unsigned long long ticket,
+                             hipStream_t s) {
+  if (world > 16) return hipErrorInvalidValue;
+  PeerFlags f{};
+  for (int r = 0; r < world; ++r) f.p[r] = peer_flags[r];
+  hipLaunchKernelGGL(k_flag_peers, dim3(1), dim3(64), 0, s, f, me, world, ticket);
+  return hipGetLastError();
+}
+
+hipError_t launch_wait_flags(const unsigned long long* my_flags, int world, unsigned long long ticket,
+                             unsigned long long* host_err, hipStream_t s) {
+  hipLaunchKernelGGL(k_wait_flags, dim3(1), dim3(64), 0, s, my_flags, world, ticket, host_err);
   return hipGetLastError();
 }
 

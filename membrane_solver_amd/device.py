@@ -394,6 +394,44 @@ class DeviceMesh:
         self._allgather_cb = L.ALLGATHER_FN(thunk)  # keep the trampoline alive
         self._chk(L.lib().ms_shard_set_allgather(self._h, self._allgather_cb, None), "ms_shard_set_allgather")
 
+    # peer-to-peer exchange of the library driver (include/membrane_hip.h, ms_shard_peer_*)
+    def shard_peer_local(self):
+        """-> (slab pointer, flag-word pointer) of this rank, as integers (contexts of one process exchange these)."""
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        self._chk(L.lib().ms_shard_peer_local(self._h, ctypes.byref(a), ctypes.byref(b)), "ms_shard_peer_local")
+        return int(a.value or 0), int(b.value or 0)
+
+    def shard_peer_set_pointers(self, slabs, flags):
+        n = len(slabs)
+        a = (ctypes.c_void_p * n)(*[ctypes.c_void_p(int(x)) for x in slabs])
+        b = (ctypes.c_void_p * n)(*[ctypes.c_void_p(int(x)) for x in flags])
+        self._chk(L.lib().ms_shard_peer_set_pointers(self._h, a, b), "ms_shard_peer_set_pointers")
+
+    def shard_peer_set_barrier(self, fn):
+        """fn() -> None: returns once every rank of this process has raised its flags (host-side wait)."""
+        def thunk(_user):
+            try:
+                fn()
+                return 0
+            except Exception:  # pragma: no cover - surfaced as MS_ERR_STATE
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        self._peer_barrier_cb = L.BARRIER_FN(thunk)  # keep the trampoline alive
+        self._chk(L.lib().ms_shard_peer_set_barrier(self._h, ctypes.cast(self._peer_barrier_cb, ctypes.c_void_p), None),
+                  "ms_shard_peer_set_barrier")
+
+    def shard_peer_export(self) -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        self._chk(L.lib().ms_shard_peer_export(self._h, buf), "ms_shard_peer_export")
+        return bytes(buf.raw)
+
+    def shard_peer_open(self, handles_all: bytes):
+        buf = ctypes.create_string_buffer(bytes(handles_all), len(handles_all))
+        self._chk(L.lib().ms_shard_peer_open(self._h, buf), "ms_shard_peer_open")
+
     def shard_step(self, *, stepper: int, step_size: float, tol: float = 1e-6, max_iter: int = 10,
                    beta: float = 0.7, c: float = 1e-4, gamma: float = 1.5, alpha_max_factor: float = 10.0,
                    restart_interval: int = 10, edge_fraction: float = 0.0, reuse_energy0: int = 2) -> StepResult:

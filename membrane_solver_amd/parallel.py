@@ -428,6 +428,27 @@ class HipShardBackend:
         dist.broadcast(idt, src=0)
         self.dm.shard_comm_init(bytes(idt.cpu().numpy().tobytes()))
 
+    def enable_peer_exchange(self):
+        """The library driver's exchange without a collective library in the step: every rank's pack kernel writes
+        its message straight into every peer's receive slab (IPC-mapped device memory over xGMI), flag words order
+        it (include/membrane_hip.h, ms_shard_peer_*).  In-process groups (tests) hand each other raw pointers;
+        process groups all-gather the IPC handles once, over whatever backend the group has."""
+        if self.exchange_mode != "halo":
+            raise L.MembraneHipError("the peer-to-peer exchange moves boundary rows only (exchange='halo')")
+        dist = self.dist
+        if hasattr(dist, "share"):  # in-process stand-in: one address space
+            mine = self.dm.shard_peer_local()
+            table = dist.share(self.rank, mine)
+            self.dm.shard_peer_set_pointers([t[0] for t in table], [t[1] for t in table])
+            # (one process, one device: the ranks share its hardware queues, so they wait for each other on the host)
+            self.dm.shard_peer_set_barrier(dist.bar.wait)
+            return
+        mine = self.dm.shard_peer_export()
+        table = [None] * self.world
+        dist.all_gather_object(table, mine)
+        self.dm.shard_peer_open(b"".join(table))
+        dist.barrier()
+
     def gather_positions(self) -> np.ndarray:
         """Assemble the full position array (owner rows of x from every rank) -- between steps a
         rank only keeps the rows it reads (own + halo) current."""

@@ -1,0 +1,107 @@
+"""The peer-to-peer exchange across PROCESSES: two ranks (two processes sharing this box's one GPU), their receive slabs
+and flag words exchanged as hipIpcMemHandle_t over a gloo process group, every boundary row written by the other rank's
+pack kernel through the IPC mapping -- no RCCL anywhere (RCCL refuses two ranks on one GPU; the peer exchange does not
+need it).  Each rank's step log must equal the single-context run's."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+RANK_SCRIPT = r"""
+import json, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["MS_ROOT"])
+from membrane_solver_amd import _lib as L, meshgen
+from membrane_solver_amd.parallel import HipShardBackend, LibraryShardedStepper
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo")
+P, T = meshgen.icosphere(24)
+P = meshgen.smooth_displace(P, 0.06)
+nv, nf = len(P), len(T)
+be = HipShardBackend(P, T, rank=rank, world=world, device=0, tile_vertices=64)
+be.dm.set_deterministic(True)
+be.configure(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING, gamma=np.full(nf, 1.1), kappa=np.full(nv, 0.9),
+             c0=np.full(nv, 0.1))
+be.enable_peer_exchange()
+drv = LibraryShardedStepper(be, stepper=L.MS_STEPPER_CG, reuse_energy0=2)
+log, step = [], 1e-3
+for _ in range(8):
+    r = drv.step(step, tol=1e-9)
+    log.append((float(r.success), r.next_step, r.energy, r.grad_norm, int(r.trials)))
+    step = r.next_step
+    if not r.success:
+        drv.reset()
+torch.cuda.synchronize()
+dist.barrier()
+print("RESULT " + json.dumps({"rank": rank, "log": log, "exchanges": drv.exchanges}), flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_two_processes_exchange_through_ipc_mapped_slabs():
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MS_ROOT=ROOT, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", RANK_SCRIPT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, e[-3000:]
+        line = [ln for ln in o.splitlines() if ln.startswith("RESULT ")]
+        assert line, (o[-500:], e[-2000:])
+        outs.append(json.loads(line[-1][7:]))
+
+    # single-context reference in this process
+    P, T = meshgen.icosphere(24)
+    P = meshgen.smooth_displace(P, 0.06)
+    nv, nf = len(P), len(T)
+    dm = DeviceMesh(P, T, tile_vertices=64)
+    dm.set_deterministic(True)
+    dm.set_surface_tension(np.full(nf, 1.1))
+    dm.set_bending_params(np.full(nv, 0.9), np.full(nv, 0.1))
+    dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING)
+    ref, step = [], 1e-3
+    for _ in range(8):
+        r = dm.step(stepper=L.MS_STEPPER_CG, step_size=step, tol=1e-9, reuse_energy0=2)
+        ref.append((float(r.success), r.next_step, r.energy, r.grad_norm, int(r.trials)))
+        step = r.next_step
+        if not r.success:
+            dm.reset_stepper()
+    dm.close()
+    ref = np.array(ref)
+    assert ref[:, 0].sum() >= 2
+    for o in outs:
+        got = np.array(o["log"])
+        assert np.array_equal(got[:, 0], ref[:, 0]), (got, ref)
+        assert np.array_equal(got[:, 4], ref[:, 4]), (got, ref)
+        assert np.allclose(got[:, 1], ref[:, 1], rtol=1e-12)
+        assert np.allclose(got[:, 2], ref[:, 2], rtol=1e-12)
+        assert np.allclose(got[:, 3], ref[:, 3], rtol=1e-9)
+        assert o["exchanges"] > 0
+    assert outs[0]["exchanges"] == outs[1]["exchanges"]

@@ -55,6 +55,16 @@ class ThreadGroup:
             self.done[k].synchronize()
         self.bar.wait()
 
+    def share(self, rank, item):
+        """Every rank contributes one Python object; all get the rank-ordered list (one address space)."""
+        if not hasattr(self, "shared"):
+            self.shared = [None] * self.world
+        self.shared[rank] = item
+        self.bar.wait()
+        out = list(self.shared)
+        self.bar.wait()
+        return out
+
     def all_reduce(self, t):
         """SUM over the ranks in rank order (the dense exchange mode): every rank reads every peer's tensor, and
         overwrites its own only after all of them have finished reading."""
@@ -82,7 +92,8 @@ class ThreadGroup:
         self.bar.wait()
 
 
-@pytest.mark.parametrize("driver,pair", [("python", "0"), ("library", "0"), ("library", "2"), ("python-dense", "0")])
+@pytest.mark.parametrize("driver,pair", [("python", "0"), ("library", "0"), ("library", "2"), ("python-dense", "0"),
+                                         ("library-peer", "0"), ("library-peer", "2")])
 @pytest.mark.parametrize("with_volume,world,level,freq,tile", [
     (False, 2, 2, 16, 64), (True, 2, 2, 16, 64), (False, 3, 2, 16, 64), (False, 2, 0, 16, 64), (True, 3, 0, 16, 64),
     (False, 4, 2, 160, 256),  # 512 000 facets, default tile size, 4 shards: sizes near the headline
@@ -149,11 +160,15 @@ def _run_shard_case(with_volume, world, level, freq, tile, driver, pair, monkeyp
         try:
             grp.bind(rank)
             be = HipShardBackend(P, T, rank=rank, world=world, device=0, tile_vertices=tile, fixed=fixed, group=grp,
-                                 debug_poison=(driver != "library"),
+                                 debug_poison=not driver.startswith("library"),
                                  exchange="dense" if driver == "python-dense" else "halo")
             be.configure(modules=mods, gamma=gamma, kappa=kappa, c0=c0, target_volume=V0)
             if driver == "library":
                 be.enable_library_driver()
+                drv = LibraryShardedStepper(be, stepper=L.MS_STEPPER_CG, reuse_energy0=level)
+            elif driver == "library-peer":
+                # no all-gather at all: every rank's pack kernel writes into every peer's slab, flag words order it
+                be.enable_peer_exchange()
                 drv = LibraryShardedStepper(be, stepper=L.MS_STEPPER_CG, reuse_energy0=level)
             else:
                 drv = ShardedStepper(be, stepper=L.MS_STEPPER_CG, reuse_energy0=level)
@@ -204,7 +219,7 @@ def _run_shard_case(with_volume, world, level, freq, tile, driver, pair, monkeyp
         for i in range(n_steps):
             ok = bool(ref[i, 0])
             trials, guards = trial_counts[0][i]
-            implicit = driver == "library" and carried and prev_failed_without_trials
+            implicit = driver.startswith("library") and carried and prev_failed_without_trials
             expect += (0 if carried else 1) + (0 if implicit else 1) + trials + guards
             carried = ok or (trials + guards == 0 and carried)
             prev_failed_without_trials = (not ok) and trials + guards == 0
