@@ -781,14 +781,16 @@ def main_sharded(args, rank, world, local_rank):
     # -- one SCALE invocation yields all three curves: the headline mesh (strong), 16 M facets (strong, the size at
     #    which 8 GPUs have 2 M facets each) and 2 M facets per GPU (weak); the latter two coincide at 8 GPUs
     extra = {}
-    if not args.no_large and not args.weak and args.freq == 320:
+    if not args.weak and args.freq == 320:
         be.dm.close()
         for key, f in (("peer_exchange", 320), ("strong_16M_facets", LARGE_FREQ), ("strong_16M_facets_peer_exchange", LARGE_FREQ),
                        ("weak_2M_facets_per_gpu", weak_frequency(world, 320))):
+            if args.no_large and f != 320:
+                continue
             try:
                 if key.endswith("peer_exchange"):
-                    extra[key] = sharded_extra_leg(args, rank, world, local_rank, f, min(args.steps, 100 if f == 320 else 40),
-                                                   min(args.warmup, 10), exchange="peer")
+                    extra[key] = sharded_extra_leg(args, rank, world, local_rank, f, args.steps if f == 320 else min(args.steps, 40),
+                                                   args.warmup if f == 320 else min(args.warmup, 10), exchange="peer")
                 elif key.startswith("weak") and f == LARGE_FREQ and "strong_16M_facets" in extra:
                     extra[key] = dict(extra["strong_16M_facets"], note="same run as strong_16M_facets at 8 GPUs")
                 elif key.startswith("weak") and f == 320:

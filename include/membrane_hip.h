@@ -448,8 +448,9 @@ int ms_shard_comm_init(ms_ctx *ctx, const void *id128);
 int ms_shard_set_allgather(ms_ctx *ctx, ms_allgather_fn fn, void *user);
 /* Peer-to-peer exchange (no collective library in the step): every rank's pack kernel stores its scalar header and
  * boundary rows straight into EVERY peer's receive slab (xGMI stores through IPC-mapped device memory), a one-wave
- * kernel then raises this rank's flag word on every peer, and the unpack kernel starts behind a bounded wait on the
- * rank's own flag words.  Two slabs alternate (a peer can be at most one exchange ahead).
+ * kernel then raises this rank's flag word on every peer, and every block row of the unpack kernel waits -- bounded:
+ * a peer that never arrives becomes an error after ~2 s, not a wave that never finishes -- for the flag word of the
+ * rank whose message it unpacks.  Two slabs alternate (a peer can be at most one exchange ahead).
  *   ms_shard_peer_export: fills handles[0..127] with the hipIpcMemHandle_t of this rank's receive slab and of its flag
  *                          words (64 bytes each); the caller all-gathers the 128-byte records in rank order;
  *   ms_shard_peer_open:   opens every peer's two handles (world x 128 bytes, rank order; the own record is skipped);

@@ -3047,8 +3047,8 @@ int ms_minimize(ms_ctx* c, const ms_minimize_params* mp, int n_steps, ms_minimiz
     // rounds may be queued ahead of the step they belong to while this loop is the only thing touching the context
     c->steps_left = n_steps - 1 - i;
     c->ahead_allowed = c->ahead_enable && i + 1 < n_steps && !mp->relax_tilts && !mp->fixed_step_mode &&
-                       c->shard_count == 1 && !c->comm && !c->allgather_cb;
-    rc = (c->shard_count > 1 || c->comm || c->allgather_cb) ? ms_shard_step(c, &mp->stepper, step_in, mp->tol, &r)
+                       c->shard_count == 1 && !c->comm && !c->allgather_cb && !c->peer_on;
+    rc = (c->shard_count > 1 || c->comm || c->allgather_cb || c->peer_on) ? ms_shard_step(c, &mp->stepper, step_in, mp->tol, &r)
                                                             : ms_step(c, &mp->stepper, step_in, mp->tol, &r);
     c->ahead_allowed = false;
     if (rc) return rc;
@@ -3364,15 +3364,17 @@ int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push, 
                                 c->bnd_off[(size_t)me + 1] - c->bnd_off[(size_t)me], p, nc, n, c->d_scal, dst, W,
                                 c->stream));
     HIPCHK(c, launch_flag_peers(flg, me, W, c->peer_ticket, c->stream));
-    if (c->peer_barrier) {
+    const unsigned long long* wait_flags = c->d_peer_flag + (size_t)par * 16;
+    if (c->peer_barrier) {  // (contexts of one process wait on the host: see ms_shard_peer_set_barrier)
       HIPCHK(c, hipStreamSynchronize(c->stream));
       if (c->peer_barrier(c->peer_barrier_user) != 0) return fail(c, MS_ERR_STATE, "peer exchange: the caller's barrier failed");
-    } else {
-      HIPCHK(c, launch_wait_flags(c->d_peer_flag + (size_t)par * 16, W, c->peer_ticket, c->d_h_err, c->stream));
+      wait_flags = nullptr;
     }
+    // every block row of the unpack kernel waits (bounded) for the flag of the rank whose message it unpacks
     HIPCHK(c, launch_unpack_boundary(c->d_bnd_rows, c->d_bnd_off, me, W, c->bnd_max, p, nc, n,
                                      c->d_peer_slab + (size_t)par * W * c->peer_stride, c->peer_stride,
-                                     c->d_h_scal_all, c->stream, c->d_h_xseq, c->xticket, /*remote_written=*/true));
+                                     c->d_h_scal_all, c->stream, c->d_h_xseq, c->xticket, /*remote_written=*/true,
+                                     wait_flags, c->peer_ticket, c->d_h_err));
   } else {
   HIPCHK(c, launch_pack_boundary(c->d_bnd_rows + c->bnd_off[(size_t)me],
                                  c->bnd_off[(size_t)me + 1] - c->bnd_off[(size_t)me], p, nc, n, c->d_scal,

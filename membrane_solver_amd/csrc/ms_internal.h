@@ -322,16 +322,16 @@ hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_of
                                   int max_rows, double* const* bufs, const int* ncomp, int n_bufs,
                                   const double* recv, size_t stride, double* scal_all, hipStream_t s,
                                   unsigned long long* host_seq = nullptr, unsigned long long ticket = 0,
-                                  bool remote_written = false);
+                                  bool remote_written = false, const unsigned long long* wait_flags = nullptr,
+                                  unsigned long long wait_ticket = 0, unsigned long long* host_err = nullptr);
 hipError_t launch_post_seq(unsigned long long* host_seq, unsigned long long ticket, hipStream_t s);
 // peer-to-peer exchange: pack straight into every peer's slab (dst[r] = that peer's slot for this rank), raise this
-// rank's flag on every peer, wait (bounded) for every peer's flag here
+// rank's flag on every peer; the unpack kernel waits (bounded) for every peer's flag here
 hipError_t launch_pack_peers(const int32_t* rows, int n_rows, const double* const* bufs, const int* ncomp, int n_bufs,
                              const double* scal, double* const* dst, int world, hipStream_t s);
 hipError_t launch_flag_peers(unsigned long long* const* peer_flags, int me, int world, unsigned long long ticket,
                              hipStream_t s);
-hipError_t launch_wait_flags(const unsigned long long* my_flags, int world, unsigned long long ticket,
-                             unsigned long long* host_err, hipStream_t s);
+
 hipError_t launch_axpy_rows(int64_t row0, int64_t row1, const int32_t* extra, int n_extra,
                             const uint8_t* vflags, double* x, const double* y, double coef,
                             hipStream_t s);

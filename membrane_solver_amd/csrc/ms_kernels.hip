@@ -3020,27 +3020,33 @@ __global__ void k_flag_peers(PeerFlags f, int me, int world, unsigned long long 
   const int r = threadIdx.x;
   if (r < world) __hip_atomic_store(f.p[r] + me, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// one wave: lane r waits until peer r's word here has reached `ticket`.  BOUNDED: a peer that never arrives ends the
-// wait after ~2 s with an error word for the host instead of a wave that never finishes
-__global__ void k_wait_flags(const unsigned long long* my_flags, int world, unsigned long long ticket,
-                             unsigned long long* host_err) {
-  const int r = threadIdx.x;
-  bool ok = r >= world;
-  for (long it = 0; it < (1L << 22) && !__all(ok); ++it) {
-    if (!ok) ok = __hip_atomic_load(my_flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= ticket;
-    if (!__all(ok)) __builtin_amdgcn_s_sleep(32);
-  }
-  if (!ok && host_err) st_sys(host_err, (1ull << 62) | ((unsigned long long)r << 32) | (ticket & 0xffffffffull));
-}
-
 // grid (ceil(max_rows/256), world); recv = world x stride doubles
 template <bool REMOTE>
 __global__ void k_unpack_boundary(const int32_t* rows_all, const int32_t* row_off, int me,
                                   RowBufs b, const double* recv, size_t stride, double* scal_all,
-                                  unsigned long long* host_seq, unsigned long long ticket) {
+                                  unsigned long long* host_seq, unsigned long long ticket,
+                                  const unsigned long long* wait_flags, unsigned long long wait_ticket,
+                                  unsigned long long* host_err) {
   const int r = blockIdx.y;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const double* src = recv + (size_t)r * stride;
+  if (REMOTE && wait_flags != nullptr) {
+    // peer-to-peer exchange: rank r's message is complete once its flag word here has reached the exchange's ticket.
+    // BOUNDED wait (a peer that never arrives ends it after ~2 s with an error word for the host instead of a wave
+    // that never finishes); the workgroup's other waves sit at the barrier meanwhile.
+    __shared__ int arrived;
+    if (threadIdx.x == 0) {
+      bool ok = false;
+      for (long it = 0; it < (1L << 22) && !ok; ++it) {
+        ok = __hip_atomic_load(wait_flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= wait_ticket;
+        if (!ok) __builtin_amdgcn_s_sleep(32);
+      }
+      arrived = ok ? 1 : 0;
+      if (!ok && host_err) st_sys(host_err, (1ull << 62) | ((unsigned long long)r << 32) | (wait_ticket & 0xffffffffull));
+    }
+    __syncthreads();
+    if (!arrived) return;
+  }
   // REMOTE: the slab was written by other GPUs (peer-to-peer exchange): read it with system-scope loads, past this
   // GPU's caches
   auto ld = [&](const double* q) {
@@ -3083,7 +3089,9 @@ hipError_t launch_pack_boundary(const int32_t* rows, int n_rows, const double* c
 hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_off, int me, int world,
                                   int max_rows, double* const* bufs, const int* ncomp, int n_bufs,
                                   const double* recv, size_t stride, double* scal_all, hipStream_t s,
-                                  unsigned long long* host_seq, unsigned long long ticket, bool remote_written) {
+                                  unsigned long long* host_seq, unsigned long long ticket, bool remote_written,
+                                  const unsigned long long* wait_flags, unsigned long long wait_ticket,
+                                  unsigned long long* host_err) {
   RowBufs b{};
   b.n = n_bufs;
   for (int k = 0; k < n_bufs; ++k) {
@@ -3094,10 +3102,10 @@ hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_of
   const int n = max_rows > MS_NSCAL ? max_rows : MS_NSCAL;
   if (remote_written)
     hipLaunchKernelGGL(k_unpack_boundary<true>, dim3((n + 255) / 256, world), dim3(256), 0, s, rows_all, row_off,
-                       me, b, recv, stride, scal_all, host_seq, ticket);
+                       me, b, recv, stride, scal_all, host_seq, ticket, wait_flags, wait_ticket, host_err);
   else
     hipLaunchKernelGGL(k_unpack_boundary<false>, dim3((n + 255) / 256, world), dim3(256), 0, s, rows_all, row_off,
-                       me, b, recv, stride, scal_all, host_seq, ticket);
+                       me, b, recv, stride, scal_all, host_seq, ticket, nullptr, 0ull, nullptr);
   return hipGetLastError();
 }
 
@@ -3127,11 +3135,6 @@ hipError_t launch_flag_peers(unsigned long long* const* peer_flags, int me, int 
   return hipGetLastError();
 }
 
-hipError_t launch_wait_flags(const unsigned long long* my_flags, int world, unsigned long long ticket,
-                             unsigned long long* host_err, hipStream_t s) {
-  hipLaunchKernelGGL(k_wait_flags, dim3(1), dim3(64), 0, s, my_flags, world, ticket, host_err);
-  return hipGetLastError();
-}
 
 // One word to the pinned mailbox after everything queued before it on the stream has completed
 // (a kernel boundary orders the earlier kernels' host writes before this one).
