@@ -5,7 +5,7 @@ set +e
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 60 --warmup 20 --cpu-steps 0"
+B="python3 $R/bench.py --steps 60 --warmup 20 --cpu-steps 0 --no-large"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- $B > $R/gpurun_out/${TAG}_stats.json 2> $R/gpurun_out/${TAG}_stats.err
 B2="python3 $R/bench.py --steps 40 --warmup 20 --cpu-steps 0 --no-roofline --headline-only"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_fetch -- $B2 > /dev/null 2> $R/gpurun_out/${TAG}_fetch.err
