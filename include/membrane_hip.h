@@ -373,6 +373,10 @@ typedef struct ms_minimize_result {
   int volume_cache_current; /* the loop ended right after a drift check that did NOT project: Body's cached
                              * volume is current, so a finalize projection starts from the cached gradient
                              * (pass it as first_step_cached to ms_project_volume_cached)               */
+  int energy_current_valid; /* the step logic already holds the module energies of the positions the loop ended at (the
+                             * accepted trial's, or the unchanged x's after a failed step; evaluation reuse level 2): */
+  double energy_current;    /* ... their sum -- Minimizer.minimize's final compute_energy() (minimizer.py:1524)
+                             * without another energy pass                                                */
 } ms_minimize_result;
 
 int ms_minimize(ms_ctx *ctx, const ms_minimize_params *params, int n_steps,

@@ -94,7 +94,8 @@ class ms_minimize_result(ctypes.Structure):
                 ("step_success", ctypes.c_int), ("accepted", ctypes.c_int), ("trials", ctypes.c_int),
                 ("guard_rejects", ctypes.c_int), ("moved", ctypes.c_int), ("step_size", ctypes.c_double),
                 ("energy_eval", ctypes.c_double), ("grad_norm", ctypes.c_double),
-                ("volume_cache_current", ctypes.c_int)]
+                ("volume_cache_current", ctypes.c_int), ("energy_current_valid", ctypes.c_int),
+                ("energy_current", ctypes.c_double)]
 
 
 class ms_step_result(ctypes.Structure):

@@ -3119,6 +3119,13 @@ int ms_minimize(ms_ctx* c, const ms_minimize_params* mp, int n_steps, ms_minimiz
     }
   }
   drop_ahead(c, /*ran=*/2);
+  if (c->carry_valid && !(c->params.modules & MS_ANY_TILT_MODS)) {
+    // the mailbox energies describe the positions the loop ended at: the caller's final energy needs no pass
+    double e[4];
+    energies_from_mailbox(c, e);
+    out->energy_current = e[0] + e[1] + e[2] + e[3];
+    out->energy_current_valid = 1;
+  }
   return MS_OK;
 }
 

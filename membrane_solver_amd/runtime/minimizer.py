@@ -523,10 +523,16 @@ class Minimizer:
             early = bool(out.converged or out.zero_step_exit)
             if out.converged:
                 logger.info("Converged in %d iterations; |grad E|=%.3e", out.iterations - 1, out.grad_norm)
+            moved_by_finalize = False
             if not out.zero_step_exit:  # minimizer.py:1324-1337 / :1516-1535 finalize the constraints
-                moved |= self._enforce(dm, "finalize", first_step_cached=bool(out.volume_cache_current))
+                moved_by_finalize = self._enforce(dm, "finalize", first_step_cached=bool(out.volume_cache_current))
+                moved |= moved_by_finalize
             if out.converged:
                 energy = float(out.energy_eval) + self._energy_offset
+            elif out.energy_current_valid and not moved_by_finalize:
+                # the step logic already holds the energies of the positions the loop ended at (reuse level 2: a pass
+                # whose result is on the device is not repeated)
+                energy = float(out.energy_current) + self._energy_offset
             else:
                 energy = float(dm.energy().sum()) + self._energy_offset
             if moved or self._device_ahead:
