@@ -723,7 +723,7 @@ def test_default_mode_ladder_at_full_size(monkeypatch):
         dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING)
         step, rows = 1e-6, []
         for _ in range(40):
-            r = dm.step(stepper=L.MS_STEPPER_CG, step_size=step)
+            r = dm.step(stepper=L.MS_STEPPER_CG, step_size=step, reuse_energy0=2)  # (level 2: the queue's precondition)
             rows.append((float(r.success), float(r.trials), r.next_step, r.energy, r.alpha))
             step = r.next_step
             if not r.success:
@@ -737,3 +737,53 @@ def test_default_mode_ladder_at_full_size(monkeypatch):
     assert np.allclose(plain[:, 2], ladder[:, 2], rtol=1e-12, atol=0)
     assert np.allclose(plain[:, 4], ladder[:, 4], rtol=1e-12, atol=0)
     assert np.allclose(plain[:, 3], ladder[:, 3], rtol=1e-10, atol=0)
+
+
+@pytest.mark.parametrize("volume_row", [False, True])
+def test_rounds_queued_ahead_do_not_change_the_trajectory(volume_row, monkeypatch):
+    """ms_minimize at FULL size (2 048 000 facets, fixed-order sums so that runs are bitwise comparable), three ways:
+    without the line-search queue (MS_SPECULATE=0: every decision on the host), with the queue but without rounds queued
+    ahead of their step (MS_AHEAD=0), and the default.  The step logs -- success, next step size, energies, |g|, <g,d>,
+    accepted alpha, trial counts of every step -- must be equal bit for bit; the queue's own book-keeping must show
+    that the device's decisions were replayed without a single difference and that rounds were adopted."""
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+
+    P, T = meshgen.icosphere(320)
+    P = meshgen.smooth_displace(P, 0.05)
+    nv, nf = len(P), len(T)
+    v0, v1, v2 = P[T[:, 0]], P[T[:, 1]], P[T[:, 2]]
+    V0 = float(np.einsum("ij,ij->i", np.cross(v1, v2), v0).sum() / 6.0)
+    logs, stats = [], []
+    for env in ({"MS_SPECULATE": "0"}, {"MS_AHEAD": "0"}, {}):
+        for k in ("MS_SPECULATE", "MS_AHEAD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dm = DeviceMesh(P, T)
+        dm.set_deterministic(True)
+        dm.set_surface_tension(np.ones(nf))
+        dm.set_bending_params(np.ones(nv), np.zeros(nv))
+        dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING | (L.MS_CON_VOLUME if volume_row else 0),
+                      target_volume=V0)
+        mp = L.ms_minimize_params()
+        mp.stepper = L.ms_stepper_params(L.MS_STEPPER_CG, 10, 0.7, 1e-4, 1.5, 10.0, 10, 0.0, 2)
+        mp.step_size, mp.tol = 1e-6, 1e-9
+        mp.fixed_step_mode, mp.fixed_step = 0, 1e-6
+        mp.max_zero_steps, mp.step_size_floor = 10, 1e-8
+        out, log = dm.minimize(mp, 36, want_log=True)
+        logs.append(np.array(log))
+        stats.append(dm.queue_stats())
+        x = dm.get_positions()
+        logs[-1] = (logs[-1], x)
+        dm.close()
+    (plain, x_plain), (queue, x_queue), (ahead, x_ahead) = logs
+    assert plain[:, 0].sum() >= 12 and plain[:, 7].max() >= 2, "the run is meant to accept steps after backtracking"
+    assert np.array_equal(plain, queue), "the queue changed the trajectory"
+    assert np.array_equal(plain, ahead), "rounds queued ahead changed the trajectory"
+    assert np.array_equal(x_plain, x_queue) and np.array_equal(x_plain, x_ahead)
+    for st in stats:
+        assert st["mismatches"] == 0, stats
+    assert stats[0]["rounds"] == 0 and stats[1]["rounds"] > 0 and stats[1]["ahead"] == 0
+    assert stats[2]["ahead"] > 0 and stats[2]["adopted"] >= stats[2]["ahead"] - stats[2]["dropped"] > 0, stats
