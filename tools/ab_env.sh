@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of one environment switch on ONE box: alternating runs of the headline bench (default and driver's setting)
-# usage: tools/r3_ab.sh VAR valA valB [n]
+# usage: tools/ab_env.sh VAR valA valB [n]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 V=$1; A=$2; B=$3; N=${4:-3}

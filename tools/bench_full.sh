@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/r3_full.sh TAG [tests] -- the GPU suite (optional) and the full default bench line with its secondary configurations
+# usage: tools/bench_full.sh TAG [tests] -- the GPU suite (optional) and the full default bench line with its secondary configurations
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out; T=$1
 cd $R

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/r3_quick.sh TAG [tests]   -- bench at the default and at the driver's setting (+ the GPU suite)
+# usage: tools/bench_quick.sh TAG [tests]   -- bench at the default and at the driver's setting (+ the GPU suite)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out; T=$1
 cd $R
