@@ -112,7 +112,7 @@ struct ms_ctx {
   struct Ahead {
     bool valid = false;
     bool go_known = false, go = false;  // the device's answer (FoldArgs::go_out) has been read / was DEC_GO
-    int kind = 0, parity = 0, src = 0, stepper = 0, max_iter = 0;
+    int kind = 0, go_kind = 0, parity = 0, src = 0, stepper = 0, max_iter = 0;
     bool implicit = false;
     double alpha0 = 0, energy0 = 0, beta = 0, c1 = 0, tol2p = 0, lim = 0;
     RoundPlanT plan;
@@ -129,11 +129,10 @@ struct ms_ctx {
   uint32_t dir_mask[2] = {0, 0};
   uint32_t* kc_gate[2] = {nullptr, nullptr};  // decision word that pass was gated on
   uint32_t cur_extra_mask = 0;            // reduce_slots: fold these slots of the ordinary partials as well
-  const unsigned long long* cur_go_par = nullptr;  // ... and take the GO decision with these parameters first
+  int cur_go_kind = 0;                    // ... and take the GO decision first (FoldArgs::go_kind and its parameters)
+  double cur_go_val[6] = {0};             // tol^2 (1+1e-9), guard bound, energy0, c, alpha_0, beta
   bool cur_gate_fold_only = false;        // the gate (and the ran check) belongs to the fold, not to the energy kernel
   bool last_hist_descent = false;         // the last direction with CG history was a descent direction
-  unsigned long long* h_go_par[2] = {nullptr, nullptr};  // pinned: parameters for it (FoldArgs::go_par)
-  unsigned long long* d_h_go_par[2] = {nullptr, nullptr};
   uint32_t* cur_go = nullptr;          // the direction fold being queued may open the next round: its GO word
   const double* cur_rhs_dev = nullptr; // the fold being queued takes its right-hand sides from the device
   long q_ahead = 0, q_adopted = 0, q_dropped = 0;
@@ -637,10 +636,15 @@ int reduce_slots(ms_ctx* c, uint32_t mask) {
   for (int sl = 0; sl < MS_NSCAL; ++sl)
     if (mask & (1u << sl)) c->expected[sl] = c->ticket;
   f.rhs_dev = c->cur_rhs_dev;
-  if (c->cur_go_par && f.dec_out && (mask & (1u << MS_S_GDOTD))) {  // merged: direction scalars + GO + Armijo decision
+  if (c->cur_go_kind && f.dec_out && (mask & (1u << MS_S_GDOTD))) {  // merged: direction scalars + GO + Armijo decision
     f.go_out = c->cur_go;
-    f.go_par = c->cur_go_par;
-    f.go_ticket = c->ticket;
+    f.go_kind = c->cur_go_kind;
+    f.go_tol2 = c->cur_go_val[0];
+    f.go_lim = c->cur_go_val[1];
+    f.go_e0 = c->cur_go_val[2];
+    f.go_c = c->cur_go_val[3];
+    f.go_alpha0 = c->cur_go_val[4];
+    f.go_beta = c->cur_go_val[5];
   }
   if (f.dec_out) c->expected[MS_MB_DEC] = c->ticket;
   HIPCHK(c, launch_reduce(f, c->stream));
@@ -925,13 +929,6 @@ int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulat
 int phase_direction(ms_ctx* c, int stepper, bool use_history, bool g_finalized = false) {
   const bool use_con = (c->params.modules & MS_CON_VOLUME) != 0;
   c->dir_implicit = false;
-  if (stepper == MS_STEPPER_CG && use_history && c->pd_neg_pg) {
-    // the previous direction was an implicit -PG: write it out for the unfused direction kernel
-    HIPCHK(c, launch_direction(c->tile0, c->tile1, c->til.nv, c->til.T, c->d_vflags, c->buf[MS_BUF_PG],
-                               c->buf[MS_BUF_GC], c->buf[MS_BUF_PD], c->buf[MS_BUF_PG], c->buf[MS_BUF_PD], c->d_scal,
-                               0, 0, c->d_partials, c->til.n_tiles, 0, c->stream, c->cur_gate, c->cur_gate_want));
-    c->pd_neg_pg = false;
-  }
   {
   ProfScope ps(c, 2);
   HIPCHK(c, launch_direction(c->tile0, c->tile1, c->til.nv, c->til.T, c->d_vflags, c->buf[MS_BUF_G],
@@ -939,7 +936,9 @@ int phase_direction(ms_ctx* c, int stepper, bool use_history, bool g_finalized =
                              c->buf[MS_BUF_PD], c->d_scal, use_con ? 1 : 0,
                              (stepper == MS_STEPPER_CG && use_history) ? 1 : 0, c->d_partials,
                              c->til.n_tiles, (g_finalized && !use_con) ? 0 : 1, c->stream, c->cur_gate,
-                             c->cur_gate_want));
+                             c->cur_gate_want,
+                             // (the previous direction was an implicit -PG: the kernel derives it, as the fused epilogue does)
+                             (stepper == MS_STEPPER_CG && use_history && c->pd_neg_pg) ? 1 : 0));
   }
   c->last_g = c->buf[MS_BUF_G];
   return reduce_slots(c, MASK_DIR);
@@ -1402,7 +1401,6 @@ void ms_destroy(ms_ctx* c) {
       free(m->h_scal);
       if (m->h_seq) (void)hipHostFree(m->h_seq);
     }
-    if (c->h_go_par[p]) (void)hipHostFree(c->h_go_par[p]);
   }
   if (c->d_dec) (void)hipFree(c->d_dec);
   if (c->h_err) (void)hipHostFree(c->h_err);
@@ -2240,10 +2238,6 @@ int spec_prepare(ms_ctx* c) {
     if (rc) return rc;
     rc = make_box(c->first_mb[p]);
     if (rc) return rc;
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_go_par[p]), sizeof(unsigned long long) * 2 * 12,
-                            hipHostMallocMapped));
-    memset(c->h_go_par[p], 0, sizeof(unsigned long long) * 2 * 12);
-    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_go_par[p]), c->h_go_par[p], 0));
   }
   HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_dec), sizeof(uint32_t) * MS_DEC_STRIDE * ms_ctx::N_DEC));
   HIPCHK(c, hipMemset(c->d_dec, 0, sizeof(uint32_t) * MS_DEC_STRIDE * ms_ctx::N_DEC));
@@ -2324,7 +2318,7 @@ void plan_round(ms_ctx* c, const ms_stepper_params* sp, double alpha, int room, 
 
 // queue a planned round into the mailboxes / decision records of `parity`.  merged: the round belongs to a step that
 // has not started -- its first launch runs right behind the gradient pass of round `go_src`, whose direction scalars
-// the round's first fold folds itself; that fold decides first whether the search happens at all (FoldArgs::go_par)
+// the round's first fold folds itself; that fold decides first whether the search happens at all (FoldArgs::go_kind)
 // and forms the Armijo right-hand sides on the device.
 int queue_round(ms_ctx* c, const ms_stepper_params* sp, const RoundPlan& plan, int parity, double energy0,
                 double g_dot_d, bool merged, int go_src, bool carry_mode, bool cg, int restart) {
@@ -2347,7 +2341,7 @@ int queue_round(ms_ctx* c, const ms_stepper_params* sp, const RoundPlan& plan, i
     c->cur_check_ran = merged;
     c->cur_dec = dec_word(c, parity, 0);
     c->cur_extra_mask = merged ? c->dir_mask[go_src] : 0u;
-    c->cur_go_par = merged ? c->d_h_go_par[go_src] : nullptr;
+    c->cur_go_kind = merged ? c->ahead.go_kind : 0;
     c->cur_go = merged ? go_word(c, go_src) : nullptr;
     for (int j = 0; j < n0; ++j) c->cur_rhs[j] = energy0 + sp->c * alphas[j] * g_dot_d;
     rc = phase_energy(c, c->params.modules, true, alphas[n0 - 1], true, false, carry_mode);
@@ -2358,7 +2352,7 @@ int queue_round(ms_ctx* c, const ms_stepper_params* sp, const RoundPlan& plan, i
     c->cur_gate_fold_only = false;
     c->cur_check_ran = false;
     c->cur_extra_mask = 0;
-    c->cur_go_par = nullptr;
+    c->cur_go_kind = 0;
     c->cur_go = nullptr;
     if (merged) c->dir_pending[go_src] = false;
     swap_mailbox(c, c->first_mb[parity]);
@@ -2476,9 +2470,7 @@ void drop_ahead(ms_ctx* c, int ran) {
 //           along d = -g with the same step size: that search's first round is queued;
 //   kind 2: the pass computes d = -g itself (gradient descent, CG restart steps): the next step's own first round.
 int queue_ahead(ms_ctx* c, const ms_stepper_params* sp, const ms_step_result* out, double tol, bool carry_mode,
-                bool cg, int restart, double a_hi_old, double r_lo_old) {
-  (void)a_hi_old;
-  (void)r_lo_old;
+                bool cg, int restart) {
   if (!c->kc_pending || c->ahead.valid) return MS_OK;
   const int src = c->kc_parity;
   if (!c->dir_pending[src]) return MS_OK;  // (the pass was queued with its own direction fold)
@@ -2512,18 +2504,14 @@ int queue_ahead(ms_ctx* c, const ms_stepper_params* sp, const ms_step_result* ou
   ah.src = src;
   ah.go = false;
   ah.go_known = false;
-  // parameters for the direction fold that is about to run (tagged entries: ms_internal.h FoldArgs::go_par)
-  {
-    const double par[7] = {kind == 1 ? 1.0 : 2.0, ah.tol2p, ah.lim, ah.energy0, sp->c, alpha0, sp->beta};
-    unsigned long long* box = c->h_go_par[src];
-    const unsigned long long t = c->ticket + 1;  // the first fold queued from here on: the round's first launch's
-    for (int k = 0; k < 7; ++k) {
-      unsigned long long b;
-      memcpy(&b, &par[k], sizeof(b));
-      __atomic_store_n(box + 2 * k, b, __ATOMIC_RELAXED);
-      __atomic_store_n(box + 2 * k + 1, b ^ t, __ATOMIC_RELEASE);
-    }
-  }
+  // what the round's first fold tests before it decides the trials (FoldArgs::go_kind)
+  ah.go_kind = kind == 1 ? 1 : 2;
+  c->cur_go_val[0] = ah.tol2p;
+  c->cur_go_val[1] = ah.lim;
+  c->cur_go_val[2] = ah.energy0;
+  c->cur_go_val[3] = sp->c;
+  c->cur_go_val[4] = alpha0;
+  c->cur_go_val[5] = sp->beta;
   // the round itself, in the state the consuming step will be in
   const bool s_hist = c->cg_have_history, s_implicit = c->dir_implicit, s_pdneg = c->pd_neg_pg;
   const int s_iter = c->cg_iter_count;
@@ -2630,9 +2618,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       rc = wait_mailbox(c, c->first_mb[ah.parity].h_seq, c->first_mb[ah.parity].expected, vals, &code);
       if (rc) return rc;
       ah.go_known = true;
-      if (code == DEC_STOP_LATE) {
-        ah.go = false;  // (the parameters reached the device too late)
-      } else {
+      {
         const double gn2 = vals[MS_S_GNORM2], gdd = vals[MS_S_GDOTD];
         const bool kind_ok = ah.kind == 1 ? gdd >= 0.0 : gdd < 0.0;
         const bool go = kind_ok && gn2 > ah.tol2p && (ah.kind == 1 ? vals[MS_S_MAXG2] : vals[MS_S_MAXD2]) < ah.lim;
@@ -2921,7 +2907,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
         if (energy_mask(c->params.modules) & (1u << sl)) put_mailbox(c, sl, v[acc][sl]);
       accept(alphas[acc], E_acc);
       if (c->ahead_allowed) {
-        rc = queue_ahead(c, sp, out, tol, carry_mode, cg, restart, a_hi, r_lo);
+        rc = queue_ahead(c, sp, out, tol, carry_mode, cg, restart);
         if (rc) return rc;
       }
       return MS_OK;
@@ -2951,7 +2937,7 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     }
     if (accepted) {
       if (c->ahead_allowed) {
-        rc = queue_ahead(c, sp, out, tol, carry_mode, cg, restart, a_hi, r_lo);
+        rc = queue_ahead(c, sp, out, tol, carry_mode, cg, restart);
         if (rc) return rc;
       }
       return MS_OK;

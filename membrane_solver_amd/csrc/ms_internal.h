@@ -53,9 +53,9 @@ enum : uint32_t {
   DEC_CONTINUE = 1,     // every trial so far was rejected: the next stage of the ladder runs
   DEC_ACCEPT_MAIN = 2,  // accepted, and the accepted trial's outputs are the ordinary ones (xt, fK, fA): the gradient pass runs
   DEC_ACCEPT_SIDE = 3,  // an EARLY trial of a multi-trial launch was accepted (energy-only evaluation): nothing queued runs
-  DEC_GO = 4,           // direction fold: the round the host queued behind the gradient pass may run
-  DEC_STOP = 5,         // direction fold: it may not (converged, the other kind of direction, guard range)
-  DEC_STOP_LATE = 6,    // ... it may not because the host's parameters were not there when the fold ran
+  DEC_GO = 4,           // (host side only: the merged fold's test passed)
+  DEC_STOP = 5,         // merged fold: the search it was queued for does not happen (converged, the other kind of
+                        // direction, guard range): nothing behind it runs
   DEC_ERR_RAN = 0x100   // flag: a gated launch ran on some of its workgroups only
 };
 
@@ -297,18 +297,17 @@ struct FoldArgs {
   // Armijo right-hand sides formed on the device (nullptr: the host's rhs[] above): rhs_dev[j], written by the direction
   // fold that opened this round (go_out below)
   const double* rhs_dev;
-  // A direction fold can open the NEXT round (ms_step queues it while the gradient pass runs): the workgroup of this
-  // fold that arrives last tests, from the direction scalars it reads back, whether the search the host expects will
-  // happen -- kind 1: the direction with history is no descent direction (<g,d> >= 0), so the stepper restarts with
-  // d = -g; kind 2: the direction just written is a descent direction -- is not converged (|g|^2 > go[1]) and stays in
-  // the unguarded range (max|d_i|^2 < go[2]), then writes DEC_GO and rhs_j = go[3] + go[4+j] <g,d> (the host's
-  // energy0 + (c alpha_j) <g,d>, alpha_j = alpha_{j-1} beta: the same roundings) to go_out, else DEC_STOP.  The
-  // parameters go[0..6] = {kind, tol^2 (1+1e-9), 0.09 min_edge^2 / ((1+1e-9) alpha_0^2), energy0, c, alpha_0, beta}
-  // arrive in pinned host memory AFTER this fold was queued (the host learns the accepted alpha later): entries
-  // {bits, bits XOR go_ticket}; a parameter that does not validate yet means DEC_STOP_LATE.
-  uint32_t* go_out;                 // {code, -, rhs[8], hand-over[8] as doubles from byte 8} or nullptr
-  const unsigned long long* go_par; // 7 tagged entries in pinned host memory
-  unsigned long long go_ticket;
+  // MERGED fold (go_kind != 0): this launch also folds the direction scalars of the gradient pass that ran in front of
+  // the energy launch (which did not wait for them), and the workgroup that arrives last first tests whether the search
+  // the host queued the launch for happens at all -- go_kind 1: the direction with history is no descent direction
+  // (<g,d> >= 0), the stepper restarts with d = -g; 2: the direction just written is a descent direction -- is not
+  // converged (|g|^2 > go_tol2) and stays in the unguarded range (max|d_i|^2 < go_lim).  If not: DEC_STOP.  If so the
+  // Armijo right-hand sides are formed here, rhs_j = go_e0 + (go_c alpha_j) <g,d>, alpha_j = alpha_{j-1} go_beta -- the
+  // host's expressions with the host's roundings -- the trials are decided, and the right-hand sides of the ladder's
+  // later alphas are left in go_out[2..] (doubles) for the gated stages behind this launch.
+  int go_kind;
+  double go_tol2, go_lim, go_e0, go_c, go_alpha0, go_beta;
+  uint32_t* go_out;
   unsigned long long* host_err;  // pinned word: set non-zero when check_ran fails
   int side_full;          // fold every slot of the early trials' sets too (they have outputs of their own and can be
                           // accepted as they are); otherwise only their energy slots, by the head workgroup
@@ -341,7 +340,7 @@ hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* 
                             const double* gC, double* d, const double* pg, const double* pd,
                             const double* scal, int use_constraint, int cg_history,
                             double* partials, int n_tiles, int write_g, hipStream_t s,
-                            const uint32_t* gate = nullptr, uint32_t gate_want = 0);
+                            const uint32_t* gate = nullptr, uint32_t gate_want = 0, int pd_neg_pg = 0);
 hipError_t launch_axpy_masked(int64_t n_rows, const uint8_t* vflags, double* x, const double* y,
                               double coef, hipStream_t s);
 hipError_t launch_permute_in(int nv, const int32_t* perm, const double* src_ext, double* dst_int,

@@ -2671,21 +2671,9 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(FoldArgs a) {
       }
   }
   if (slot < 0) return;
-  // A direction fold that may open the next round needs the host's parameters (pinned host memory: every word is a
-  // PCIe read of ~0.2 us, and they do not overlap).  ONE lane of the launch -- thread 0 of the first slot's workgroup --
-  // requests them now, next to its partials, and hands them on in device memory before it counts in.
-  const bool par_reader = a.go_par != nullptr && a.go_out != nullptr && task == t_e && threadIdx.x == 0;
   // merged: this launch folds the direction scalars of the gradient pass in front of the energy launch TOGETHER with
   // that launch's energies (the energy launch did not wait for them: one fold and one kernel boundary per step less)
-  const bool merged = a.go_par != nullptr && a.dec_out != nullptr;
-  unsigned long long gp_b[7], gp_t[7];
-  if (par_reader) {
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      gp_b[k] = __hip_atomic_load(a.go_par + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      gp_t[k] = __hip_atomic_load(a.go_par + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
+  const bool merged = a.go_kind != 0 && a.dec_out != nullptr;
   double rhs_d[MS_MAX_TRIALS];
   if (a.rhs_dev != nullptr && a.dec_out != nullptr && task >= t_e && task < t_rest && threadIdx.x == 0) {
 #pragma unroll
@@ -2704,7 +2692,6 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(FoldArgs a) {
   }
   if (!open) {  // (task 0) an earlier stage has decided (or failed): later readers of THIS stage's word see the same
     if (a.dec_out != nullptr) st_agent(a.dec_out, prev);
-    if (a.go_out != nullptr) st_agent(a.go_out, DEC_STOP);  // (the gradient pass stayed out: nothing follows it)
     return;
   }
   if (slot == MS_P_RAN) return;
@@ -2713,61 +2700,9 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(FoldArgs a) {
 #if MS_GATE_PROBE
   if (set == a.n_sets - 1) g_shadow[slot] = r;
 #endif
-  if (a.go_out != nullptr && a.dec_out == nullptr) {
-    // a direction fold that may open the next round: every slot's workgroup counts in, the last one decides
-    double* const hand = reinterpret_cast<double*>(a.go_out + 2) + 8;  // {valid, kind, tol2, lim, E0, c, alpha0, beta}
-    if (par_reader) {
-      bool have = true;
-#pragma unroll
-      for (int k = 0; k < 7; ++k) have = have && ((gp_b[k] ^ gp_t[k]) == a.go_ticket);
-      st_agent(hand, have ? 1.0 : 0.0);
-#pragma unroll
-      for (int k = 0; k < 7; ++k) st_agent(hand + 1 + k, __longlong_as_double((long long)gp_b[k]));
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const uint32_t arrived = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (arrived != (uint32_t)(n_reg * n_rest + a.n_sets * n_e - 1)) return;
-    st_agent(a.counter, 0u);
-    double par[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) par[k] = ld_agent(hand + k);
-    double* const sc = a.set[a.n_sets - 1].scal;
-    const double gn2 = ld_agent(sc + MS_S_GNORM2), gdd = ld_agent(sc + MS_S_GDOTD);
-    const double md2 = ld_agent(sc + MS_S_MAXD2), mg2 = ld_agent(sc + MS_S_MAXG2);
-    uint32_t go = DEC_STOP_LATE;
-    if (par[0] == 1.0) {
-      const bool restart = par[1] == 1.0;
-      const double slope = restart ? -gn2 : gdd;  // <g,d> of the search that follows
-      const bool kind_ok = restart ? gdd >= 0.0 : gdd < 0.0;
-      go = (kind_ok && gn2 > par[2] && (restart ? mg2 : md2) < par[3]) ? DEC_GO : DEC_STOP;
-      if (go == DEC_GO) {
-        // rhs_j = energy0 + (c alpha_j) <g,d> with alpha_j = alpha_{j-1} beta: the host's expressions, rounding for
-        // rounding.  (Read by the NEXT kernels of the stream only: the kernel boundary orders them behind these stores.)
-        double* const rhs = reinterpret_cast<double*>(a.go_out + 2);
-        double al = par[6];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          st_agent(rhs + k, __dadd_rn(par[4], __dmul_rn(__dmul_rn(par[5], al), slope)));
-          al = __dmul_rn(al, par[7]);
-        }
-      }
-    }
-    st_agent(a.go_out, go);
-    if (a.set[a.n_sets - 1].host_box) post_entry(a.set[a.n_sets - 1].host_box, MS_MB_DEC, (unsigned long long)go, a.ticket);
-    return;
-  }
   if (a.dec_out == nullptr || (!merged && task >= t_rest)) return;
   // a stage that is decided here: its energies' workgroups (merged: every slot's) count in once their scalar store has
   // completed; the one that comes last decides
-  double* const hand = merged ? reinterpret_cast<double*>(a.go_out + 2) + 8 : nullptr;
-  if (par_reader) {
-    bool have = true;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) have = have && ((gp_b[k] ^ gp_t[k]) == a.go_ticket);
-    st_agent(hand, have ? 1.0 : 0.0);
-#pragma unroll
-    for (int k = 0; k < 7; ++k) st_agent(hand + 1 + k, __longlong_as_double((long long)gp_b[k]));
-  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const uint32_t arrived = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (arrived != (uint32_t)(a.n_sets * n_e + (merged ? n_reg * n_rest : 0) - 1)) return;
@@ -2776,31 +2711,23 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(FoldArgs a) {
   bool decide = true;
   double m_e0 = 0.0, m_c = 0.0, m_al = 0.0, m_beta = 0.0, m_slope = 0.0;
   if (merged) {
-    // first: does the search the host queued this launch for happen at all?  (FoldArgs::go_par: kind 1 -- the direction
+    // first: does the search the host queued this launch for happen at all?  (FoldArgs::go_kind: 1 -- the direction
     // with history is no descent direction, the stepper restarts along -g; kind 2 -- the direction just written is one;
     // not converged; unguarded range)
-    double par[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) par[k] = ld_agent(hand + k);
     double* const sc = a.set[a.n_sets - 1].scal;
     const double gn2 = ld_agent(sc + MS_S_GNORM2), gdd = ld_agent(sc + MS_S_GDOTD);
     const double md2 = ld_agent(sc + MS_S_MAXD2), mg2 = ld_agent(sc + MS_S_MAXG2);
-    if (par[0] != 1.0) {
-      code = DEC_STOP_LATE;
+    const bool restart = a.go_kind == 1;
+    m_slope = restart ? -gn2 : gdd;  // <g,d> of the search
+    const bool kind_ok = restart ? gdd >= 0.0 : gdd < 0.0;
+    if (!(kind_ok && gn2 > a.go_tol2 && (restart ? mg2 : md2) < a.go_lim)) {
+      code = DEC_STOP;
       decide = false;
-    } else {
-      const bool restart = par[1] == 1.0;
-      m_slope = restart ? -gn2 : gdd;  // <g,d> of the search
-      const bool kind_ok = restart ? gdd >= 0.0 : gdd < 0.0;
-      if (!(kind_ok && gn2 > par[2] && (restart ? mg2 : md2) < par[3])) {
-        code = DEC_STOP;
-        decide = false;
-      }
-      m_e0 = par[4];
-      m_c = par[5];
-      m_al = par[6];
-      m_beta = par[7];
     }
+    m_e0 = a.go_e0;
+    m_c = a.go_c;
+    m_al = a.go_alpha0;
+    m_beta = a.go_beta;
   }
   for (int j = 0; j < a.n_sets && decide; ++j) {
     double E = 0.0;
@@ -2844,11 +2771,8 @@ hipError_t launch_reduce(const FoldArgs& a, hipStream_t s) {
   const int nb = (a.check_ran ? 1 : 0) + a.n_sets * __builtin_popcount(em) +
                  (a.side_full ? a.n_sets : 1) * __builtin_popcount(a.slot_mask & ~em);
   if (nb == 0) return hipSuccess;
-  if ((a.dec_out != nullptr || a.go_out != nullptr) && a.counter == nullptr) return hipErrorInvalidValue;
-  if (a.dec_out != nullptr && em == 0) return hipErrorInvalidValue;
-  if (a.go_out != nullptr && a.go_par == nullptr) return hipErrorInvalidValue;
-  if (a.go_out != nullptr && a.dec_out == nullptr && a.n_sets != 1) return hipErrorInvalidValue;
-  if (a.go_par != nullptr && a.go_out == nullptr) return hipErrorInvalidValue;
+  if (a.dec_out != nullptr && (a.counter == nullptr || em == 0)) return hipErrorInvalidValue;
+  if (a.go_kind != 0 && (a.dec_out == nullptr || a.go_out == nullptr)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(RBLOCK), 0, s, a);
   return hipGetLastError();
 }
@@ -2872,7 +2796,7 @@ __global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, c
                                                      const double* scal, int use_constraint,
                                                      int cg_history, double* partials,
                                                      int n_tiles, int write_g, const uint32_t* gate,
-                                                     uint32_t gate_want) {
+                                                     uint32_t gate_want, int pd_neg_pg) {
   __shared__ double red[16];
   const int tile = tile0 + blockIdx.x;
   if (gate != nullptr && !gate_open(gate, gate_want, partials + (size_t)MS_P_RAN * n_tiles + tile)) return;
@@ -2902,7 +2826,8 @@ __global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, c
       const V3 p = mk(pg[o], pg[o + 1], pg[o + 2]);
       const double beta = dot_pinned(gi, gi - p) / (dot_pinned(p, p) + 1.0e-20);
       if (!(beta < 0.0)) {
-        const V3 q = mk(pd[o], pd[o + 1], pd[o + 2]);
+        // (pd_neg_pg: the previous direction was an implicit -PG -- derived, not loaded, as in the fused epilogue)
+        const V3 q = pd_neg_pg ? -p : mk(pd[o], pd[o + 1], pd[o + 2]);
         di = mk(fma(beta, q.x, -gi.x), fma(beta, q.y, -gi.y), fma(beta, q.z, -gi.z));
       }
     }
@@ -2937,10 +2862,11 @@ hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* 
                             const double* gC, double* d, const double* pg, const double* pd,
                             const double* scal, int use_constraint, int cg_history,
                             double* partials, int n_tiles, int write_g, hipStream_t s, const uint32_t* gate,
-                            uint32_t gate_want) {
+                            uint32_t gate_want, int pd_neg_pg) {
   if (tile1 <= tile0) return hipSuccess;
   hipLaunchKernelGGL(k_direction, dim3(tile1 - tile0), dim3(BLOCK), 0, s, tile0, nv, T, vflags, g,
-                     gC, d, pg, pd, scal, use_constraint, cg_history, partials, n_tiles, write_g, gate, gate_want);
+                     gC, d, pg, pd, scal, use_constraint, cg_history, partials, n_tiles, write_g, gate, gate_want,
+                     pd_neg_pg);
   return hipGetLastError();
 }
 
