@@ -162,6 +162,10 @@ typedef struct ms_stepper_params {
                               volume (volume.enforce_constraint: 3 linearised steps,
                               tol 1e-12) BEFORE its energy is taken; a rejected
                               trial restores the positions.  Unqueued trials.      */
+  int precondition;        /* conjugate_gradient.py:74-76 (CG only): the direction is
+                              built from the row-normalised gradient g_i/(|g_i|+1e-8);
+                              the history and the Armijo slope keep the raw gradient.
+                              Unfused direction pass, unqueued trials.              */
 } ms_stepper_params;
 
 typedef struct ms_step_result {

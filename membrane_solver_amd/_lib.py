@@ -62,7 +62,8 @@ class ms_stepper_params(ctypes.Structure):
     _fields_ = [("stepper", ctypes.c_int), ("max_iter", ctypes.c_int), ("beta", ctypes.c_double),
                 ("c", ctypes.c_double), ("gamma", ctypes.c_double),
                 ("alpha_max_factor", ctypes.c_double), ("restart_interval", ctypes.c_int),
-                ("edge_fraction", ctypes.c_double), ("reuse_energy0", ctypes.c_int), ("enforce_volume", ctypes.c_int)]
+                ("edge_fraction", ctypes.c_double), ("reuse_energy0", ctypes.c_int), ("enforce_volume", ctypes.c_int),
+                ("precondition", ctypes.c_int)]
 
 
 class ms_tilt_relax_params(ctypes.Structure):

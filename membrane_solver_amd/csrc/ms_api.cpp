@@ -87,6 +87,7 @@ struct ms_ctx {
   // CG history's previous direction is -PG, which the next fused direction pass derives instead of loading.
   bool dir_implicit = false;
   bool pd_neg_pg = false;
+  bool precond = false;      // ms_stepper_params.precondition of the step in progress (CG only)
   // speculative line-search ladder (ms_step): when the last accepted step needed n > 1 Armijo trials, the next
   // n trials are queued at once; stage k > 0 runs only if the device-side Armijo test of stage k-1 failed
   // (k_armijo_gate).  Each stage posts its scalars to its own mailbox; the host takes the same decisions from the
@@ -938,7 +939,8 @@ int phase_direction(ms_ctx* c, int stepper, bool use_history, bool g_finalized =
                              c->til.n_tiles, (g_finalized && !use_con) ? 0 : 1, c->stream, c->cur_gate,
                              c->cur_gate_want,
                              // (the previous direction was an implicit -PG: the kernel derives it, as the fused epilogue does)
-                             (stepper == MS_STEPPER_CG && use_history && c->pd_neg_pg) ? 1 : 0));
+                             (stepper == MS_STEPPER_CG && use_history && c->pd_neg_pg) ? 1 : 0,
+                             (stepper == MS_STEPPER_CG && c->precond) ? 1 : 0));
   }
   c->last_g = c->buf[MS_BUF_G];
   return reduce_slots(c, MASK_DIR);
@@ -1085,7 +1087,8 @@ void energies_from_mailbox(const ms_ctx* c, double e[4]) {
 int queue_energy_and_gradient(ms_ctx* c, int stepper, bool use_history, bool skip_energy = false) {
   const uint32_t mods = c->params.modules;
   // lambda needs a global reduction first; the tilt module adds into g after K_C
-  const bool constraint = (mods & (MS_CON_VOLUME | MS_TILT_SHAPE_MODS)) != 0;
+  // (and a preconditioned direction -- conjugate_gradient.py:74-76 -- is the direction kernel's)
+  const bool constraint = (mods & (MS_CON_VOLUME | MS_TILT_SHAPE_MODS)) != 0 || (stepper == MS_STEPPER_CG && c->precond);
   // K_C reads the reduced volume (already reduced when the energy pass is skipped)
   const bool penalty = skip_energy || (mods & MS_MOD_VOLUME_PENALTY) != 0;
   int rc = MS_OK;
@@ -1100,7 +1103,10 @@ int queue_energy_and_gradient(ms_ctx* c, int stepper, bool use_history, bool ski
   }
   rc = phase_gradient(c, mods, c->buf[MS_BUF_G], false, 0, /*reduce_now=*/false);
   if (rc) return rc;
-  rc = reduce_slots(c, (penalty ? 0u : energy_mask(mods)) | MASK_GRAD);
+  // (<g,gC> / <gC,gC> exist only with a row or a tilt module behind K_C)
+  const uint32_t gmask = (mods & (MS_CON_VOLUME | MS_TILT_SHAPE_MODS)) ? MASK_GRAD : 0u;
+  const uint32_t fmask = (penalty ? 0u : energy_mask(mods)) | gmask;
+  if (fmask) rc = reduce_slots(c, fmask);
   if (rc) return rc;
   return phase_direction(c, stepper, use_history);
 }
@@ -2580,16 +2586,20 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   // the direction cannot ride in the gradient kernel's epilogue when a constraint row has to be projected out first
   // (lambda needs a global reduction) or when a tilt module adds its shape gradient behind K_C
   const bool volrow = (c->params.modules & MS_CON_VOLUME) != 0;
+  // conjugate_gradient.py:74-76: the direction comes from the row-normalised gradient -- never an implicit -G, never
+  // the fused epilogue, and no queued rounds (their gradient pass carries the fused epilogue)
+  const bool precond = cg && sp->precondition != 0;
+  c->precond = precond;
   int rc;
   bool restart_sd = false;
   const bool tilt_shape = (c->params.modules & MS_TILT_SHAPE_MODS) != 0;
   if (carried_x && c->grad_valid && !tilt_shape && c->til.T <= 256 &&
-      (!volrow || (!use_history && c->maxg2_valid))) {
+      (!volrow || (!use_history && c->maxg2_valid && !precond))) {
     // x has not moved since the last gradient pass (failed search, stepper reset): only the
     // direction changes.  k_direction on the finalized g repeats the fused epilogue's
     // arithmetic and reduction order exactly.  (With a constraint row G is the projected gradient the direction
     // kernel wrote back: a steepest-descent restart reads it as it is; projecting it a second time is not on.)
-    restart_sd = !use_history && c->maxg2_valid;
+    restart_sd = !use_history && c->maxg2_valid && !precond;
     if (restart_sd) {
       // steepest-descent restart: d = -g, whose scalars the gradient pass already reduced
       // (|g|^2; <g,d> = -|g|^2 and max|d_i|^2 = max|g_i|^2 exactly) -- no fold, no host round trip
@@ -2747,7 +2757,8 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   // the enforcer lane (ms_stepper_params.enforce_volume): every trial is projected onto the target volume before its
   // energy is taken -- three more passes per trial, one trial at a time
   const bool enforce = sp->enforce_volume != 0 && volrow && !tilt;
-  const bool can_chain = c->speculate && carry_mode && !tilt && !(c->params.modules & MS_MOD_VOLUME_PENALTY) && !enforce;
+  const bool can_chain = c->speculate && carry_mode && !tilt && !(c->params.modules & MS_MOD_VOLUME_PENALTY) && !enforce &&
+                         !precond;
   // a round queued by the step before (while its gradient pass was running): the round of THIS search's first
   // iteration if it was queued for exactly what this step has computed by itself
   bool adopted = false;
@@ -3584,6 +3595,7 @@ int ms_shard_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, doub
   if (!c || !sp || !out) return fail(c, MS_ERR_INVALID, "ms_shard_step: NULL argument");
   const uint32_t mods = c->params.modules;
   if (mods & MS_ANY_TILT_MODS) return fail(c, MS_ERR_STATE, "the tilt modules are not sharded yet (single GPU only)");
+  if (sp->precondition) return fail(c, MS_ERR_STATE, "ConjugateGradient(precondition=True) is not sharded (single GPU only)");
   memset(out, 0, sizeof(*out));
   const bool cg = sp->stepper == MS_STEPPER_CG;
   const int restart = sp->restart_interval > 0 ? sp->restart_interval : 10;

@@ -340,7 +340,8 @@ hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* 
                             const double* gC, double* d, const double* pg, const double* pd,
                             const double* scal, int use_constraint, int cg_history,
                             double* partials, int n_tiles, int write_g, hipStream_t s,
-                            const uint32_t* gate = nullptr, uint32_t gate_want = 0, int pd_neg_pg = 0);
+                            const uint32_t* gate = nullptr, uint32_t gate_want = 0, int pd_neg_pg = 0,
+                            int precond = 0);
 hipError_t launch_axpy_masked(int64_t n_rows, const uint8_t* vflags, double* x, const double* y,
                               double coef, hipStream_t s);
 hipError_t launch_permute_in(int nv, const int32_t* perm, const double* src_ext, double* dst_int,

@@ -2796,7 +2796,7 @@ __global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, c
                                                      const double* scal, int use_constraint,
                                                      int cg_history, double* partials,
                                                      int n_tiles, int write_g, const uint32_t* gate,
-                                                     uint32_t gate_want, int pd_neg_pg) {
+                                                     uint32_t gate_want, int pd_neg_pg, int precond) {
   __shared__ double red[16];
   const int tile = tile0 + blockIdx.x;
   if (gate != nullptr && !gate_open(gate, gate_want, partials + (size_t)MS_P_RAN * n_tiles + tile)) return;
@@ -2821,14 +2821,22 @@ __global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, c
       gi = mk(gi.x - lam * c.x, gi.y - lam * c.y, gi.z - lam * c.z);
     }
     if (fixed) gi = mk(0, 0, 0);
-    V3 di = -gi;
+    // conjugate_gradient.py:74-76 precondition: the direction is built from g_i / (|g_i| + 1e-8) (norm as numpy
+    // takes it: the squares added left to right); history, |g|^2 and <g,d> keep the raw rows
+    V3 gh = gi;
+    if (precond) {
+      const double nrm = sqrt(__dadd_rn(__dadd_rn(__dmul_rn(gi.x, gi.x), __dmul_rn(gi.y, gi.y)), __dmul_rn(gi.z, gi.z)));
+      const double den = nrm + 1.0e-8;
+      gh = mk(gi.x / den, gi.y / den, gi.z / den);
+    }
+    V3 di = -gh;
     if (cg_history) {
       const V3 p = mk(pg[o], pg[o + 1], pg[o + 2]);
-      const double beta = dot_pinned(gi, gi - p) / (dot_pinned(p, p) + 1.0e-20);
+      const double beta = dot_pinned(gh, gh - p) / (dot_pinned(p, p) + 1.0e-20);
       if (!(beta < 0.0)) {
         // (pd_neg_pg: the previous direction was an implicit -PG -- derived, not loaded, as in the fused epilogue)
         const V3 q = pd_neg_pg ? -p : mk(pd[o], pd[o + 1], pd[o + 2]);
-        di = mk(fma(beta, q.x, -gi.x), fma(beta, q.y, -gi.y), fma(beta, q.z, -gi.z));
+        di = mk(fma(beta, q.x, -gh.x), fma(beta, q.y, -gh.y), fma(beta, q.z, -gh.z));
       }
     }
     if (fixed) di = mk(0, 0, 0);
@@ -2862,11 +2870,11 @@ hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* 
                             const double* gC, double* d, const double* pg, const double* pd,
                             const double* scal, int use_constraint, int cg_history,
                             double* partials, int n_tiles, int write_g, hipStream_t s, const uint32_t* gate,
-                            uint32_t gate_want, int pd_neg_pg) {
+                            uint32_t gate_want, int pd_neg_pg, int precond) {
   if (tile1 <= tile0) return hipSuccess;
   hipLaunchKernelGGL(k_direction, dim3(tile1 - tile0), dim3(BLOCK), 0, s, tile0, nv, T, vflags, g,
                      gC, d, pg, pd, scal, use_constraint, cg_history, partials, n_tiles, write_g, gate, gate_want,
-                     pd_neg_pg);
+                     pd_neg_pg, precond);
   return hipGetLastError();
 }
 

@@ -298,16 +298,16 @@ class DeviceMesh:
     def step(self, *, stepper: int, step_size: float, tol: float = 1e-6, max_iter: int = 10,
              beta: float = 0.7, c: float = 1e-4, gamma: float = 1.5, alpha_max_factor: float = 10.0,
              restart_interval: int = 10, edge_fraction: float = 0.0,
-             reuse_energy0: int = 0, enforce_volume: int = 0) -> StepResult:
+             reuse_energy0: int = 0, enforce_volume: int = 0, precondition: int = 0) -> StepResult:
         # the parameter block and the result struct are reused between calls: at ~140 us per
         # step every microsecond of ctypes marshalling shows
         key = (stepper, max_iter, beta, c, gamma, alpha_max_factor, restart_interval, edge_fraction,
-               reuse_energy0, enforce_volume)
+               reuse_energy0, enforce_volume, precondition)
         cache = self.__dict__.get("_step_cache")
         if cache is None or cache[0] != key:
             sp = L.ms_stepper_params(int(stepper), int(max_iter), float(beta), float(c), float(gamma),
                                      float(alpha_max_factor), int(restart_interval), float(edge_fraction),
-                                     int(reuse_energy0), int(enforce_volume))
+                                     int(reuse_energy0), int(enforce_volume), int(precondition))
             r = L.ms_step_result()
             cache = (key, sp, r, ctypes.byref(sp), ctypes.byref(r), L.lib().ms_step)
             self._step_cache = cache

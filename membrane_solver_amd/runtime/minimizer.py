@@ -463,7 +463,8 @@ class Minimizer:
         mp.stepper = L.ms_stepper_params(int(st.stepper_id), int(st._max_iter_for(self.mesh)), float(st.beta),
                                          float(st.c), float(st.gamma), float(st.alpha_max_factor),
                                          int(extra.get("restart_interval", 10)), edge_fraction,
-                                         int(st.reuse_energy0), int(getattr(st, "enforce_volume", 0)))
+                                         int(st.reuse_energy0), int(getattr(st, "enforce_volume", 0)),
+                                         int(extra.get("precondition", 0)))
         step_mode = str(gp.get("step_size_mode", "adaptive") or "adaptive").lower()
         mp.step_size = float(self.step_size)
         mp.tol = float(self.tol)

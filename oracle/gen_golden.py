@@ -39,6 +39,7 @@ ap.add_argument("--only-defects", action="store_true", help="angle-defect vector
 ap.add_argument("--only-guard", action="store_true", help="guard / exhausted-search / volume-drift trajectories only")
 ap.add_argument("--only-config5", action="store_true", help="the caveolin deck of BASELINE config 5 only")
 ap.add_argument("--only-enforcer", action="store_true", help="line-search enforcer-lane trajectories only")
+ap.add_argument("--only-precondition", action="store_true", help="ConjugateGradient(precondition=True) trajectories only")
 args = ap.parse_args()
 
 sys.dont_write_bytecode = True
@@ -1185,6 +1186,33 @@ def gen_enforcer_lane():
 
 
 # ---------------------------------------------------------------------------
+# (k2) ConjugateGradient(precondition=True) (conjugate_gradient.py:74-76): direction from the row-normalised gradient
+# ---------------------------------------------------------------------------
+def gen_precondition():
+    P8, T8 = meshgen.icosphere(8)
+    P8 = meshgen.smooth_displace(P8, 0.05)
+    base = {"surface_tension": 1.0, "bending_modulus": 1.0, "bending_energy_model": "helfrich",
+            "volume_constraint_mode": "lagrange", "volume_projection_during_minimization": False,
+            "mesh_quality_auto_repair_enabled": False}
+    cases = [
+        # (one restart at iteration 10; a first step long enough for backtracking)
+        ("traj_ico8_cg_precondition.npz", [], 0.0, 12, 4e-3),
+        ("traj_ico8_cg_precondition_volume.npz", ["volume"], 0.3, 8, 1e-3),
+    ]
+    for fname, cons, c0, n_steps, step0 in cases:
+        mm = build_mesh(P8, T8, dict(base, spontaneous_curvature=c0))
+        add_body(mm)
+        mm.energy_modules = ["surface", "bending"]
+        mm.constraint_modules = list(cons)
+        out = run_trajectory(fname, mm, ConjugateGradient(precondition=True), n_steps, step_size=step0)
+        out["kappa"] = np.array(1.0)
+        out["c0"] = np.array(c0)
+        out["precondition"] = np.array(1)
+        np.savez_compressed(os.path.join(OUT, fname), **out)
+        print("%s E_final=%.16g" % (fname, out["E_final"]), out["step_log"].tolist())
+
+
+# ---------------------------------------------------------------------------
 # (l) BASELINE config 5 on its own deck: meshes/caveolin/kozlov_1disk_3d_tensionless_bilayer_profile.yaml.
 #     Kept from the deck: positions, triangle rows, fixed / tilt_fixed_in / tilt_fixed_out flags, the "disk" group
 #     rows, every global parameter and the energy-module list.  NOT kept: its three constraint modules
@@ -1322,6 +1350,9 @@ if __name__ == "__main__":
     if "--only-enforcer" in sys.argv:
         gen_enforcer_lane()
         sys.exit(0)
+    if "--only-precondition" in sys.argv:
+        gen_precondition()
+        sys.exit(0)
     if "--only-disk" in sys.argv:
         gen_disk_target()
         sys.exit(0)
@@ -1348,4 +1379,5 @@ if __name__ == "__main__":
     gen_angle_defects()
     gen_guard_and_enforce()
     gen_enforcer_lane()
+    gen_precondition()
     gen_config5()

@@ -899,8 +899,9 @@ class ConjugateGradient:
     """runtime/steppers/conjugate_gradient.py:17-119 (per-row Polak-Ribiere)."""
 
     def __init__(self, restart_interval=10, max_iter=10, beta=0.7, c=1e-4, gamma=1.5,
-                 alpha_max_factor=10.0):
+                 alpha_max_factor=10.0, precondition=False):
         self.restart_interval = restart_interval
+        self.precondition = precondition
         self.max_iter, self.beta, self.c, self.gamma, self.alpha_max_factor = (
             max_iter, beta, c, gamma, alpha_max_factor)
         self.reset()
@@ -913,6 +914,8 @@ class ConjugateGradient:
 
     def step(self, p: Problem, grad, step_size, enforcer=None) -> LineSearchResult:
         g = grad
+        if self.precondition:  # :74-76 (history and the Armijo slope keep the raw gradient)
+            g = g / (np.linalg.norm(g, axis=1)[:, None] + 1e-8)
         if self.prev_grad is None or self.iter_count % self.restart_interval == 0:
             direction = -g
         else:

@@ -53,6 +53,11 @@ CASES = {
     "traj_ico8_cg_bending_volume_enforcer.npz": (["surface", "bending"], ["volume"], "cg",
                                                  dict(BASE, bending_modulus=1.0, spontaneous_curvature=0.3,
                                                       volume_projection_during_minimization=True)),
+    # ConjugateGradient(precondition=True) (ms_stepper_params.precondition): backtracking, a restart, exhausted
+    # searches; with the row, non-descent directions every other step
+    "traj_ico8_cg_precondition.npz": (["surface", "bending"], [], "cgp", dict(BASE, bending_modulus=1.0)),
+    "traj_ico8_cg_precondition_volume.npz": (["surface", "bending"], ["volume"], "cgp",
+                                             dict(BASE, bending_modulus=1.0, spontaneous_curvature=0.3)),
 }
 # positions against the reference: the drift cases resolve the 1 % effect of the cached-gradient first projection
 # step on a 7e-7 displacement, so they are held to a tighter bound than the historical 1e-8
@@ -73,7 +78,7 @@ def test_minimizer_reproduces_reference_trajectory(fname):
         gp["volume_stiffness"] = float(g["gp_volume_stiffness"])
         gp["surface_tension"] = float(g["gp_surface_tension"])
     mesh = _build(g, mods, cons, gp, "target_volume" in g)
-    stepper = GradientDescent() if kind == "gd" else ConjugateGradient()
+    stepper = GradientDescent() if kind == "gd" else ConjugateGradient(precondition=(kind == "cgp"))
     log = []
     orig = stepper.device_step
 
@@ -379,7 +384,8 @@ def test_reuse_levels_bitwise_identical_multitile_with_rejections(deterministic)
 
 @pytest.mark.parametrize("fname", ["traj_ico8_cg_surface_bending_volume.npz", "traj_cube_gd.npz",
                                    "traj_ico8_gd_volume_drift.npz", "traj_ico4_gd_tilt_volume_drift.npz",
-                                   "traj_ico6_cg_guard.npz",
+                                   "traj_ico6_cg_guard.npz", "traj_ico8_cg_precondition.npz",
+                                   "traj_ico8_cg_precondition_volume.npz",
                                    "traj_ico4_gd_surface_tilt.npz"])
 def test_library_loop_equals_python_loop(fname, deterministic):
     """Minimizer.minimize runs the loop inside the library (ms_minimize) when nobody watches the
@@ -399,7 +405,7 @@ def test_library_loop_equals_python_loop(fname, deterministic):
     outs = []
     for watched in (False, True):
         mesh = _build(g, mods, cons, gp, "target_volume" in g)
-        stepper = GradientDescent() if kind == "gd" else ConjugateGradient()
+        stepper = GradientDescent() if kind == "gd" else ConjugateGradient(precondition=(kind == "cgp"))
         if watched:
             orig = stepper.device_step
             stepper.device_step = lambda dm, m, step_size, tol=0.0, _o=orig: _o(dm, m, step_size, tol=tol)

@@ -183,6 +183,15 @@ TRAJ = {
                                                  {"bending_modulus": 1.0, "spontaneous_curvature": 0.3,
                                                   "volume_constraint_mode": "lagrange",
                                                   "volume_projection_during_minimization": True}),
+    # ConjugateGradient(precondition=True) (conjugate_gradient.py:74-76): backtracking, a restart, exhausted searches;
+    # with the Lagrange row: non-descent directions (line_search.py:325-328) every other step
+    "traj_ico8_cg_precondition.npz": (["surface", "bending"], [], "cgp",
+                                      {"bending_modulus": 1.0, "volume_constraint_mode": "lagrange",
+                                       "volume_projection_during_minimization": False}),
+    "traj_ico8_cg_precondition_volume.npz": (["surface", "bending"], ["volume"], "cgp",
+                                             {"bending_modulus": 1.0, "spontaneous_curvature": 0.3,
+                                              "volume_constraint_mode": "lagrange",
+                                              "volume_projection_during_minimization": False}),
 }
 
 
@@ -198,7 +207,7 @@ def test_minimizer_port_reproduces_reference_trajectory(fname):
     E0, grad0 = mp.energy_and_gradient(p, p.positions)
     assert abs(E0 - g["E0"]) <= 1e-12 * abs(g["E0"])
     assert relerr(grad0, g["grad0"]) < 1e-11
-    stepper = mp.GradientDescent() if kind == "gd" else mp.ConjugateGradient()
+    stepper = mp.GradientDescent() if kind == "gd" else mp.ConjugateGradient(precondition=(kind == "cgp"))
     n = int(g["n_steps"])
     res = mp.minimize(p, stepper, n, step_size=float(g["step_size0"]))
     log = g["step_log"]
