@@ -179,13 +179,20 @@ struct ms_ctx {
   double* xt2 = nullptr;         // ... of early trial 0 (MS_PAIR_LEAN=0, the sharded pair)
   double* fK2 = nullptr;
   double* fA2 = nullptr;
-  int pred_trials = 1;           // trials the last successful search needed
-  // line-search history of the last LS_HIST accepted steps (prediction only -- never changes a result):
-  // the accepted alpha and the smallest alpha rejected on the way to it (INFINITY: accepted at once)
+  // line-search history (prediction only -- never changes a result), kept per kind of direction: [0] searches along
+  // d = -g (gradient descent, CG restarts), [1] along a direction with CG history.  In the steady state of the
+  // headline workload the two alternate and behave nothing alike (the second kind is no descent direction or runs out
+  // of trials); one shared record would have every search predict the other kind.
+  //   pred_trials: trials the last search of the kind spent (an exhausted one: all of them)
+  //   acc / rej: of the last LS_HIST accepted steps the accepted alpha and the smallest alpha rejected on the way to
+  //   it (INFINITY: accepted at once)
   static constexpr int LS_HIST = 8;
-  double ls_acc[LS_HIST] = {0};
-  double ls_rej[LS_HIST] = {0};
-  int ls_n = 0;
+  struct LsHist {
+    int pred_trials = 1;
+    double acc[LS_HIST] = {0};
+    double rej[LS_HIST] = {0};
+    int n = 0;
+  } ls[2];
   bool ls_reset = true;          // MS_LS_RESET=0: never forget the history on a regime change
   bool speculate = true;         // MS_SPECULATE=0 switches the ladder off
   bool relax_va_valid = false;  // a leaflet relaxation is running: tf[l].va describes the current x
@@ -541,6 +548,16 @@ int disk_target_pass(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alp
 constexpr uint32_t MASK_GRAD = (1u << MS_S_GGC) | (1u << MS_S_GCGC);
 constexpr uint32_t MASK_DIR = (1u << MS_S_GNORM2) | (1u << MS_S_GDOTD) | (1u << MS_S_MAXD2) | (1u << MS_S_MAXG2);
 
+// MS_TRACE_STEPS=1: one stderr line per step of ms_minimize (what the search did, host time since the step before,
+// running queue statistics)
+bool trace_steps() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MS_TRACE_STEPS");
+    v = (e && atoi(e) != 0) ? 1 : 0;
+  }
+  return v == 1;
+}
 // MS_TRACE_QUEUE=1: one stderr line per fold launch / mailbox swap / fetch (debugging the line-search queue)
 bool trace_queue() {
   static int v = -1;
@@ -2269,7 +2286,7 @@ void swap_mailbox(ms_ctx* c, ms_ctx::Mailbox& m) {
 namespace {
 // plan a round from `alpha` on (prediction only: the same alphas are tested in the same order whatever is chosen)
 void plan_round(ms_ctx* c, const ms_stepper_params* sp, double alpha, int room, int rejected_here, double a_hi,
-                double r_lo, bool ls_warm, int trials_so_far, RoundPlan& plan) {
+                double r_lo, bool ls_warm, int pred_trials, int trials_so_far, RoundPlan& plan, bool ahead = false) {
   const bool multi_ok = c->pair_enable && c->side[0].partials != nullptr && (c->params.modules & MS_MOD_BENDING) != 0;
   const int n0_cap = !multi_ok ? 1 : (c->pair_lean_enable ? MS_MAX_TRIALS : (c->fK3 ? 3 : 2));
   double* alphas = plan.alphas;
@@ -2286,15 +2303,22 @@ void plan_round(ms_ctx* c, const ms_stepper_params* sp, double alpha, int room, 
   const int force = c->pair_force;
   if (!force && c->escalate && multi_ok && rejected_here >= c->escalate_after) {
     n0 = std::max(1, std::min(std::min(n_alpha, n0_cap), rejected_here));
+  } else if (!force && !ahead && c->escalate && multi_ok && !ls_warm && room >= 3 && pred_trials - trials_so_far >= room) {
+    // no history of accepted alphas, and the last search of this kind ran out of its trials (in the cold phase of the
+    // headline run: every search along a CG direction): this one is expected to as well -- as many trials per launch
+    // as there are sets.  (One search that needed five trials says little about the next: an early accept in a
+    // multi-trial launch costs more than the rounds it saves.  And not in a round queued ahead: whether that search
+    // happens at all is a guess already.)
+    n0 = std::min(n_alpha, n0_cap);
   } else {
-    const bool can_spec = force || (ls_warm ? r_lo < INFINITY : c->pred_trials > 1);
+    const bool can_spec = force || (ls_warm ? r_lo < INFINITY : pred_trials > 1);
     int depth = 1;
     if (can_spec) {
       // how many trials to queue: as many as the last search needed (cold), or -- once there is a history --
       // one per alpha that still lies above (most of) the range where alphas were accepted lately
       const int room4 = std::min(1 + ms_ctx::SPEC_STAGES, n_alpha);
       const int want = force ? std::min(std::min(force, 3), room4)
-                             : (ls_warm ? room4 : std::min(c->pred_trials - trials_so_far, room4));
+                             : (ls_warm ? room4 : std::min(pred_trials - trials_so_far, room4));
       while (depth < want) {
         if (!force && ls_warm && !(alphas[depth - 1] > 0.9 * a_hi)) break;
         ++depth;
@@ -2489,13 +2513,14 @@ int queue_ahead(ms_ctx* c, const ms_stepper_params* sp, const ms_step_result* ou
     return flush_dir_fold(c, src);  // (the step it would belong to is not part of this call)
   // line-search history as the consuming step will see it (accept() has just added this search)
   double a_hi = 0.0, r_lo = INFINITY;
-  for (int k = 0; k < std::min(c->ls_n, (int)ms_ctx::LS_HIST); ++k) {
-    a_hi = std::max(a_hi, c->ls_acc[k]);
-    r_lo = std::min(r_lo, c->ls_rej[k]);
+  const ms_ctx::LsHist& lh = c->ls[kind == 3 ? 1 : 0];  // (kinds 1 and 2 search along -g)
+  for (int k = 0; k < std::min(lh.n, (int)ms_ctx::LS_HIST); ++k) {
+    a_hi = std::max(a_hi, lh.acc[k]);
+    r_lo = std::min(r_lo, lh.rej[k]);
   }
   const int max_iter = sp->max_iter > 0 ? sp->max_iter : 10;
   ms_ctx::Ahead& ah = c->ahead;
-  plan_round(c, sp, alpha0, max_iter, 0, a_hi, r_lo, c->ls_n >= 2, 0, ah.plan);
+  plan_round(c, sp, alpha0, max_iter, 0, a_hi, r_lo, lh.n >= 2, lh.pred_trials, 0, ah.plan, /*ahead=*/true);
   if (ah.plan.n0 + ah.plan.n_st > 8) return flush_dir_fold(c, src);  // (the fold forms eight right-hand sides)
   ah.kind = kind;
   ah.stepper = sp->stepper;
@@ -2712,11 +2737,12 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   // what the recent searches say about the acceptance threshold: no alpha above a_hi was accepted, and alphas
   // down to r_lo were rejected (INFINITY: nothing was rejected lately -- the step size is still growing)
   double a_hi = 0.0, r_lo = INFINITY;
-  for (int k = 0; k < std::min(c->ls_n, (int)ms_ctx::LS_HIST); ++k) {
-    a_hi = std::max(a_hi, c->ls_acc[k]);
-    r_lo = std::min(r_lo, c->ls_rej[k]);
+  ms_ctx::LsHist& lh = c->ls[use_history ? 1 : 0];
+  for (int k = 0; k < std::min(lh.n, (int)ms_ctx::LS_HIST); ++k) {
+    a_hi = std::max(a_hi, lh.acc[k]);
+    r_lo = std::min(r_lo, lh.rej[k]);
   }
-  const bool ls_warm = c->ls_n >= 2;
+  const bool ls_warm = lh.n >= 2;
   // what an accepted trial at `alpha` does (positions, carry flags, CG history, result fields)
   auto accept = [&](double alpha_acc, double E_t) {
     std::swap(c->buf[MS_BUF_X], c->buf[MS_BUF_XT]);
@@ -2742,12 +2768,12 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
     out->energy = E_t;
     out->volume = c->h_scal[MS_S_VOL];
     out->next_step = std::min(alpha_acc * sp->gamma, alpha_max);
-    c->pred_trials = std::max(1, out->trials);
+    lh.pred_trials = std::max(1, out->trials);
     // an alpha far below everything accepted lately: the step-size regime has changed, the history predicts nothing
-    if (c->ls_reset && c->ls_n > 0 && alpha_acc < 0.5 * a_hi) c->ls_n = 0;
-    c->ls_acc[c->ls_n % ms_ctx::LS_HIST] = alpha_acc;
-    c->ls_rej[c->ls_n % ms_ctx::LS_HIST] = min_rejected;
-    ++c->ls_n;
+    if (c->ls_reset && lh.n > 0 && alpha_acc < 0.5 * a_hi) lh.n = 0;
+    lh.acc[lh.n % ms_ctx::LS_HIST] = alpha_acc;
+    lh.rej[lh.n % ms_ctx::LS_HIST] = min_rejected;
+    ++lh.n;
     c->kc_pending = kc_queued;
   };
   // the queue needs: carry mode (a trial is a complete energy pass), energies the device can add up the way the
@@ -2837,7 +2863,8 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       c->kc_use_history = cg && ((c->cg_iter_count + 1) % restart != 0);
       ++c->q_adopted;
     } else {
-      plan_round(c, sp, alpha, max_iter - it, out->trials + out->guard_rejects, a_hi, r_lo, ls_warm, out->trials, plan);
+      plan_round(c, sp, alpha, max_iter - it, out->trials + out->guard_rejects, a_hi, r_lo, ls_warm, lh.pred_trials,
+                 out->trials, plan);
       parity = c->next_parity;
       c->next_parity ^= 1;
       rc = queue_round(c, sp, plan, parity, energy0, g_dot_d, /*merged=*/false, 0, carry_mode, cg, restart);
@@ -2961,7 +2988,8 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
   }
   const double reduced = std::max(alpha * sp->beta, 0.0);  // :425-426
   out->next_step = std::max(reduced, step_size * sp->beta);
-  if (c->ls_reset) c->ls_n = 0;  // a search that ran out of trials: same
+  if (c->ls_reset) lh.n = 0;  // a search that ran out of trials: same
+  lh.pred_trials = std::max(1, out->trials + out->guard_rejects);
   if (carry_mode && !unchained_ran) {
     // every trial was rejected and x has not moved: G and the host's scalars still describe x (the queued rounds post
     // to mailboxes of their own); only the bending factors in fK / fA and the device scalars are the last trial's
@@ -3049,6 +3077,17 @@ int ms_minimize(ms_ctx* c, const ms_minimize_params* mp, int n_steps, ms_minimiz
                                                             : ms_step(c, &mp->stepper, step_in, mp->tol, &r);
     c->ahead_allowed = false;
     if (rc) return rc;
+    if (trace_steps()) {
+      static double t_prev = 0.0;
+      struct timespec ts;
+      clock_gettime(CLOCK_MONOTONIC, &ts);
+      const double t_now = 1e6 * (double)ts.tv_sec + 1e-3 * (double)ts.tv_nsec;
+      fprintf(stderr, "[mss] %3d ok %d trials %2d alpha %.3e g.d %+.2e  %7.0f us  rounds %lld multi %lld wasted %lld side %lld ahead %lld adopted %lld dropped %lld\n",
+              i, r.success, r.trials, r.alpha, r.g_dot_d, t_prev > 0.0 ? t_now - t_prev : 0.0, (long long)c->q_rounds,
+              (long long)c->q_multi, (long long)c->q_wasted, (long long)c->q_side_accepts, (long long)c->q_ahead,
+              (long long)c->q_adopted, (long long)c->q_dropped);
+      t_prev = t_now;
+    }
     out->iterations = i + 1;
     out->energy_eval = r.energy_eval;
     out->grad_norm = r.grad_norm;
@@ -3683,14 +3722,15 @@ int ms_shard_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, doub
   const int max_iter = sp->max_iter > 0 ? sp->max_iter : 10;
   // line-search history (same bookkeeping as ms_step: prediction only)
   double min_rejected = INFINITY, a_hi = 0.0, r_lo = INFINITY;
-  for (int k = 0; k < std::min(c->ls_n, (int)ms_ctx::LS_HIST); ++k) {
-    a_hi = std::max(a_hi, c->ls_acc[k]);
-    r_lo = std::min(r_lo, c->ls_rej[k]);
+  ms_ctx::LsHist& lh = c->ls[use_history ? 1 : 0];
+  for (int k = 0; k < std::min(lh.n, (int)ms_ctx::LS_HIST); ++k) {
+    a_hi = std::max(a_hi, lh.acc[k]);
+    r_lo = std::min(r_lo, lh.rej[k]);
   }
   auto remember = [&](double alpha_acc) {
-    c->ls_acc[c->ls_n % ms_ctx::LS_HIST] = alpha_acc;
-    c->ls_rej[c->ls_n % ms_ctx::LS_HIST] = min_rejected;
-    ++c->ls_n;
+    lh.acc[lh.n % ms_ctx::LS_HIST] = alpha_acc;
+    lh.rej[lh.n % ms_ctx::LS_HIST] = min_rejected;
+    ++lh.n;
   };
   auto accepted = [&](double alpha_acc, double E_t) -> int {
     int r2 = ms_phase_commit_trial(c, alpha_acc, cg ? 1 : 0);
@@ -3716,7 +3756,7 @@ int ms_shard_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, doub
   // exchange (both trials' scalars in the header, both factor sets' boundary rows behind it)
   const bool pair = c->pair_enable && carry_mode && bend && !penalty && max_iter >= 2 &&
                     alpha * max_dir < safe_limit && alpha * sp->beta >= 1e-8 &&
-                    (c->pair_force || (c->ls_n >= 2 && alpha > 1.05 * a_hi && r_lo < INFINITY));
+                    (c->pair_force || (lh.n >= 2 && alpha > 1.05 * a_hi && r_lo < INFINITY));
   if (pair) {
     rc = spec_prepare(c);
     if (rc) return rc;
