@@ -497,7 +497,11 @@ def main_single(args):
         torch.cuda.synchronize()
         dt0 = time.perf_counter() - t0
         out["all_reference_passes_repeated"] = {"value": args.steps / dt0, "unit": "steps/s",
-                                                "ms_per_step": 1e3 * dt0 / args.steps, "reuse_level": 0}
+                                                "ms_per_step": 1e3 * dt0 / args.steps, "reuse_level": 0,
+                                                "steps_accepted": int(mz.last_run["accepted"]),
+                                                "line_search_trials": int(mz.last_run["trials"]),
+                                                "window": "continues the headline run (5 untimed steps, then K): past "
+                                                          "the cold phase of the line searches, not the headline's window"}
         stepper.reuse_energy0 = args.reuse_level
 
     # -- the same K steps with fixed-order (bitwise reproducible) vertex sums -------------------
@@ -511,7 +515,11 @@ def main_single(args):
         torch.cuda.synchronize()
         dtd = time.perf_counter() - t0
         out["deterministic_mode"] = {"value": args.steps / dtd, "unit": "steps/s",
-                                     "ms_per_step": 1e3 * dtd / args.steps}
+                                     "ms_per_step": 1e3 * dtd / args.steps,
+                                     "steps_accepted": int(mz.last_run["accepted"]),
+                                     "line_search_trials": int(mz.last_run["trials"]),
+                                     "window": "continues the headline run (5 untimed steps, then K): past the cold "
+                                               "phase of the line searches, not the headline's window"}
         mz.deterministic = False
         mz.minimize(2, sync_mesh=False)
 
