@@ -188,7 +188,8 @@ const char *ms_last_error(const ms_ctx *ctx); /* ctx may be NULL */
 
 /*
  * Build a context: vertices are put in patch order (recursive coordinate bisection down to single tiles), cut into tiles
- * of `tile_vertices` owned vertices (0 = 256), and the tile->facet /
+ * of `tile_vertices` owned vertices (0 = 256; 64, 128, 129..256 or 512 -- 129..255 rows run on the 256-thread
+ * instances), and the tile->facet /
  * tile->halo-vertex CSR is pushed to HBM once.  Replaces the per-step reads of
  * Mesh.triangle_row_cache / fixed_mask / boundary_vertex_ids
  * (geometry/mesh.py:597-624, :210-232, :304-319).  `fixed`, `boundary`,

@@ -308,6 +308,7 @@ DeviceMesh device_mesh(const ms_ctx* c) {
   DeviceMesh m;
   m.nv = c->til.nv;
   m.T = c->til.T;
+  m.own = c->til.own;
   m.n_tiles = c->til.n_tiles;
   m.has_boundary = c->has_boundary ? 1 : 0;
   m.tile_facet_off = c->d_tile_facet_off;
@@ -514,7 +515,7 @@ int disk_target_pass(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alp
   a.tile0 = c->tile0;
   a.tile1 = c->tile1;
   a.nv = c->til.nv;
-  a.T = c->til.T;
+  a.T = c->til.own;  // (row stride of the streaming kernels)
   a.n_tiles = c->til.n_tiles;
   a.vflags = c->d_vflags;
   a.disk = f.disk;
@@ -938,7 +939,7 @@ int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulat
   }
   // the gradient kernel's <g, gC> partials predate those additions: take them again of the complete gradient
   if (added_after && g_out && (modules & MS_CON_VOLUME))
-    HIPCHK(c, launch_row_dot(c->tile0, c->tile1, c->til.nv, c->til.T, g_out, c->buf[MS_BUF_GC], c->d_partials,
+    HIPCHK(c, launch_row_dot(c->tile0, c->tile1, c->til.nv, c->til.own, g_out, c->buf[MS_BUF_GC], c->d_partials,
                              c->til.n_tiles, c->stream));
   if (reduce_now) return reduce_slots(c, dir_mode ? MASK_DIR : MASK_GRAD);
   return MS_OK;
@@ -949,7 +950,7 @@ int phase_direction(ms_ctx* c, int stepper, bool use_history, bool g_finalized =
   c->dir_implicit = false;
   {
   ProfScope ps(c, 2);
-  HIPCHK(c, launch_direction(c->tile0, c->tile1, c->til.nv, c->til.T, c->d_vflags, c->buf[MS_BUF_G],
+  HIPCHK(c, launch_direction(c->tile0, c->tile1, c->til.nv, c->til.own, c->d_vflags, c->buf[MS_BUF_G],
                              c->buf[MS_BUF_GC], c->buf[MS_BUF_D], c->buf[MS_BUF_PG],
                              c->buf[MS_BUF_PD], c->d_scal, use_con ? 1 : 0,
                              (stepper == MS_STEPPER_CG && use_history) ? 1 : 0, c->d_partials,
@@ -1213,7 +1214,7 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
   const Tiling& t = c->til;
   c->tile0 = std::min(t.n_tiles, shard_rank * t.tiles_per_shard);
   c->tile1 = std::min(t.n_tiles, (shard_rank + 1) * t.tiles_per_shard);
-  c->cap = t.T + t.max_halo;
+  c->cap = t.own + t.max_halo;
   {
     const size_t le = energy_lds_bytes(t.T, c->cap, t.max_ent, true, true, true);
     const size_t lg = gradient_lds_bytes(t.T, c->cap, t.max_ent, true, true);
@@ -1248,7 +1249,7 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
   CREATE_CHK(upload(c, &c->d_perm, t.perm));
   CREATE_CHK(upload(c, &c->d_tile_facet_off, t.tile_facet_off));
   CREATE_CHK(upload(c, &c->d_tile_facets, t.tile_facets));
-  if (t.T + t.max_halo <= 1024) {
+  if (t.own + t.max_halo <= 1024) {
     std::vector<uint32_t> packed(t.tile_facets.size());
     for (size_t i = 0; i < packed.size(); ++i) {
       const TileFacet& f = t.tile_facets[i];
@@ -1310,7 +1311,7 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
   {
     // boundary lists of every rank (each rank derives all of them from the shared tiling)
     const int W = shard_count;
-    const int rows_per = t.tiles_per_shard * t.T;
+    const int rows_per = t.tiles_per_shard * t.own;
     std::vector<std::vector<int32_t>> lists((size_t)W);
     std::vector<int32_t> my_halo;
     for (int tile = 0; tile < t.n_tiles; ++tile) {
@@ -1713,7 +1714,7 @@ int tilt_eval(ms_ctx* c, bool trial, bool gradient) {
     if ((mods & f.mod_tilt) && c->relax_va_valid && f.va) {
       // positions frozen, vertex areas at hand: the reference's own form of this evaluation, one streaming pass
       ProfScope ps(c, 6);
-      HIPCHK(c, launch_tvec(4, c->tile0, c->tile1, c->til.nv, c->til.T, c->d_vflags, f.grad, f.va, f.dir, tilts,
+      HIPCHK(c, launch_tvec(4, c->tile0, c->tile1, c->til.nv, c->til.own, c->d_vflags, f.grad, f.va, f.dir, tilts,
                             nullptr, nullptr, nullptr, f.k_tilt, gradient ? 1 : 0, c->d_partials, c->til.n_tiles,
                             c->stream, f.fixed_bit, f.s_etilt, f.s_rz));
       mask |= 1u << f.s_etilt;
@@ -1792,7 +1793,7 @@ int relax_fields(ms_ctx* c, const ms_tilt_relax_params* rp, TiltField** fl, int 
   if (rc) return rc;
   auto tvec = [&](TiltField& f, int mode, const double* src, double* out, double coef, int flag) -> int {
     ProfScope ps(c, 6);
-    HIPCHK(c, launch_tvec(mode, c->tile0, c->tile1, t.nv, t.T, c->d_vflags, f.grad, f.minv, f.dir, f.tilts, src,
+    HIPCHK(c, launch_tvec(mode, c->tile0, c->tile1, t.nv, t.own, c->d_vflags, f.grad, f.minv, f.dir, f.tilts, src,
                           c->d_tn, out, coef, flag, c->d_partials, t.n_tiles, c->stream, f.fixed_bit, f.s_gn2,
                           f.s_rz));
     return MS_OK;
@@ -2150,7 +2151,7 @@ int ms_get_vertex_buffer(ms_ctx* c, int buffer, double* out) {
   if ((buffer == MS_BUF_D && c->dir_implicit) || (buffer == MS_BUF_PD && c->pd_neg_pg)) {
     // the direction asked for exists only as -G / -PG: write it out
     const int src = buffer == MS_BUF_D ? MS_BUF_G : MS_BUF_PG;
-    HIPCHK(c, launch_direction(c->tile0, c->tile1, c->til.nv, c->til.T, c->d_vflags, c->buf[src], c->buf[MS_BUF_GC],
+    HIPCHK(c, launch_direction(c->tile0, c->tile1, c->til.nv, c->til.own, c->d_vflags, c->buf[src], c->buf[MS_BUF_GC],
                                c->buf[buffer], c->buf[MS_BUF_PG], c->buf[MS_BUF_PD], c->d_scal, 0, 0, c->d_partials,
                                c->til.n_tiles, 0, c->stream));
     if (buffer == MS_BUF_D) c->dir_implicit = false; else c->pd_neg_pg = false;
@@ -3213,7 +3214,7 @@ int ms_phase_commit_trial(ms_ctx* c, double alpha, int keep_history) {
     // of its tiles (d is valid there after the boundary exchange); same expression as the
     // trial pass, so the committed doubles are the evaluated ones
     const Tiling& t = c->til;
-    const int64_t rows_per = (int64_t)t.tiles_per_shard * t.T;
+    const int64_t rows_per = (int64_t)t.tiles_per_shard * t.own;
     HIPCHK(c, launch_axpy_rows(c->shard_rank * rows_per, (c->shard_rank + 1) * rows_per, c->d_halo_rows,
                                c->n_halo_rows, c->d_vflags, c->buf[MS_BUF_X], trial_dir(c), trial_alpha(c, alpha),
                                c->stream));
@@ -3871,9 +3872,9 @@ int ms_shard_info(ms_ctx* c, int64_t* nvp, int64_t* row0, int64_t* row1, int64_t
   if (!c) return MS_ERR_INVALID;
   const Tiling& t = c->til;
   if (nvp) *nvp = t.nvp;
-  if (rows_per_shard) *rows_per_shard = (int64_t)t.tiles_per_shard * t.T;
-  if (row0) *row0 = (int64_t)c->shard_rank * t.tiles_per_shard * t.T;
-  if (row1) *row1 = (int64_t)(c->shard_rank + 1) * t.tiles_per_shard * t.T;
+  if (rows_per_shard) *rows_per_shard = (int64_t)t.tiles_per_shard * t.own;
+  if (row0) *row0 = (int64_t)c->shard_rank * t.tiles_per_shard * t.own;
+  if (row1) *row1 = (int64_t)(c->shard_rank + 1) * t.tiles_per_shard * t.own;
   return MS_OK;
 }
 
@@ -3944,7 +3945,7 @@ int ms_plan_tiling(int nv, int nf, const double* positions, const int32_t* tri, 
   if (rc != MS_OK) return fail(nullptr, rc, err);
   int64_t owners = 0, owned_corners = 0;
   for (int tile = 0; tile < t.n_tiles; ++tile) {
-    const int n_owned = std::min(t.T, t.nv - tile * t.T);
+    const int n_owned = std::min(t.own, t.nv - tile * t.own);
     for (int p = t.tile_facet_off[tile]; p < t.tile_facet_off[tile + 1]; ++p) {
       const TileFacet& f = t.tile_facets[p];
       if (f.flags & TF_OWNER) ++owners;
@@ -3958,7 +3959,7 @@ int ms_plan_tiling(int nv, int nf, const double* positions, const int32_t* tri, 
   stats[4] = t.dropped_facets;
   stats[5] = owners;
   stats[6] = owned_corners;
-  stats[7] = (int64_t)gradient_lds_bytes(t.T, t.T + t.max_halo, t.max_ent, true, true);
+  stats[7] = (int64_t)gradient_lds_bytes(t.T, t.own + t.max_halo, t.max_ent, true, true);
   if (perm_out) memcpy(perm_out, t.perm.data(), sizeof(int32_t) * (size_t)nv);
   return MS_OK;
 }
@@ -3973,7 +3974,7 @@ int ms_plan_tiling_conflicts(int nv, int nf, const double* positions, const int3
   double rd_cyc = 0, at_cyc = 0, rd_free = 0, at_free = 0;
   int64_t rd_groups = 0, at_groups = 0;
   for (int tile = 0; tile < t.n_tiles; ++tile) {
-    const int n_owned = std::min(t.T, t.nv - tile * t.T);
+    const int n_owned = std::min(t.own, t.nv - tile * t.own);
     const int f0 = t.tile_facet_off[tile], f1 = t.tile_facet_off[tile + 1];
     for (int k = 0; k < 3; ++k) {
       for (int g0 = f0; g0 < f1; g0 += 32) {  // reads: 32 lanes, bank pair = slot mod 32, same slot broadcasts

@@ -68,10 +68,11 @@ constexpr uint8_t VF_TILT_FIXED_OUT = 16;  // vertex.tilt_fixed_out (minimizer.p
 // Host-side result of the tiling pass.
 struct Tiling {
   int nv = 0, nf = 0, T = 256;
+  int own = 256;               // vertex rows a tile owns (<= T = threads per workgroup): tile t owns rows [t*own, (t+1)*own)
   int n_tiles = 0;             // tiles covering real vertices
   int n_tiles_padded = 0;      // multiple of shard_count
   int tiles_per_shard = 0;
-  int64_t nvp = 0;             // padded vertex rows = n_tiles_padded * T
+  int64_t nvp = 0;             // padded vertex rows = n_tiles_padded * own
   std::vector<int32_t> perm;   // internal row -> external row   (nv)
   std::vector<int32_t> iperm;  // external row -> internal row   (nv)
   std::vector<int32_t> tile_facet_off;  // n_tiles+1
@@ -99,6 +100,7 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
 // ---- device-side view handed to kernels ---------------------------------
 struct DeviceMesh {
   int nv, T, n_tiles;
+  int own;                // vertex rows per tile (<= T = threads per workgroup)
   int has_boundary;       // any vertex carries VF_BOUNDARY (uniform fast-path switch)
   const int32_t* tile_facet_off;
   const TileFacet* tile_facets;

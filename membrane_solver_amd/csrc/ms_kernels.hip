@@ -330,8 +330,8 @@ struct TileCtx {
 __device__ __forceinline__ TileCtx tile_ctx(const DeviceMesh& m, int tile) {
   TileCtx t;
   t.tile = tile;
-  t.v_lo = tile * m.T;
-  t.n_owned = min(m.T, m.nv - t.v_lo);
+  t.v_lo = tile * m.own;
+  t.n_owned = min(m.own, m.nv - t.v_lo);
   t.h0 = m.tile_halo_off[tile];
   t.nh = m.tile_halo_off[tile + 1] - t.h0;
   t.f0 = m.tile_facet_off[tile];

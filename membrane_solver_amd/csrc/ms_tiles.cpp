@@ -56,8 +56,12 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
     return MS_ERR_INVALID;
   }
   if (T <= 0) T = 256;
+  // rows per tile R <= threads per workgroup T: 129..255 rows run on the 256-thread instances (the tile count, and with
+  // it the fill of the last round of workgroups, is the caller's to choose)
+  int R = T;
+  if (T > 128 && T < 256) T = 256;
   if (!(T == 64 || T == 128 || T == 256 || T == 512)) {
-    err = "ms_create: tile_vertices must be 64, 128, 256 or 512 (one thread per owned vertex)";
+    err = "ms_create: tile_vertices must be 64, 128, 129..256 or 512 (one thread per owned vertex)";
     return MS_ERR_INVALID;
   }
   if (shard_count < 1) shard_count = 1;
@@ -65,6 +69,7 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
   out.nv = nv;
   out.nf = nf;
   out.T = T;
+  out.own = R;
 
   // ---- 1. patch order: sort vertices along a 3D Hilbert curve --------------
   double lo[3] = {positions[0], positions[1], positions[2]};
@@ -110,7 +115,7 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
       const Range r = stack.back();
       stack.pop_back();
       const int n = r.hi - r.lo;
-      const int tiles = (n + T - 1) / T;
+      const int tiles = (n + R - 1) / R;
       if (tiles <= 1) {
         std::sort(out.perm.begin() + r.lo, out.perm.begin() + r.hi,
                   [&](int32_t a, int32_t b) { return key[a] < key[b] || (key[a] == key[b] && a < b); });
@@ -126,7 +131,7 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
       int ax = 0;
       for (int d = 1; d < 3; ++d)
         if (bhi[d] - blo[d] > bhi[ax] - blo[ax]) ax = d;
-      const int mid = r.lo + (tiles / 2) * T;
+      const int mid = r.lo + (tiles / 2) * R;
       std::nth_element(out.perm.begin() + r.lo, out.perm.begin() + mid, out.perm.begin() + r.hi,
                        [&](int32_t a, int32_t b) {
                          const double pa = positions[3 * (size_t)a + ax], pb = positions[3 * (size_t)b + ax];
@@ -140,10 +145,10 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
   for (int i = 0; i < nv; ++i) out.iperm[out.perm[i]] = i;
 
   // ---- 2. tiles -----------------------------------------------------------
-  out.n_tiles = (nv + T - 1) / T;
+  out.n_tiles = (nv + R - 1) / R;
   out.tiles_per_shard = (out.n_tiles + shard_count - 1) / shard_count;
   out.n_tiles_padded = out.tiles_per_shard * shard_count;
-  out.nvp = (int64_t)out.n_tiles_padded * T;
+  out.nvp = (int64_t)out.n_tiles_padded * R;
 
   // count facet instances per tile (a facet is listed by every tile owning one
   // of its corners)
@@ -156,7 +161,7 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
     }
     int n = 0;
     for (int k = 0; k < 3; ++k) {
-      int t = iv[k] / T;
+      int t = iv[k] / R;
       bool dup = false;
       for (int j = 0; j < n; ++j) dup |= (tl[j] == t);
       if (!dup) tl[n++] = t;
@@ -198,7 +203,7 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
     int tl[3], iv[3];
     int n = tiles_of(f, tl, iv);
     if (n < 0) continue;
-    int owner_tile = iv[0] / T;
+    int owner_tile = iv[0] / R;
     for (int j = 0; j < n; ++j) {
       size_t p = (size_t)cursor[tl[j]]++;
       inst_v[3 * p] = iv[0];
@@ -228,8 +233,8 @@ int build_tiling(int nv, int nf, const double* positions, const int32_t* tri,
   std::vector<int32_t> order;
   std::vector<uint8_t> taken;
   for (int t = 0; t < out.n_tiles; ++t) {
-    const int v_lo = t * T;
-    const int v_hi = std::min(nv, v_lo + T);
+    const int v_lo = t * R;
+    const int v_hi = std::min(nv, v_lo + R);
     const size_t b = (size_t)out.tile_facet_off[t], e = (size_t)out.tile_facet_off[t + 1];
     const size_t n = e - b;
     halo_tmp.clear();

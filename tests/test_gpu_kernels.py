@@ -30,7 +30,7 @@ def _mesh(g, **kw):
 
 
 @pytest.mark.parametrize("name", ["ico4", "ico8", "disk5", "ico5_noisy"])
-@pytest.mark.parametrize("tile", [64, 256])
+@pytest.mark.parametrize("tile", [64, 200, 256])
 def test_surface_volume_match_reference(L, name, tile):
     g = load_golden(f"mesh_{name}.npz")
     dm = _mesh(g, tile_vertices=tile)
@@ -55,7 +55,7 @@ def test_surface_volume_match_reference(L, name, tile):
 
 
 @pytest.mark.parametrize("name", ["ico4", "ico8", "disk5", "ico5_noisy"])
-@pytest.mark.parametrize("tile", [64, 256])
+@pytest.mark.parametrize("tile", [64, 200, 256])
 def test_bending_matches_reference(L, name, tile):
     g = load_golden(f"mesh_{name}.npz")
     nv = g["positions"].shape[0]

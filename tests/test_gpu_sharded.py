@@ -97,6 +97,7 @@ class ThreadGroup:
 @pytest.mark.parametrize("with_volume,world,level,freq,tile", [
     (False, 2, 2, 16, 64), (True, 2, 2, 16, 64), (False, 3, 2, 16, 64), (False, 2, 0, 16, 64), (True, 3, 0, 16, 64),
     (False, 4, 2, 160, 256),  # 512 000 facets, default tile size, 4 shards: sizes near the headline
+    (True, 3, 2, 40, 200),  # tiles of 200 rows on the 256-thread instances: the shards' row ranges follow the rows
 ])
 def test_shards_match_single_context(with_volume, world, level, freq, tile, driver, pair, monkeypatch):
     """driver "python": parallel.ShardedStepper drives the phase API; "library": the same control

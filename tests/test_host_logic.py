@@ -98,6 +98,11 @@ def test_bisection_tiles_are_compact():
     assert st[5] == nf and st[6] == 3 * nf
     assert st[1] < 1.17 * nf, list(st)
     assert st[2] <= 128, list(st)
+    # tiles of 200 rows (they run on the 256-thread instances): every vertex and every corner is still owned exactly once
+    assert lib.ms_plan_tiling(nv, nf, P.ctypes.data_as(L._D), T.ctypes.data_as(L._I32), 200, 1, st,
+                              perm.ctypes.data_as(L._I32)) == 0
+    assert st[0] == (nv + 199) // 200 and sorted(perm.tolist()) == list(range(nv))
+    assert st[5] == nf and st[6] == 3 * nf
 
 
 def test_array_mesh_accessors_and_managers():
