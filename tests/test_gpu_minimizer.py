@@ -309,6 +309,61 @@ def test_full_size_properties(freq, kind):
     dm.close()
 
 
+@pytest.mark.parametrize("freq", [81, 320])
+def test_full_size_rotation_and_scaling_laws(freq):
+    """Size-independent laws at BASELINE sizes (131 220 / 2 048 000 facets), none of which the kernels know about:
+    - a rigid rotation leaves every energy unchanged and rotates the gradient;
+    - scaling the surface by s: E_surface ~ s^2 (gradient ~ s), the Willmore energy (c0 = 0) does not change
+      (gradient ~ 1/s), the enclosed volume ~ s^3 (read through the penalty energy k/2 (V - V0)^2 with V0 = 0, k = 2).
+    The gradient bounds are gross (the bending back-propagation amplifies rounding by ~1/h^2: measured against the
+    oracle in test_full_size_energy_and_gradient_match_oracle); the energies are held to 1e-11."""
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+
+    P, T = meshgen.icosphere(freq)
+    P = meshgen.smooth_displace(P, 0.05)
+    nv, nf = P.shape[0], T.shape[0]
+    dm = DeviceMesh(P, T)
+    dm.set_surface_tension(np.ones(nf))
+    dm.set_bending_params(np.ones(nv), np.zeros(nv))
+    both = L.MS_MOD_SURFACE | L.MS_MOD_BENDING
+    # (rotating / scaling the INPUT rounds every coordinate anew: 1e-16 in x is ~1e-16 / h^2 in the curvature and more
+    # in its differences -- 3e-8 of max|g| at 131 220 facets)
+    gtol = 1e-6 if freq <= 81 else 1e-4
+
+    def evaluate(X, modules, **kw):
+        dm.set_positions(X)
+        dm.set_params(modules=modules, **kw)
+        return dm.energy_and_gradient()
+
+    e0, g0 = evaluate(P, both)
+    es0, gs0 = evaluate(P, L.MS_MOD_SURFACE)
+    ev0, _ = evaluate(P, L.MS_MOD_VOLUME_PENALTY, volume_stiffness=2.0, target_volume=0.0)
+    V0 = np.sqrt(ev0.sum())
+    assert abs(V0 - 4.0 * np.pi / 3.0) < 0.3  # (a displaced unit sphere)
+    # rotation (a proper one, from a QR factorisation)
+    Q, _r = np.linalg.qr(np.random.default_rng(5).normal(size=(3, 3)))
+    if np.linalg.det(Q) < 0:
+        Q[:, 0] = -Q[:, 0]
+    e1, g1 = evaluate(P @ Q.T, both)
+    assert np.allclose(e1, e0, rtol=1e-11, atol=0)
+    assert relerr(g1, g0 @ Q.T) < gtol
+    # scaling
+    s = 1.7
+    e2, g2 = evaluate(s * P, both)
+    es2, gs2 = evaluate(s * P, L.MS_MOD_SURFACE)
+    assert abs(es2[0] - s * s * es0[0]) <= 1e-12 * es2[0]
+    assert relerr(gs2, s * gs0) < 1e-10  # (per-vertex sums of facet terms that cancel to ~h of their size)
+    assert abs(e2[0] - s * s * e0[0]) <= 1e-12 * e2[0]
+    assert abs(e2[1] - e0[1]) <= 1e-11 * e0[1]  # Willmore: scale-invariant
+    gb0, gb2 = g0 - gs0, g2 - gs2
+    assert relerr(gb2, gb0 / s) < gtol
+    ev2, _ = evaluate(s * P, L.MS_MOD_VOLUME_PENALTY, volume_stiffness=2.0, target_volume=0.0)
+    assert abs(np.sqrt(ev2.sum()) - s ** 3 * V0) <= 1e-12 * s ** 3 * V0
+    dm.close()
+
+
 @pytest.mark.parametrize("fname", sorted(CASES))
 def test_evaluation_reuse_levels_are_bitwise_identical(fname, deterministic):
     """ms_stepper_params.reuse_energy0 = 0 (re-evaluate everything the reference re-evaluates),
