@@ -3185,6 +3185,7 @@ int ms_phase_gradient(ms_ctx* c) {
 
 int ms_phase_direction(ms_ctx* c, int stepper, int use_history) {
   if (!c) return MS_ERR_INVALID;
+  c->precond = false;  // (the phase API has no preconditioned lane: never inherit one from an earlier ms_step)
   return phase_direction(c, stepper, use_history != 0);
 }
 
@@ -3636,6 +3637,7 @@ int ms_shard_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, doub
   const uint32_t mods = c->params.modules;
   if (mods & MS_ANY_TILT_MODS) return fail(c, MS_ERR_STATE, "the tilt modules are not sharded yet (single GPU only)");
   if (sp->precondition) return fail(c, MS_ERR_STATE, "ConjugateGradient(precondition=True) is not sharded (single GPU only)");
+  c->precond = false;
   memset(out, 0, sizeof(*out));
   const bool cg = sp->stepper == MS_STEPPER_CG;
   const int restart = sp->restart_interval > 0 ? sp->restart_interval : 10;
