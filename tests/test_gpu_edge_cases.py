@@ -195,6 +195,20 @@ def test_tile_size_and_instance_choice_do_not_change_the_results(L):
         assert np.allclose(e, e0, rtol=1e-12, atol=0), key
         assert relerr(g, g0) < tol, (key, relerr(g, g0), repeat, noise)
         assert abs(E - E0) <= 1e-12 * abs(E0) and tr == tr0, key
+    # the fixed-order (CSR gather) instances with fewer rows per tile than threads
+    det = {}
+    for tile in (256, 200):
+        dm = DeviceMesh(P, T, tile_vertices=tile)
+        dm.set_deterministic(True)
+        dm.set_surface_tension(np.ones(nf))
+        dm.set_bending_params(kappa, c0)
+        dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING | L.MS_CON_VOLUME, target_volume=4.0)
+        det[tile] = dm.energy_and_gradient()
+        e_again, g_again = dm.energy_and_gradient()
+        assert np.array_equal(g_again, det[tile][1]) and np.array_equal(e_again, det[tile][0])  # bitwise repeatable
+        dm.close()
+    assert np.allclose(det[200][0], det[256][0], rtol=1e-12, atol=0)
+    assert relerr(det[200][1], det[256][1]) < tol
 
 
 def test_high_valence_hub_takes_the_unpacked_record_path(L):
