@@ -2522,7 +2522,7 @@ int queue_ahead(ms_ctx* c, const ms_stepper_params* sp, const ms_step_result* ou
   const int max_iter = sp->max_iter > 0 ? sp->max_iter : 10;
   ms_ctx::Ahead& ah = c->ahead;
   plan_round(c, sp, alpha0, max_iter, 0, a_hi, r_lo, lh.n >= 2, lh.pred_trials, 0, ah.plan, /*ahead=*/true);
-  if (ah.plan.n0 + ah.plan.n_st > 8) return flush_dir_fold(c, src);  // (the fold forms eight right-hand sides)
+  if (ah.plan.n0 + ah.plan.n_st > MS_MAX_TRIALS) return flush_dir_fold(c, src);  // (the fold forms that many right-hand sides)
   ah.kind = kind;
   ah.stepper = sp->stepper;
   ah.implicit = kind == 1;
