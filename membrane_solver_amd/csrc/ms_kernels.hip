@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? (VOLROW ? 4 : MS_LE
   double gam_nx = 0.0;
   if (t.f0 + tid < t.f1) {
     tf_nx = facet_load<PACKED>(a.m, (size_t)(t.f0 + tid));
-    gam_nx = (LEAN || a.m.gamma_uniform) ? a.m.gamma_const : a.m.tf_gamma[t.f0 + tid];
+    gam_nx = a.m.gamma_uniform ? a.m.gamma_const : a.m.tf_gamma[t.f0 + tid];
   }
 
   int cur = 0, end = 0;  // this vertex's CSR range
@@ -1249,10 +1249,10 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? (VOLROW ? 4 : MS_LE
   for (int c0f = t.f0; c0f < (MS_ABL_NOLOOP ? t.f0 : t.f1); c0f += T) {
     const int p = c0f + tid;
     const TileFacet tf = facet_unpack<PACKED>(tf_nx);
-    const double gam = LEAN ? a.m.gamma_const : gam_nx;  // (lean: a kernel argument, no vector register)
+    const double gam = (LEAN && a.m.gamma_uniform) ? a.m.gamma_const : gam_nx;  // (uniform: a kernel argument)
     if (p + T < t.f1) {
       tf_nx = facet_load<PACKED>(a.m, (size_t)(p + T));
-      if (!LEAN) gam_nx = a.m.gamma_uniform ? a.m.gamma_const : a.m.tf_gamma[p + T];
+      if (!LEAN || !a.m.gamma_uniform) gam_nx = a.m.gamma_uniform ? a.m.gamma_const : a.m.tf_gamma[p + T];
     }
     if (p < t.f1) {
 #if MS_ABL_NOGATHER
@@ -1615,7 +1615,7 @@ bool gradient_lean_instance(const GradientArgs& a) {
   const bool bend = (a.modules & MS_MOD_BENDING) != 0;
   const bool leaf = bend && a.bt_vert != nullptr;
   return a.m.T == FAST_T && a.m.tile_facets32 != nullptr && !leaf && bend && a.bending_grad_mode != MS_GRAD_APPROX &&
-         a.m.gamma_uniform && !a.m.has_boundary && !(a.modules & MS_MOD_VOLUME_PENALTY) && !no_lean() && !a.m.no_fast;
+         !a.m.has_boundary && !(a.modules & MS_MOD_VOLUME_PENALTY) && !no_lean() && !a.m.no_fast;
 }
 
 hipError_t launch_gradient(const GradientArgs& a_in, int cap, int max_ent, hipStream_t s) {
