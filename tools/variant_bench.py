@@ -22,8 +22,34 @@ cases = {
     "c0 = 0.1 uniform": dict(c0=np.full(nv, 0.1)),
     "1 % of the vertices pinned": dict(fixed=(rng.uniform(size=nv) < 0.01)),
 }
+
+
+def open_cap():
+    """the same sphere with a polar cap cut off: a boundary ring (pinned, as a rim usually is)"""
+    keep = (P[T].max(axis=1)[:, 2] < 0.97)
+    T2 = T[keep]
+    used = np.zeros(nv, bool)
+    used[T2.ravel()] = True
+    remap = np.cumsum(used) - 1
+    P2, T2 = P[used], remap[T2].astype(np.int32)
+    e = np.sort(np.concatenate([T2[:, [0, 1]], T2[:, [1, 2]], T2[:, [2, 0]]]), axis=1)
+    key = e[:, 0].astype(np.int64) * len(P2) + e[:, 1]
+    uniq, cnt = np.unique(key, return_counts=True)
+    b = uniq[cnt == 1]
+    isb = np.zeros(len(P2), bool)
+    isb[b // len(P2)] = True
+    isb[b % len(P2)] = True
+    return np.ascontiguousarray(P2), np.ascontiguousarray(T2), isb
+
+
+cases["open surface (polar cap cut off, rim pinned)"] = dict(open=True)
 for name, kw in cases.items():
-    dm = DeviceMesh(P, T, fixed=kw.get("fixed"))
+    if kw.get("open"):
+        P, T, isb = open_cap()
+        nv, nf = len(P), len(T)
+        dm = DeviceMesh(P, T, fixed=isb, boundary=isb)
+    else:
+        dm = DeviceMesh(P, T, fixed=kw.get("fixed"))
     dm.set_surface_tension(kw.get("gamma", np.ones(nf)))
     dm.set_bending_params(kw.get("kappa", np.ones(nv)), kw.get("c0", np.zeros(nv)))
     dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING)
