@@ -1705,40 +1705,59 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
   const bool have_d = a.d != nullptr;
 
   V3 tv = mk(0, 0, 0);  // this thread's owned tilt
-  if (tid < t.n_owned) {
-    const int v = t.v_lo + tid;
-    const size_t g = 3 * (size_t)v;
-    const bool mv = have_d && !(a.m.vflags[v] & VF_FIXED);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const double xo = a.x[g + c];
-      px[c * cap + tid] = mv ? axpy1(xo, a.alpha, a.d[g + c]) : xo;
+  // facet records are fetched one chunk ahead; every load of a row set is issued before the first LDS write (the
+  // stores may alias the inputs as far as the compiler knows: interleaved, the stage-in is one HBM round trip per
+  // component)
+  FacetRec<false> tf_nx = facet_null<false>();
+  if (t.f0 + tid < t.f1) tf_nx = facet_load<false>(a.m, (size_t)(t.f0 + tid));
+  {
+    struct Row {
+      double x0, x1, x2, t0, t1, t2;
+    };
+    auto load_row = [&](int v) {
+      Row r;
+      const size_t g = 3 * (size_t)v;
+      const uint8_t fl = a.m.vflags[v];
+      r.x0 = a.x[g];
+      r.x1 = a.x[g + 1];
+      r.x2 = a.x[g + 2];
+      if (have_d) {
+        const double d0 = a.d[g], d1 = a.d[g + 1], d2 = a.d[g + 2];
+        if (!(fl & VF_FIXED)) {
+          r.x0 = axpy1(r.x0, a.alpha, d0);
+          r.x1 = axpy1(r.x1, a.alpha, d1);
+          r.x2 = axpy1(r.x2, a.alpha, d2);
+        }
+      }
+      r.t0 = a.tilts[g];
+      r.t1 = a.tilts[g + 1];
+      r.t2 = a.tilts[g + 2];
+      return r;
+    };
+    auto put_row = [&](const Row& r, int sl) {
+      px[sl] = r.x0;
+      px[cap + sl] = r.x1;
+      px[2 * cap + sl] = r.x2;
+      const V3 th = mk(r.t0, r.t1, r.t2);
+      tq[sl] = dot(th, th);
+      if (cons) {
+        tl[sl] = r.t0;
+        tl[cap + sl] = r.t1;
+        tl[2 * cap + sl] = r.t2;
+      }
+    };
+    const bool own = tid < t.n_owned, has_h = tid < t.nh;
+    int hv = 0;
+    if (has_h) hv = a.m.halo_ids[t.h0 + tid];
+    Row ro{}, rh{};
+    if (own) ro = load_row(t.v_lo + tid);
+    if (has_h) rh = load_row(hv);
+    if (own) {
+      put_row(ro, tid);
+      tv = mk(ro.t0, ro.t1, ro.t2);
     }
-    tv = mk(a.tilts[g], a.tilts[g + 1], a.tilts[g + 2]);
-    tq[tid] = dot(tv, tv);
-    if (cons) {
-      tl[tid] = tv.x;
-      tl[cap + tid] = tv.y;
-      tl[2 * cap + tid] = tv.z;
-    }
-  }
-  for (int h = tid; h < t.nh; h += T) {
-    const int v = a.m.halo_ids[t.h0 + h];
-    const int sl = t.n_owned + h;
-    const size_t g = 3 * (size_t)v;
-    const bool mv = have_d && !(a.m.vflags[v] & VF_FIXED);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const double xo = a.x[g + c];
-      px[c * cap + sl] = mv ? axpy1(xo, a.alpha, a.d[g + c]) : xo;
-    }
-    const V3 th = mk(a.tilts[g], a.tilts[g + 1], a.tilts[g + 2]);
-    tq[sl] = dot(th, th);
-    if (cons) {
-      tl[sl] = th.x;
-      tl[cap + sl] = th.y;
-      tl[2 * cap + sl] = th.z;
-    }
+    if (has_h) put_row(rh, t.n_owned + tid);
+    for (int h = tid + T; h < t.nh; h += T) put_row(load_row(a.m.halo_ids[t.h0 + h]), t.n_owned + h);
   }
   if (MODE != 0) {  // (modes 1-3 gather per vertex)
     const uint16_t* gv = a.m.tile_voff + (size_t)t.tile * (T + 1);
@@ -1760,8 +1779,9 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
   for (int c0 = t.f0; c0 < t.f1; c0 += T) {
     const int p = c0 + tid;
     double cf_a0 = 0, cf_a1 = 0, cf_a2 = 0, cf_t0 = 0, cf_t1 = 0, cf_t2 = 0;
+    const TileFacet tf = facet_unpack<false>(tf_nx);
+    if (p + T < t.f1) tf_nx = facet_load<false>(a.m, (size_t)(p + T));
     if (p < t.f1) {
-      const TileFacet tf = a.m.tile_facets[p];
       const V3 v0 = lds_v3(px, cap, tf.l0), v1 = lds_v3(px, cap, tf.l1), v2 = lds_v3(px, cap, tf.l2);
       const V3 e0 = v2 - v1, e1 = v0 - v2, e2 = v1 - v0;
       const V3 n = cross(e2, -e1);
@@ -2002,6 +2022,9 @@ __global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
 
   int cur = 0, end = 0;
   uint8_t own_fl = 0;
+  // facet records are fetched one chunk ahead (their HBM latency overlaps the staging / the previous chunk's arithmetic)
+  FacetRec<false> tf_nx = facet_null<false>();
+  if (t.f0 + tid < t.f1) tf_nx = facet_load<false>(a.m, (size_t)(t.f0 + tid));
   {
     const bool own = tid < t.n_owned;
     const int v_own = t.v_lo + tid;
@@ -2071,20 +2094,19 @@ __global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
   double ax = 0, ay = 0, az = 0;  // MODE 1: ax = sum va_eff div ; MODE 2: tilt gradient
   for (int c0f = t.f0; c0f < t.f1; c0f += T) {
     const int p = c0f + tid;
+    const TileFacet tf = facet_unpack<false>(tf_nx);
+    if (p + T < t.f1) tf_nx = facet_load<false>(a.m, (size_t)(p + T));
     if (p < t.f1) {
-      const TileFacet tf = a.m.tile_facets[p];
       const V3 v0 = lds_v3(px, cap, tf.l0), v1 = lds_v3(px, cap, tf.l1), v2 = lds_v3(px, cap, tf.l2);
       const V3 e0 = v2 - v1, e1 = v0 - v2, e2 = v1 - v0;
       const double l0 = dot(e0, e0), l1 = dot(e1, e1), l2 = dot(e2, e2);
       const V3 n = cross(e2, -e1);
       const double n2 = dot(n, n);
       const double A2 = sqrt(n2);
-      // P1 basis gradients and the facet divergence
+      // P1 basis gradients and the facet divergence (one reciprocal of |n|^2 for the nine components)
       const double denom = n2 > 1.0e-20 ? n2 : 1.0e-20;
-      const V3 c0v = cross(n, e0), c1v = cross(n, e1), c2v = cross(n, e2);
-      const V3 g0 = mk(c0v.x / denom, c0v.y / denom, c0v.z / denom);
-      const V3 g1 = mk(c1v.x / denom, c1v.y / denom, c1v.z / denom);
-      const V3 g2 = mk(c2v.x / denom, c2v.y / denom, c2v.z / denom);
+      const double i2 = 1.0 / denom;
+      const V3 g0 = i2 * cross(n, e0), g1 = i2 * cross(n, e1), g2 = i2 * cross(n, e2);
       const V3 tt0 = lds_v3(tl, cap, tf.l0), tt1 = lds_v3(tl, cap, tf.l1), tt2 = lds_v3(tl, cap, tf.l2);
       // div_term = s * div_f t (bending_tilt_in.py:46: s = -1; out and the single field: +1)
       const double dv = a.div_sign * (dot(tt0, g0) + dot(tt1, g1) + dot(tt2, g2));
@@ -2128,7 +2150,6 @@ __global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
         const double dE = a.div_sign * ((k0 * t0 * ve0 + k1 * t1 * ve1) + k2 * t2 * ve2);
         const V3 w = (cross(e0, tt0) + cross(e1, tt1)) + cross(e2, tt2);
         const double ndw = dot(n, w);
-        const double i2 = 1.0 / denom;
         const V3 ddn = i2 * w - ((2.0 * ndw) * (i2 * i2)) * n;
         const V3 d0 = i2 * cross(tt0, n), d1 = i2 * cross(tt1, n), d2 = i2 * cross(tt2, n);
         const V3 ga = dE * ((cross(-e1, ddn) - d0) + d2);
