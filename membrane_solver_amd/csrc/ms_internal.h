@@ -261,11 +261,11 @@ hipError_t launch_energy(const EnergyArgs& a, bool guard, int cap, int max_ent, 
 hipError_t launch_gradient(const GradientArgs& a, int cap, int max_ent, hipStream_t s);
 bool gradient_lean_instance(const GradientArgs& a);  // which k_gradient instantiation launch_gradient picks
 // mode 0: energy partial (MS_S_ETILT); 1: energy + gradients; 2: project tilts to tangent
-size_t tilt_lds_bytes(int T, int cap, int max_ent, bool consistent = false);
+size_t tilt_lds_bytes(int T, int cap, int max_ent, bool consistent = false, int mode = 1);
 hipError_t launch_tilt(const TiltArgs& a, int mode, int cap, int max_ent, hipStream_t s);
 // bending_tilt facet pass.  mode 0: energy (MS_S_EBT); 1: energy + back-prop factors;
 // 2: energy + tilt gradient
-size_t bt_lds_bytes(int T, int cap, int max_ent);
+size_t bt_lds_bytes(int T, int cap, int max_ent, int mode = 1);
 hipError_t launch_bt(const BtArgs& a, int mode, int cap, int max_ent, hipStream_t s);
 // tilt smoothness (Dirichlet) pass.  mode 0: energy (MS_S_ETS); 1: energy + tilt gradient; 2: Jacobi diagonal
 size_t ts_lds_bytes(int T, int cap, int max_ent);

@@ -1696,7 +1696,8 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
   double* tl = tq + cap;  // consistent mass only: the tilt vectors themselves
   const bool cons = (MODE == 0 || MODE == 1) && a.consistent;
   double* stg = tl + (cons ? 3 * cap : 0);
-  double* red = stg + 10 * T;
+  // (MODE 0 -- energy only -- gathers nothing: no staging block, no CSR; a third of the LDS, twice the workgroups per CU)
+  double* red = stg + (MODE == 0 ? 0 : 10 * T);
   uint16_t* voff = reinterpret_cast<uint16_t*>(red + 16);
   uint16_t* vent = voff + (T + 2);
 
@@ -1964,7 +1965,8 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
   }
 }
 
-size_t tilt_lds_bytes(int T, int cap, int max_ent, bool consistent) {
+size_t tilt_lds_bytes(int T, int cap, int max_ent, bool consistent, int mode) {
+  if (mode == 0) return ((consistent ? 7 : 4) * (size_t)cap + 16) * sizeof(double);
   return ((consistent ? 7 : 4) * (size_t)cap + 10 * (size_t)T + 16) * sizeof(double) +
          2 * ((size_t)T + 2 + max_ent + 8);
 }
@@ -1972,7 +1974,7 @@ size_t tilt_lds_bytes(int T, int cap, int max_ent, bool consistent) {
 hipError_t launch_tilt(const TiltArgs& a, int mode, int cap, int max_ent, hipStream_t s) {
   const int nb = a.tile1 - a.tile0;
   if (nb <= 0) return hipSuccess;
-  const size_t lds = tilt_lds_bytes(a.m.T, cap, max_ent, (mode == 0 || mode == 1) && a.consistent);
+  const size_t lds = tilt_lds_bytes(a.m.T, cap, max_ent, (mode == 0 || mode == 1) && a.consistent, mode);
   hipError_t e;
 #define MS_LAUNCH_T(M)                                                                  \
   do {                                                                                  \
@@ -2013,8 +2015,9 @@ __global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
   double* kp = bs + cap;
   double* stg = kp + cap;
   double* red = stg;
-  uint16_t* vent = reinterpret_cast<uint16_t*>(stg + 9 * T);
-  uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + ((max_ent + 3) & ~3));
+  // (MODE 0 -- energy only -- gathers nothing: the staging block shrinks to the reduction scratch, no CSR)
+  uint16_t* vent = reinterpret_cast<uint16_t*>(stg + (MODE == 0 ? 16 : 9 * T));
+  uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + (MODE == 0 ? 0 : ((max_ent + 3) & ~3)));
 
   const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
   const int tid = threadIdx.x;
@@ -2212,7 +2215,8 @@ __global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
   }
 }
 
-size_t bt_lds_bytes(int T, int cap, int max_ent) {
+size_t bt_lds_bytes(int T, int cap, int max_ent, int mode) {
+  if (mode == 0) return (8 * (size_t)cap + 16) * sizeof(double) + (((size_t)cap + 15) / 16) * 16;
   return (8 * (size_t)cap + 9 * (size_t)T) * sizeof(double) + 2 * ((size_t)((max_ent + 3) & ~3)) +
          (((size_t)cap + 15) / 16) * 16;
 }
@@ -2220,7 +2224,7 @@ size_t bt_lds_bytes(int T, int cap, int max_ent) {
 hipError_t launch_bt(const BtArgs& a, int mode, int cap, int max_ent, hipStream_t s) {
   const int nb = a.tile1 - a.tile0;
   if (nb <= 0) return hipSuccess;
-  const size_t lds = bt_lds_bytes(a.m.T, cap, max_ent);
+  const size_t lds = bt_lds_bytes(a.m.T, cap, max_ent, mode);
   hipError_t e;
 #define MS_LAUNCH_B(M)                                                                      \
   do {                                                                                      \
