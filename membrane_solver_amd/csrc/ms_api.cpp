@@ -442,11 +442,14 @@ int tilt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* src
 }
 // bending_tilt facet pass (mode 0 energy / 1 + factors / 2 + tilt gradient) on the positions of
 // the preceding energy pass; `tilts` = the tangent tilts belonging to those positions
-int bt_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, const double* tilts);
-int bt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* tilts) {
-  return bt_pass_f(c, c->tf[0], mode, use_dir, alpha, tilts);
+int bt_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, const double* tilts,
+              bool with_tilt_energy = false);
+int bt_pass(ms_ctx* c, int mode, bool use_dir, double alpha, const double* tilts, bool with_tilt_energy = false) {
+  return bt_pass_f(c, c->tf[0], mode, use_dir, alpha, tilts, with_tilt_energy);
 }
-int bt_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, const double* tilts) {
+// with_tilt_energy (mode 0): the kernel also sums the field's tilt-magnitude energy (per-facet form) from the rows it
+// stages anyway -- same operations as k_tilt's energy-only launch, which the caller then leaves out
+int bt_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, const double* tilts, bool with_tilt_energy) {
   if (!f.tilts) return fail(c, MS_ERR_STATE, "bending_tilt module active but its tilt field was never set");
   const bool leaflet = &f != &c->tf[0];
   if (leaflet && (!f.kappa || !f.bt_vert))
@@ -472,6 +475,8 @@ int bt_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, con
   a.g = c->buf[MS_BUF_G];
   a.div_sign = f.div_sign;
   a.e_slot = f.s_ebt;
+  a.k_tilt_fused = (with_tilt_energy && mode == 0) ? f.k_tilt : 0.0;
+  a.e_tilt_slot = f.s_etilt;
   {
     ProfScope ps(c, 5);
     HIPCHK(c, launch_bt(a, mode, c->cap, c->til.max_ent, c->stream));
@@ -1689,15 +1694,21 @@ int tilt_eval(ms_ctx* c, bool trial, bool gradient) {
   const size_t b3 = sizeof(double) * 3 * (size_t)c->til.nvp;
   if (mods & MS_TILT_MODS) {
     const double* tilts = trial ? c->tf[0].trial : c->tf[0].tilts;
-    if (mods & MS_MOD_TILT) {
+    // energy only, both modules of the field: the bending_tilt kernel sums the tilt-magnitude energy as well (it has
+    // the tilt rows staged; a non-zero rigidity, or the slot would not be written)
+    const bool fuse = !gradient && (mods & MS_MOD_TILT) && (mods & MS_MOD_BENDING_TILT) && c->tf[0].k_tilt != 0.0 &&
+                      !c->tf[0].consistent;
+    if ((mods & MS_MOD_TILT) && !fuse) {
       rc = tilt_pass(c, gradient ? 1 : 0, false, 0.0, tilts, nullptr, /*shape_gradient=*/false);
       if (rc) return rc;
+      mask |= 1u << MS_S_ETILT;
+    } else if (fuse) {
       mask |= 1u << MS_S_ETILT;
     } else if (gradient) {
       HIPCHK(c, hipMemsetAsync(c->tf[0].grad, 0, b3, c->stream));
     }
     if (mods & MS_MOD_BENDING_TILT) {
-      rc = bt_pass(c, gradient ? 2 : 0, false, 0.0, tilts);
+      rc = bt_pass(c, gradient ? 2 : 0, false, 0.0, tilts, fuse);
       if (rc) return rc;
       mask |= 1u << MS_S_EBT;
     }

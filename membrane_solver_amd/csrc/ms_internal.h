@@ -237,6 +237,10 @@ struct BtArgs {
   double* g;               // mode 3: shape gradient of the divergence term ADDED here
   double div_sign;         // -1 inner leaflet, +1 outer leaflet / single field
   int e_slot;              // reduction slot of the energy partial (MS_S_EBT / _IN / _OUT)
+  // mode 0 only: also the tilt-magnitude energy of the same field (modules/energy/tilt.py:99-172, per-facet form) from
+  // the rows this kernel has staged anyway -- k_tilt's energy-only launch is not needed then.  0 = off.
+  double k_tilt_fused;
+  int e_tilt_slot;
 };
 
 struct TsArgs {

@@ -2016,7 +2016,7 @@ __global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
   double* stg = kp + cap;
   double* red = stg;
   // (MODE 0 -- energy only -- gathers nothing: the staging block shrinks to the reduction scratch, no CSR)
-  uint16_t* vent = reinterpret_cast<uint16_t*>(stg + (MODE == 0 ? 16 : 9 * T));
+  uint16_t* vent = reinterpret_cast<uint16_t*>(stg + (MODE == 0 ? 32 : 9 * T));
   uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + (MODE == 0 ? 0 : ((max_ent + 3) & ~3)));
 
   const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
@@ -2093,7 +2093,7 @@ __global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
   }
   __syncthreads();
 
-  double e_bt = 0.0;
+  double e_bt = 0.0, e_tl = 0.0;
   double ax = 0, ay = 0, az = 0;  // MODE 1: ax = sum va_eff div ; MODE 2: tilt gradient
   for (int c0f = t.f0; c0f < t.f1; c0f += T) {
     const int p = c0f + tid;
@@ -2137,6 +2137,12 @@ __global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
       const double t0 = bs[tf.l0] + dv, t1 = bs[tf.l1] + dv, t2 = bs[tf.l2] + dv;
       const double k0 = kp[tf.l0], k1 = kp[tf.l1], k2 = kp[tf.l2];
       if (tf.flags & TF_OWNER) e_bt += 0.5 * ((k0 * (t0 * t0) * ve0 + k1 * (t1 * t1) * ve1) + k2 * (t2 * t2) * ve2);
+      if (MODE == 0 && a.k_tilt_fused != 0.0 && A2 >= 1.0e-12 && (tf.flags & TF_OWNER)) {
+        // k_tilt's MODE 0 term, operation for operation: 1/2 k_t (sum |t_k|^2 / 3) * area
+        const double sq = (dot(tt0, tt0) + dot(tt1, tt1)) + dot(tt2, tt2);
+        const double coeff = 0.5 * a.k_tilt_fused * (sq / 3.0);
+        e_tl += coeff * (0.5 * A2);
+      }
       double* s = stg + tid;
       if (MODE == 1) {
         s[0 * T] = ve0 * dv;
@@ -2207,7 +2213,12 @@ __global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
     }
   }
   if (MODE != 0) __syncthreads();  // red aliases the staging block
-  {
+  if (MODE == 0 && a.k_tilt_fused != 0.0) {
+    const double vals[2] = {e_bt, e_tl};
+    const int ops[2] = {0, 0};
+    const int slots[2] = {a.e_slot, a.e_tilt_slot};
+    block_reduce_store<2>(vals, ops, slots, red, a.partials + t.tile, (size_t)a.m.n_tiles);
+  } else {
     const double vals[1] = {e_bt};
     const int ops[1] = {0};
     const int slots[1] = {a.e_slot};
@@ -2216,7 +2227,7 @@ __global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
 }
 
 size_t bt_lds_bytes(int T, int cap, int max_ent, int mode) {
-  if (mode == 0) return (8 * (size_t)cap + 16) * sizeof(double) + (((size_t)cap + 15) / 16) * 16;
+  if (mode == 0) return (8 * (size_t)cap + 32) * sizeof(double) + (((size_t)cap + 15) / 16) * 16;
   return (8 * (size_t)cap + 9 * (size_t)T) * sizeof(double) + 2 * ((size_t)((max_ent + 3) & ~3)) +
          (((size_t)cap + 15) / 16) * 16;
 }
