@@ -813,9 +813,11 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
       if (rc) return rc;
       tilts = c->tf[0].trial;
     }
-    if (modules & MS_MOD_TILT) rc = tilt_pass(c, 0, use_dir, alpha, tilts);
+    // energy only, both modules: the bending_tilt kernel sums the tilt-magnitude energy as well (tilt_eval does the same)
+    const bool fuse = (modules & MS_MOD_TILT) && bt && !write_factors && c->tf[0].k_tilt != 0.0 && !c->tf[0].consistent;
+    if ((modules & MS_MOD_TILT) && !fuse) rc = tilt_pass(c, 0, use_dir, alpha, tilts);
     if (rc) return rc;
-    if (bt) rc = bt_pass(c, write_factors ? 1 : 0, use_dir, alpha, tilts);
+    if (bt) rc = bt_pass(c, write_factors ? 1 : 0, use_dir, alpha, tilts, fuse);
     if (rc) return rc;
     if (modules & MS_MOD_TILT_SMOOTH) rc = ts_pass(c, 0, use_dir, alpha, tilts);
     if (rc) return rc;
