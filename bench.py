@@ -348,6 +348,48 @@ def rates(steps, accepted, trials, guard_rejects, level, dt):
             "evaluations": {"line_search_energy_passes": e_evals, "energy_plus_gradient": g_evals}}
 
 
+def config5_deck(device, steps=40):
+    """BASELINE configs[4]: the caveolin deck as the reference parses it (tests/golden/traj_config5_deck_gd.npz --
+    positions, rows, flags, parameters and module list; its three constraint modules are outside the hot path), one
+    coupled relax_leaflet_tilts call with the deck's inner steps and the deck's `g` steps."""
+    import torch
+
+    from membrane_solver_amd.geometry.mesh import ArrayMesh
+    from membrane_solver_amd.runtime.constraint_manager import ConstraintModuleManager
+    from membrane_solver_amd.runtime.energy_manager import EnergyModuleManager
+    from membrane_solver_amd.runtime.minimizer import Minimizer
+    from membrane_solver_amd.runtime.steppers import GradientDescent
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "traj_config5_deck_gd.npz"), allow_pickle=False)
+    mods = [str(m) for m in g["modules"]]
+    mesh = ArrayMesh(g["positions0"], g["tri"], fixed=g["fixed"], surface_tension=g["gamma"], tilts_in=g["tilts_in0"],
+                     tilts_out=g["tilts_out0"], tilt_fixed_in=g["tilt_fixed_in"], tilt_fixed_out=g["tilt_fixed_out"],
+                     global_parameters=json.loads(str(g["gp_json"])), energy_modules=mods, constraint_modules=[])
+    mesh.disk_rows_in = mesh.disk_rows_out = g["disk_rows"]
+    mz = Minimizer(mesh, mesh.global_parameters, GradientDescent(), EnergyModuleManager(mods),
+                   ConstraintModuleManager([]), quiet=True, step_size=float(g["step_size0"]), device=device)
+    _mir, dm = mz._device()
+    mz._relax_tilts(dm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        mz._relax_tilts(dm)
+    torch.cuda.synchronize()
+    t_rel = (time.perf_counter() - t0) / 5
+    mz.minimize(4, sync_mesh=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = mz.minimize(steps, sync_mesh=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gp = mesh.global_parameters
+    return {"workload": f"config 5 deck ({len(g['positions0'])} vertices, {len(g['tri'])} facets): " + " + ".join(mods)
+                        + f"; tilt_solve_mode {gp.get('tilt_solve_mode')}, {gp.get('tilt_inner_steps')} inner steps",
+            "value": steps / dt, "unit": "steps/s", "ms_per_step": 1e3 * dt / steps, "relaxation_ms": 1e3 * t_rel,
+            "steps": steps, "energy_end": float(res["energy"]),
+            "note": "launch-latency scale: a step is ~25 tiny launches and two host round trips per inner CG step"}
+
+
 def secondary_config(name, freq, mods, cons, stepper_name, *, volume_row, step_size, steps, warmup, device):
     """One more configuration of BASELINE.json next to the headline, as an object of the same JSON line: steps/s,
     accepted steps/s, what the line searches did, and the gradient kernel instance of that module set with its
@@ -575,6 +617,13 @@ def main_single(args):
             out["config3_volume_row"]["vs_no_row"] = out["config3_volume_row"]["value"] / out["value"]
         except Exception as exc:  # secondary figures never cost the headline line
             print(f"[bench] secondary configurations skipped: {exc!r}", file=sys.stderr)
+
+    # -- BASELINE configs[4] on its own deck (204 facets: launches and host round trips, not kernels) -------------
+    if not args.headline_only and not args.volume and args.freq == 320:
+        try:
+            out["config5_deck"] = config5_deck(local_rank)
+        except Exception as exc:
+            print(f"[bench] config 5 deck leg skipped: {exc!r}", file=sys.stderr)
 
     # -- the N = 1 point of the 16-million-facet strong-scaling curve (bench.py --gpus N reports the others) --------
     if not args.headline_only and not args.no_large and not args.volume and args.freq == 320:
