@@ -255,6 +255,12 @@ struct ms_ctx {
   std::vector<void*> peer_opened;           // hipIpcOpenMemHandle results to close
   bool peer_on = false;
   unsigned long long peer_ticket = 0;
+  // MS_PEER_WAIT=stream: the flag words are raised and awaited by stream memory operations (hipStreamWriteValue64 behind
+  // the pack kernel, hipStreamWaitValue64 in front of the unpack kernel) instead of a flag kernel and a waiting wave:
+  // nothing of this rank occupies the GPU while it waits for a peer.  The wait itself has no bound -- the host's poll
+  // has (2 s), and releases the words itself before it reports the error.
+  bool peer_stream_ops = false;
+  hipStream_t peer_aux = nullptr;           // (the release after a timeout goes through a stream of its own)
   ms_barrier_fn peer_barrier = nullptr;     // contexts of one process: host-side wait instead of the waiting wave
   void* peer_barrier_user = nullptr;
   double sh_scal[MS_NSCAL] = {0};  // rank-ordered fold of the last exchanges
@@ -1418,6 +1424,7 @@ void ms_destroy(ms_ctx* c) {
   for (void* q : c->peer_opened) (void)hipIpcCloseMemHandle(q);
   if (c->d_peer_slab) (void)hipFree(c->d_peer_slab);
   if (c->d_peer_flag) (void)hipFree(c->d_peer_flag);
+  if (c->peer_aux) (void)hipStreamDestroy(c->peer_aux);
   if (c->comm) shard_comm_destroy(c->comm);
   if (c->d_xsend) (void)hipFree(c->d_xsend);
   if (c->d_xrecv) (void)hipFree(c->d_xrecv);
@@ -3421,8 +3428,21 @@ int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push, 
     HIPCHK(c, launch_pack_peers(c->d_bnd_rows + c->bnd_off[(size_t)me],
                                 c->bnd_off[(size_t)me + 1] - c->bnd_off[(size_t)me], p, nc, n, c->d_scal, dst, W,
                                 c->stream));
-    HIPCHK(c, launch_flag_peers(flg, me, W, c->peer_ticket, c->stream));
+    const bool stream_ops = c->peer_stream_ops && !c->peer_barrier;
+    if (stream_ops) {
+      // (the pack kernel's stores are system-scope write-through and complete before the kernel does: the value
+      // written behind it in stream order is the release)
+      for (int r = 0; r < W; ++r) HIPCHK(c, hipStreamWriteValue64(c->stream, flg[r] + me, c->peer_ticket, 0));
+    } else {
+      HIPCHK(c, launch_flag_peers(flg, me, W, c->peer_ticket, c->stream));
+    }
     const unsigned long long* wait_flags = c->d_peer_flag + (size_t)par * 16;
+    if (stream_ops) {
+      for (int r = 0; r < W; ++r)
+        HIPCHK(c, hipStreamWaitValue64(c->stream, const_cast<unsigned long long*>(wait_flags) + r, c->peer_ticket,
+                                       hipStreamWaitValueGte, ~0ull));
+      wait_flags = nullptr;  // (the unpack kernel starts when every word has arrived)
+    }
     if (c->peer_barrier) {  // (contexts of one process wait on the host: see ms_shard_peer_set_barrier)
       HIPCHK(c, hipStreamSynchronize(c->stream));
       if (c->peer_barrier(c->peer_barrier_user) != 0) return fail(c, MS_ERR_STATE, "peer exchange: the caller's barrier failed");
@@ -3455,11 +3475,29 @@ int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push, 
                                    c->d_h_scal_all, c->stream, c->d_h_xseq, c->xticket));
   }
   bool seen = false;
+  const bool watchdog = c->peer_on && c->peer_stream_ops && !c->peer_barrier;
+  struct timespec w0;
+  if (watchdog) clock_gettime(CLOCK_MONOTONIC, &w0);
   for (long spin = 0; spin < 20000000L; ++spin) {
     seen = true;
     for (int r = 0; r < W && seen; ++r) seen = __atomic_load_n(c->h_xseq + r, __ATOMIC_ACQUIRE) >= c->xticket;
     if (seen) break;
     __builtin_ia32_pause();
+    if (watchdog && (spin & 0xfff) == 0xfff) {
+      struct timespec w1;
+      clock_gettime(CLOCK_MONOTONIC, &w1);
+      if ((double)(w1.tv_sec - w0.tv_sec) + 1e-9 * (double)(w1.tv_nsec - w0.tv_nsec) > 2.0) {
+        // a peer's word has not arrived: the stream sits in an unbounded wait.  Release it (this rank's own words,
+        // through another stream), let the queue drain, report.
+        const int par = (int)(c->peer_ticket & 1);
+        if (!c->peer_aux) HIPCHK(c, hipStreamCreateWithFlags(&c->peer_aux, hipStreamNonBlocking));
+        for (int r = 0; r < W; ++r)
+          HIPCHK(c, hipStreamWriteValue64(c->peer_aux, c->d_peer_flag + (size_t)par * 16 + r, c->peer_ticket, 0));
+        HIPCHK(c, hipStreamSynchronize(c->peer_aux));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return fail(c, MS_ERR_STATE, "peer exchange: a peer's flag word did not arrive within 2 s (stream wait released by the host)");
+      }
+    }
   }
   if (!seen) HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->peer_on && c->h_err && (__atomic_load_n(c->h_err, __ATOMIC_ACQUIRE) >> 62) == 1)
@@ -3609,6 +3647,14 @@ int ms_shard_peer_open(ms_ctx* c, const void* handles_all) {
     c->peer_flags[(size_t)r] = static_cast<unsigned long long*>(pf);
   }
   c->peer_on = true;
+  if (const char* e = getenv("MS_PEER_WAIT")) {
+    if (strcmp(e, "stream") == 0) {
+      int can = 0;
+      HIPCHK(c, hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device));
+      if (!can) return fail(c, MS_ERR_STATE, "MS_PEER_WAIT=stream: the device has no stream wait-value operations");
+      c->peer_stream_ops = true;
+    }
+  }
   return MS_OK;
 }
 
