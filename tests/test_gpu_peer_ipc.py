@@ -50,7 +50,10 @@ dist.destroy_process_group()
 """
 
 
-def test_two_processes_exchange_through_ipc_mapped_slabs():
+@pytest.mark.parametrize("wait", ["kernel", "stream"])
+def test_two_processes_exchange_through_ipc_mapped_slabs(wait):
+    """wait "kernel": flag kernel + bounded in-kernel wait (the default); "stream": MS_PEER_WAIT=stream, the flag words
+    raised and awaited by hipStreamWriteValue64 / hipStreamWaitValue64 on the IPC-mapped words."""
     from membrane_solver_amd import _lib as L
     from membrane_solver_amd import meshgen
     from membrane_solver_amd.device import DeviceMesh
@@ -62,6 +65,9 @@ def test_two_processes_exchange_through_ipc_mapped_slabs():
     for rank in range(2):
         env = dict(os.environ, MS_ROOT=ROOT, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+        env.pop("MS_PEER_WAIT", None)
+        if wait == "stream":
+            env["MS_PEER_WAIT"] = "stream"
         procs.append(subprocess.Popen([sys.executable, "-c", RANK_SCRIPT], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = []
