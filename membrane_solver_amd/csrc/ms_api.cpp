@@ -259,6 +259,8 @@ struct ms_ctx {
   // the pack kernel, hipStreamWaitValue64 in front of the unpack kernel) instead of a flag kernel and a waiting wave:
   // nothing of this rank occupies the GPU while it waits for a peer.  The wait itself has no bound -- the host's poll
   // has (2 s), and releases the words itself before it reports the error.
+  PeerFlags* d_peer_flagtab = nullptr;      // [2]: per exchange parity, the peers' flag rows (read by the pack kernel)
+  unsigned int* d_peer_arrived = nullptr;   // 16 block counters of the pack kernel
   bool peer_stream_ops = false;
   hipStream_t peer_aux = nullptr;           // (the release after a timeout goes through a stream of its own)
   ms_barrier_fn peer_barrier = nullptr;     // contexts of one process: host-side wait instead of the waiting wave
@@ -1425,6 +1427,8 @@ void ms_destroy(ms_ctx* c) {
   if (c->d_peer_slab) (void)hipFree(c->d_peer_slab);
   if (c->d_peer_flag) (void)hipFree(c->d_peer_flag);
   if (c->peer_aux) (void)hipStreamDestroy(c->peer_aux);
+  if (c->d_peer_flagtab) (void)hipFree(c->d_peer_flagtab);
+  if (c->d_peer_arrived) (void)hipFree(c->d_peer_arrived);
   if (c->comm) shard_comm_destroy(c->comm);
   if (c->d_xsend) (void)hipFree(c->d_xsend);
   if (c->d_xrecv) (void)hipFree(c->d_xrecv);
@@ -3425,15 +3429,19 @@ int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push, 
       dst[r] = c->peer_slabs[(size_t)r] + ((size_t)par * W + (size_t)me) * c->peer_stride;
       flg[r] = c->peer_flags[(size_t)r] + (size_t)par * 16;
     }
+    const bool stream_ops = c->peer_stream_ops && !c->peer_barrier;
+    // (the pack kernel's last block per peer raises the flag word itself; with stream memory operations the words are
+    // written behind the kernel instead)
+    const bool fused_flags = !stream_ops && c->d_peer_flagtab != nullptr;
     HIPCHK(c, launch_pack_peers(c->d_bnd_rows + c->bnd_off[(size_t)me],
                                 c->bnd_off[(size_t)me + 1] - c->bnd_off[(size_t)me], p, nc, n, c->d_scal, dst, W,
-                                c->stream));
-    const bool stream_ops = c->peer_stream_ops && !c->peer_barrier;
+                                c->stream, fused_flags ? c->d_peer_flagtab + par : nullptr, c->d_peer_arrived, me,
+                                c->peer_ticket));
     if (stream_ops) {
       // (the pack kernel's stores are system-scope write-through and complete before the kernel does: the value
       // written behind it in stream order is the release)
       for (int r = 0; r < W; ++r) HIPCHK(c, hipStreamWriteValue64(c->stream, flg[r] + me, c->peer_ticket, 0));
-    } else {
+    } else if (!fused_flags) {
       HIPCHK(c, launch_flag_peers(flg, me, W, c->peer_ticket, c->stream));
     }
     const unsigned long long* wait_flags = c->d_peer_flag + (size_t)par * 16;
@@ -3602,6 +3610,24 @@ int peer_alloc(ms_ctx* c) {
 }
 }  // namespace
 
+namespace {
+// the peers' flag rows as the pack kernel reads them: one table per exchange parity
+int peer_flag_table(ms_ctx* c) {
+  const int W = c->shard_count;
+  PeerFlags tab[2];
+  memset(tab, 0, sizeof(tab));
+  for (int par = 0; par < 2; ++par)
+    for (int r = 0; r < W; ++r) tab[par].p[r] = c->peer_flags[(size_t)r] + (size_t)par * 16;
+  if (!c->d_peer_flagtab) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_peer_flagtab), sizeof(tab)));
+  HIPCHK(c, hipMemcpy(c->d_peer_flagtab, tab, sizeof(tab), hipMemcpyHostToDevice));
+  if (!c->d_peer_arrived) {
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_peer_arrived), sizeof(unsigned int) * 16));
+    HIPCHK(c, hipMemset(c->d_peer_arrived, 0, sizeof(unsigned int) * 16));
+  }
+  return MS_OK;
+}
+}  // namespace
+
 int ms_shard_peer_local(ms_ctx* c, void** recv_slab, void** flag_words) {
   if (!c || !recv_slab || !flag_words) return MS_ERR_INVALID;
   int rc = peer_alloc(c);
@@ -3646,6 +3672,8 @@ int ms_shard_peer_open(ms_ctx* c, const void* handles_all) {
     c->peer_slabs[(size_t)r] = static_cast<double*>(ps);
     c->peer_flags[(size_t)r] = static_cast<unsigned long long*>(pf);
   }
+  rc = peer_flag_table(c);
+  if (rc) return rc;
   c->peer_on = true;
   if (const char* e = getenv("MS_PEER_WAIT")) {
     if (strcmp(e, "stream") == 0) {
@@ -3671,6 +3699,8 @@ int ms_shard_peer_set_pointers(ms_ctx* c, void* const* recv_slabs, void* const* 
   }
   if (c->peer_slabs[(size_t)c->shard_rank] != c->d_peer_slab)
     return fail(c, MS_ERR_INVALID, "ms_shard_peer_set_pointers: the own entry must be ms_shard_peer_local's");
+  rc = peer_flag_table(c);
+  if (rc) return rc;
   c->peer_on = true;
   return MS_OK;
 }

@@ -332,8 +332,15 @@ hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_of
 hipError_t launch_post_seq(unsigned long long* host_seq, unsigned long long ticket, hipStream_t s);
 // peer-to-peer exchange: pack straight into every peer's slab (dst[r] = that peer's slot for this rank), raise this
 // rank's flag on every peer; the unpack kernel waits (bounded) for every peer's flag here
+struct PeerFlags {
+  unsigned long long* p[16];  // this exchange parity's flag rows of the peers (device table: ms_ctx::d_peer_flagtab)
+};
+// d_flags != nullptr: the last block to finish for a peer raises this rank's word there (no flag kernel); d_arrived: 16
+// zeroed counters
 hipError_t launch_pack_peers(const int32_t* rows, int n_rows, const double* const* bufs, const int* ncomp, int n_bufs,
-                             const double* scal, double* const* dst, int world, hipStream_t s);
+                             const double* scal, double* const* dst, int world, hipStream_t s,
+                             const PeerFlags* d_flags = nullptr, unsigned int* d_arrived = nullptr, int me = 0,
+                             unsigned long long ticket = 0);
 hipError_t launch_flag_peers(unsigned long long* const* peer_flags, int me, int world, unsigned long long ticket,
                              hipStream_t s);
 

@@ -2971,19 +2971,31 @@ struct PeerDst {
 __device__ __forceinline__ void st_sys_f64(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__global__ void k_pack_peers(const int32_t* rows, int n_rows, RowBufs b, const double* scal, PeerDst dst) {
+// flags != nullptr: the block that finishes LAST for peer y raises this rank's flag word there (no flag kernel behind
+// the pack): every block completes its stores (system-scope fence), then counts itself in at agent scope; the last one
+// has thereby acquired all the others' and publishes the ticket with a system-scope release
+__global__ void k_pack_peers(const int32_t* rows, int n_rows, RowBufs b, const double* scal, PeerDst dst,
+                             const PeerFlags* flags, unsigned int* arrived, int me, unsigned long long ticket) {
   double* send = dst.p[blockIdx.y];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < MS_NSCAL) st_sys_f64(send + j, ld_agent(scal + j));
-  if (j >= n_rows) return;
-  const size_t v = (size_t)rows[j];
-  double* o = send + MS_NSCAL + (size_t)j * b.comps;
-  for (int k = 0; k < b.n; ++k)
-    for (int c = 0; c < b.ncomp[k]; ++c) st_sys_f64(o++, b.p[k][v * b.ncomp[k] + c]);
+  if (j < n_rows) {
+    const size_t v = (size_t)rows[j];
+    double* o = send + MS_NSCAL + (size_t)j * b.comps;
+    for (int k = 0; k < b.n; ++k)
+      for (int c = 0; c < b.ncomp[k]; ++c) st_sys_f64(o++, b.p[k][v * b.ncomp[k] + c]);
+  }
+  if (flags == nullptr) return;
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int before = __hip_atomic_fetch_add(arrived + blockIdx.y, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (before == gridDim.x - 1) {
+      __hip_atomic_store(arrived + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next launch)
+      __hip_atomic_store(flags->p[blockIdx.y] + me, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
-struct PeerFlags {
-  unsigned long long* p[16];
-};
 // queued behind the pack kernel (whose stores have completed and been released by then): lane r raises this rank's
 // word on peer r
 __global__ void k_flag_peers(PeerFlags f, int me, int world, unsigned long long ticket) {
@@ -3080,7 +3092,8 @@ hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_of
 }
 
 hipError_t launch_pack_peers(const int32_t* rows, int n_rows, const double* const* bufs, const int* ncomp, int n_bufs,
-                             const double* scal, double* const* dst, int world, hipStream_t s) {
+                             const double* scal, double* const* dst, int world, hipStream_t s,
+                             const PeerFlags* d_flags, unsigned int* d_arrived, int me, unsigned long long ticket) {
   if (world > 16) return hipErrorInvalidValue;
   RowBufs b{};
   b.n = n_bufs;
@@ -3092,7 +3105,8 @@ hipError_t launch_pack_peers(const int32_t* rows, int n_rows, const double* cons
   PeerDst d{};
   for (int r = 0; r < world; ++r) d.p[r] = dst[r];
   const int n = n_rows > MS_NSCAL ? n_rows : MS_NSCAL;
-  hipLaunchKernelGGL(k_pack_peers, dim3((n + 255) / 256, world), dim3(256), 0, s, rows, n_rows, b, scal, d);
+  hipLaunchKernelGGL(k_pack_peers, dim3((n + 255) / 256, world), dim3(256), 0, s, rows, n_rows, b, scal, d, d_flags,
+                     d_arrived, me, ticket);
   return hipGetLastError();
 }
 
