@@ -316,11 +316,97 @@ def spawn_ranks(args, argv):
     return 0
 
 
-def bench_mesh(freq):
+_MESH_CACHE: dict = {}
+T_PROCESS_START = time.perf_counter()
+
+
+def bench_mesh(freq, cache=None):
+    """The displaced icosphere of frequency `freq`; kept for the life of the process (the 16 M-facet mesh serves up to
+    three legs of one invocation)."""
     from membrane_solver_amd import meshgen
 
-    P, T = meshgen.icosphere(freq)
-    return meshgen.smooth_displace(P, 0.05), T
+    cache = _MESH_CACHE if cache is None else cache
+    if freq not in cache:
+        P, T = meshgen.icosphere(freq)
+        cache[freq] = (meshgen.smooth_displace(P, 0.05), T)
+    return cache[freq]
+
+
+def shared_bench_mesh(freq, rank, world, barrier, tag=None, shm_dir="/dev/shm", cache=None):
+    """bench_mesh() for a group of ranks on ONE node: rank 0 builds the mesh and hands it to the others through files in
+    /dev/shm (np.save / np.load), instead of `world` processes running the same 30-second NumPy generator side by side
+    on the node's cores.  `barrier` is a callable every rank calls (dist.barrier).  Falls back to building locally when
+    the files cannot be written or read."""
+    cache = _MESH_CACHE if cache is None else cache  # (per process; the tests' in-process ranks pass their own)
+    if freq in cache or world <= 1:
+        return bench_mesh(freq, cache)
+    tag = tag or os.environ.get("MASTER_PORT", "0")
+    base = os.path.join(shm_dir, f"ms_bench_mesh_{tag}_f{freq}")
+    ok_path = base + ".ok"
+    if rank == 0:
+        try:
+            P, T = bench_mesh(freq, cache)
+            np.save(base + "_P.npy", P)
+            np.save(base + "_T.npy", T)
+            with open(ok_path, "w") as fh:
+                fh.write("1")
+        except OSError as exc:
+            print(f"[bench] mesh f={freq} not shared through {shm_dir}: {exc!r}", file=sys.stderr)
+    barrier()
+    if rank != 0:
+        try:
+            if not os.path.exists(ok_path):
+                raise OSError("rank 0 wrote no mesh files")
+            cache[freq] = (np.load(base + "_P.npy"), np.load(base + "_T.npy"))
+        except (OSError, ValueError) as exc:
+            print(f"[bench] rank {rank}: mesh f={freq} built locally ({exc!r})", file=sys.stderr)
+            bench_mesh(freq, cache)
+    barrier()
+    if rank == 0:
+        for suffix in ("_P.npy", "_T.npy", ".ok"):
+            try:
+                os.unlink(base + suffix)
+            except OSError:
+                pass
+    return cache[freq]
+
+
+class LegBudget:
+    """Wall-clock budget of one bench.py invocation (MS_BENCH_BUDGET_S, default 300 s, counted from process start): the
+    contract line must appear within the driver's patience, so an extra leg only starts when its ESTIMATED cost still
+    fits.  The estimate of a leg is the measured cost per facet of the legs that have run (set-up and timed run
+    together) times the leg's facet count, 1.5 x padded; before any leg has run, `first_guess_s_per_mfacet`."""
+
+    def __init__(self, budget_s=None, now=time.perf_counter, t0=None, first_guess_s_per_mfacet=6.0):
+        env = os.environ.get("MS_BENCH_BUDGET_S")
+        self.budget_s = float(budget_s if budget_s is not None else (env if env else 300.0))
+        self.now = now
+        self.t0 = T_PROCESS_START if t0 is None else t0
+        self.rate = float(first_guess_s_per_mfacet)  # seconds per million facets
+        self.n_obs = 0
+        self.log = []
+
+    def elapsed(self):
+        return self.now() - self.t0
+
+    def estimate(self, nf):
+        return 1.5 * self.rate * (nf / 1e6)
+
+    def allows(self, nf):
+        return self.elapsed() + self.estimate(nf) <= self.budget_s
+
+    def observe(self, name, nf, seconds):
+        r = seconds / max(nf / 1e6, 1e-9)
+        self.rate = r if self.n_obs == 0 else max(self.rate, r)
+        self.n_obs += 1
+        self.log.append({"leg": name, "facets": int(nf), "wall_s": round(float(seconds), 2)})
+
+    def skip_note(self, name, nf):
+        note = (f"skipped: {self.elapsed():.0f} s elapsed + an estimated {self.estimate(nf):.0f} s would pass "
+                f"MS_BENCH_BUDGET_S={self.budget_s:.0f}")
+        self.log.append({"leg": name, "facets": int(nf), "skipped": True})
+        return {"note": note}
+
 
 
 GP = {"surface_tension": 1.0, "bending_modulus": 1.0, "bending_energy_model": "helfrich",
@@ -656,7 +742,7 @@ def sharded_extra_leg(args, rank, world, local_rank, freq, steps, warmup, exchan
     from membrane_solver_amd import _lib as L
     from membrane_solver_amd.parallel import HipShardBackend, LibraryShardedStepper, ShardedStepper
 
-    P, T = bench_mesh(freq)
+    P, T = shared_bench_mesh(freq, rank, world, dist.barrier)
     nv, nf = P.shape[0], T.shape[0]
     be = HipShardBackend(P, T, rank=rank, world=world, device=local_rank, tile_vertices=args.tile)
     be.configure(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING, gamma=np.ones(nf), kappa=np.ones(nv), c0=np.zeros(nv))
@@ -715,6 +801,8 @@ def sharded_extra_leg(args, rank, world, local_rank, freq, steps, warmup, exchan
            "driver": "library" if lib else "python",
            "exchange": ("peer-to-peer: pack kernels store into the peers' IPC-mapped slabs, flag words, bounded wait"
                         if exchange == "peer" else "RCCL all-gather")}
+    if exchange == "peer" and lib:
+        out["peer_memory"] = be.dm.peer_memory_kind()
     be.dm.close()
     return out
 
@@ -738,8 +826,10 @@ def main_sharded(args, rank, world, local_rank):
         os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()), "RANK": "0",
                            "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    budget = LegBudget()
+    t_leg0 = time.perf_counter()
     freq = weak_frequency(world, args.freq) if args.weak else args.freq
-    P, T = bench_mesh(freq)
+    P, T = shared_bench_mesh(freq, rank, world, dist.barrier)
     nv, nf = P.shape[0], T.shape[0]
     be = HipShardBackend(P, T, rank=rank, world=world, device=local_rank, tile_vertices=args.tile)
     if args.deterministic:
@@ -837,6 +927,10 @@ def main_sharded(args, rank, world, local_rank):
         dist.barrier()
     # -- one SCALE invocation yields all three curves: the headline mesh (strong), 16 M facets (strong, the size at
     #    which 8 GPUs have 2 M facets each) and 2 M facets per GPU (weak); the latter two coincide at 8 GPUs
+    budget.observe("headline", nf, time.perf_counter() - t_leg0)
+    if rank == 0:
+        print(f"[bench] leg headline (f={freq}): {budget.log[-1]['wall_s']} s; {budget.elapsed():.0f} s since process start, "
+              f"budget {budget.budget_s:.0f} s", file=sys.stderr)
     extra = {}
     if not args.weak and args.freq == 320:
         be.dm.close()
@@ -844,6 +938,16 @@ def main_sharded(args, rank, world, local_rank):
                        ("weak_2M_facets_per_gpu", weak_frequency(world, 320))):
             if args.no_large and f != 320:
                 continue
+            reuses = key.startswith("weak") and ((f == LARGE_FREQ and "strong_16M_facets" in extra) or f == 320)
+            # rank 0's clock decides for everybody (a leg is a collective)
+            go = torch.tensor([1 if (reuses or budget.allows(20 * f * f)) else 0], dtype=torch.int32, device=be.device)
+            dist.broadcast(go, src=0)
+            if int(go.item()) == 0:
+                extra[key] = budget.skip_note(key, 20 * f * f)
+                if rank == 0:
+                    print(f"[bench] leg {key} (f={f}) {extra[key]['note']}", file=sys.stderr)
+                continue
+            t_leg = time.perf_counter()
             try:
                 if key.endswith("peer_exchange"):
                     extra[key] = sharded_extra_leg(args, rank, world, local_rank, f, args.steps if f == 320 else min(args.steps, 40),
@@ -857,6 +961,11 @@ def main_sharded(args, rank, world, local_rank):
             except Exception as exc:  # an extra leg never costs the headline line
                 print(f"[bench] rank {rank}: leg {key} skipped: {exc!r}", file=sys.stderr)
                 extra[key] = None
+            if not reuses:
+                budget.observe(key, 20 * f * f, time.perf_counter() - t_leg)
+                if rank == 0:
+                    print(f"[bench] leg {key} (f={f}): {budget.log[-1]['wall_s']} s; {budget.elapsed():.0f} s since "
+                          f"process start", file=sys.stderr)
     sys.stdout.flush()
     os.dup2(stdout_fd, 1)
     os.close(stdout_fd)
@@ -883,6 +992,7 @@ def main_sharded(args, rank, world, local_rank):
             "exchange_bytes_per_rank_max": int((L.MS_NSCAL + 10 * be.boundary["max_rows"]) * 8),
             "energy_end": float(getattr(r, "energy", getattr(r, "energy_eval", float("nan")))),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "legs": {"budget_s": budget.budget_s, "wall_s_total": round(budget.elapsed(), 1), "log": budget.log},
         }), flush=True)
     os.dup2(2, 1)  # (communicator teardown may print as well)
     dist.destroy_process_group()

@@ -294,6 +294,12 @@ int ms_set_leaflet_disk_target(ms_ctx *ctx, int leaflet, const uint8_t *disk_row
 int ms_set_leaflet_bending(ms_ctx *ctx, int leaflet, const double *kappa /* nv */, const double *c0 /* nv */);
 int ms_leaflet_tilt_energy_and_gradient(ms_ctx *ctx, double *energy, double *grad_in /* nv*3 or NULL */,
                                         double *grad_out /* nv*3 or NULL */);
+/* The same evaluation with module_form != 0: the magnitude modules tilt_in / tilt_out in their OWN mass mode, as
+ * the plugin API evaluates them when a caller hands it tilt_in_grad_arr / tilt_out_grad_arr -- lumped
+ * k A_f/3 t_k, or consistent k A_f/12 (2 t_k + t_a + t_b) per corner
+ * (modules/energy/tilt_leaflet.py:101-150).  module_form == 0 is the call above. */
+int ms_leaflet_tilt_energy_and_gradient_ex(ms_ctx *ctx, int module_form, double *energy,
+                                           double *grad_in /* nv*3 or NULL */, double *grad_out /* nv*3 or NULL */);
 int ms_relax_leaflet_tilts(ms_ctx *ctx, const ms_tilt_relax_params *params,
                            int *iters_out, int *evals_out);
 
@@ -481,6 +487,11 @@ int ms_shard_step(ms_ctx *ctx, const ms_stepper_params *params, double step_size
 int64_t ms_shard_exchange_count(const ms_ctx *ctx);
 /* ranks of the context's RCCL communicator as ncclCommCount reports them (0: no communicator) */
 int ms_shard_comm_ranks(ms_ctx *ctx);
+/* Kind of device memory the peer exchange's receive slabs and flag words live in: 0 uncached (MTYPE_UC, what the
+ * collective library's own IPC signal buffers use), 1 fine-grained, 2 plain hipMalloc (coarse-grained: coherent across
+ * GPUs at kernel boundaries only -- the fallback when the other kinds cannot be allocated or exported); -1 before
+ * the slabs exist.  No reference counterpart (the reference is single-process). */
+int ms_shard_peer_memory_kind(const ms_ctx *ctx);
 
 /* Per-vertex state in caller-owned device memory (e.g. a torch tensor, so RCCL
  * collectives can run on it in place).  ms_state_bytes gives the size;

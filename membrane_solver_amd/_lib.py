@@ -147,6 +147,7 @@ SIGNATURES = {
     "ms_set_leaflet_disk_target": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ctypes.c_uint8),
                                                   ctypes.POINTER(ms_disk_target_params)]),
     "ms_leaflet_tilt_energy_and_gradient": (ctypes.c_int, [_P, _D, _D, _D]),
+    "ms_leaflet_tilt_energy_and_gradient_ex": (ctypes.c_int, [_P, ctypes.c_int, _D, _D, _D]),
     "ms_relax_leaflet_tilts": (ctypes.c_int, [_P, ctypes.POINTER(ms_tilt_relax_params),
                                               ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "ms_set_positions": (ctypes.c_int, [_P, _D]),
@@ -186,6 +187,7 @@ SIGNATURES = {
                                      ctypes.POINTER(ms_step_result)]),
     "ms_shard_exchange_count": (ctypes.c_int64, [_P]),
     "ms_shard_comm_ranks": (ctypes.c_int, [_P]),
+    "ms_shard_peer_memory_kind": (ctypes.c_int, [_P]),
     "ms_state_bytes": (ctypes.c_size_t, [_P]),
     "ms_rebind_state": (ctypes.c_int, [_P, _P, ctypes.c_size_t]),
     "ms_fetch_scalars": (ctypes.c_int, [_P, _D]),

@@ -196,6 +196,8 @@ struct ms_ctx {
   bool ls_reset = true;          // MS_LS_RESET=0: never forget the history on a regime change
   bool speculate = true;         // MS_SPECULATE=0 switches the ladder off
   bool relax_va_valid = false;  // a leaflet relaxation is running: tf[l].va describes the current x
+  bool tilt_module_form = false;  // tilt_eval: the magnitude modules in their own mass mode (the plugin API's form,
+                                  // tilt_leaflet.py:101-150) instead of the relaxation's vertex-area form
   int factors_leaflet = 0;  // which leaflet's back-prop factors fK/fA hold (1 in, 2 out; 0: not a leaflet's)
   double* d_bt_vert = nullptr;    // (nvp,4) bending_tilt per-vertex record of the last energy pass
   bool bt_valid = false;          // d_bt_vert describes the current x
@@ -254,6 +256,7 @@ struct ms_ctx {
   std::vector<unsigned long long*> peer_flags;
   std::vector<void*> peer_opened;           // hipIpcOpenMemHandle results to close
   bool peer_on = false;
+  int peer_mem_kind = -1;                   // 0 uncached, 1 fine-grained, 2 plain hipMalloc (peer_alloc)
   unsigned long long peer_ticket = 0;
   // MS_PEER_WAIT=stream: the flag words are raised and awaited by stream memory operations (hipStreamWriteValue64 behind
   // the pack kernel, hipStreamWaitValue64 in front of the unpack kernel) instead of a flag kernel and a waiting wave:
@@ -282,8 +285,11 @@ struct ms_ctx {
   struct ProfRec {
     hipEvent_t a, b;
     int kind;
-    bool gated;  // may have been an empty (skipped) launch
+    int ran_idx;  // gated launch: entry of d_prof_ran that says whether its gate was open (-1: not gated)
   };
+  static constexpr int PROF_RAN_CAP = 1 << 16;
+  uint32_t* d_prof_ran = nullptr;
+  int prof_ran_next = 0;
   std::vector<ProfRec> prof_pending;
   std::vector<hipEvent_t> prof_pool;
   double prof_ms[MS_PROF_KINDS] = {0};
@@ -358,12 +364,18 @@ struct HostTiming {
 };
 static HostTiming g_host_timing;
 
+// A gated launch that found its gate closed returns at once: not a sample of the kernel.  Whether it ran is what the
+// decision word said when the launch read it; with profiling on, a one-lane kernel behind the launch (outside its event
+// bracket) records exactly that comparison -- the word cannot change in between, only a later fold rewrites it.  (Rounds
+// 1-3 guessed from the duration, "< 12 us = empty", which discarded every real launch of a 131 k-facet mesh.)
 struct ProfScope {
   ms_ctx* c;
   hipEvent_t a = nullptr, b = nullptr;
   int kind;
-  bool gated = false;
-  ProfScope(ms_ctx* ctx, int k, bool maybe_skipped = false) : c(ctx), kind(k), gated(maybe_skipped) {
+  const uint32_t* gate = nullptr;
+  uint32_t want = 0;
+  ProfScope(ms_ctx* ctx, int k, const uint32_t* gate_word = nullptr, uint32_t gate_want = 0)
+      : c(ctx), kind(k), gate(gate_word), want(gate_want) {
     if (!c->profiling || k < 0) return;
     auto get = [&]() {
       hipEvent_t e = nullptr;
@@ -382,7 +394,12 @@ struct ProfScope {
   ~ProfScope() {
     if (!c->profiling || kind < 0 || !a || !b) return;
     (void)hipEventRecord(b, c->stream);
-    c->prof_pending.push_back({a, b, kind, gated});
+    int ran_idx = -1;
+    if (gate != nullptr && c->d_prof_ran != nullptr && c->prof_ran_next < ms_ctx::PROF_RAN_CAP) {
+      ran_idx = c->prof_ran_next++;
+      (void)launch_gate_probe(gate, want, c->d_prof_ran + ran_idx, c->stream);
+    }
+    c->prof_pending.push_back({a, b, kind, ran_idx});
   }
 };
 
@@ -437,6 +454,7 @@ int tilt_pass_f(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alpha, c
   a.e_slot = slot_override >= 0 ? slot_override : f.s_etilt;
   a.consistent = (f.consistent && !lumped) ? 1 : 0;
   a.tg_accumulate = tg_accumulate ? 1 : 0;
+  a.cons_tilt_grad = (a.consistent && c->tilt_module_form) ? 1 : 0;
   a.va_out = nullptr;
   {
     ProfScope ps(c, 4);
@@ -614,7 +632,7 @@ int reduce_slots(ms_ctx* c, uint32_t mask) {
     return MS_OK;
   }
   mask |= c->cur_extra_mask;
-  ProfScope ps(c, 3, c->cur_gate != nullptr);
+  ProfScope ps(c, 3, c->cur_gate, c->cur_gate_want);
   ++c->ticket;
   if (trace_queue())
     fprintf(stderr, "[msq] fold ticket %llu mask %#x -> %s gate %p want %u dec %p trials %d\n",
@@ -739,7 +757,7 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
   a.bending_model = c->params.bending_model;
   a.modules = modules;
   if (!lbt) {
-    ProfScope ps(c, a.pair > 3 ? 10 : (a.pair == 3 ? 8 : (a.pair ? 7 : 0)), c->cur_gate != nullptr);
+    ProfScope ps(c, a.pair > 3 ? 10 : (a.pair == 3 ? 8 : (a.pair ? 7 : 0)), a.gate, a.gate_want);
     const double t_l0 = g_host_timing.on ? HostTiming::now() : 0.0;
     HIPCHK(c, launch_energy(a, guard && use_dir, c->cap, c->til.max_ent, c->stream));
     if (g_host_timing.on && g_host_timing.armed) {
@@ -783,6 +801,7 @@ int phase_energy(ms_ctx* c, uint32_t modules, bool use_dir, double alpha, bool w
       ta.e_slot = MS_S_ETILT;
       ta.consistent = 0;
       ta.tg_accumulate = 0;
+      ta.cons_tilt_grad = 0;
       ta.va_out = nullptr;
       if (!ta.tilts) return fail(c, MS_ERR_STATE, "bending_tilt_in/out active but ms_set_leaflet_tilts was never called");
       ProfScope ps(c, 4);
@@ -906,7 +925,7 @@ int phase_gradient(ms_ctx* c, uint32_t modules_in, double* g_out, bool accumulat
   a.tilts = nullptr;
   a.div_sign = 1.0;
   if (n_lbt == 0) {
-    ProfScope ps(c, gradient_lean_instance(a) ? 9 : 1, c->cur_gate != nullptr);
+    ProfScope ps(c, gradient_lean_instance(a) ? 9 : 1, a.gate, a.gate_want);
     HIPCHK(c, launch_gradient(a, c->cap, c->til.max_ent, c->stream));
   }
   for (int k = 0; k < n_lbt; ++k) {
@@ -964,7 +983,7 @@ int phase_direction(ms_ctx* c, int stepper, bool use_history, bool g_finalized =
   const bool use_con = (c->params.modules & MS_CON_VOLUME) != 0;
   c->dir_implicit = false;
   {
-  ProfScope ps(c, 2);
+  ProfScope ps(c, 2, c->cur_gate, c->cur_gate_want);
   HIPCHK(c, launch_direction(c->tile0, c->tile1, c->til.nv, c->til.own, c->d_vflags, c->buf[MS_BUF_G],
                              c->buf[MS_BUF_GC], c->buf[MS_BUF_D], c->buf[MS_BUF_PG],
                              c->buf[MS_BUF_PD], c->d_scal, use_con ? 1 : 0,
@@ -998,6 +1017,7 @@ int check_queue_error(ms_ctx* c) {
   if (!c->h_err) return MS_OK;
   const unsigned long long e = __atomic_load_n(c->h_err, __ATOMIC_ACQUIRE);
   if (e == 0) return MS_OK;
+  __atomic_store_n(c->h_err, 0ull, __ATOMIC_RELEASE);  // reported once (the caller gets MS_ERR_STATE for this call)
   char msg[256];
   snprintf(msg, sizeof(msg),
            "line-search queue: a gated launch ran on %llu of its %d workgroups (fold ticket %llu): the workgroups of one "
@@ -1022,7 +1042,9 @@ int wait_mailbox(ms_ctx* c, unsigned long long* h_seq, const unsigned long long*
     }
     return true;
   };
-  bool done = c->tile1 <= c->tile0;
+  // (an empty shard -- 9 tiles over 8 ranks leave ranks 5..7 without one -- waits like any other: k_reduce posts the
+  // neutral value of every slot for an empty tile range, and `bits` is only ever filled by arrived())
+  bool done = false;
   for (long spin = 0; !done && spin < 20000000L; ++spin) {
     done = arrived();
     if (done) {
@@ -1446,6 +1468,7 @@ void ms_destroy(ms_ctx* c) {
   }
   if (c->d_dec) (void)hipFree(c->d_dec);
   if (c->h_err) (void)hipHostFree(c->h_err);
+  if (c->d_prof_ran) (void)hipFree(c->d_prof_ran);
   for (auto& sd : c->side) {
     if (sd.partials) (void)hipFree(sd.partials);
     if (sd.scal) (void)hipFree(sd.scal);
@@ -1597,6 +1620,7 @@ int ms_angle_defects(ms_ctx* c, double* defects) {
   a.e_slot = MS_S_ETILT;
   a.consistent = 0;
   a.tg_accumulate = 0;
+  a.cons_tilt_grad = 0;
   a.va_out = nullptr;
   hipError_t e = launch_tilt(a, 4, c->cap, t.max_ent, c->stream);
   int rc = MS_OK;
@@ -1633,6 +1657,7 @@ int ms_curvature_fields(ms_ctx* c, double* mean_curvature_normal, double* h_area
   a.e_slot = MS_S_ETILT;
   a.consistent = 0;
   a.tg_accumulate = 0;
+  a.cons_tilt_grad = 0;
   a.va_out = nullptr;
   a.fields = d_out;
   a.fields_rows = t.nvp;
@@ -1743,7 +1768,9 @@ int tilt_eval(ms_ctx* c, bool trial, bool gradient) {
                             c->stream, f.fixed_bit, f.s_etilt, f.s_rz));
       mask |= 1u << f.s_etilt;
     } else if (mods & f.mod_tilt) {
-      rc = tilt_pass_f(c, f, gradient ? 1 : 0, false, 0.0, tilts, nullptr, /*shape_gradient=*/false, /*lumped=*/true);
+      // (module form -- ms_leaflet_tilt_energy_and_gradient_ex: the field's own mass mode, tilt gradient included)
+      rc = tilt_pass_f(c, f, gradient ? 1 : 0, false, 0.0, tilts, nullptr, /*shape_gradient=*/false,
+                       /*lumped=*/!c->tilt_module_form);
       if (rc) return rc;
       mask |= 1u << f.s_etilt;
     } else if (gradient) {
@@ -1846,6 +1873,7 @@ int relax_fields(ms_ctx* c, const ms_tilt_relax_params* rp, TiltField** fl, int 
       a.e_slot = f.s_etilt;
       a.consistent = 0;
       a.tg_accumulate = 0;
+  a.cons_tilt_grad = 0;
       a.va_out = f.va;
       HIPCHK(c, launch_tilt(a, 3, c->cap, t.max_ent, c->stream));
     }
@@ -2115,12 +2143,19 @@ int leaflet_ready(ms_ctx* c, const char* who, TiltField** fl, int* nf) {
 }  // namespace
 
 int ms_leaflet_tilt_energy_and_gradient(ms_ctx* c, double* energy, double* grad_in, double* grad_out) {
+  return ms_leaflet_tilt_energy_and_gradient_ex(c, 0, energy, grad_in, grad_out);
+}
+
+int ms_leaflet_tilt_energy_and_gradient_ex(ms_ctx* c, int module_form, double* energy, double* grad_in,
+                                           double* grad_out) {
   if (!c || !energy) return fail(c, MS_ERR_INVALID, "ms_leaflet_tilt_energy_and_gradient: NULL argument");
   TiltField* fl[2];
   int nf = 0;
   int rc = leaflet_ready(c, "ms_leaflet_tilt_energy_and_gradient", fl, &nf);
   if (rc) return rc;
+  c->tilt_module_form = module_form != 0;
   rc = tilt_eval(c, false, true);
+  c->tilt_module_form = false;
   if (rc) return rc;
   rc = fetch(c);
   if (rc) return rc;
@@ -2663,7 +2698,9 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
       rc = phase_direction(c, sp->stepper, use_history, /*g_finalized=*/true);
     }
   } else if (c->kc_pending && carried_x && !(c->params.modules & MS_TILT_SHAPE_MODS) && c->kc_stepper == sp->stepper &&
-             c->kc_use_history == use_history) {
+             c->kc_use_history == use_history && !precond) {
+    // (a queued pass always carries the plain fused direction: a caller that switched precondition on between two
+    // steps must not adopt it)
     // the gradient + direction pass of this x was queued behind the line search that accepted it (gated on the
     // acceptance) and has run: take its scalars from its mailbox
     c->kc_pending = false;
@@ -3460,7 +3497,7 @@ int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push, 
     HIPCHK(c, launch_unpack_boundary(c->d_bnd_rows, c->d_bnd_off, me, W, c->bnd_max, p, nc, n,
                                      c->d_peer_slab + (size_t)par * W * c->peer_stride, c->peer_stride,
                                      c->d_h_scal_all, c->stream, c->d_h_xseq, c->xticket, /*remote_written=*/true,
-                                     wait_flags, c->peer_ticket, c->d_h_err));
+                                     wait_flags, c->peer_ticket, c->d_h_err + 1));  // (a word of its own: h_err[0] is the queue's)
   } else {
   HIPCHK(c, launch_pack_boundary(c->d_bnd_rows + c->bnd_off[(size_t)me],
                                  c->bnd_off[(size_t)me + 1] - c->bnd_off[(size_t)me], p, nc, n, c->d_scal,
@@ -3508,9 +3545,11 @@ int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push, 
     }
   }
   if (!seen) HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->peer_on && c->h_err && (__atomic_load_n(c->h_err, __ATOMIC_ACQUIRE) >> 62) == 1)
+  if (c->peer_on && c->h_err && (__atomic_load_n(c->h_err + 1, __ATOMIC_ACQUIRE) >> 62) == 1) {
+    const unsigned long long e = __atomic_exchange_n(c->h_err + 1, 0ull, __ATOMIC_ACQ_REL);  // reported once
     return fail(c, MS_ERR_STATE, "peer exchange: a peer's flag did not arrive within the bounded wait (rank " +
-                                     std::to_string((int)((*c->h_err >> 32) & 0xff)) + ")");
+                                     std::to_string((int)((e >> 32) & 0xff)) + ")");
+  }
   // fold in rank order: every rank adds the same doubles in the same order
   for (int sl : SH_SUM)
     if (slots & (1u << sl)) {
@@ -3601,9 +3640,37 @@ int peer_alloc(ms_ctx* c) {
   if (rc) return rc;
   c->peer_stride = (size_t)MS_NSCAL + 10 * (size_t)c->bnd_max;
   const size_t sb = sizeof(double) * 2 * (size_t)c->shard_count * c->peer_stride;
-  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_peer_slab), sb));
+  // The slabs and flag words are written by OTHER GPUs over xGMI while a kernel of this one is resident and polls them.
+  // Ordinary hipMalloc memory is coarse-grained (cached read-write in this GPU's L2, coherent across agents only at
+  // kernel boundaries): a resident wave could keep reading a stale flag or a boundary row of exchange k-2.  Uncached
+  // (MTYPE_UC) device memory is what the collective library's own IPC signal buffers use; fine-grained is the second
+  // choice; plain hipMalloc stays as the last resort (MS_PEER_MEM=uncached|finegrained|default forces one).
+  const char* want = getenv("MS_PEER_MEM");
+  const unsigned kinds[3] = {hipDeviceMallocUncached, hipDeviceMallocFinegrained, hipDeviceMallocDefault};
+  const char* names[3] = {"uncached", "finegrained", "default"};
+  c->peer_mem_kind = -1;
+  for (int k = 0; k < 3 && c->peer_mem_kind < 0; ++k) {
+    if (want && *want && strcmp(want, names[k]) != 0) continue;
+    void *ps = nullptr, *pf = nullptr;
+    hipError_t e1 = kinds[k] == hipDeviceMallocDefault ? hipMalloc(&ps, sb) : hipExtMallocWithFlags(&ps, sb, kinds[k]);
+    hipError_t e2 = e1 != hipSuccess ? e1
+                    : (kinds[k] == hipDeviceMallocDefault ? hipMalloc(&pf, sizeof(unsigned long long) * 32)
+                                                          : hipExtMallocWithFlags(&pf, sizeof(unsigned long long) * 32, kinds[k]));
+    hipIpcMemHandle_t probe;
+    // (memory that cannot be exported is of no use here: ms_shard_peer_export would fail later)
+    if (e1 == hipSuccess && e2 == hipSuccess && hipIpcGetMemHandle(&probe, ps) == hipSuccess &&
+        hipIpcGetMemHandle(&probe, pf) == hipSuccess) {
+      c->d_peer_slab = static_cast<double*>(ps);
+      c->d_peer_flag = static_cast<unsigned long long*>(pf);
+      c->peer_mem_kind = k;
+    } else {
+      (void)hipGetLastError();
+      if (ps) (void)hipFree(ps);
+      if (pf) (void)hipFree(pf);
+    }
+  }
+  if (c->peer_mem_kind < 0) return fail(c, MS_ERR_HIP, "peer exchange: no exportable device memory for the slabs / flag words");
   HIPCHK(c, hipMemset(c->d_peer_slab, 0, sb));
-  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_peer_flag), sizeof(unsigned long long) * 32));
   HIPCHK(c, hipMemset(c->d_peer_flag, 0, sizeof(unsigned long long) * 32));
   HIPCHK(c, hipDeviceSynchronize());
   return MS_OK;
@@ -3714,6 +3781,8 @@ int ms_shard_peer_set_barrier(ms_ctx* c, ms_barrier_fn fn, void* user) {
 
 int64_t ms_shard_exchange_count(const ms_ctx* c) { return c ? (int64_t)c->sh_exchanges : 0; }
 
+int ms_shard_peer_memory_kind(const ms_ctx* c) { return (c && c->d_peer_slab) ? c->peer_mem_kind : -1; }
+
 int ms_shard_comm_ranks(ms_ctx* c) {
   if (!c || !c->comm || !g_rccl.CommCount) return 0;
   int n = 0;
@@ -3726,6 +3795,10 @@ int ms_shard_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, doub
   const uint32_t mods = c->params.modules;
   if (mods & MS_ANY_TILT_MODS) return fail(c, MS_ERR_STATE, "the tilt modules are not sharded yet (single GPU only)");
   if (sp->precondition) return fail(c, MS_ERR_STATE, "ConjugateGradient(precondition=True) is not sharded (single GPU only)");
+  // (line_search.py:428-487: every trial projected onto the target volume -- the projection is not sharded; running the
+  // plain lane instead would be a different trajectory, silently)
+  if (sp->enforce_volume)
+    return fail(c, MS_ERR_STATE, "volume_projection_during_minimization (the enforcer lane of the line search) is not sharded (single GPU only)");
   c->precond = false;
   memset(out, 0, sizeof(*out));
   const bool cg = sp->stepper == MS_STEPPER_CG;
@@ -4000,6 +4073,10 @@ int ms_queue_stats(ms_ctx* c, int64_t stats[8]) {
 
 int ms_profile_enable(ms_ctx* c, int on) {
   if (!c) return MS_ERR_INVALID;
+  if (on && !c->d_prof_ran) {
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_prof_ran), sizeof(uint32_t) * ms_ctx::PROF_RAN_CAP));
+    HIPCHK(c, hipMemset(c->d_prof_ran, 0, sizeof(uint32_t) * ms_ctx::PROF_RAN_CAP));
+  }
   c->profiling = on != 0;
   return MS_OK;
 }
@@ -4007,10 +4084,16 @@ int ms_profile_enable(ms_ctx* c, int on) {
 int ms_profile_read(ms_ctx* c, double total_ms[MS_PROF_KINDS], int64_t launches[MS_PROF_KINDS]) {
   if (!c || !total_ms || !launches) return MS_ERR_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<uint32_t> ran((size_t)c->prof_ran_next);
+  if (c->prof_ran_next > 0)
+    HIPCHK(c, hipMemcpy(ran.data(), c->d_prof_ran, sizeof(uint32_t) * ran.size(), hipMemcpyDeviceToHost));
+  c->prof_ran_next = 0;
   for (auto& r : c->prof_pending) {
     float ms = 0.f;
-    // a gated launch that found its gate closed returns at once (a few us): not a sample of the kernel
-    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && !(r.gated && ms < 0.012f)) {
+    // a gated launch that found its gate closed (the probe behind it saw another code than the one it was queued for)
+    // is not a sample of the kernel
+    const bool empty = r.ran_idx >= 0 && ran[(size_t)r.ran_idx] == 0u;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && !empty) {
       c->prof_ms[r.kind] += ms;
       c->prof_n[r.kind] += 1;
     }

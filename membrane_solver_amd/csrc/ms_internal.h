@@ -200,6 +200,8 @@ struct TiltArgs {
   int e_slot;             // reduction slot of the energy partial (MS_S_ETILT / _IN / _OUT)
   int consistent;         // tilt_leaflet.py:101-114: consistent P1 mass coeff (energy / shape gradient)
   int tg_accumulate;      // mode 1: ADD the tilt gradient instead of writing it
+  int cons_tilt_grad;     // mode 1 with `consistent`: the tilt gradient takes the consistent P1 mass too,
+                          // k A_f/12 (2 t_k + t_a + t_b) per corner (tilt_leaflet.py:124-150), instead of k t_v A_v
   double* va_out;         // mode 3: barycentric vertex areas (nvp) or nullptr
   double* fields;         // mode 5: curvature fields, four planes of (fields_rows, 3) -- see k_tilt
   int64_t fields_rows;
@@ -330,6 +332,8 @@ hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_of
                                   bool remote_written = false, const unsigned long long* wait_flags = nullptr,
                                   unsigned long long wait_ticket = 0, unsigned long long* host_err = nullptr);
 hipError_t launch_post_seq(unsigned long long* host_seq, unsigned long long ticket, hipStream_t s);
+// profiling only: *out = (*gate == want), one lane, queued right behind a gated launch (ms_profile_*)
+hipError_t launch_gate_probe(const uint32_t* gate, uint32_t want, uint32_t* out, hipStream_t s);
 // peer-to-peer exchange: pack straight into every peer's slab (dst[r] = that peer's slot for this rank), raise this
 // rank's flag on every peer; the unpack kernel waits (bounded) for every peer's flag here
 struct PeerFlags {

@@ -1777,9 +1777,14 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
     end = voff[tid + 1];
   }
   double cf_area = 0.0, cf_theta = 0.0;  // MODE 5 vertex accumulators: mixed area, angle sum (K in ax, ay, az)
+  // MODE 1, consistent mass with a.cons_tilt_grad: the module's own tilt gradient k A_f/12 (2 t_k + t_a + t_b)
+  // (tilt_leaflet.py:124-150), gathered per vertex through a second pass over the staging block
+  const bool cons_tg = MODE == 1 && cons && a.cons_tilt_grad;
+  double tgx = 0.0, tgy = 0.0, tgz = 0.0;
   for (int c0 = t.f0; c0 < t.f1; c0 += T) {
     const int p = c0 + tid;
     double cf_a0 = 0, cf_a1 = 0, cf_a2 = 0, cf_t0 = 0, cf_t1 = 0, cf_t2 = 0;
+    V3 ctg0 = mk(0, 0, 0), ctg1 = mk(0, 0, 0), ctg2 = mk(0, 0, 0);
     const TileFacet tf = facet_unpack<false>(tf_nx);
     if (p + T < t.f1) tf_nx = facet_load<false>(a.m, (size_t)(p + T));
     if (p < t.f1) {
@@ -1833,6 +1838,12 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
           if (cons) {  // tilt_leaflet.py:91-114: (k/12)(sum |t|^2 + t0.t1 + t1.t2 + t2.t0)
             const V3 t0 = lds_v3(tl, cap, tf.l0), t1 = lds_v3(tl, cap, tf.l1), t2 = lds_v3(tl, cap, tf.l2);
             coeff = (a.k_tilt / 12.0) * (((sq + dot(t0, t1)) + dot(t1, t2)) + dot(t2, t0));
+            if (cons_tg) {  // :124-150: tri_factor ((2 t_k) + t_a + t_b), tri_factor = k A_f / 12
+              const double tri = (a.k_tilt * area) / 12.0;
+              ctg0 = tri * (((2.0 * t0) + t1) + t2);
+              ctg1 = tri * (((2.0 * t1) + t2) + t0);
+              ctg2 = tri * (((2.0 * t2) + t0) + t1);
+            }
           }
           if (tf.flags & TF_OWNER) e_tilt += coeff * area;
           if (MODE == 1) {
@@ -1883,6 +1894,23 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
         ++cur;
       }
       __syncthreads();
+      if (cons_tg) {  // second sub-phase: the per-corner consistent tilt gradients through the same staging block
+        if (p < t.f1) {
+          double* s2 = stg + tid;
+          s2[0 * T] = ctg0.x; s2[1 * T] = ctg0.y; s2[2 * T] = ctg0.z;
+          s2[3 * T] = ctg1.x; s2[4 * T] = ctg1.y; s2[5 * T] = ctg1.z;
+          s2[6 * T] = ctg2.x; s2[7 * T] = ctg2.y; s2[8 * T] = ctg2.z;
+        }
+        __syncthreads();
+        for (int q = cur0; q < cur; ++q) {
+          const int ent = vent[q];
+          const double* s2 = stg + ((ent >> 2) - lo) + 3 * (ent & 3) * T;
+          tgx += s2[0];
+          tgy += s2[T];
+          tgz += s2[2 * T];
+        }
+        __syncthreads();
+      }
       if (MODE == 5) {  // second sub-phase: corner areas and angles through the same staging block
         if (p < t.f1) {
           double* s2 = stg + tid;
@@ -1923,14 +1951,16 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
         a.g[o + 1] += ay;
         a.g[o + 2] += az;
       }
+      // lumped: k t_v A_v with the barycentric A_v; consistent (module form): the gathered per-corner vectors
+      const V3 tg = cons_tg ? mk(tgx, tgy, tgz) : mk(a.k_tilt * tv.x * aw, a.k_tilt * tv.y * aw, a.k_tilt * tv.z * aw);
       if (a.tg_accumulate) {
-        a.tilt_grad[o] += a.k_tilt * tv.x * aw;
-        a.tilt_grad[o + 1] += a.k_tilt * tv.y * aw;
-        a.tilt_grad[o + 2] += a.k_tilt * tv.z * aw;
+        a.tilt_grad[o] += tg.x;
+        a.tilt_grad[o + 1] += tg.y;
+        a.tilt_grad[o + 2] += tg.z;
       } else {
-        a.tilt_grad[o] = a.k_tilt * tv.x * aw;
-        a.tilt_grad[o + 1] = a.k_tilt * tv.y * aw;
-        a.tilt_grad[o + 2] = a.k_tilt * tv.z * aw;
+        a.tilt_grad[o] = tg.x;
+        a.tilt_grad[o + 1] = tg.y;
+        a.tilt_grad[o + 2] = tg.z;
       }
     } else if (MODE == 2) {
       V3 nrm = mk(ax, ay, az);
@@ -2739,8 +2769,16 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(FoldArgs a) {
   if (a.dec_out == nullptr || (!merged && task >= t_rest)) return;
   // a stage that is decided here: its energies' workgroups (merged: every slot's) count in once their scalar store has
   // completed; the one that comes last decides
+  // release: this workgroup's scalar store is visible at agent scope before its arrival; acquire: the last arriver's
+  // loads of the other workgroups' energies below are ordered behind their arrivals (the same handoff as
+  // k_pack_peers' last block).  At most ~10 lanes of a launch execute this, on L2s the kernel boundary has just
+  // written back.
+#ifndef MS_REDUCE_RELAXED
+  const uint32_t arrived = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else  // (A/B build: the hand-placed form of rounds 2-3)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const uint32_t arrived = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   if (arrived != (uint32_t)(a.n_sets * n_e + (merged ? n_reg * n_rest : 0) - 1)) return;
   st_agent(a.counter, 0u);  // (the next fold of the stream starts from zero)
   uint32_t code = DEC_CONTINUE;
@@ -3125,6 +3163,14 @@ hipError_t launch_flag_peers(unsigned long long* const* peer_flags, int me, int 
 __global__ void k_post_seq(unsigned long long* host_seq, unsigned long long ticket) {
   __threadfence_system();
   *reinterpret_cast<volatile unsigned long long*>(host_seq) = ticket;
+}
+
+__global__ void k_gate_probe(const uint32_t* gate, uint32_t want, uint32_t* out) {
+  *out = ld_agent(gate) == want ? 1u : 0u;
+}
+hipError_t launch_gate_probe(const uint32_t* gate, uint32_t want, uint32_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_gate_probe, dim3(1), dim3(1), 0, s, gate, want, out);
+  return hipGetLastError();
 }
 
 hipError_t launch_post_seq(unsigned long long* host_seq, unsigned long long ticket, hipStream_t s) {

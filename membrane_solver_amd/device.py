@@ -239,15 +239,17 @@ class DeviceMesh:
         self._chk(L.lib().ms_get_leaflet_tilts(self._h, lf, _pd(out)), "ms_get_leaflet_tilts")
         return out
 
-    def leaflet_tilt_energy_and_gradient(self, want_gradient: bool = True):
+    def leaflet_tilt_energy_and_gradient(self, want_gradient: bool = True, module_form: bool = False):
         """-> (tilt-dependent energy, dE/dt_in, dE/dt_out) at frozen positions, magnitude modules
-        in their vertex-area form (evaluation_manager.py:630-742 with tilt_vertex_areas)."""
+        in their vertex-area form (evaluation_manager.py:630-742 with tilt_vertex_areas); with
+        ``module_form`` in their own mass mode, as the plugin API evaluates them
+        (tilt_leaflet.py:101-150: lumped, or consistent k A/12 (2 t_k + t_a + t_b))."""
         e = ctypes.c_double(0.0)
         gi = np.empty((self.nv, 3), dtype=np.float64) if want_gradient else None
         go = np.empty((self.nv, 3), dtype=np.float64) if want_gradient else None
-        self._chk(L.lib().ms_leaflet_tilt_energy_and_gradient(self._h, ctypes.byref(e), _pd(gi) if want_gradient else None,
-                                                              _pd(go) if want_gradient else None),
-                  "ms_leaflet_tilt_energy_and_gradient")
+        self._chk(L.lib().ms_leaflet_tilt_energy_and_gradient_ex(
+            self._h, 1 if module_form else 0, ctypes.byref(e), _pd(gi) if want_gradient else None,
+            _pd(go) if want_gradient else None), "ms_leaflet_tilt_energy_and_gradient_ex")
         return float(e.value), gi, go
 
     def relax_leaflet_tilts(self, *, solver: str = "cg", max_iters: int, step_size: float, tol: float = 0.0,
@@ -450,6 +452,12 @@ class DeviceMesh:
 
     def shard_exchange_count(self) -> int:
         return int(L.lib().ms_shard_exchange_count(self._h))
+
+    def peer_memory_kind(self) -> str:
+        """Memory kind of the peer exchange's slabs / flag words (ms_shard_peer_memory_kind)."""
+        k = int(L.lib().ms_shard_peer_memory_kind(self._h))
+        return {0: "uncached device memory", 1: "fine-grained device memory",
+                2: "plain hipMalloc (coarse-grained)"}.get(k, "not allocated")
 
     # -- shard boundary exchange ------------------------------------------------
     def boundary_info(self):

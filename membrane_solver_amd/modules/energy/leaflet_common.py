@@ -252,9 +252,6 @@ def evaluate(mesh, global_params, param_resolver, *, kind: str, leaflet: str, po
     if tilt_grad_arr is not None and np.shape(tilt_grad_arr) != (nv, 3):
         raise ValueError(f"tilt_grad_arr for leaflet '{leaflet}' must have shape (N_vertices, 3)")
     params = device_params(param_resolver, global_params, leaflet)
-    if kind == "tilt" and tilt_grad_arr is not None and params["mass_mode"] == "consistent":
-        raise L.MembraneHipError("the consistent-mass tilt gradient of tilt_in/tilt_out is outside the HIP hot "
-                                 "path (the relaxation uses the vertex-area form; energy and shape gradient are on it)")
     mir = mirror_for(mesh)
     dm = mir.sync(positions=None if positions is mesh.positions_view() else positions)
     other = "out" if leaflet == "in" else "in"
@@ -291,6 +288,7 @@ def evaluate(mesh, global_params, param_resolver, *, kind: str, leaflet: str, po
     else:
         E = float(dm.energy()[3])
     if tilt_grad_arr is not None:
-        _e, gi, go = dm.leaflet_tilt_energy_and_gradient(want_gradient=True)
+        # the module's own mass mode (tilt_leaflet.py:116-150): lumped k A/3 t_k or consistent k A/12 (2 t_k + t_a + t_b)
+        _e, gi, go = dm.leaflet_tilt_energy_and_gradient(want_gradient=True, module_form=(kind == "tilt"))
         tilt_grad_arr += gi if leaflet == "in" else go
     return E

@@ -40,14 +40,8 @@ def test_leaflet_plugins_match_reference(name, mass):
         grad = np.zeros_like(pos)
         tg = np.zeros_like(pos)
         kw = {"tilt_in_grad_arr": tg} if lf == "in" else {"tilt_out_grad_arr": tg}
-        consistent_tilt = mod.startswith("tilt_i") or mod.startswith("tilt_o")
-        consistent_tilt = consistent_tilt and ((mass == "consistent") == (lf == "in"))
-        if consistent_tilt:
-            # energy + shape gradient are on the device, the consistent-mass tilt gradient is refused loudly
-            with pytest.raises(L.MembraneHipError, match="consistent-mass tilt gradient"):
-                module.compute_energy_and_gradient_array(mesh, gp, res, positions=pos, index_map=mesh.vertex_index_to_row,
-                                                         grad_arr=grad, tilts_in=tin, tilts_out=tout, **kw)
-            kw = {}
+        # (tilt_in / tilt_out with consistent mass: the tilt gradient k A/12 (2 t_k + t_a + t_b) of
+        # tilt_leaflet.py:124-150 is k_tilt's second gather pass -- SURVEY row a15 in full)
         E = module.compute_energy_and_gradient_array(mesh, gp, res, positions=pos, index_map=mesh.vertex_index_to_row,
                                                      grad_arr=grad, tilts_in=tin, tilts_out=tout, **kw)
         assert abs(E - g[f"{key}_{mod}_E"]) <= 1e-12 * abs(g[f"{key}_{mod}_E"])

@@ -229,3 +229,52 @@ def test_bench_launcher_command_and_schema_helpers(monkeypatch):
             "share_of_kernel_time"} <= set(r)
     rt = bench.rates(20, 10, 21, 0, 2, 0.002)
     assert rt["accepted_steps_per_s"] == 5000.0 and rt["evaluations_per_s"] == (21 + 10) / 0.002
+
+
+def test_bench_leg_budget_and_shared_mesh(tmp_path, monkeypatch):
+    """bench.py --gpus N: an extra leg starts only while its estimated cost fits MS_BENCH_BUDGET_S, and rank 0's mesh
+    reaches the other ranks through files instead of every rank running the generator."""
+    import threading
+
+    import bench
+
+    clock = {"t": 0.0}
+    b = bench.LegBudget(budget_s=100.0, now=lambda: clock["t"], t0=0.0, first_guess_s_per_mfacet=5.0)
+    assert b.estimate(2_000_000) == pytest.approx(15.0)        # 1.5 x 5 s per million facets
+    assert b.allows(2_000_000)
+    clock["t"] = 20.0
+    b.observe("headline", 2_048_000, 20.0)                     # measured: ~9.8 s per million facets
+    assert b.estimate(2_048_000) == pytest.approx(30.0)
+    assert b.allows(2_048_000)                                 # 20 + 30 <= 100
+    assert not b.allows(16_380_500)                            # 20 + 240 > 100
+    note = b.skip_note("strong_16M_facets", 16_380_500)
+    assert "skipped" in note["note"] and "MS_BENCH_BUDGET_S=100" in note["note"]
+    clock["t"] = 75.0
+    assert not b.allows(2_048_000)                             # 75 + 30 > 100
+    b.observe("fast leg", 2_048_000, 2.0)                      # the estimate never drops below the slowest leg seen
+    assert b.estimate(2_048_000) == pytest.approx(30.0)
+    assert [e["leg"] for e in b.log] == ["headline", "strong_16M_facets", "fast leg"] and b.log[1]["skipped"]
+    monkeypatch.setenv("MS_BENCH_BUDGET_S", "42")
+    assert bench.LegBudget().budget_s == 42.0
+
+    # two "ranks" (threads, each with the cache a process of its own would have) share one mesh: only rank 0 runs
+    # the generator
+    from membrane_solver_amd import meshgen
+
+    calls = []
+    real = meshgen.icosphere
+    monkeypatch.setattr(meshgen, "icosphere", lambda f: (calls.append(f), real(f))[1])
+    bar = threading.Barrier(2)
+    out, caches = {}, {0: {}, 1: {}}
+
+    def rank_fn(r):
+        out[r] = bench.shared_bench_mesh(3, r, 2, bar.wait, tag="t", shm_dir=str(tmp_path), cache=caches[r])
+
+    t1 = threading.Thread(target=rank_fn, args=(1,))
+    t1.start()
+    rank_fn(0)
+    t1.join()
+    assert calls == [3]
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert out[0][1].shape == (180, 3) and 3 in caches[1]
+    assert not list(tmp_path.iterdir())                        # rank 0 removed the files

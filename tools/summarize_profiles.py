@@ -20,23 +20,39 @@ if os.path.exists(js):
 # The line-search queue launches trial / gradient kernels that test an Armijo gate and return
 # at once when it is closed.  Such empty dispatches (a few us) are not samples of the kernel: besides rocprofv3's own
 # table, write one computed from the kernel trace without them -- the figure bench.py's HIP events report.
-EMPTY_NS = 12000
+# A kernel trace does not say what a gated launch read in its decision word (bench.py's own HIP-event figures do: the
+# library queues a one-lane probe behind every gated launch while profiling).  Here a dispatch of a gated tile kernel
+# counts as empty when it is BOTH shorter than 5 us and shorter than 0.4 x the longest dispatch of the same
+# instantiation: an empty dispatch is 2-3.5 us whatever the mesh, a real one is never a small fraction of its siblings
+# (rounds 1-3 used a flat 12 us, which threw away every real launch of the 131 k-facet configuration).
+EMPTY_NS = 5000
+EMPTY_FRAC = 0.4
 TILE_KERNELS = ("ms::k_energy", "ms::k_gradient", "ms::k_reduce")
+
+
+def empty_limits(rows):
+    longest = collections.defaultdict(int)
+    for name, d in rows:
+        if any(t in name for t in TILE_KERNELS[:2]):
+            longest[name] = max(longest[name], d)
+    return {name: min(EMPTY_NS, EMPTY_FRAC * m) for name, m in longest.items()}
+
+
 kt = glob.glob(os.path.join(root, "gpurun_out", f"{tag}_stats", "*", "*kernel_trace.csv"))
 if kt:
     durs = collections.defaultdict(list)
     skipped = collections.Counter()
-    for r in csv.DictReader(open(kt[0])):
-        name = r["Kernel_Name"]
-        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-        if any(t in name for t in TILE_KERNELS[:2]) and d < EMPTY_NS:
+    trace = [(r["Kernel_Name"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(kt[0]))]
+    lim = empty_limits(trace)
+    for name, d in trace:
+        if d < lim.get(name, 0):
             skipped[name] += 1
             continue
         durs[name].append(d)
     tot = sum(sum(v) for v in durs.values()) or 1
     with open(os.path.join(out, f"{tag}_kernel_stats_nonempty.csv"), "w", newline="") as f:
-        f.write(f"# from {os.path.basename(kt[0])}: dispatches of the gated tile kernels shorter than {EMPTY_NS} ns (gate closed,\n")
-        f.write("# immediate return) are left out; column EmptyDispatches counts them\n")
+        f.write(f"# from {os.path.basename(kt[0])}: dispatches of the gated tile kernels shorter than {EMPTY_NS} ns AND than\n")
+        f.write(f"# {EMPTY_FRAC} x the instantiation's longest dispatch (gate closed, immediate return) are left out; column EmptyDispatches counts them\n")
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "EmptyDispatches"])
         for name, v in sorted(durs.items(), key=lambda kv: -sum(kv[1])):
@@ -46,10 +62,11 @@ rows = []
 for sub in ("fetch", "write", "sq"):
     for f in glob.glob(os.path.join(root, "gpurun_out", f"{tag}_{sub}", "*", "*counter_collection.csv")):
         acc = collections.defaultdict(list)
-        for r in csv.DictReader(open(f)):
+        recs = list(csv.DictReader(open(f)))
+        lim = empty_limits([(r["Kernel_Name"].split("(")[0], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in recs])
+        for r in recs:
             k = r["Kernel_Name"].split("(")[0]
-            empty = (any(t in k for t in TILE_KERNELS[:2])
-                     and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) < EMPTY_NS)
+            empty = int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) < lim.get(k, 0)
             if "ms::" in k and not empty:
                 acc[(r["Counter_Name"], k)].append(float(r["Counter_Value"]))
         for (c, k), v in sorted(acc.items()):
@@ -57,7 +74,7 @@ for sub in ("fetch", "write", "sq"):
 with open(os.path.join(out, f"{tag}_pmc_summary.csv"), "w", newline="") as f:
     f.write("# FETCH_SIZE/WRITE_SIZE in KiB per dispatch; on gfx950 FETCH_SIZE counts 1/2 of the bytes\n")
     f.write("# (calibrated on ms::k_direction / k_gradient's direction epilogue with known bytes) -> double it.\n")
-    f.write(f"# dispatches of the gated tile kernels shorter than {EMPTY_NS} ns (gate closed) are left out.\n")
+    f.write(f"# dispatches of the gated tile kernels shorter than {EMPTY_NS} ns and than {EMPTY_FRAC} x the longest (gate closed) are left out.\n")
     w = csv.writer(f)
     w.writerow(["counter", "kernel", "dispatches", "avg", "min", "max"])
     for r in rows:
