@@ -532,6 +532,19 @@ int ms_profile_read(ms_ctx *ctx, double total_ms[MS_PROF_KINDS],
  * host replays it from the same doubles), [5] rounds queued for a step that had not started yet (behind the running
  * gradient pass; ms_minimize only), [6] those the step adopted, [7] those dropped. */
 int ms_queue_stats(ms_ctx *ctx, int64_t stats[8]);
+/* One-tile meshes (every mesh the reference's own benchmarks and decks use: <= 256 vertices): the library records its
+ * kernel launches and runs them pack by pack in ONE workgroup (k_exec) instead of launching each -- same device code,
+ * same results bit for bit, a few launches per step instead of dozens.  MS_EXEC=0 in the environment switches it off.
+ * Tilt relaxations (ms_relax_tilts / ms_relax_leaflet_tilts) then run as ONE launch: the command lists of the loop are
+ * captured once and the reference's control flow (tilt_relaxation.py:303-421, 885-1230) runs in that workgroup
+ * (MS_EXEC_RELAX=0: host-driven loop over packs).
+ * stats: {active now, packs launched, launches recorded, bit 0 wanted (inactive while profiling) | relaxation
+ * programs run << 8}.  No reference counterpart. */
+int ms_exec_stats(ms_ctx *ctx, int64_t stats[4]);
+/* Diagnostic of the same interpreter: on != 0 arms a device buffer to which every record run appends its duration
+ * (s_memrealtime); a call also returns what has accumulated since the last one, per (kind, mode) pair: rows of
+ * {kind, mode | instance << 16, count, total microseconds} (max_rows rows of 4 doubles; NULL: just arm / disarm). */
+int ms_exec_trace(ms_ctx *ctx, int on, double *rows, int max_rows, int *n_rows);
 
 /* Host-only planning pass (no GPU needed): runs the same tiling ms_create
  * uses and reports stats[0..7] = {n_tiles, facet_instances, max_halo,

@@ -76,6 +76,8 @@ struct ms_ctx {
     // disk tilt target (tilt_disk_target_in/out): tagged rows, parameters, the difference field
     uint8_t* disk = nullptr;
     double* diff = nullptr;
+    double* dt_target = nullptr;   // theta(r) r_hat of the tagged rows on the frozen surface of a running relaxation
+    bool dt_target_valid = false;
     ms_disk_target_params dt = {};
     uint32_t mod_dt = 0;
     int s_edt = 0, s_dtr = 0;
@@ -295,9 +297,51 @@ struct ms_ctx {
   double prof_ms[MS_PROF_KINDS] = {0};
   int64_t prof_n[MS_PROF_KINDS] = {0};
   std::string err;
+  // one-tile meshes: launches are recorded and run by ONE workgroup, pack by pack (ms_internal.h: ExecRecorder)
+  ExecRecorder exec;
+  bool exec_relax = true;    // tilt relaxations run as a device program (CK_RELAX); MS_EXEC_RELAX=0: host-driven
+  double* d_relax_cells = nullptr;           // [0] trial coefficient, [1] Fletcher-Reeves beta (written by the program)
+  unsigned long long* h_relax_box = nullptr; // pinned result mailbox of the program: {iterations, evaluations, parity, done}
+  unsigned long long* d_h_relax_box = nullptr;
+  unsigned long long relax_ticket = 0;
+  long relax_programs = 0;
+  bool exec_on = false;      // the recorder is attached to `stream`
+  bool exec_wanted = false;  // ... and is to be re-attached when profiling (which needs one launch per kernel) ends
 };
 
 namespace {
+
+// The stream for an operation that is NOT one of the library's recorded kernel launches (copies, memsets, stream
+// synchronisation, collectives): whatever the one-workgroup interpreter has recorded so far is launched first, so the
+// operation finds the stream in the state the launch-per-kernel path would have left it in.
+inline hipStream_t S(ms_ctx* c) {
+  if (c->exec_on) (void)c->exec.flush();
+  return c->stream;
+}
+inline int exec_flush(ms_ctx* c) {
+  if (!c->exec_on) return MS_OK;
+  const hipError_t e = c->exec.flush();
+  if (e == hipSuccess) return MS_OK;
+  c->err = std::string("k_exec launch: ") + hipGetErrorString(e);
+  return MS_ERR_HIP;
+}
+
+// zero-fill in stream order (a record of its own in a one-tile context: no flush)
+inline int zero_doubles(ms_ctx* c, double* p, size_t bytes) {
+  if (c->exec_on) {
+    ExecMemsetArgs a;
+    a.p = p;
+    a.n = (int64_t)(bytes / sizeof(double));
+    const hipError_t e = c->exec.push(CK_MEMSET, 0, 0, 0, 1, 0, 0, &a, sizeof(a));
+    if (e == hipSuccess) return MS_OK;
+    c->err = std::string("k_exec record: ") + hipGetErrorString(e);
+    return MS_ERR_HIP;
+  }
+  const hipError_t e = hipMemsetAsync(p, 0, bytes, c->stream);
+  if (e == hipSuccess) return MS_OK;
+  c->err = std::string("hipMemsetAsync: ") + hipGetErrorString(e);
+  return MS_ERR_HIP;
+}
 
 inline const double* trial_dir(const ms_ctx* c) { return c->dir_implicit ? c->buf[MS_BUF_G] : c->buf[MS_BUF_D]; }
 inline double trial_alpha(const ms_ctx* c, double alpha) { return c->dir_implicit ? -alpha : alpha; }
@@ -565,14 +609,30 @@ int disk_target_pass(ms_ctx* c, TiltField& f, int mode, bool use_dir, double alp
   a.scal = c->d_scal;
   a.partials = c->d_partials;
   a.r_slot = f.s_dtr;
+  a.target = nullptr;
+  // a relaxation in progress: x is frozen, so the disk radius and the target profile theta(r) r_hat are computed ONCE
+  // (relax_fields primes them) and every evaluation of the relaxation only takes the difference
+  const bool frozen = c->relax_va_valid && !use_dir;
   {
     ProfScope ps(c, 6);
-    if (!(f.dt.radius > 0.0)) {
-      HIPCHK(c, launch_disk_target(a, 0, c->stream));
-      int rc = reduce_slots(c, 1u << f.s_dtr);
-      if (rc) return rc;
+    if (frozen && !f.dt_target) {
+      const size_t b3 = sizeof(double) * 3 * (size_t)c->til.nvp;
+      HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&f.dt_target), b3));
+      HIPCHK(c, hipMemset(f.dt_target, 0, b3));
     }
-    HIPCHK(c, launch_disk_target(a, 1, c->stream));
+    a.target = frozen ? f.dt_target : nullptr;
+    if (!frozen || !f.dt_target_valid) {
+      if (!(f.dt.radius > 0.0)) {
+        HIPCHK(c, launch_disk_target(a, 0, c->stream));
+        int rc = reduce_slots(c, 1u << f.s_dtr);
+        if (rc) return rc;
+      }
+      if (frozen) {
+        HIPCHK(c, launch_disk_target(a, 2, c->stream));
+        f.dt_target_valid = true;
+      }
+    }
+    HIPCHK(c, launch_disk_target(a, frozen ? 3 : 1, c->stream));
   }
   return tilt_pass_f(c, f, mode, use_dir, alpha, f.diff, nullptr, shape_gradient, /*lumped=*/true, f.dt.strength,
                      f.s_edt, tilt_gradient);
@@ -1045,6 +1105,7 @@ int wait_mailbox(ms_ctx* c, unsigned long long* h_seq, const unsigned long long*
   // (an empty shard -- 9 tiles over 8 ranks leave ranks 5..7 without one -- waits like any other: k_reduce posts the
   // neutral value of every slot for an empty tile range, and `bits` is only ever filled by arrived())
   bool done = false;
+  if (int rc_f = exec_flush(c)) return rc_f;  // (one-tile contexts: what was recorded runs now)
   for (long spin = 0; !done && spin < 20000000L; ++spin) {
     done = arrived();
     if (done) {
@@ -1057,7 +1118,7 @@ int wait_mailbox(ms_ctx* c, unsigned long long* h_seq, const unsigned long long*
     __builtin_ia32_pause();
   }
   if (!done) {
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(S(c)));
     // everything queued has run: an entry that is still behind belongs to a gated fold that found its gate closed
     // although the host expected it to run -- host and device disagreed on an Armijo test.  Never continue on that.
     if (!arrived()) {
@@ -1177,17 +1238,17 @@ int upload(ms_ctx* c, Tp** dst, const std::vector<Tp>& src, size_t min_elems = 1
 
 int ext_to_patch(ms_ctx* c, const double* host, double* dst, int ncomp) {
   const size_t bytes = sizeof(double) * (size_t)c->til.nv * ncomp;
-  HIPCHK(c, hipMemcpyAsync(c->d_stage, host, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_stage, host, bytes, hipMemcpyHostToDevice, S(c)));
   HIPCHK(c, launch_permute_in(c->til.nv, c->d_perm, c->d_stage, dst, ncomp, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(S(c)));
   return MS_OK;
 }
 
 int patch_to_ext(ms_ctx* c, const double* src, double* host, int ncomp) {
   const size_t bytes = sizeof(double) * (size_t)c->til.nv * ncomp;
   HIPCHK(c, launch_permute_out(c->til.nv, c->d_perm, src, c->d_stage, ncomp, c->stream));
-  HIPCHK(c, hipMemcpyAsync(host, c->d_stage, bytes, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(host, c->d_stage, bytes, hipMemcpyDeviceToHost, S(c)));
+  HIPCHK(c, hipStreamSynchronize(S(c)));
   return MS_OK;
 }
 
@@ -1414,6 +1475,18 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
   c->params.volume_stiffness = 1000.0;
   c->params.target_volume = 0.0;
   c->last_g = c->buf[MS_BUF_G];
+  // A mesh of ONE tile: every kernel is one workgroup and a step is launches and host round trips -- record the launches
+  // and run them pack by pack in one workgroup (k_exec).  MS_EXEC=0 keeps the launch-per-kernel path (A/B, tests).
+  c->exec_wanted = t.n_tiles == 1 && t.T == 256 && t.own == 256 && shard_count == 1 &&
+                   !(getenv("MS_EXEC") != nullptr && atoi(getenv("MS_EXEC")) == 0);
+  if (c->exec_wanted) {
+    c->exec.stream = c->stream;
+    c->exec.T = t.T;
+    exec_attach(&c->exec);
+    c->exec_on = true;
+    c->pair_enable = false;  // (several trials per launch buy nothing inside one workgroup)
+    c->exec_relax = !(getenv("MS_EXEC_RELAX") != nullptr && atoi(getenv("MS_EXEC_RELAX")) == 0);
+  }
   CREATE_CHK(ext_to_patch(c, positions, c->buf[MS_BUF_X], 3));
 #undef CREATE_CHK
 #undef CREATE_HIP
@@ -1432,6 +1505,11 @@ void ms_destroy(ms_ctx* c) {
   }
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->exec_on) {
+    (void)c->exec.flush();
+    exec_detach(&c->exec);
+    c->exec_on = false;
+  }
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (!c->own_state) c->state = nullptr;
   void* ptrs[] = {c->d_perm, c->d_tile_facet_off, c->d_tile_facets, c->d_tile_facets32, c->d_tf_gamma, c->d_volgrad_cache,
@@ -1469,6 +1547,11 @@ void ms_destroy(ms_ctx* c) {
   if (c->d_dec) (void)hipFree(c->d_dec);
   if (c->h_err) (void)hipHostFree(c->h_err);
   if (c->d_prof_ran) (void)hipFree(c->d_prof_ran);
+  if (c->exec.d_stamps) (void)hipFree(c->exec.d_stamps);
+  for (int l = 0; l < 3; ++l)
+    if (c->tf[l].dt_target) (void)hipFree(c->tf[l].dt_target);
+  if (c->d_relax_cells) (void)hipFree(c->d_relax_cells);
+  if (c->h_relax_box) (void)hipHostFree(c->h_relax_box);
   for (auto& sd : c->side) {
     if (sd.partials) (void)hipFree(sd.partials);
     if (sd.scal) (void)hipFree(sd.scal);
@@ -1492,7 +1575,7 @@ void ms_destroy(ms_ctx* c) {
 
 int ms_set_stream(ms_ctx* c, void* hip_stream) {
   if (!c) return MS_ERR_INVALID;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(S(c)));
   if (c->own_stream && c->stream) {
     HIPCHK(c, hipStreamDestroy(c->stream));
     c->own_stream = false;
@@ -1503,13 +1586,14 @@ int ms_set_stream(ms_ctx* c, void* hip_stream) {
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
   }
+  c->exec.stream = c->stream;  // (nothing is pending: S(c) above launched it)
   return MS_OK;
 }
 
 int ms_set_surface_tension(ms_ctx* c, const double* gamma) {
   if (!c || !gamma) return fail(c, MS_ERR_INVALID, "ms_set_surface_tension: NULL argument");
   const Tiling& t = c->til;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(S(c)));
   std::vector<double> g(t.tile_facets.size());
   for (size_t p = 0; p < g.size(); ++p) g[p] = gamma[t.tile_facet_ext[p]];
   c->gamma_uniform = true;
@@ -1525,7 +1609,7 @@ int ms_set_surface_tension(ms_ctx* c, const double* gamma) {
 int ms_set_bending_params(ms_ctx* c, const double* kappa, const double* c0) {
   if (!c || !kappa || !c0) return fail(c, MS_ERR_INVALID, "ms_set_bending_params: NULL argument");
   const Tiling& t = c->til;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(S(c)));
   std::vector<double> k((size_t)t.nvp, 0.0), z((size_t)t.nvp, 0.0);
   c->kc_uniform = true;
   c->kappa_const = kappa[0];
@@ -1600,7 +1684,7 @@ int ms_angle_defects(ms_ctx* c, double* defects) {
   const Tiling& t = c->til;
   double* d_out = nullptr;
   HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(double) * (size_t)std::max<int64_t>(1, t.nvp)));
-  HIPCHK(c, hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)std::max<int64_t>(1, t.nvp), c->stream));
+  HIPCHK(c, hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)std::max<int64_t>(1, t.nvp), S(c)));
   TiltArgs a;
   a.fields = nullptr;
   a.fields_rows = 0;
@@ -1626,7 +1710,7 @@ int ms_angle_defects(ms_ctx* c, double* defects) {
   int rc = MS_OK;
   if (e != hipSuccess) rc = fail(c, MS_ERR_HIP, std::string("ms_angle_defects: ") + hipGetErrorString(e));
   if (rc == MS_OK) rc = patch_to_ext(c, d_out, defects, 1);
-  (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(S(c));
   (void)hipFree(d_out);
   return rc;
 }
@@ -1639,7 +1723,7 @@ int ms_curvature_fields(ms_ctx* c, double* mean_curvature_normal, double* h_area
   const size_t plane = 3 * (size_t)std::max<int64_t>(1, t.nvp);
   double* d_out = nullptr;
   HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(double) * 4 * plane));
-  HIPCHK(c, hipMemsetAsync(d_out, 0, sizeof(double) * 4 * plane, c->stream));
+  HIPCHK(c, hipMemsetAsync(d_out, 0, sizeof(double) * 4 * plane, S(c)));
   TiltArgs a;
   a.m = device_mesh(c);
   a.tile0 = c->tile0;
@@ -1667,7 +1751,7 @@ int ms_curvature_fields(ms_ctx* c, double* mean_curvature_normal, double* h_area
   double* outs[4] = {mean_curvature_normal, h_area_anglesum, defect_kg, principal};
   for (int k = 0; k < 4 && rc == MS_OK; ++k)
     if (outs[k]) rc = patch_to_ext(c, d_out + (size_t)k * plane, outs[k], 3);
-  (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(S(c));
   (void)hipFree(d_out);
   return rc;
 }
@@ -1714,7 +1798,7 @@ int ms_set_tilt_fixed(ms_ctx* c, const uint8_t* tilt_fixed) {
   }
   c->tf[0].any_free = t.nv == 0;
   for (int i = 0; i < t.nv && !c->tf[0].any_free; ++i) c->tf[0].any_free = !(c->h_vflags[(size_t)i] & VF_TILT_FIXED);
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(S(c)));
   HIPCHK(c, hipMemcpy(c->d_vflags, c->h_vflags.data(), c->h_vflags.size(), hipMemcpyHostToDevice));
   return MS_OK;
 }
@@ -1743,7 +1827,7 @@ int tilt_eval(ms_ctx* c, bool trial, bool gradient) {
     } else if (fuse) {
       mask |= 1u << MS_S_ETILT;
     } else if (gradient) {
-      HIPCHK(c, hipMemsetAsync(c->tf[0].grad, 0, b3, c->stream));
+      if (int rz = zero_doubles(c, c->tf[0].grad, b3)) return rz;
     }
     if (mods & MS_MOD_BENDING_TILT) {
       rc = bt_pass(c, gradient ? 2 : 0, false, 0.0, tilts, fuse);
@@ -1774,7 +1858,7 @@ int tilt_eval(ms_ctx* c, bool trial, bool gradient) {
       if (rc) return rc;
       mask |= 1u << f.s_etilt;
     } else if (gradient) {
-      HIPCHK(c, hipMemsetAsync(f.grad, 0, b3, c->stream));
+      if (int rz = zero_doubles(c, f.grad, b3)) return rz;
     }
     if (mods & f.mod_bt) {
       rc = bt_pass_f(c, f, gradient ? 2 : 0, false, 0.0, tilts);
@@ -1811,6 +1895,175 @@ double tilt_energy_from_mailbox(const ms_ctx* c) {
 int ensure_bt_record(ms_ctx* c) {
   if (!(c->params.modules & (MS_MOD_BENDING_TILT | MS_LEAFLET_BT)) || c->bt_valid) return MS_OK;
   return phase_energy(c, c->params.modules, false, 0.0, false, false, false, /*reduce_now=*/false);
+}
+
+// The relaxation loop of relax_fields as a device program: the command lists the loop launches over and over are
+// CAPTURED once (both parities of the tilts <-> trial swap), the control flow runs in the interpreter's workgroup
+// (ms_exec.inc: exec_relax).  *used = false: not possible here (the caller runs the host-driven loop).
+int relax_program(ms_ctx* c, const ms_tilt_relax_params* rp, TiltField** fl, int nf, uint32_t norm_mask, int* iters,
+                  int* evals, bool* used) {
+  *used = false;
+  if (nf < 1 || nf > 2) return MS_OK;
+  const Tiling& t = c->til;
+  if (!c->d_relax_cells) {
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_relax_cells), sizeof(double) * 2));
+    HIPCHK(c, hipMemset(c->d_relax_cells, 0, sizeof(double) * 2));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_relax_box), sizeof(unsigned long long) * 8, hipHostMallocMapped));
+    memset(c->h_relax_box, 0, sizeof(unsigned long long) * 8);
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_h_relax_box), c->h_relax_box, 0));
+  }
+  int rc = exec_flush(c);  // (the set-up passes recorded so far run first, as a pack of their own)
+  if (rc) return rc;
+  ExecRecorder& R = c->exec;
+  const bool along_dir = rp->solver != 0;
+  ExecRelaxHead head;
+  memset(&head, 0, sizeof(head));
+  // -- capture -------------------------------------------------------------------------------------------------
+  const unsigned long long s_ticket = c->ticket;
+  unsigned long long s_expected[MS_MB_WORDS];
+  memcpy(s_expected, c->expected, sizeof(s_expected));
+  const long s_cmds = R.cmds;
+  R.capture = true;
+  auto count = [&]() { return (int)reinterpret_cast<const ExecPackHead*>(R.buf.data())->n_cmds; };
+  auto fail_capture = [&](int code) {
+    R.capture = false;
+    R.buf.clear();
+    R.cmds = s_cmds;
+    c->ticket = s_ticket;
+    memcpy(c->expected, s_expected, sizeof(s_expected));
+    return code;
+  };
+  hipError_t he = R.push(CK_RELAX, 0, 0, 0, 1, 0, 0, &head, sizeof(head));
+  if (he != hipSuccess) return fail_capture(MS_OK);
+  const size_t head_at = sizeof(ExecPackHead);
+  auto tvec = [&](TiltField& f, int mode, const double* src, double* out, int flag) -> hipError_t {
+    return launch_tvec(mode, c->tile0, c->tile1, t.nv, t.own, c->d_vflags, f.grad, f.minv, f.dir, f.tilts, src, c->d_tn,
+                       out, 0.0, flag, c->d_partials, t.n_tiles, c->stream, f.fixed_bit, f.s_gn2, f.s_rz);
+  };
+  bool ok = true;
+  for (int par = 0; par < 2 && ok; ++par) {
+    head.off_grad[par] = (int32_t)R.buf.size();
+    int n0 = count();
+    ok = ok && tilt_eval(c, false, true) == MS_OK;
+    for (int k = 0; k < nf && ok; ++k) ok = tvec(*fl[k], 0, nullptr, nullptr, 0) == hipSuccess;
+    ok = ok && reduce_slots(c, norm_mask) == MS_OK;
+    head.n_grad[par] = count() - n0;
+    head.off_trial[par] = (int32_t)R.buf.size();
+    n0 = count();
+    for (int k = 0; k < nf && ok; ++k) {
+      TiltField& f = *fl[k];
+      ok = tvec(f, 2, along_dir ? f.dir : f.grad, f.trial, 1) == hipSuccess;
+    }
+    ok = ok && tilt_eval(c, true, false) == MS_OK;
+    head.n_trial[par] = count() - n0;
+    for (int k = 0; k < nf; ++k) std::swap(fl[k]->tilts, fl[k]->trial);  // (twice in all: back where they were)
+  }
+  head.off_dir0 = (int32_t)R.buf.size();
+  {
+    const int n0 = count();
+    for (int k = 0; k < nf && ok; ++k) ok = tvec(*fl[k], 1, nullptr, nullptr, 1) == hipSuccess;
+    head.n_dir0 = count() - n0;
+  }
+  head.off_dir1 = (int32_t)R.buf.size();
+  {
+    const int n0 = count();
+    for (int k = 0; k < nf && ok; ++k) ok = tvec(*fl[k], 1, nullptr, nullptr, 0) == hipSuccess;
+    head.n_dir1 = count() - n0;
+  }
+  if (!ok) return fail_capture(MS_OK);  // (e.g. the program does not fit the largest pack: host-driven loop)
+  std::vector<unsigned char> prog;
+  prog.swap(R.buf);
+  const size_t prog_lds = R.lds;
+  R.capture = false;
+  R.cmds = s_cmds;
+  c->ticket = s_ticket;
+  memcpy(c->expected, s_expected, sizeof(s_expected));
+  // -- patch: the trial / direction passes take their coefficient from the program's cells, the folds post nothing
+  {
+    size_t at = head_at + sizeof(ExecCmdHead) + sizeof(ExecRelaxHead);
+    while (at + sizeof(ExecCmdHead) <= prog.size()) {
+      ExecCmdHead h;
+      memcpy(&h, prog.data() + at, sizeof(h));
+      unsigned char* args = prog.data() + at + sizeof(ExecCmdHead);
+      if (h.kind == CK_TVEC) {
+        TvecArgs a;
+        memcpy(&a, args, sizeof(a));
+        if (a.mode == 2) a.coef_dev = c->d_relax_cells;
+        if (a.mode == 1 && (int32_t)at >= head.off_dir1) a.coef_dev = c->d_relax_cells + 1;
+        memcpy(args, &a, sizeof(a));
+      } else if (h.kind == CK_REDUCE) {
+        FoldArgs a;
+        memcpy(&a, args, sizeof(a));
+        for (int j = 0; j < MS_MAX_TRIALS; ++j) a.set[j].host_box = nullptr;
+        memcpy(args, &a, sizeof(a));
+      }
+      at += h.bytes;
+    }
+  }
+  // -- the head ---------------------------------------------------------------------------------------------------
+  head.solver = rp->solver;
+  head.max_iters = rp->max_iters;
+  head.nf = nf;
+  head.step_size = rp->step_size;
+  head.tol = rp->tol;
+  {
+    const uint32_t mods = c->params.modules;  // (the order of tilt_energy_from_mailbox)
+    int n = 0;
+    if (mods & MS_MOD_TILT) head.e_slot[n++] = MS_S_ETILT;
+    if (mods & MS_MOD_BENDING_TILT) head.e_slot[n++] = MS_S_EBT;
+    if (mods & MS_MOD_TILT_SMOOTH) head.e_slot[n++] = MS_S_ETS;
+    for (int l = 1; l <= 2; ++l) {
+      const TiltField& f = c->tf[l];
+      if (mods & f.mod_tilt) head.e_slot[n++] = f.s_etilt;
+      if (mods & f.mod_smooth) head.e_slot[n++] = f.s_ets;
+      if (mods & f.mod_bt) head.e_slot[n++] = f.s_ebt;
+      if (mods & f.mod_dt) head.e_slot[n++] = f.s_edt;
+    }
+    head.n_e = n;
+  }
+  for (int k = 0; k < nf; ++k) {
+    head.s_gn2[k] = fl[k]->s_gn2;
+    head.s_rz[k] = fl[k]->s_rz;
+  }
+  head.scal = c->d_scal;
+  head.cells = c->d_relax_cells;
+  head.host_box = c->d_h_relax_box;
+  head.ticket = ++c->relax_ticket;
+  head.total_bytes = (int32_t)(prog.size() - head_at);
+  {
+    ExecCmdHead h;
+    memcpy(&h, prog.data() + head_at, sizeof(h));
+    h.pad = head.total_bytes;
+    memcpy(prog.data() + head_at, &h, sizeof(h));
+    memcpy(prog.data() + head_at + sizeof(h), &head, sizeof(head));
+    reinterpret_cast<ExecPackHead*>(prog.data())->n_cmds = 1;  // (the lists belong to the CK_RELAX record)
+  }
+  he = R.launch_pack(prog, prog_lds);
+  if (he != hipSuccess) return fail_hip(c, he, "k_exec (relaxation program)");
+  ++c->relax_programs;
+  // -- result ------------------------------------------------------------------------------------------------------
+  auto entry = [&](int k, unsigned long long* v) {
+    const unsigned long long tag = __atomic_load_n(&c->h_relax_box[2 * k + 1], __ATOMIC_ACQUIRE);
+    *v = __atomic_load_n(&c->h_relax_box[2 * k], __ATOMIC_ACQUIRE);
+    return (*v ^ tag) == head.ticket;
+  };
+  unsigned long long v[4] = {0, 0, 0, 0};
+  bool done = false;
+  for (long spin = 0; !done && spin < 400000000L; ++spin) {
+    done = entry(3, &v[3]) && entry(0, &v[0]) && entry(1, &v[1]) && entry(2, &v[2]);
+    if (!done) __builtin_ia32_pause();
+  }
+  if (!done) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    done = entry(3, &v[3]) && entry(0, &v[0]) && entry(1, &v[1]) && entry(2, &v[2]);
+    if (!done) return fail(c, MS_ERR_STATE, "relaxation program: the result mailbox was not posted");
+  }
+  *iters = (int)v[0];
+  *evals = (int)v[1];
+  if (v[2] & 1ull)
+    for (int k = 0; k < nf; ++k) std::swap(fl[k]->tilts, fl[k]->trial);
+  *used = true;
+  return MS_OK;
 }
 
 // TiltRelaxationManager.relax_tilts (tilt_relaxation.py:237-424) for one field and
@@ -1891,11 +2144,23 @@ int relax_fields(ms_ctx* c, const ms_tilt_relax_params* rp, TiltField** fl, int 
     if (rc) return rc;
     std::swap(f.tilts, f.trial);
   }
-  struct VaScope {  // the cached vertex areas are valid only while this relaxation runs (x frozen)
+  struct VaScope {  // the cached vertex areas / disk-target profiles are valid only while this relaxation runs (x frozen)
     ms_ctx* c;
-    ~VaScope() { c->relax_va_valid = false; }
+    ~VaScope() {
+      c->relax_va_valid = false;
+      for (int l = 0; l < 3; ++l) c->tf[l].dt_target_valid = false;
+    }
   } va_scope{c};
   c->relax_va_valid = jacobi_smooth_by_param;  // leaflet driver only (the single field has no such form)
+  for (int k = 0; k < nf && c->relax_va_valid; ++k) {
+    // prime the frozen-surface caches of the disk target (radius, theta(r) r_hat) before the loop: every evaluation of
+    // the relaxation -- and the device program's captured lists -- then only take differences
+    TiltField& f = *fl[k];
+    f.dt_target_valid = false;
+    if (!(mods & f.mod_dt)) continue;
+    rc = disk_target_pass(c, f, 0, false, 0.0, f.tilts, false, false);
+    if (rc) return rc;
+  }
   auto grad_at = [&](double* E, double* gnorm, double* rz) -> int {
     int r = tilt_eval(c, false, true);
     if (r) return r;
@@ -1945,6 +2210,19 @@ int relax_fields(ms_ctx* c, const ms_tilt_relax_params* rp, TiltField** fl, int 
     }
     return MS_OK;
   };
+  if (c->exec_on && c->exec_relax) {
+    // one-tile context: the whole solve below as ONE launch (ms_internal.h: ExecRelaxHead)
+    bool used = false;
+    rc = relax_program(c, rp, fl, nf, norm_mask, &iters, &evals, &used);
+    if (rc) return rc;
+    if (used) {
+      if (iters_out) *iters_out = iters;
+      if (evals_out) *evals_out = evals;
+      c->carry_valid = c->grad_valid = false;
+      c->factors_valid = c->factors_valid && !(mods & (MS_MOD_BENDING_TILT | MS_LEAFLET_BT));
+      return MS_OK;
+    }
+  }
   const double tol = rp->tol > 0.0 ? rp->tol : 0.0;
   double E0 = 0.0, gnorm = 0.0, rz_old = 0.0;
   if (rp->solver == 0) {  // gradient descent (:312-351 / :892-1058)
@@ -2062,7 +2340,7 @@ int ms_set_leaflet_tilts(ms_ctx* c, int leaflet, const double* tilts, const uint
     for (int i = 0; i < t.nv && !f.any_free; ++i) f.any_free = !(c->h_vflags[(size_t)i] & f.fixed_bit);
   }
   if (flags_changed) {
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(S(c)));
     HIPCHK(c, hipMemcpy(c->d_vflags, c->h_vflags.data(), c->h_vflags.size(), hipMemcpyHostToDevice));
   }
   c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
@@ -2076,7 +2354,7 @@ int ms_set_leaflet_bending(ms_ctx* c, int leaflet, const double* kappa, const do
     return fail(c, MS_ERR_INVALID, "ms_set_leaflet_bending: leaflet must be MS_LEAFLET_IN or MS_LEAFLET_OUT");
   TiltField& f = c->tf[1 + leaflet];
   const Tiling& t = c->til;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(S(c)));
   if (!f.kappa) {
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&f.kappa), sizeof(double) * (size_t)t.nvp));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&f.c0), sizeof(double) * (size_t)t.nvp));
@@ -2103,7 +2381,7 @@ int ms_set_leaflet_disk_target(ms_ctx* c, int leaflet, const uint8_t* disk_rows,
   const Tiling& t = c->til;
   const double nn = std::sqrt(p->normal[0] * p->normal[0] + p->normal[1] * p->normal[1] + p->normal[2] * p->normal[2]);
   if (!(nn >= 1e-15)) return fail(c, MS_ERR_INVALID, "ms_set_leaflet_disk_target: a plane normal is required");
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(S(c)));
   if (!f.disk) {
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&f.disk), (size_t)t.nvp));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&f.diff), sizeof(double) * 3 * (size_t)t.nvp));
@@ -2993,9 +3271,9 @@ int ms_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, double tol
         const double* sx = acc == 0 ? c->xt2 : c->xt3;
         const double* sk = acc == 0 ? c->fK2 : c->fK3;
         const double* sa = acc == 0 ? c->fA2 : c->fA3;
-        HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_XT], sx, sizeof(double) * 3 * nvp, hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FK], sk, sizeof(double) * 3 * nvp, hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FA], sa, sizeof(double) * 2 * nvp, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_XT], sx, sizeof(double) * 3 * nvp, hipMemcpyDeviceToDevice, S(c)));
+        HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FK], sk, sizeof(double) * 3 * nvp, hipMemcpyDeviceToDevice, S(c)));
+        HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FA], sa, sizeof(double) * 2 * nvp, hipMemcpyDeviceToDevice, S(c)));
         for (int sl = 0; sl < MS_NSCAL; ++sl)
           if (energy_mask(c->params.modules) & (1u << sl)) put_mailbox(c, sl, v[acc][sl]);
       }
@@ -3070,7 +3348,7 @@ int ms_project_volume_cached(ms_ctx* c, double target, double tol, int max_iter,
   const size_t row_bytes = sizeof(double) * 3 * (size_t)c->til.nvp;
   if (!c->d_volgrad_cache) {
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_volgrad_cache), row_bytes));
-    HIPCHK(c, hipMemsetAsync(c->d_volgrad_cache, 0, row_bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_volgrad_cache, 0, row_bytes, S(c)));
   }
   int it = 0;
   double V = 0.0;
@@ -3093,7 +3371,7 @@ int ms_project_volume_cached(ms_ctx* c, double target, double tol, int max_iter,
       rc = fetch(c);
       if (rc) return rc;
       norm2 = c->h_scal[MS_S_GCGC];
-      HIPCHK(c, hipMemcpyAsync(c->d_volgrad_cache, c->buf[MS_BUF_GC], row_bytes, hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->d_volgrad_cache, c->buf[MS_BUF_GC], row_bytes, hipMemcpyDeviceToDevice, S(c)));
       c->volgrad_cache_norm2 = norm2;
       c->volgrad_cache_valid = true;
     }
@@ -3285,7 +3563,7 @@ int ms_phase_commit_trial(ms_ctx* c, double alpha, int keep_history) {
   }
   const size_t n3 = 3 * (size_t)c->til.nvp;
   HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_XT], c->buf[MS_BUF_X], n3 * sizeof(double),
-                           hipMemcpyDeviceToDevice, c->stream));
+                           hipMemcpyDeviceToDevice, S(c)));
   HIPCHK(c, launch_axpy_masked(c->til.nvp, c->d_vflags, c->buf[MS_BUF_XT], trial_dir(c), trial_alpha(c, alpha),
                                c->stream));
   return ms_phase_accept(c, keep_history);
@@ -3374,8 +3652,8 @@ int ms_unpack_boundary(ms_ctx* c, int n_buffers, const int* buffer_ids, const vo
                                    p, nc, n_buffers, static_cast<const double*>(recv_dev),
                                    stride_bytes / sizeof(double), c->d_scal_all, c->stream));
   HIPCHK(c, hipMemcpyAsync(scal_all_host, c->d_scal_all, sizeof(double) * MS_NSCAL * (size_t)c->shard_count,
-                           hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+                           hipMemcpyDeviceToHost, S(c)));
+  HIPCHK(c, hipStreamSynchronize(S(c)));
   return MS_OK;
 }
 
@@ -3477,19 +3755,19 @@ int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push, 
     if (stream_ops) {
       // (the pack kernel's stores are system-scope write-through and complete before the kernel does: the value
       // written behind it in stream order is the release)
-      for (int r = 0; r < W; ++r) HIPCHK(c, hipStreamWriteValue64(c->stream, flg[r] + me, c->peer_ticket, 0));
+      for (int r = 0; r < W; ++r) HIPCHK(c, hipStreamWriteValue64(S(c), flg[r] + me, c->peer_ticket, 0));
     } else if (!fused_flags) {
       HIPCHK(c, launch_flag_peers(flg, me, W, c->peer_ticket, c->stream));
     }
     const unsigned long long* wait_flags = c->d_peer_flag + (size_t)par * 16;
     if (stream_ops) {
       for (int r = 0; r < W; ++r)
-        HIPCHK(c, hipStreamWaitValue64(c->stream, const_cast<unsigned long long*>(wait_flags) + r, c->peer_ticket,
+        HIPCHK(c, hipStreamWaitValue64(S(c), const_cast<unsigned long long*>(wait_flags) + r, c->peer_ticket,
                                        hipStreamWaitValueGte, ~0ull));
       wait_flags = nullptr;  // (the unpack kernel starts when every word has arrived)
     }
     if (c->peer_barrier) {  // (contexts of one process wait on the host: see ms_shard_peer_set_barrier)
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, hipStreamSynchronize(S(c)));
       if (c->peer_barrier(c->peer_barrier_user) != 0) return fail(c, MS_ERR_STATE, "peer exchange: the caller's barrier failed");
       wait_flags = nullptr;
     }
@@ -3503,15 +3781,15 @@ int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push, 
                                  c->bnd_off[(size_t)me + 1] - c->bnd_off[(size_t)me], p, nc, n, c->d_scal,
                                  c->d_xsend, c->stream));
   if (c->allgather_cb) {
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(S(c)));
     if (c->allgather_cb(c->allgather_user, c->d_xsend, c->d_xrecv, count * sizeof(double)) != 0)
       return fail(c, MS_ERR_STATE, "caller-supplied all-gather failed");
   } else if (c->comm) {
-    const int r = g_rccl.AllGather(c->d_xsend, c->d_xrecv, count, /*ncclDouble*/ 8, c->comm, c->stream);
+    const int r = g_rccl.AllGather(c->d_xsend, c->d_xrecv, count, /*ncclDouble*/ 8, c->comm, S(c));
     if (r != 0)
       return fail(c, MS_ERR_HIP, std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"));
   } else if (W == 1) {
-    HIPCHK(c, hipMemcpyAsync(c->d_xrecv, c->d_xsend, count * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_xrecv, c->d_xsend, count * sizeof(double), hipMemcpyDeviceToDevice, S(c)));
   } else {
     return fail(c, MS_ERR_STATE, "ms_shard_step: no communicator (ms_shard_comm_init / ms_shard_set_allgather / ms_shard_peer_*)");
   }
@@ -3539,12 +3817,12 @@ int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push, 
         for (int r = 0; r < W; ++r)
           HIPCHK(c, hipStreamWriteValue64(c->peer_aux, c->d_peer_flag + (size_t)par * 16 + r, c->peer_ticket, 0));
         HIPCHK(c, hipStreamSynchronize(c->peer_aux));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipStreamSynchronize(S(c)));
         return fail(c, MS_ERR_STATE, "peer exchange: a peer's flag word did not arrive within 2 s (stream wait released by the host)");
       }
     }
   }
-  if (!seen) HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!seen) HIPCHK(c, hipStreamSynchronize(S(c)));
   if (c->peer_on && c->h_err && (__atomic_load_n(c->h_err + 1, __ATOMIC_ACQUIRE) >> 62) == 1) {
     const unsigned long long e = __atomic_exchange_n(c->h_err + 1, 0ull, __ATOMIC_ACQ_REL);  // reported once
     return fail(c, MS_ERR_STATE, "peer exchange: a peer's flag did not arrive within the bounded wait (rank " +
@@ -3579,7 +3857,7 @@ int shard_exchange(ms_ctx* c, int n, const int* ids, uint32_t slots, bool push, 
     c->sh_scal2[MS_S_MINEDGE2] = m;
   }
   if (push)
-    HIPCHK(c, hipMemcpyAsync(c->d_scal, c->sh_scal, sizeof(double) * MS_NSCAL, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_scal, c->sh_scal, sizeof(double) * MS_NSCAL, hipMemcpyHostToDevice, S(c)));
   ++c->sh_exchanges;
   return MS_OK;
 }
@@ -3905,7 +4183,7 @@ int ms_shard_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, doub
       c->factors_valid = true;
       if (penalty)
         HIPCHK(c, hipMemcpyAsync(c->d_scal, c->sh_scal, sizeof(double) * MS_NSCAL, hipMemcpyHostToDevice,
-                                 c->stream));
+                                 S(c)));
       c->sh_carry_valid = true;
     }
     out->success = 1;
@@ -3942,8 +4220,8 @@ int ms_shard_step(ms_ctx* c, const ms_stepper_params* sp, double step_size, doub
     if (E0 <= energy0 + sp->c * alpha0 * g_dot_d) {
       // the unexpected case: trial 0's factors (boundary rows included) are in the second set
       const size_t nvp = (size_t)c->til.nvp;
-      HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FK], c->fK2, sizeof(double) * 3 * nvp, hipMemcpyDeviceToDevice, c->stream));
-      HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FA], c->fA2, sizeof(double) * 2 * nvp, hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FK], c->fK2, sizeof(double) * 3 * nvp, hipMemcpyDeviceToDevice, S(c)));
+      HIPCHK(c, hipMemcpyAsync(c->buf[MS_BUF_FA], c->fA2, sizeof(double) * 2 * nvp, hipMemcpyDeviceToDevice, S(c)));
       for (int sl : {(int)MS_S_ESURF, (int)MS_S_VOL, (int)MS_S_EBEND, (int)MS_S_MINEDGE2}) c->sh_scal[sl] = c->sh_scal2[sl];
       return accepted(alpha0, E0);
     }
@@ -3990,7 +4268,7 @@ int ms_rebind_state(ms_ctx* c, void* device_base, size_t bytes) {
   if (!c || !device_base) return fail(c, MS_ERR_INVALID, "ms_rebind_state: NULL argument");
   const size_t need = ms_state_bytes(c);
   if (bytes < need) return fail(c, MS_ERR_INVALID, "ms_rebind_state: buffer smaller than ms_state_bytes");
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(S(c)));
   HIPCHK(c, hipMemcpy(device_base, c->state, need, hipMemcpyDeviceToDevice));
   double* nb = static_cast<double*>(device_base);
   for (int b = 0; b <= MS_BUF_FA; ++b) c->buf[b] = nb + (c->buf[b] - c->state);
@@ -4015,12 +4293,13 @@ int ms_store_scalars(ms_ctx* c, const double* in) {
   c->carry_valid = c->grad_valid = c->bt_valid = c->maxg2_valid = false;
   c->sh_carry_valid = c->sh_grad_valid = false;
   HIPCHK(c, hipMemcpyAsync(c->d_scal, c->h_scal, sizeof(double) * MS_NSCAL, hipMemcpyHostToDevice,
-                           c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+                           S(c)));
+  HIPCHK(c, hipStreamSynchronize(S(c)));
   return MS_OK;
 }
 
 int ms_device_buffer(ms_ctx* c, int buffer, void** dev_ptr, size_t* bytes) {
+  if (c) (void)exec_flush(c);  // (the caller may read the buffer on its own stream: nothing stays recorded)
   if (!c || !dev_ptr || buffer < 0 || buffer >= MS_BUF_COUNT) return MS_ERR_INVALID;
   *dev_ptr = c->buf[buffer];
   if (bytes) {
@@ -4071,11 +4350,71 @@ int ms_queue_stats(ms_ctx* c, int64_t stats[8]) {
   return MS_OK;
 }
 
+int ms_exec_stats(ms_ctx* c, int64_t stats[4]) {
+  if (!c || !stats) return MS_ERR_INVALID;
+  stats[0] = c->exec_on ? 1 : 0;
+  stats[1] = c->exec.launches;
+  stats[2] = c->exec.cmds;
+  stats[3] = (c->exec_wanted ? 1 : 0) | ((int64_t)c->relax_programs << 8);
+  return MS_OK;
+}
+
+// Diagnostic: how long does each record of the one-workgroup interpreter take?  on != 0 arms a device buffer that
+// k_exec appends {kind, mode, instance, duration} to; reading returns, per (kind, mode) pair seen, the count and the
+// total duration in microseconds -- rows of {kind, mode | inst << 16, count, total_us} -- and clears the buffer.
+int ms_exec_trace(ms_ctx* c, int on, double* rows, int max_rows, int* n_rows) {
+  if (!c) return MS_ERR_INVALID;
+  if (n_rows) *n_rows = 0;
+  int rc = exec_flush(c);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->exec.d_stamps && rows && max_rows > 0 && n_rows) {
+    std::vector<unsigned long long> h((size_t)2 * EXEC_STAMP_CAP);
+    HIPCHK(c, hipMemcpy(h.data(), c->exec.d_stamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    const size_t n = (size_t)std::min<unsigned long long>(h[0], (unsigned long long)EXEC_STAMP_CAP - 1);
+    std::map<unsigned long long, std::pair<long, double>> acc;
+    for (size_t i = 0; i < n; ++i) {
+      auto& e = acc[h[1 + 2 * i]];
+      e.first += 1;
+      e.second += 0.01 * (double)h[2 + 2 * i];  // s_memrealtime: 100 MHz
+    }
+    int k = 0;
+    for (auto& kv : acc) {
+      if (k >= max_rows) break;
+      rows[4 * k] = (double)(kv.first >> 32);
+      rows[4 * k + 1] = (double)(kv.first & 0xffffffffull);
+      rows[4 * k + 2] = (double)kv.second.first;
+      rows[4 * k + 3] = kv.second.second;
+      ++k;
+    }
+    *n_rows = k;
+  }
+  if (on && !c->exec.d_stamps)
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->exec.d_stamps), sizeof(unsigned long long) * 2 * EXEC_STAMP_CAP));
+  if (c->exec.d_stamps) HIPCHK(c, hipMemset(c->exec.d_stamps, 0, sizeof(unsigned long long) * 2 * EXEC_STAMP_CAP));
+  if (!on && c->exec.d_stamps) {
+    (void)hipFree(c->exec.d_stamps);
+    c->exec.d_stamps = nullptr;
+  }
+  return MS_OK;
+}
+
 int ms_profile_enable(ms_ctx* c, int on) {
   if (!c) return MS_ERR_INVALID;
   if (on && !c->d_prof_ran) {
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_prof_ran), sizeof(uint32_t) * ms_ctx::PROF_RAN_CAP));
     HIPCHK(c, hipMemset(c->d_prof_ran, 0, sizeof(uint32_t) * ms_ctx::PROF_RAN_CAP));
+  }
+  // per-kernel timing needs one launch per kernel: the one-workgroup interpreter steps aside while it is on
+  if (on && c->exec_on) {
+    int rc = exec_flush(c);
+    if (rc) return rc;
+    exec_detach(&c->exec);
+    c->exec_on = false;
+  } else if (!on && c->exec_wanted && !c->exec_on) {
+    c->exec.stream = c->stream;
+    exec_attach(&c->exec);
+    c->exec_on = true;
   }
   c->profiling = on != 0;
   return MS_OK;
@@ -4083,7 +4422,7 @@ int ms_profile_enable(ms_ctx* c, int on) {
 
 int ms_profile_read(ms_ctx* c, double total_ms[MS_PROF_KINDS], int64_t launches[MS_PROF_KINDS]) {
   if (!c || !total_ms || !launches) return MS_ERR_INVALID;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(S(c)));
   std::vector<uint32_t> ran((size_t)c->prof_ran_next);
   if (c->prof_ran_next > 0)
     HIPCHK(c, hipMemcpy(ran.data(), c->d_prof_ran, sizeof(uint32_t) * ran.size(), hipMemcpyDeviceToHost));

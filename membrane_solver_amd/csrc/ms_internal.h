@@ -215,7 +215,9 @@ struct DiskTargetArgs {   // tilt_disk_target_in.py:160-286
   const double* d;        // direction or nullptr (positions x + alpha d)
   double alpha;
   const double* tilts;
-  double* diff;           // mode 1 out: t - theta(r) r_hat on the disk rows, 0 elsewhere
+  double* diff;           // mode 1 / 3 out: t - theta(r) r_hat on the disk rows, 0 elsewhere
+  double* target;         // mode 2 out / mode 3 in: theta(r) r_hat of the tagged rows at FROZEN positions (tilt
+                          // relaxations evaluate the profile dozens of times on the same surface), NaN = profile off
   double theta_b, lambda, radius;  // radius <= 0: read scal[r_slot]
   double center[3], normal[3];
   const double* scal;
@@ -258,6 +260,142 @@ struct TsArgs {
   double* partials;
   int e_slot;              // reduction slot of the energy partial (MS_S_ETS / _IN / _OUT)
 };
+
+// stream kernels (one workgroup of BLOCK threads per tile): their arguments as structs, so that the same device body
+// serves the ordinary launch and the one-workgroup interpreter (k_exec)
+struct TvecArgs {
+  int mode, tile0, nv, T;
+  const uint8_t* vflags;
+  double* tg;
+  const double* minv;
+  double* dir;
+  const double* tilts;
+  const double* src;
+  const double* normals;
+  double* out;
+  double coef;
+  const double* coef_dev;  // device programs (k_exec): the coefficient is read from here instead (nullptr: `coef`)
+  int flag;
+  double* partials;
+  int n_tiles;
+  uint8_t fixed_bit;
+  int s_gn2, s_rz;
+};
+struct DirectionArgs {
+  int tile0, nv, T;
+  const uint8_t* vflags;
+  double* g;
+  const double* gC;
+  double* d;
+  const double* pg;
+  const double* pd;
+  const double* scal;
+  int use_constraint, cg_history;
+  double* partials;
+  int n_tiles, write_g;
+  const uint32_t* gate;
+  uint32_t gate_want;
+  int pd_neg_pg, precond;
+};
+struct RowDotArgs {
+  int tile0, nv, T;
+  const double* g;
+  const double* gC;
+  double* partials;
+  int n_tiles;
+};
+struct AxpyMaskedArgs {
+  int64_t n_rows;
+  const uint8_t* vflags;
+  double* x;
+  const double* y;
+  double coef;
+};
+
+// ---- the one-workgroup interpreter (k_exec) ------------------------------------------------------------------------
+// When a context's mesh is ONE tile, every kernel of the library is one workgroup (folds: a handful), a step is dozens of
+// launches of a few microseconds of work each, and what the step costs is launches and host round trips.  Such a
+// context attaches an ExecRecorder to its stream: the launchers then append {kind, instance, arguments} records to a
+// pack instead of launching, and the pack is launched as ONE kernel -- k_exec, one workgroup, which runs the recorded
+// device bodies (the same code as the ordinary kernels) in order, a workgroup barrier between them -- when the host
+// needs the device to make progress (it is about to wait for a mailbox, or touches the stream directly).  The pack
+// travels as the kernel's argument block.  Results are bit for bit those of the launch-per-kernel path.
+enum : uint16_t {
+  CK_ENERGY = 1, CK_GRADIENT, CK_TILT, CK_BT, CK_TS, CK_TVEC, CK_DISK, CK_REDUCE, CK_DIRECTION, CK_ROWDOT,
+  CK_AXPY_MASKED, CK_MEMSET, CK_RELAX
+};
+struct ExecCmdHead {
+  uint16_t kind;
+  uint16_t bytes;     // of the whole record (head + arguments), a multiple of 8
+  int32_t mode;       // template MODE of the tilt-family kernels, launch mode of the stream kernels
+  int32_t cap, max_ent;
+  int32_t grid;       // blocks of the ordinary launch: the body runs for block 0 .. grid-1 in turn
+  uint32_t inst;      // template instance (energy / gradient: see exec_energy_inst / exec_gradient_inst)
+  int32_t mesh;       // which DeviceMesh of the pack head the tile kernels' arguments go with
+  int32_t pad;
+};
+static_assert(sizeof(ExecCmdHead) == 32, "ExecCmdHead is 32 bytes");
+constexpr int EXEC_MESHES = 3;       // distinct DeviceMesh values per pack (plain, inner leaflet, outer leaflet)
+constexpr int EXEC_PACK_BYTES = 3968;  // kernel-argument block of one k_exec launch (HIP allows 4096)
+struct ExecPackHead {
+  int32_t n_cmds, bytes;
+  int32_t T, pad;
+  // diagnostic (ms_exec_trace): when set, thread 0 appends {kind << 32 | mode, duration in 10 ns ticks} per record run;
+  // word 0 of the buffer counts the entries
+  unsigned long long* stamps;
+  DeviceMesh m[EXEC_MESHES];
+};
+constexpr int EXEC_STAMP_CAP = 1 << 16;
+struct ExecMemsetArgs {
+  double* p;
+  int64_t n;  // doubles
+};
+// CK_RELAX: the tilt relaxation (TiltRelaxationManager.relax_tilts / relax_leaflet_tilts,
+// runtime/steppers/tilt_relaxation.py:237-424, 426-1478) as a PROGRAM: the record is followed by command lists the
+// host captured once -- "gradient at the current tilts", "trial field + its energy", "first direction", "next
+// direction", each for both parities of the tilts <-> trial pointer swap an acceptance is -- and the workgroup walks
+// the reference's control flow itself (Fletcher-Reeves CG or gradient descent, up to 12 halvings, accept on E1 <= E0),
+// reading the folded scalars where the host would read its mailbox.  No launch and no host round trip inside a
+// relaxation; the host gets {iterations, evaluations, final parity} in one mailbox post.
+struct ExecRelaxHead {
+  int32_t solver, max_iters, nf, n_e;
+  double step_size, tol;
+  int32_t e_slot[16];               // energy slots in the host's order of addition (tilt_energy_from_mailbox)
+  int32_t s_gn2[2], s_rz[2];
+  const double* scal;               // device scalars the lists' folds write
+  double* cells;                    // [0] the trial coefficient (sign * step), [1] the Fletcher-Reeves beta
+  unsigned long long* host_box;     // pinned result mailbox: entries 0..3 = iterations, evaluations, parity, status
+  unsigned long long ticket;
+  int32_t off_grad[2], n_grad[2];   // list offsets (bytes from the pack base) and lengths (records)
+  int32_t off_trial[2], n_trial[2];
+  int32_t off_dir0, n_dir0, off_dir1, n_dir1;
+  int32_t total_bytes, pad;         // record + lists (the interpreter's main loop skips them)
+};
+struct ExecRecorder {
+  hipStream_t stream = nullptr;
+  int T = 0;
+  std::vector<unsigned char> buf;  // ExecPackHead + records
+  int n_mesh = 0;
+  size_t lds = 0;                  // dynamic LDS the recorded bodies need (max)
+  long launches = 0, cmds = 0;     // statistics
+  bool capture = false;            // records are collected for a program (CK_RELAX): no size limit, never launched
+  unsigned long long* d_stamps = nullptr;  // ms_exec_trace: per-record durations go here
+  // args/bytes: the kernel's argument struct; tile kernels (mesh != nullptr) are stored without their leading DeviceMesh
+  hipError_t push(uint16_t kind, int mode, int cap, int max_ent, int grid, uint32_t inst, size_t lds_bytes,
+                  const void* args, size_t bytes, const DeviceMesh* mesh = nullptr);
+  hipError_t flush();
+  // launch `pack` (ExecPackHead + records, any size up to the largest k_exec variant) as it is
+  hipError_t launch_pack(const std::vector<unsigned char>& pack, size_t lds_bytes);
+};
+constexpr int EXEC_PACK_MID = 12160, EXEC_PACK_BIG = 28544;  // larger argument blocks for programs (CK_RELAX)
+ExecRecorder* exec_find(hipStream_t s);   // the recorder attached to a stream, or nullptr
+void exec_attach(ExecRecorder* r);
+void exec_detach(ExecRecorder* r);
+// launchers that are not recorded flush first (stream order)
+inline hipError_t exec_sync(hipStream_t s) {
+  ExecRecorder* r = exec_find(s);
+  return r ? r->flush() : hipSuccess;
+}
 
 // kernel launchers (ms_kernels.hip).  cap = T + max halo (LDS patch slots),
 // max_ent = largest per-tile vertex->corner entry count.

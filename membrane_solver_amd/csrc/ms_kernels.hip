@@ -17,8 +17,12 @@
 // Each device routine cites the reference code it restates (paths relative to
 // the reference checkout).
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 
 #include "ms_internal.h"
 
@@ -432,10 +436,11 @@ __device__ unsigned long long g_stamps[8 * 16384];
 #define MS_STAMP(k) do {} while (0)
 #define MS_STAMP_ID() do {} while (0)
 #endif
+// (energy_body: the kernel's code as a device function of (arguments, LDS base, block index) -- k_energy below is its
+// one-block-per-tile launch; the one-workgroup interpreter k_exec runs the same body command by command)
 template <bool BEND, bool GUARD, int TT, int CAPC, bool ATOMIC, int MULTI = 0>
-__global__ __launch_bounds__(TT ? TT : 512, (TT == 256 && BEND && !GUARD && ATOMIC) ? MS_KA_SLOTS : 1) MS_WPE_ENERGY void k_energy(EnergyArgs a, int cap_rt, int max_ent) {
-  extern __shared__ double lds[];
-  int bid = blockIdx.x;
+__device__ __forceinline__ void energy_body(EnergyArgs& a, int cap_rt, int max_ent, double* lds, int block_id) {
+  int bid = block_id;
   double* const ran_row = a.partials + (size_t)MS_P_RAN * a.m.n_tiles;  // (of the ordinary partials)
   bool last_trial = true;  // this workgroup evaluates the launch's last trial (ordinary outputs)
   if (MULTI) {
@@ -874,6 +879,12 @@ __global__ __launch_bounds__(TT ? TT : 512, (TT == 256 && BEND && !GUARD && ATOM
 #endif
 }
 
+template <bool BEND, bool GUARD, int TT, int CAPC, bool ATOMIC, int MULTI = 0>
+__global__ __launch_bounds__(TT ? TT : 512, (TT == 256 && BEND && !GUARD && ATOMIC) ? MS_KA_SLOTS : 1) MS_WPE_ENERGY void k_energy(EnergyArgs a, int cap_rt, int max_ent) {
+  extern __shared__ double lds[];
+  energy_body<BEND, GUARD, TT, CAPC, ATOMIC, MULTI>(a, cap_rt, max_ent, lds, (int)blockIdx.x);
+}
+
 static size_t u16_bytes(int T, int max_ent) { return 2 * ((size_t)((max_ent + 3) & ~3)); }
 
 size_t energy_lds_bytes(int T, int cap, int max_ent, bool bend, bool guard, bool flags, bool atomic) {
@@ -928,6 +939,15 @@ hipError_t launch_energy(const EnergyArgs& a_in, bool guard, int cap, int max_en
   static const size_t lds_min = variant_env("MS_KA_LDS_MIN") ? (size_t)atol(variant_env("MS_KA_LDS_MIN")) : 0;
   const size_t lds = std::max(lds_min, energy_lds_bytes(a.m.T, cap, max_ent, bend, guard, a.m.has_boundary != 0, atomic));
   hipError_t e;
+  if (ExecRecorder* r = exec_find(s)) {
+    // one-workgroup interpreter: the T = 256 instances, one trial per launch (the context switched multi-trial launches
+    // off); anything else runs as an ordinary launch behind what has been recorded
+    if (fast && !a.pair)
+      return r->push(CK_ENERGY, 0, cap, max_ent, nb, (bend ? 1u : 0u) | (guard ? 2u : 0u) | (atomic ? 4u : 0u), lds, &a,
+                     sizeof(a), &a.m);
+    e = r->flush();
+    if (e != hipSuccess) return e;
+  }
 #define MS_LAUNCH_E(B, G, TT, CC, AT)                                                              \
   do {                                                                                             \
     e = ensure_lds(k_energy<B, G, TT, CC, AT>, lds);                                               \
@@ -1028,8 +1048,7 @@ hipError_t launch_energy(const EnergyArgs& a_in, bool guard, int cap, int max_en
 // previous-direction rows (dir_mode != 2, or pd = -pg after an implicit steepest-descent step): 8 registers fewer live
 // through the facet loop, which is what lets the kernel fit 128 VGPRs = 4 resident workgroups per CU instead of 3.
 template <int BENDMODE, bool VOLROW, int TT, int CAPC, bool ATOMIC, bool LEAN = false>
-__global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? (VOLROW ? 4 : MS_LEAN_SLOTS) : 3) : 1) MS_WPE_GRADIENT void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
-  extern __shared__ double lds[];
+__device__ __forceinline__ void gradient_body(const GradientArgs& a, int cap_rt, int max_ent, double* lds, int block_id) {
   constexpr bool BEND = BENDMODE != 0;
   // BENDMODE 3: leaflet bending_tilt (bt_gradient.py:89-389): analytic back-propagation whose effective-area
   // factor is per corner, 1/2 kappa_k (base_k + s div_f t)^2; `fae` then holds base_k
@@ -1051,7 +1070,7 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? (VOLROW ? 4 : MS_LE
   uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + (ATOMIC ? 0 : ((max_ent + 3) & ~3)));
   // queued behind a line search: runs only if the decision word says the accepted point is the one in the ordinary
   // buffers (DEC_ACCEPT_MAIN)
-  const int my_tile = a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0);
+  const int my_tile = a.tile0 + xcd_tile(block_id, a.tile1 - a.tile0);
 #if MS_GATE_PROBE
   if (a.gate != nullptr) {
     const double truth = ld_agent(a.scal + MS_S_EBEND);
@@ -1068,13 +1087,13 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? (VOLROW ? 4 : MS_LE
         atomicAdd(&g_probe[2], 1ull);
         atomicAdd(&g_probe[16 + xcc], 1ull);
       }
-      if (blockIdx.x == 0) atomicAdd(&g_probe[3], 1ull);  // gated launches probed
+      if (block_id == 0) atomicAdd(&g_probe[3], 1ull);  // gated launches probed
     }
   }
 #endif
   if (a.gate != nullptr && !gate_open(a.gate, a.gate_want, a.partials + (size_t)MS_P_RAN * a.m.n_tiles + my_tile)) return;
 
-  const int blk = blockIdx.x;
+  const int blk = block_id;
   (void)blk;
   MS_STAMP(0);
   MS_STAMP_ID();
@@ -1602,6 +1621,12 @@ __global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? (VOLROW ? 4 : MS_LE
 #endif
 }
 
+template <int BENDMODE, bool VOLROW, int TT, int CAPC, bool ATOMIC, bool LEAN = false>
+__global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? (VOLROW ? 4 : MS_LEAN_SLOTS) : 3) : 1) MS_WPE_GRADIENT void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
+  extern __shared__ double lds[];
+  gradient_body<BENDMODE, VOLROW, TT, CAPC, ATOMIC, LEAN>(a, cap_rt, max_ent, lds, (int)blockIdx.x);
+}
+
 size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow, bool atomic, bool leaf) {
   const size_t cols = atomic ? (volrow ? 6 : 3) : (volrow ? 18 : 9);
   size_t d = 3 * (size_t)cap + (bend ? 5 * (size_t)cap : 0) + (leaf ? 4 * (size_t)cap : 0) + cols * (size_t)T + 4 * 16;
@@ -1630,6 +1655,15 @@ hipError_t launch_gradient(const GradientArgs& a_in, int cap, int max_ent, hipSt
   const bool leaf = bend && a.bt_vert != nullptr;
   const size_t lds = gradient_lds_bytes(a.m.T, cap, max_ent, bend, volrow, atomic, leaf);
   hipError_t e;
+  if (ExecRecorder* r = exec_find(s)) {
+    const int mode_r = !bend ? 0 : (leaf ? 3 : (a.bending_grad_mode == MS_GRAD_APPROX ? 2 : 1));
+    if (fast || mode_r == 3)
+      return r->push(CK_GRADIENT, 0, cap, max_ent, nb,
+                     (gradient_lean_instance(a) ? 1u : 0u) | (volrow ? 2u : 0u) | (atomic ? 4u : 0u) | ((uint32_t)mode_r << 4),
+                     lds, &a, sizeof(a), &a.m);
+    e = r->flush();
+    if (e != hipSuccess) return e;
+  }
 #define MS_LAUNCH_G(M, V, TT, CC, AT)                                                                \
   do {                                                                                               \
     e = ensure_lds(k_gradient<M, V, TT, CC, AT>, lds);                                               \
@@ -1688,8 +1722,7 @@ hipError_t launch_gradient(const GradientArgs& a_in, int cap, int max_ent, hipSt
 // LDS: px[3][cap] | tq[cap] | stg[10][T] | red[16] | voff, vent (u16)
 // ---------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) {
-  extern __shared__ double lds[];
+__device__ __forceinline__ void tilt_body(const TiltArgs& a, int cap, int max_ent, double* lds, int block_id) {
   const int T = a.m.T;
   double* px = lds;
   double* tq = px + 3 * cap;
@@ -1701,7 +1734,7 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
   uint16_t* voff = reinterpret_cast<uint16_t*>(red + 16);
   uint16_t* vent = voff + (T + 2);
 
-  const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
+  const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(block_id, a.tile1 - a.tile0));
   const int tid = threadIdx.x;
   const bool have_d = a.d != nullptr;
 
@@ -1995,6 +2028,12 @@ __global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) 
   }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(512) void k_tilt(TiltArgs a, int cap, int max_ent) {
+  extern __shared__ double lds[];
+  tilt_body<MODE>(a, cap, max_ent, lds, (int)blockIdx.x);
+}
+
 size_t tilt_lds_bytes(int T, int cap, int max_ent, bool consistent, int mode) {
   if (mode == 0) return ((consistent ? 7 : 4) * (size_t)cap + 16) * sizeof(double);
   return ((consistent ? 7 : 4) * (size_t)cap + 10 * (size_t)T + 16) * sizeof(double) +
@@ -2006,6 +2045,7 @@ hipError_t launch_tilt(const TiltArgs& a, int mode, int cap, int max_ent, hipStr
   if (nb <= 0) return hipSuccess;
   const size_t lds = tilt_lds_bytes(a.m.T, cap, max_ent, (mode == 0 || mode == 1) && a.consistent, mode);
   hipError_t e;
+  if (ExecRecorder* r = exec_find(s)) return r->push(CK_TILT, mode, cap, max_ent, nb, 0, lds, &a, sizeof(a), &a.m);
 #define MS_LAUNCH_T(M)                                                                  \
   do {                                                                                  \
     e = ensure_lds(k_tilt<M>, lds);                                                     \
@@ -2036,8 +2076,7 @@ hipError_t launch_tilt(const TiltArgs& a, int mode, int cap, int max_ent, hipStr
 // LDS: px[3][cap] | tl[3][cap] | bs[cap] | kp[cap] | stg[9][T] (red aliases it) | vent | fl
 // ---------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
-  extern __shared__ double lds[];
+__device__ __forceinline__ void bt_body(const BtArgs& a, int cap, int max_ent, double* lds, int block_id) {
   const int T = a.m.T;
   double* px = lds;
   double* tl = px + 3 * cap;
@@ -2049,7 +2088,7 @@ __global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
   uint16_t* vent = reinterpret_cast<uint16_t*>(stg + (MODE == 0 ? 32 : 9 * T));
   uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + (MODE == 0 ? 0 : ((max_ent + 3) & ~3)));
 
-  const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
+  const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(block_id, a.tile1 - a.tile0));
   const int tid = threadIdx.x;
   const bool have_d = a.d != nullptr;
 
@@ -2256,6 +2295,12 @@ __global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
   }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(512) void k_bt(BtArgs a, int cap, int max_ent) {
+  extern __shared__ double lds[];
+  bt_body<MODE>(a, cap, max_ent, lds, (int)blockIdx.x);
+}
+
 size_t bt_lds_bytes(int T, int cap, int max_ent, int mode) {
   if (mode == 0) return (8 * (size_t)cap + 32) * sizeof(double) + (((size_t)cap + 15) / 16) * 16;
   return (8 * (size_t)cap + 9 * (size_t)T) * sizeof(double) + 2 * ((size_t)((max_ent + 3) & ~3)) +
@@ -2267,6 +2312,7 @@ hipError_t launch_bt(const BtArgs& a, int mode, int cap, int max_ent, hipStream_
   if (nb <= 0) return hipSuccess;
   const size_t lds = bt_lds_bytes(a.m.T, cap, max_ent, mode);
   hipError_t e;
+  if (ExecRecorder* r = exec_find(s)) return r->push(CK_BT, mode, cap, max_ent, nb, 0, lds, &a, sizeof(a), &a.m);
 #define MS_LAUNCH_B(M)                                                                      \
   do {                                                                                      \
     e = ensure_lds(k_bt<M>, lds);                                                           \
@@ -2287,8 +2333,7 @@ hipError_t launch_bt(const BtArgs& a, int mode, int cap, int max_ent, hipStream_
 // LDS: px[3][cap] | tl[3][cap] | stg[9][T] (red aliases it) | vent
 // ---------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(512) void k_tsmooth(TsArgs a, int cap, int max_ent) {
-  extern __shared__ double lds[];
+__device__ __forceinline__ void ts_body(const TsArgs& a, int cap, int max_ent, double* lds, int block_id) {
   const int T = a.m.T;
   double* px = lds;
   double* tl = px + 3 * cap;
@@ -2296,7 +2341,7 @@ __global__ __launch_bounds__(512) void k_tsmooth(TsArgs a, int cap, int max_ent)
   double* red = stg;
   uint16_t* vent = reinterpret_cast<uint16_t*>(stg + 9 * T);
 
-  const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(blockIdx.x, a.tile1 - a.tile0));
+  const TileCtx t = tile_ctx(a.m, a.tile0 + xcd_tile(block_id, a.tile1 - a.tile0));
   const int tid = threadIdx.x;
   const bool have_d = a.d != nullptr;
   int cur = 0, end = 0;
@@ -2429,6 +2474,12 @@ __global__ __launch_bounds__(512) void k_tsmooth(TsArgs a, int cap, int max_ent)
   }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(512) void k_tsmooth(TsArgs a, int cap, int max_ent) {
+  extern __shared__ double lds[];
+  ts_body<MODE>(a, cap, max_ent, lds, (int)blockIdx.x);
+}
+
 size_t ts_lds_bytes(int T, int cap, int max_ent) {
   return (6 * (size_t)cap + 9 * (size_t)T) * sizeof(double) + 2 * ((size_t)((max_ent + 3) & ~3)) + 64;
 }
@@ -2438,6 +2489,7 @@ hipError_t launch_ts(const TsArgs& a, int mode, int cap, int max_ent, hipStream_
   if (nb <= 0) return hipSuccess;
   const size_t lds = ts_lds_bytes(a.m.T, cap, max_ent);
   hipError_t e;
+  if (ExecRecorder* r = exec_find(s)) return r->push(CK_TS, mode, cap, max_ent, nb, 0, lds, &a, sizeof(a), &a.m);
 #define MS_LAUNCH_S(M)                                                                      \
   do {                                                                                      \
     e = ensure_lds(k_tsmooth<M>, lds);                                                      \
@@ -2458,14 +2510,22 @@ hipError_t launch_ts(const TsArgs& a, int mode, int cap, int max_ent, hipStream_
 //                 tilt-fixed rows keep t unless keep_fixed == 0 (the initial projection)
 //   mode 3 MINV : out[v] (the accumulated Jacobi diagonal) -> its clamped inverse
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_tvec(int mode, int tile0, int nv, int T, const uint8_t* vflags,
-                                                double* tg, const double* minv, double* dir,
-                                                const double* tilts, const double* src,
-                                                const double* normals, double* out, double coef,
-                                                int flag, double* partials, int n_tiles,
-                                                uint8_t fixed_bit, int s_gn2, int s_rz) {
+// (stream kernels as device bodies too: arguments in one struct, the block index a parameter; blockDim.x = BLOCK)
+__device__ __forceinline__ void tvec_body(const TvecArgs& a, int block_id) {
   __shared__ double red[16];
-  const int tile = tile0 + blockIdx.x;
+  const int mode = a.mode, nv = a.nv, T = a.T, flag = a.flag, n_tiles = a.n_tiles, s_gn2 = a.s_gn2, s_rz = a.s_rz;
+  const uint8_t* const vflags = a.vflags;
+  double* const tg = a.tg;
+  const double* const minv = a.minv;
+  double* const dir = a.dir;
+  const double* const tilts = a.tilts;
+  const double* const src = a.src;
+  const double* const normals = a.normals;
+  double* const out = a.out;
+  double* const partials = a.partials;
+  const double coef = a.coef_dev != nullptr ? ld_agent(a.coef_dev) : a.coef;
+  const uint8_t fixed_bit = a.fixed_bit;
+  const int tile = a.tile0 + block_id;
   double s0 = 0.0, s1 = 0.0;
   for (int i = threadIdx.x; i < T; i += BLOCK) {
     const int v = tile * T + i;
@@ -2538,13 +2598,19 @@ __global__ __launch_bounds__(BLOCK) void k_tvec(int mode, int tile0, int nv, int
   }
 }
 
+__global__ __launch_bounds__(BLOCK) void k_tvec(TvecArgs a) { tvec_body(a, (int)blockIdx.x); }
+
 hipError_t launch_tvec(int mode, int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* tg,
                        const double* minv, double* dir, const double* tilts, const double* src,
                        const double* normals, double* out, double coef, int flag, double* partials,
                        int n_tiles, hipStream_t s, uint8_t fixed_bit, int s_gn2, int s_rz) {
   if (tile1 <= tile0) return hipSuccess;
-  hipLaunchKernelGGL(k_tvec, dim3(tile1 - tile0), dim3(BLOCK), 0, s, mode, tile0, nv, T, vflags, tg, minv,
-                     dir, tilts, src, normals, out, coef, flag, partials, n_tiles, fixed_bit, s_gn2, s_rz);
+  TvecArgs a;
+  a.mode = mode; a.tile0 = tile0; a.nv = nv; a.T = T; a.vflags = vflags; a.tg = tg; a.minv = minv; a.dir = dir;
+  a.tilts = tilts; a.src = src; a.normals = normals; a.out = out; a.coef = coef; a.flag = flag; a.partials = partials;
+  a.n_tiles = n_tiles; a.fixed_bit = fixed_bit; a.s_gn2 = s_gn2; a.s_rz = s_rz; a.coef_dev = nullptr;
+  if (ExecRecorder* r = exec_find(s)) return r->push(CK_TVEC, 0, 0, 0, tile1 - tile0, 0, 0, &a, sizeof(a));
+  hipLaunchKernelGGL(k_tvec, dim3(tile1 - tile0), dim3(BLOCK), 0, s, a);
   return hipGetLastError();
 }
 
@@ -2570,13 +2636,29 @@ __device__ __forceinline__ double bessel_i1_series30(double x) {  // :148-157, s
   return out;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_disk_target(DiskTargetArgs a, int mode) {
+__device__ __forceinline__ void disk_target_body(const DiskTargetArgs& a, int mode, int block_id) {
   __shared__ double red[16];
-  const int tile = a.tile0 + blockIdx.x;
+  const int tile = a.tile0 + block_id;
   double rmax = 0.0;
   double R = a.radius, den = 1.0;
   bool off = false;
-  if (mode == 1) {
+  if (mode == 3) {
+    // positions frozen (a tilt relaxation): theta(r) r_hat of every tagged row was written to a.target once (mode 2);
+    // the difference field is t - target, the same two roundings as mode 1 takes
+    for (int i = threadIdx.x; i < a.T; i += BLOCK) {
+      const int v = tile * a.T + i;
+      if (v >= a.nv) break;
+      const size_t o = 3 * (size_t)v;
+      V3 df = mk(0, 0, 0);
+      if (a.disk[v] && a.target[o + 0] == a.target[o + 0])  // (NaN in the cache: the profile is switched off, :219-228)
+        df = mk(a.tilts[o] - a.target[o], a.tilts[o + 1] - a.target[o + 1], a.tilts[o + 2] - a.target[o + 2]);
+      a.diff[o] = df.x;
+      a.diff[o + 1] = df.y;
+      a.diff[o + 2] = df.z;
+    }
+    return;
+  }
+  if (mode == 1 || mode == 2) {
     if (!(R > 0.0)) R = ld_agent(a.scal + a.r_slot);
     off = !(R > 0.0);                         // :219-220
     if (!off && !(fabs(a.lambda) < 1.0e-12)) {
@@ -2606,7 +2688,19 @@ __global__ __launch_bounds__(BLOCK) void k_disk_target(DiskTargetArgs a, int mod
         double theta;
         if (fabs(a.lambda) < 1.0e-12) theta = (a.theta_b * rl) / R;
         else theta = (a.theta_b * bessel_i1_series30(a.lambda * rl)) / den;
-        df = mk(a.tilts[o] - theta * rh.x, a.tilts[o + 1] - theta * rh.y, a.tilts[o + 2] - theta * rh.z);
+        // theta(r) r_hat, rounded, THEN the difference (the reference's two numpy operations; also what lets a cached
+        // target field -- mode 2 / 3 -- give the same doubles)
+        const V3 tg = mk(__dmul_rn(theta, rh.x), __dmul_rn(theta, rh.y), __dmul_rn(theta, rh.z));
+        if (mode == 2) {
+          a.target[o] = tg.x;
+          a.target[o + 1] = tg.y;
+          a.target[o + 2] = tg.z;
+        } else {
+          df = mk(a.tilts[o] - tg.x, a.tilts[o + 1] - tg.y, a.tilts[o + 2] - tg.z);
+        }
+      } else if (mode == 2) {
+        const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+        a.target[o] = a.target[o + 1] = a.target[o + 2] = qnan;  // (profile off: mode 3 leaves the difference at zero)
       }
     }
     if (mode == 1) {
@@ -2621,8 +2715,13 @@ __global__ __launch_bounds__(BLOCK) void k_disk_target(DiskTargetArgs a, int mod
   }
 }
 
+__global__ __launch_bounds__(BLOCK) void k_disk_target(DiskTargetArgs a, int mode) {
+  disk_target_body(a, mode, (int)blockIdx.x);
+}
+
 hipError_t launch_disk_target(const DiskTargetArgs& a, int mode, hipStream_t s) {
   if (a.tile1 <= a.tile0) return hipSuccess;
+  if (ExecRecorder* r = exec_find(s)) return r->push(CK_DISK, mode, 0, 0, a.tile1 - a.tile0, 0, 0, &a, sizeof(a));
   hipLaunchKernelGGL(k_disk_target, dim3(a.tile1 - a.tile0), dim3(BLOCK), 0, s, a, mode);
   return hipGetLastError();
 }
@@ -2702,85 +2801,44 @@ __device__ __forceinline__ void post_entry(unsigned long long* box, int entry, u
 // Every workgroup reads the gate word (one word, written by an earlier kernel); with the gate closed nothing is stored
 // or posted, workgroup 0 only hands the earlier decision on (later stages and the gradient pass test THIS stage's
 // word) and checks that no workgroup of the gated producer ran.
-__global__ __launch_bounds__(RBLOCK) void k_reduce(FoldArgs a) {
-  __shared__ double red[16];
-  const uint32_t e_mask = a.slot_mask & a.e_mask;
-  const uint32_t rest_mask = a.slot_mask & ~e_mask;
-  const uint32_t prev = a.gate != nullptr ? ld_agent(a.gate) : a.gate_want;  // (consumed after the fold's loads)
-  const int n_e = __popc(e_mask);                       // energy slots per set (<= 2)
-  const int n_rest = __popc(rest_mask);                 // other slots per set
-  const int n_reg = a.side_full ? a.n_sets : 1;         // sets whose other slots are folded too: all, or the last trial's
-  const int t_e = a.check_ran ? 1 : 0;                  // first energy task (task 0: the ran count)
+// task index of a fold launch -> (set, slot): task 0 the ran count of a gated producer (check_ran), then the energy
+// slots of every set, then the remaining slots of the last set (side_full: of every set); slot < 0: no such task
+__device__ __forceinline__ void fold_task(const FoldArgs& a, int task, uint32_t e_mask, uint32_t rest_mask, int& set, int& slot) {
+  const int n_e = __popc(e_mask);
+  const int n_rest = __popc(rest_mask);
+  const int n_reg = a.side_full ? a.n_sets : 1;
+  const int t_e = a.check_ran ? 1 : 0;
   const int t_rest = t_e + a.n_sets * n_e;
-  const int task = blockIdx.x;
-  int set, slot = -1;
-  {
-    uint32_t m = 0;
-    int k = 0;
-    if (task < t_e) {
-      set = a.n_sets - 1;
-      slot = MS_P_RAN;
-    } else if (task < t_rest) {  // energy slot k of set `set`
-      set = (task - t_e) / n_e;
-      k = (task - t_e) % n_e;
-      m = e_mask;
-    } else {
-      const int r = task - t_rest;
-      set = a.n_sets - n_reg + r / n_rest;
-      k = r % n_rest;
-      m = rest_mask;
+  slot = -1;
+  set = a.n_sets - 1;
+  uint32_t m = 0;
+  int k = 0;
+  if (task < t_e) {
+    slot = MS_P_RAN;
+  } else if (task < t_rest) {  // energy slot k of set `set`
+    set = (task - t_e) / n_e;
+    k = (task - t_e) % n_e;
+    m = e_mask;
+  } else {
+    if (n_rest == 0) return;
+    const int r = task - t_rest;
+    if (r >= n_reg * n_rest) return;
+    set = a.n_sets - n_reg + r / n_rest;
+    k = r % n_rest;
+    m = rest_mask;
+  }
+  for (int s = 0; s < MS_NSCAL && slot < 0; ++s)
+    if (m & (1u << s)) {
+      if (k == 0) slot = s;
+      --k;
     }
-    for (int s = 0; s < MS_NSCAL && slot < 0; ++s)
-      if (m & (1u << s)) {
-        if (k == 0) slot = s;
-        --k;
-      }
-  }
-  if (slot < 0) return;
-  // merged: this launch folds the direction scalars of the gradient pass in front of the energy launch TOGETHER with
-  // that launch's energies (the energy launch did not wait for them: one fold and one kernel boundary per step less)
-  const bool merged = a.go_kind != 0 && a.dec_out != nullptr;
-  double rhs_d[MS_MAX_TRIALS];
-  if (a.rhs_dev != nullptr && a.dec_out != nullptr && task >= t_e && task < t_rest && threadIdx.x == 0) {
-#pragma unroll
-    for (int j = 0; j < MS_MAX_TRIALS; ++j) rhs_d[j] = j < a.n_sets ? ld_agent(a.rhs_dev + j) : 0.0;
-  }
-  double q[RU];
-  fold_issue(q, a.set[set].partials, a.n_tiles, a.tile0, a.tile1, slot);
-  const bool open = prev == a.gate_want;
-  if (!open && task != 0) return;
-  const double r = fold_finish(q, a.set[set].partials, a.n_tiles, a.tile0, a.tile1, slot, red);
-  if (threadIdx.x != 0) return;
-  if (slot == MS_P_RAN) {
-    const double want = open ? (double)(a.tile1 - a.tile0) : 0.0;
-    if (r != want && a.host_err)
-      st_sys(a.host_err, ((unsigned long long)a.ticket << 24) | (unsigned long long)(unsigned int)r | (1ull << 63));
-  }
-  if (!open) {  // (task 0) an earlier stage has decided (or failed): later readers of THIS stage's word see the same
-    if (a.dec_out != nullptr) st_agent(a.dec_out, prev);
-    return;
-  }
-  if (slot == MS_P_RAN) return;
-  if (a.set[set].scal) st_agent(a.set[set].scal + slot, r);
-  if (a.set[set].host_box) post_entry(a.set[set].host_box, slot, (unsigned long long)__double_as_longlong(r), a.ticket);
-#if MS_GATE_PROBE
-  if (set == a.n_sets - 1) g_shadow[slot] = r;
-#endif
-  if (a.dec_out == nullptr || (!merged && task >= t_rest)) return;
-  // a stage that is decided here: its energies' workgroups (merged: every slot's) count in once their scalar store has
-  // completed; the one that comes last decides
-  // release: this workgroup's scalar store is visible at agent scope before its arrival; acquire: the last arriver's
-  // loads of the other workgroups' energies below are ordered behind their arrivals (the same handoff as
-  // k_pack_peers' last block).  At most ~10 lanes of a launch execute this, on L2s the kernel boundary has just
-  // written back.
-#ifndef MS_REDUCE_RELAXED
-  const uint32_t arrived = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-#else  // (A/B build: the hand-placed form of rounds 2-3)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const uint32_t arrived = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-  if (arrived != (uint32_t)(a.n_sets * n_e + (merged ? n_reg * n_rest : 0) - 1)) return;
-  st_agent(a.counter, 0u);  // (the next fold of the stream starts from zero)
+}
+
+// The decision a fold takes once all of its sums are stored (k_reduce: by the workgroup that arrives last; the
+// one-workgroup fold: by thread 0 behind a barrier): does the search happen at all (merged folds), which trial passes
+// its Armijo test first -- the host's expressions with the host's roundings -- and the code every gated kernel behind
+// the stage reads.
+__device__ __forceinline__ void fold_decide(const FoldArgs& a, uint32_t e_mask, bool merged, const double (&rhs_d)[MS_MAX_TRIALS]) {
   uint32_t code = DEC_CONTINUE;
   bool decide = true;
   double m_e0 = 0.0, m_c = 0.0, m_al = 0.0, m_beta = 0.0, m_slope = 0.0;
@@ -2839,6 +2897,121 @@ __global__ __launch_bounds__(RBLOCK) void k_reduce(FoldArgs a) {
   if (a.set[a.n_sets - 1].host_box) post_entry(a.set[a.n_sets - 1].host_box, MS_MB_DEC, (unsigned long long)code, a.ticket);
 }
 
+__device__ __forceinline__ void reduce_body(const FoldArgs& a, int block_id) {
+  __shared__ double red[16];
+  const uint32_t e_mask = a.slot_mask & a.e_mask;
+  const uint32_t rest_mask = a.slot_mask & ~e_mask;
+  const uint32_t prev = a.gate != nullptr ? ld_agent(a.gate) : a.gate_want;  // (consumed after the fold's loads)
+  const int n_e = __popc(e_mask);                       // energy slots per set (<= 2)
+  const int n_rest = __popc(rest_mask);                 // other slots per set
+  const int n_reg = a.side_full ? a.n_sets : 1;         // sets whose other slots are folded too: all, or the last trial's
+  const int t_e = a.check_ran ? 1 : 0;                  // first energy task (task 0: the ran count)
+  const int t_rest = t_e + a.n_sets * n_e;
+  const int task = block_id;
+  int set, slot;
+  fold_task(a, task, e_mask, rest_mask, set, slot);
+  if (slot < 0) return;
+  // merged: this launch folds the direction scalars of the gradient pass in front of the energy launch TOGETHER with
+  // that launch's energies (the energy launch did not wait for them: one fold and one kernel boundary per step less)
+  const bool merged = a.go_kind != 0 && a.dec_out != nullptr;
+  double rhs_d[MS_MAX_TRIALS];
+  if (a.rhs_dev != nullptr && a.dec_out != nullptr && task >= t_e && task < t_rest && threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < MS_MAX_TRIALS; ++j) rhs_d[j] = j < a.n_sets ? ld_agent(a.rhs_dev + j) : 0.0;
+  }
+  double q[RU];
+  fold_issue(q, a.set[set].partials, a.n_tiles, a.tile0, a.tile1, slot);
+  const bool open = prev == a.gate_want;
+  if (!open && task != 0) return;
+  const double r = fold_finish(q, a.set[set].partials, a.n_tiles, a.tile0, a.tile1, slot, red);
+  if (threadIdx.x != 0) return;
+  if (slot == MS_P_RAN) {
+    const double want = open ? (double)(a.tile1 - a.tile0) : 0.0;
+    if (r != want && a.host_err)
+      st_sys(a.host_err, ((unsigned long long)a.ticket << 24) | (unsigned long long)(unsigned int)r | (1ull << 63));
+  }
+  if (!open) {  // (task 0) an earlier stage has decided (or failed): later readers of THIS stage's word see the same
+    if (a.dec_out != nullptr) st_agent(a.dec_out, prev);
+    return;
+  }
+  if (slot == MS_P_RAN) return;
+  if (a.set[set].scal) st_agent(a.set[set].scal + slot, r);
+  if (a.set[set].host_box) post_entry(a.set[set].host_box, slot, (unsigned long long)__double_as_longlong(r), a.ticket);
+#if MS_GATE_PROBE
+  if (set == a.n_sets - 1) g_shadow[slot] = r;
+#endif
+  if (a.dec_out == nullptr || (!merged && task >= t_rest)) return;
+  // a stage that is decided here: its energies' workgroups (merged: every slot's) count in once their scalar store has
+  // completed; the one that comes last decides
+  // Hand-over to the last arriver.  Release side: the scalar store above is an agent-scope write-through store and has
+  // COMPLETED (vmcnt 0) before this workgroup counts itself in.  Acquire side: the decider's loads below are agent-scope
+  // loads that are control-dependent on the value this read-modify-write returns, and the signal fence keeps the
+  // compiler from moving them above it.  The formal form -- one __ATOMIC_ACQ_REL read-modify-write, -DMS_REDUCE_ACQREL
+  // -- adds a cache write-back and an invalidate per arriving lane: measured +1..1.5 us per fold (8.3 -> 9.6 us by HIP
+  // events, headline 17.5 -> 17.2 k steps/s, gpurun_out/r4a); the host's replay of every decision catches a wrong one
+  // either way.
+#ifdef MS_REDUCE_ACQREL
+  const uint32_t arrived = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint32_t arrived = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#endif
+  if (arrived != (uint32_t)(a.n_sets * n_e + (merged ? n_reg * n_rest : 0) - 1)) return;
+  st_agent(a.counter, 0u);  // (the next fold of the stream starts from zero)
+  fold_decide(a, e_mask, merged, rhs_d);
+}
+
+// The same fold for a range of ONE tile, by ONE workgroup (the interpreter k_exec): thread t does task t -- a fold
+// over one tile is that tile's partial through the fold's neutral element, the arithmetic of fold_finish / block_reduce
+// for a single contributor (sums: 0.0 + x; min / max against the neutral; the volume's 1/6) -- all stores and mailbox
+// posts of the launch leave together, and thread 0 decides behind one barrier.  Bit for bit k_reduce's results.
+__device__ __forceinline__ void reduce_one_tile(const FoldArgs& a, int n_tasks) {
+  const uint32_t e_mask = a.slot_mask & a.e_mask;
+  const uint32_t rest_mask = a.slot_mask & ~e_mask;
+  const uint32_t prev = a.gate != nullptr ? ld_agent(a.gate) : a.gate_want;
+  const bool open = prev == a.gate_want;
+  const bool merged = a.go_kind != 0 && a.dec_out != nullptr;
+  const int task = (int)threadIdx.x;
+  int set = 0, slot = -1;
+  if (task < n_tasks) fold_task(a, task, e_mask, rest_mask, set, slot);
+  if (slot >= 0 && (open || task == 0)) {
+    double x = 0.0;
+    // (the set is picked with constant indices: a dynamically indexed argument struct would move to scratch)
+#pragma unroll
+    for (int j = 0; j < MS_MAX_TRIALS; ++j)
+      if (j == set) x = a.set[j].partials[(size_t)slot * a.n_tiles + a.tile0];
+    const int op = fold_op(slot);
+    double r = op == 0 ? 0.0 + x : (op == 1 ? fmin(1.0e300, x) : fmax(0.0, x));
+    if (a.tile1 <= a.tile0) r = op == 1 ? 1.0e300 : 0.0;
+    if (slot == MS_S_VOL) r = r / 6.0;
+    if (slot == MS_P_RAN) {
+      const double want = open ? (double)(a.tile1 - a.tile0) : 0.0;
+      if (r != want && a.host_err)
+        st_sys(a.host_err, ((unsigned long long)a.ticket << 24) | (unsigned long long)(unsigned int)r | (1ull << 63));
+    }
+    if (!open) {
+      if (a.dec_out != nullptr) st_agent(a.dec_out, prev);
+    } else if (slot != MS_P_RAN) {
+#pragma unroll
+      for (int j = 0; j < MS_MAX_TRIALS; ++j)
+        if (j == set) {
+          if (a.set[j].scal) st_agent(a.set[j].scal + slot, r);
+          if (a.set[j].host_box) post_entry(a.set[j].host_box, slot, (unsigned long long)__double_as_longlong(r), a.ticket);
+        }
+    }
+  }
+  __syncthreads();  // (every store above has completed)
+  if (threadIdx.x == 0 && open && a.dec_out != nullptr) {
+    double rhs_d[MS_MAX_TRIALS];
+#pragma unroll
+    for (int j = 0; j < MS_MAX_TRIALS; ++j) rhs_d[j] = (a.rhs_dev != nullptr && j < a.n_sets) ? ld_agent(a.rhs_dev + j) : 0.0;
+    fold_decide(a, e_mask, merged, rhs_d);
+  }
+}
+
+__global__ __launch_bounds__(RBLOCK) void k_reduce(FoldArgs a) { reduce_body(a, (int)blockIdx.x); }
+
 hipError_t launch_reduce(const FoldArgs& a, hipStream_t s) {
   if (a.n_sets < 1 || a.n_sets > MS_MAX_TRIALS) return hipErrorInvalidValue;
   const uint32_t em = a.slot_mask & a.e_mask;
@@ -2847,6 +3020,8 @@ hipError_t launch_reduce(const FoldArgs& a, hipStream_t s) {
   if (nb == 0) return hipSuccess;
   if (a.dec_out != nullptr && (a.counter == nullptr || em == 0)) return hipErrorInvalidValue;
   if (a.go_kind != 0 && (a.dec_out == nullptr || a.go_out == nullptr)) return hipErrorInvalidValue;
+  // (one workgroup: the fold's tasks run one after the other; with one tile a fold is a copy of that tile's partials)
+  if (ExecRecorder* r = exec_find(s)) return r->push(CK_REDUCE, 0, 0, 0, nb, 0, 0, &a, sizeof(a));
   hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(RBLOCK), 0, s, a);
   return hipGetLastError();
 }
@@ -2864,15 +3039,21 @@ hipError_t launch_reduce(const FoldArgs& a, hipStream_t s) {
 //       d[fixed] = 0                (conjugate_gradient.py:78-96)
 //   partials: |g|^2, <g,d>, max |d_i|^2 over movable rows (line_search.py:317-321)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, const uint8_t* vflags,
-                                                     double* g, const double* gC, double* d,
-                                                     const double* pg, const double* pd,
-                                                     const double* scal, int use_constraint,
-                                                     int cg_history, double* partials,
-                                                     int n_tiles, int write_g, const uint32_t* gate,
-                                                     uint32_t gate_want, int pd_neg_pg, int precond) {
+__device__ __forceinline__ void direction_body(const DirectionArgs& a, int block_id) {
   __shared__ double red[16];
-  const int tile = tile0 + blockIdx.x;
+  const int nv = a.nv, T = a.T, use_constraint = a.use_constraint, cg_history = a.cg_history, n_tiles = a.n_tiles;
+  const int write_g = a.write_g, pd_neg_pg = a.pd_neg_pg, precond = a.precond;
+  const uint8_t* const vflags = a.vflags;
+  double* const g = a.g;
+  const double* const gC = a.gC;
+  double* const d = a.d;
+  const double* const pg = a.pg;
+  const double* const pd = a.pd;
+  const double* const scal = a.scal;
+  double* const partials = a.partials;
+  const uint32_t* const gate = a.gate;
+  const uint32_t gate_want = a.gate_want;
+  const int tile = a.tile0 + block_id;
   if (gate != nullptr && !gate_open(gate, gate_want, partials + (size_t)MS_P_RAN * n_tiles + tile)) return;
   double lam = 0.0;
   bool project = false;
@@ -2940,25 +3121,34 @@ __global__ __launch_bounds__(BLOCK) void k_direction(int tile0, int nv, int T, c
   if (threadIdx.x == 0) out[MS_S_MAXG2 * ps] = r;
 }
 
+__global__ __launch_bounds__(BLOCK) void k_direction(DirectionArgs a) { direction_body(a, (int)blockIdx.x); }
+
 hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* g,
                             const double* gC, double* d, const double* pg, const double* pd,
                             const double* scal, int use_constraint, int cg_history,
                             double* partials, int n_tiles, int write_g, hipStream_t s, const uint32_t* gate,
                             uint32_t gate_want, int pd_neg_pg, int precond) {
   if (tile1 <= tile0) return hipSuccess;
-  hipLaunchKernelGGL(k_direction, dim3(tile1 - tile0), dim3(BLOCK), 0, s, tile0, nv, T, vflags, g,
-                     gC, d, pg, pd, scal, use_constraint, cg_history, partials, n_tiles, write_g, gate, gate_want,
-                     pd_neg_pg, precond);
+  DirectionArgs a;
+  a.tile0 = tile0; a.nv = nv; a.T = T; a.vflags = vflags; a.g = g; a.gC = gC; a.d = d; a.pg = pg; a.pd = pd;
+  a.scal = scal; a.use_constraint = use_constraint; a.cg_history = cg_history; a.partials = partials;
+  a.n_tiles = n_tiles; a.write_g = write_g; a.gate = gate; a.gate_want = gate_want; a.pd_neg_pg = pd_neg_pg;
+  a.precond = precond;
+  if (ExecRecorder* r = exec_find(s)) return r->push(CK_DIRECTION, 0, 0, 0, tile1 - tile0, 0, 0, &a, sizeof(a));
+  hipLaunchKernelGGL(k_direction, dim3(tile1 - tile0), dim3(BLOCK), 0, s, a);
   return hipGetLastError();
 }
 
 // <g, gC> per tile, for module sets that add into g AFTER the gradient kernel computed that inner product in its
 // epilogue (the tilt magnitude / disk-target / leaflet bending_tilt shape gradients): the KKT multiplier of
 // runtime/constraint_manager.py:293-301 is taken of the COMPLETE gradient.  <gC, gC> is unchanged.
-__global__ __launch_bounds__(BLOCK) void k_row_dot(int tile0, int nv, int T, const double* g, const double* gC,
-                                                   double* partials, int n_tiles) {
+__device__ __forceinline__ void row_dot_body(const RowDotArgs& a, int block_id) {
   __shared__ double red[16];
-  const int tile = tile0 + blockIdx.x;
+  const int nv = a.nv, T = a.T, n_tiles = a.n_tiles;
+  const double* const g = a.g;
+  const double* const gC = a.gC;
+  double* const partials = a.partials;
+  const int tile = a.tile0 + block_id;
   double acc = 0.0;
   for (int i = threadIdx.x; i < T; i += BLOCK) {
     const int v = tile * T + i;
@@ -2970,10 +3160,15 @@ __global__ __launch_bounds__(BLOCK) void k_row_dot(int tile0, int nv, int T, con
   if (threadIdx.x == 0) partials[(size_t)MS_S_GGC * n_tiles + tile] = r;
 }
 
+__global__ __launch_bounds__(BLOCK) void k_row_dot(RowDotArgs a) { row_dot_body(a, (int)blockIdx.x); }
+
 hipError_t launch_row_dot(int tile0, int tile1, int nv, int T, const double* g, const double* gC, double* partials,
                           int n_tiles, hipStream_t s) {
   if (tile1 <= tile0) return hipSuccess;
-  hipLaunchKernelGGL(k_row_dot, dim3(tile1 - tile0), dim3(BLOCK), 0, s, tile0, nv, T, g, gC, partials, n_tiles);
+  RowDotArgs a;
+  a.tile0 = tile0; a.nv = nv; a.T = T; a.g = g; a.gC = gC; a.partials = partials; a.n_tiles = n_tiles;
+  if (ExecRecorder* r = exec_find(s)) return r->push(CK_ROWDOT, 0, 0, 0, tile1 - tile0, 0, 0, &a, sizeof(a));
+  hipLaunchKernelGGL(k_row_dot, dim3(tile1 - tile0), dim3(BLOCK), 0, s, a);
   return hipGetLastError();
 }
 
@@ -3094,6 +3289,7 @@ __global__ void k_unpack_boundary(const int32_t* rows_all, const int32_t* row_of
 hipError_t launch_pack_boundary(const int32_t* rows, int n_rows, const double* const* bufs,
                                 const int* ncomp, int n_bufs, const double* scal, double* send,
                                 hipStream_t s) {
+  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
   RowBufs b{};
   b.n = n_bufs;
   for (int k = 0; k < n_bufs; ++k) {
@@ -3112,6 +3308,7 @@ hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_of
                                   unsigned long long* host_seq, unsigned long long ticket, bool remote_written,
                                   const unsigned long long* wait_flags, unsigned long long wait_ticket,
                                   unsigned long long* host_err) {
+  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
   RowBufs b{};
   b.n = n_bufs;
   for (int k = 0; k < n_bufs; ++k) {
@@ -3132,6 +3329,7 @@ hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_of
 hipError_t launch_pack_peers(const int32_t* rows, int n_rows, const double* const* bufs, const int* ncomp, int n_bufs,
                              const double* scal, double* const* dst, int world, hipStream_t s,
                              const PeerFlags* d_flags, unsigned int* d_arrived, int me, unsigned long long ticket) {
+  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
   if (world > 16) return hipErrorInvalidValue;
   RowBufs b{};
   b.n = n_bufs;
@@ -3150,6 +3348,7 @@ hipError_t launch_pack_peers(const int32_t* rows, int n_rows, const double* cons
 
 hipError_t launch_flag_peers(unsigned long long* const* peer_flags, int me, int world, unsigned long long ticket,
                              hipStream_t s) {
+  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
   if (world > 16) return hipErrorInvalidValue;
   PeerFlags f{};
   for (int r = 0; r < world; ++r) f.p[r] = peer_flags[r];
@@ -3169,11 +3368,13 @@ __global__ void k_gate_probe(const uint32_t* gate, uint32_t want, uint32_t* out)
   *out = ld_agent(gate) == want ? 1u : 0u;
 }
 hipError_t launch_gate_probe(const uint32_t* gate, uint32_t want, uint32_t* out, hipStream_t s) {
+  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
   hipLaunchKernelGGL(k_gate_probe, dim3(1), dim3(1), 0, s, gate, want, out);
   return hipGetLastError();
 }
 
 hipError_t launch_post_seq(unsigned long long* host_seq, unsigned long long ticket, hipStream_t s) {
+  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
   hipLaunchKernelGGL(k_post_seq, dim3(1), dim3(1), 0, s, host_seq, ticket);
   return hipGetLastError();
 }
@@ -3197,6 +3398,7 @@ __global__ void k_axpy_rows(int64_t row0, int64_t row1, const int32_t* extra, in
 hipError_t launch_axpy_rows(int64_t row0, int64_t row1, const int32_t* extra, int n_extra,
                             const uint8_t* vflags, double* x, const double* y, double coef,
                             hipStream_t s) {
+  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
   const int64_t n = (row1 - row0) + n_extra;
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_axpy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, row0, row1, extra,
@@ -3205,20 +3407,23 @@ hipError_t launch_axpy_rows(int64_t row0, int64_t row1, const int32_t* extra, in
 }
 
 // x[i] += coef * y[i] on movable rows (volume projection, constraints/volume.py:137-141)
-__global__ void k_axpy_masked(int64_t n_rows, const uint8_t* vflags, double* x, const double* y,
-                              double coef) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= 3 * n_rows) return;
-  if (vflags[j / 3] & VF_FIXED) return;
-  x[j] = axpy1(x[j], coef, y[j]);
+__device__ __forceinline__ void axpy_masked_body(const AxpyMaskedArgs& a, int block_id) {
+  const int64_t j = (int64_t)block_id * blockDim.x + threadIdx.x;
+  if (j >= 3 * a.n_rows) return;
+  if (a.vflags[j / 3] & VF_FIXED) return;
+  a.x[j] = axpy1(a.x[j], a.coef, a.y[j]);
 }
+__global__ void k_axpy_masked(AxpyMaskedArgs a) { axpy_masked_body(a, (int)blockIdx.x); }
 
 hipError_t launch_axpy_masked(int64_t n_rows, const uint8_t* vflags, double* x, const double* y,
                               double coef, hipStream_t s) {
   if (n_rows <= 0) return hipSuccess;
   const int64_t n = 3 * n_rows;
-  hipLaunchKernelGGL(k_axpy_masked, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s,
-                     n_rows, vflags, x, y, coef);
+  AxpyMaskedArgs a;
+  a.n_rows = n_rows; a.vflags = vflags; a.x = x; a.y = y; a.coef = coef;
+  if (ExecRecorder* r = exec_find(s))
+    return r->push(CK_AXPY_MASKED, 0, 0, 0, (int)((n + BLOCK - 1) / BLOCK), 0, 0, &a, sizeof(a));
+  hipLaunchKernelGGL(k_axpy_masked, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, a);
   return hipGetLastError();
 }
 
@@ -3239,6 +3444,7 @@ __global__ void k_permute_out(int nv, const int32_t* perm, const double* src_int
 }
 hipError_t launch_permute_in(int nv, const int32_t* perm, const double* src_ext, double* dst_int,
                              int ncomp, hipStream_t s) {
+  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
   const int64_t n = (int64_t)nv * ncomp;
   hipLaunchKernelGGL(k_permute_in, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, nv,
                      perm, src_ext, dst_int, ncomp);
@@ -3246,6 +3452,7 @@ hipError_t launch_permute_in(int nv, const int32_t* perm, const double* src_ext,
 }
 hipError_t launch_permute_out(int nv, const int32_t* perm, const double* src_int, double* dst_ext,
                               int ncomp, hipStream_t s) {
+  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
   const int64_t n = (int64_t)nv * ncomp;
   hipLaunchKernelGGL(k_permute_out, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, nv,
                      perm, src_int, dst_ext, ncomp);
@@ -3378,6 +3585,8 @@ hipError_t launch_curvature_raw(int nv, int nf, const double* pos, const int32_t
                      tri, k_vecs, areas, weights, va0, va1, va2);
   return hipGetLastError();
 }
+
+#include "ms_exec.inc"
 
 }  // namespace ms
 #if MS_GATE_PROBE

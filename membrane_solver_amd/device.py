@@ -526,6 +526,29 @@ class DeviceMesh:
                 "side_accepts": int(v[3]), "mismatches": int(v[4]), "ahead": int(v[5]), "adopted": int(v[6]),
                 "dropped": int(v[7])}
 
+    def exec_stats(self):
+        """One-workgroup interpreter of one-tile meshes (include/membrane_hip.h, ms_exec_stats)."""
+        v = np.zeros(4, dtype=np.int64)
+        self._chk(L.lib().ms_exec_stats(self._h, v.ctypes.data_as(L._I64)), "ms_exec_stats")
+        return {"active": bool(v[0]), "packs": int(v[1]), "launches_recorded": int(v[2]), "wanted": bool(v[3] & 1),
+                "relax_programs": int(v[3] >> 8)}
+
+    EXEC_KINDS = {1: "energy", 2: "gradient", 3: "tilt", 4: "bt", 5: "tsmooth", 6: "tvec", 7: "disk_target", 8: "reduce",
+                  9: "direction", 10: "row_dot", 11: "axpy_masked", 12: "memset", 13: "relax"}
+
+    def exec_trace(self, on: bool = True):
+        """Per-record durations of the one-workgroup interpreter since the last call (ms_exec_trace):
+        -> list of {kind, mode, inst, count, total_us, avg_us}."""
+        rows = np.zeros((256, 4), dtype=np.float64)
+        n = ctypes.c_int(0)
+        self._chk(L.lib().ms_exec_trace(self._h, 1 if on else 0, _pd(rows), 256, ctypes.byref(n)), "ms_exec_trace")
+        out = []
+        for k in range(n.value):
+            kind, mi, cnt, tot = int(rows[k, 0]), int(rows[k, 1]), int(rows[k, 2]), float(rows[k, 3])
+            out.append({"kind": self.EXEC_KINDS.get(kind, str(kind)), "mode": mi & 0xffff, "inst": mi >> 16, "count": cnt,
+                        "total_us": tot, "avg_us": tot / max(cnt, 1)})
+        return out
+
     def shard_info(self):
         v = [ctypes.c_int64(0) for _ in range(4)]
         self._chk(L.lib().ms_shard_info(self._h, *[ctypes.byref(x) for x in v]), "ms_shard_info")
