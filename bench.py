@@ -514,6 +514,14 @@ def secondary_config(name, freq, mods, cons, stepper_name, *, volume_row, step_s
            "value": steps / dt, "unit": "steps/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
            "steps_accepted": res["steps_accepted"], "line_search_trials": res["line_search_trials"],
            **rates(steps, res["steps_accepted"], res["line_search_trials"], run.get("guard_rejects", 0), 2, dt)}
+    rs = dm.resident_stats()
+    if rs["steps"] == 0 and rs["co_resident"] >= 0:
+        out["resident_step_kernel"] = dict(rs, note="eligible module set, but no step ran in the resident kernel")
+    if rs["steps"] > 0:
+        out["resident_step_kernel"] = dict(rs, note=(
+            "the timed steps ran in the resident kernel (csrc/ms_resident.inc: one launch for many steps, a workgroup per "
+            "tile, grid barriers between the phases); the per-kernel figures below are of the kernel-per-phase path, "
+            "measured in a separate pass with per-kernel timing on (which switches the resident kernel off)"))
     n_prof = min(steps, 40)
     dm.profile_enable(True)
     dm.profile_read()

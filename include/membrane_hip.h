@@ -541,6 +541,14 @@ int ms_queue_stats(ms_ctx *ctx, int64_t stats[8]);
  * stats: {active now, packs launched, launches recorded, bit 0 wanted (inactive while profiling) | relaxation
  * programs run << 8}.  No reference counterpart. */
 int ms_exec_stats(ms_ctx *ctx, int64_t stats[4]);
+/* Meshes whose tiles all fit on the chip at once (a few hundred tiles): ms_minimize runs the steps of the surface
+ * (+ volume constraint row) / gradient-descent lane in ONE launch per call -- one workgroup per tile keeps its tile in
+ * LDS across steps, grid barriers between the phases of a step, every workgroup folds the partials itself
+ * (runtime/minimizer.py:1189-1535, runtime/steppers/line_search.py:267-426 for that lane).  A step the kernel cannot
+ * take (guard range, exhausted search, drift projection, convergence) goes through the ordinary path.
+ * MS_RESIDENT=0 switches it off.  stats: {co-residency (-1 not asked, 0 no, 1 yes), launches, steps taken, steps
+ * declined}.  No reference counterpart. */
+int ms_resident_stats(ms_ctx *ctx, int64_t stats[4]);
 /* Diagnostic of the same interpreter: on != 0 arms a device buffer to which every record run appends its duration
  * (s_memrealtime); a call also returns what has accumulated since the last one, per (kind, mode) pair: rows of
  * {kind, mode | instance << 16, count, total microseconds} (max_rows rows of 4 doubles; NULL: just arm / disarm). */

@@ -298,6 +298,16 @@ struct ms_ctx {
   int64_t prof_n[MS_PROF_KINDS] = {0};
   std::string err;
   // one-tile meshes: launches are recorded and run by ONE workgroup, pack by pack (ms_internal.h: ExecRecorder)
+  // the resident step kernel (ms_resident.inc): meshes whose tiles all fit on the chip at once
+  bool resident_enable = true;   // MS_RESIDENT=0 switches it off
+  int resident_ok = -1;          // -1 not asked yet; 0 / 1: every tile's workgroup can be co-resident
+  size_t resident_lds = 0;
+  double* d_res_partials = nullptr;
+  unsigned int* d_res_bar = nullptr;
+  double* d_res_log = nullptr;
+  double* d_res_result = nullptr;
+  std::vector<double> h_res_log;
+  long resident_launches = 0, resident_steps = 0, resident_bails = 0;
   ExecRecorder exec;
   bool exec_relax = true;    // tilt relaxations run as a device program (CK_RELAX); MS_EXEC_RELAX=0: host-driven
   double* d_relax_cells = nullptr;           // [0] trial coefficient, [1] Fletcher-Reeves beta (written by the program)
@@ -1469,6 +1479,7 @@ int ms_create(ms_ctx** out, int device, int nv, int nf, const double* positions,
   c->no_fast = variant_env("MS_NO_FAST") != nullptr && atoi(variant_env("MS_NO_FAST")) != 0;
   c->pair_lean_enable = !(getenv("MS_PAIR_LEAN") != nullptr && atoi(getenv("MS_PAIR_LEAN")) == 0);
   c->deterministic = getenv("MS_DETERMINISTIC") != nullptr && atoi(getenv("MS_DETERMINISTIC")) != 0;
+  c->resident_enable = !(getenv("MS_RESIDENT") != nullptr && atoi(getenv("MS_RESIDENT")) == 0);
   c->params.modules = MS_MOD_SURFACE;
   c->params.bending_model = MS_BEND_HELFRICH;
   c->params.bending_grad_mode = MS_GRAD_ANALYTIC;
@@ -1548,6 +1559,10 @@ void ms_destroy(ms_ctx* c) {
   if (c->h_err) (void)hipHostFree(c->h_err);
   if (c->d_prof_ran) (void)hipFree(c->d_prof_ran);
   if (c->exec.d_stamps) (void)hipFree(c->exec.d_stamps);
+  if (c->d_res_partials) (void)hipFree(c->d_res_partials);
+  if (c->d_res_bar) (void)hipFree(c->d_res_bar);
+  if (c->d_res_log) (void)hipFree(c->d_res_log);
+  if (c->d_res_result) (void)hipFree(c->d_res_result);
   for (int l = 0; l < 3; ++l)
     if (c->tf[l].dt_target) (void)hipFree(c->tf[l].dt_target);
   if (c->d_relax_cells) (void)hipFree(c->d_relax_cells);
@@ -3391,6 +3406,105 @@ int ms_project_volume(ms_ctx* c, double target, double tol, int max_iter, int* i
   return ms_project_volume_cached(c, target, tol, max_iter, 0, iters_out, volume_out);
 }
 
+namespace {
+constexpr int RES_CHUNK = 4096;  // steps per launch (rows of the device step log)
+
+// can the steps of this ms_minimize call run in the resident kernel?  (surface + volume row, gradient descent, plain
+// Armijo search with evaluation reuse; everything else keeps the kernel-per-phase path)
+bool resident_eligible(ms_ctx* c, const ms_minimize_params* mp) {
+  const uint32_t mods = c->params.modules;
+  const ms_stepper_params& sp = mp->stepper;
+  if (!c->resident_enable || c->profiling || c->exec_on) return false;
+  if (c->shard_count != 1 || c->comm || c->allgather_cb || c->peer_on) return false;
+  if (c->til.T != 256 || c->til.own != 256 || !c->d_tile_facets32 || c->til.n_tiles < 2 || c->til.n_tiles > 2048) return false;
+  if (!(mods & MS_MOD_SURFACE) || (mods & ~(MS_MOD_SURFACE | MS_CON_VOLUME | MS_TRACK_VOLUME))) return false;
+  if (sp.stepper != MS_STEPPER_GD || sp.precondition || sp.enforce_volume || sp.reuse_energy0 < 2 || sp.edge_fraction > 0.0)
+    return false;
+  if (mp->relax_tilts || mp->fixed_step_mode) return false;
+  if (c->resident_ok < 0) {
+    c->resident_lds = resident_lds_bytes(c->cap, c->til.max_ent, c->til.max_tile_facets, false);
+    int ok = 0;
+    if (resident_fits(c->til.n_tiles, c->resident_lds, c->device, &ok) != hipSuccess) {
+      (void)hipGetLastError();
+      ok = 0;
+    }
+    c->resident_ok = ok;
+    if (trace_steps())
+      fprintf(stderr, "[mss] resident step kernel: %d tiles, %zu bytes of LDS per workgroup -> co-resident: %d\n",
+              c->til.n_tiles, c->resident_lds, ok);
+  }
+  return c->resident_ok == 1;
+}
+
+struct ResidentOutcome {
+  int steps = 0, reason = RES_DONE;
+  double step_size = 0.0, energy = 0.0, volume = 0.0;
+};
+
+// up to max_steps steps in one launch; the step log rows land in c->h_res_log
+int resident_run(ms_ctx* c, const ms_minimize_params* mp, int max_steps, double step_size, ResidentOutcome* ro) {
+  const Tiling& t = c->til;
+  const ms_stepper_params& sp = mp->stepper;
+  const int n = std::min(max_steps, RES_CHUNK);
+  if (!c->d_res_partials) {
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_res_partials), sizeof(double) * 4 * MS_NPART * (size_t)t.n_tiles));
+    HIPCHK(c, hipMemset(c->d_res_partials, 0, sizeof(double) * 4 * MS_NPART * (size_t)t.n_tiles));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_res_bar), sizeof(unsigned int) * RESIDENT_BAR_WORDS));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_res_log), sizeof(double) * 8 * RES_CHUNK));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_res_result), sizeof(double) * 8));
+  }
+  ResidentArgs a;
+  a.m = device_mesh(c);
+  a.x = c->buf[MS_BUF_X];
+  a.d = c->buf[MS_BUF_D];
+  a.partials = c->d_res_partials;
+  a.bar = c->d_res_bar;
+  a.log = c->d_res_log;
+  a.result = c->d_res_result;
+  a.n_steps = n;
+  a.volrow = (c->params.modules & MS_CON_VOLUME) ? 1 : 0;
+  a.want_vol = (c->params.modules & (MS_CON_VOLUME | MS_TRACK_VOLUME)) ? 1 : 0;
+  a.atomic = c->deterministic ? 0 : 1;
+  a.max_iter = sp.max_iter > 0 ? sp.max_iter : 10;
+  a.step_size = step_size;
+  a.tol = mp->tol;
+  a.c1 = sp.c;
+  a.beta = sp.beta;
+  a.gamma = sp.gamma;
+  a.alpha_max_factor = sp.alpha_max_factor;
+  a.drift_check = mp->drift_check;
+  a.target_volume = mp->target_volume;
+  a.volume_tolerance = mp->volume_tolerance;
+  a.cap = c->cap;
+  a.max_ent = t.max_ent;
+  HIPCHK(c, hipMemsetAsync(c->d_res_bar, 0, sizeof(unsigned int) * RESIDENT_BAR_WORDS, S(c)));
+  HIPCHK(c, launch_resident(a, c->resident_lds, c->stream));
+  double res[8];
+  HIPCHK(c, hipMemcpyAsync(res, c->d_res_result, sizeof(res), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  ro->steps = (int)res[0];
+  ro->reason = (int)res[1];
+  ro->step_size = res[2];
+  ro->energy = res[3];
+  ro->volume = res[4];
+  ++c->resident_launches;
+  c->resident_steps += ro->steps;
+  if (trace_steps())
+    fprintf(stderr, "[mss] resident launch: asked %d steps from step size %.3e -> took %d, reason %d, %d barriers\n", n,
+            step_size, ro->steps, ro->reason, (int)res[7]);
+  if (ro->steps > 0) {
+    c->h_res_log.resize((size_t)8 * ro->steps);
+    HIPCHK(c, hipMemcpy(c->h_res_log.data(), c->d_res_log, sizeof(double) * 8 * (size_t)ro->steps, hipMemcpyDeviceToHost));
+    // x has moved; nothing the step logic carries from earlier evaluations describes it any more
+    c->carry_valid = c->grad_valid = c->factors_valid = c->maxg2_valid = c->bt_valid = false;
+    c->kc_pending = false;
+    c->dir_implicit = false;
+  }
+  if (ro->reason == RES_TIMEOUT) return fail(c, MS_ERR_STATE, "resident step kernel: a grid barrier timed out");
+  return MS_OK;
+}
+}  // namespace
+
 int ms_minimize(ms_ctx* c, const ms_minimize_params* mp, int n_steps, ms_minimize_result* out,
                 double* step_log) {
   if (!c || !mp || !out) return fail(c, MS_ERR_INVALID, "ms_minimize: NULL argument");
@@ -3399,8 +3513,62 @@ int ms_minimize(ms_ctx* c, const ms_minimize_params* mp, int n_steps, ms_minimiz
   int zero_steps = 0;
   out->step_success = 1;
   out->step_size = step_size;
+  const bool resident = resident_eligible(c, mp);
+  int resident_cooldown = 0;       // iterations to leave to the ordinary path after the kernel declined a step
+  bool res_energy_valid = false;   // the last step taken was the resident kernel's: its energy is the current x's
+  double res_energy = 0.0;
   for (int i = 0; i < n_steps; ++i) {
     int rc;
+    if (resident && resident_cooldown == 0 && n_steps - i >= 2) {
+      // ---- as many steps as it will take in ONE launch (ms_resident.inc); bookkeeping per step as below ------------
+      drop_ahead(c, /*ran=*/2);
+      ResidentOutcome ro;
+      rc = resident_run(c, mp, n_steps - i, step_size, &ro);
+      if (rc) return rc;
+      for (int k = 0; k < ro.steps; ++k) {
+        const double* row = c->h_res_log.data() + 8 * (size_t)k;
+        out->iterations = i + k + 1;
+        out->energy_eval = row[3];
+        out->grad_norm = row[4];
+        if (step_log) memcpy(step_log + 8 * (size_t)(i + k), row, sizeof(double) * 8);
+        out->step_success = 1;
+        out->volume_cache_current = mp->drift_check ? 1 : 0;
+        out->trials += (int)row[7];
+        step_size = row[1];
+        ++out->accepted;
+        out->moved = 1;
+        out->step_size = step_size;
+        zero_steps = 0;
+      }
+      if (ro.steps > 0) {
+        res_energy_valid = true;
+        res_energy = ro.energy;
+      }
+      i += ro.steps;
+      if (ro.reason == RES_DRIFT) {  // :1478-1513, for the step just taken
+        if (mp->project_on_drift) {
+          int iters = 0;
+          rc = ms_project_volume_cached(c, mp->target_volume, 1e-12, 12, 1, &iters, nullptr);
+          if (rc) return rc;
+          out->volume_cache_current = 0;
+          res_energy_valid = false;
+        }
+        ms_reset_stepper(c);
+      } else if (ro.reason != RES_DONE) {
+        // convergence, guard range, an exhausted search, a non-descent direction: this iteration through the ordinary
+        // path (x is as the last completed step left it), and a few more before the kernel is asked again
+        resident_cooldown = ro.reason == RES_CONVERGED ? 0 : 8;
+        ++c->resident_bails;
+      }
+      if (i >= n_steps) break;
+      if (ro.reason == RES_DONE || ro.reason == RES_DRIFT) {
+        --i;  // (the loop increment: the next iteration is i)
+        continue;
+      }
+    } else if (resident_cooldown > 0) {
+      --resident_cooldown;
+    }
+    res_energy_valid = false;
     if (mp->relax_tilts) {  // minimizer.py:1237-1307: before the convergence check
       rc = (c->params.modules & MS_LEAFLET_MODS) ? ms_relax_leaflet_tilts(c, &mp->relax, nullptr, nullptr)
                                                   : ms_relax_tilts(c, &mp->relax, nullptr, nullptr);
@@ -3495,7 +3663,10 @@ int ms_minimize(ms_ctx* c, const ms_minimize_params* mp, int n_steps, ms_minimiz
     }
   }
   drop_ahead(c, /*ran=*/2);
-  if (c->carry_valid && !(c->params.modules & MS_ANY_TILT_MODS)) {
+  if (res_energy_valid) {  // (surface energy of the x the resident kernel ended at: the accepted trial's)
+    out->energy_current = res_energy;
+    out->energy_current_valid = 1;
+  } else if (c->carry_valid && !(c->params.modules & MS_ANY_TILT_MODS)) {
     // the mailbox energies describe the positions the loop ended at: the caller's final energy needs no pass
     double e[4];
     energies_from_mailbox(c, e);
@@ -4347,6 +4518,15 @@ int ms_queue_stats(ms_ctx* c, int64_t stats[8]) {
   stats[5] = c->q_ahead;
   stats[6] = c->q_adopted;
   stats[7] = c->q_dropped;
+  return MS_OK;
+}
+
+int ms_resident_stats(ms_ctx* c, int64_t stats[4]) {
+  if (!c || !stats) return MS_ERR_INVALID;
+  stats[0] = c->resident_ok;
+  stats[1] = c->resident_launches;
+  stats[2] = c->resident_steps;
+  stats[3] = c->resident_bails;
   return MS_OK;
 }
 

@@ -397,6 +397,34 @@ inline hipError_t exec_sync(hipStream_t s) {
   return r ? r->flush() : hipSuccess;
 }
 
+// the resident step kernel (ms_resident.inc): many minimizer steps of the surface (+ volume row) / gradient-descent lane
+// in one launch, one workgroup per tile, grid barriers between the phases
+struct ResidentArgs {
+  DeviceMesh m;
+  double* x;               // (nvp,3) positions: read at entry, owned rows written back at exit
+  double* d;               // (nvp,3) direction rows (tile-boundary rows are read by the neighbours)
+  double* partials;        // [2][2][MS_NPART][n_tiles]: consecutive phases alternate; two trials per search phase
+  unsigned int* bar;       // barrier words (zeroed by the host before the launch)
+  double* log;             // [n_steps][8] step log rows (ms_minimize's layout), written by workgroup 0
+  double* result;          // [8]: steps done, reason, step size, energy, volume, min_edge^2, trials, barriers
+  int n_steps, volrow, want_vol, atomic, max_iter;
+  double step_size, tol, c1, beta, gamma, alpha_max_factor;
+  int drift_check;
+  double target_volume, volume_tolerance;
+  int cap, max_ent;
+};
+enum : int {
+  RES_DONE = 0,        // all requested steps taken
+  RES_CONVERGED = 1,   // |g| < tol at the top of step `steps done` (no step taken there)
+  RES_BAIL = 2,        // step `steps done` needs the ordinary path (guard range, non-descent, exhausted search)
+  RES_DRIFT = 3,       // step `steps done - 1` was accepted and the volume drifted past the tolerance
+  RES_TIMEOUT = 4      // a grid barrier timed out (never expected: the host re-runs from the last consistent x)
+};
+constexpr int RESIDENT_BAR_WORDS = 11 * 32;
+size_t resident_lds_bytes(int cap, int max_ent, int max_tile_facets, bool atomic);
+hipError_t resident_fits(int n_tiles, size_t lds, int device, int* resident);
+hipError_t launch_resident(const ResidentArgs& a, size_t lds, hipStream_t s);
+
 // kernel launchers (ms_kernels.hip).  cap = T + max halo (LDS patch slots),
 // max_ent = largest per-tile vertex->corner entry count.
 size_t energy_lds_bytes(int T, int cap, int max_ent, bool bend, bool guard, bool flags, bool atomic = false);

@@ -118,7 +118,9 @@ __device__ __forceinline__ double block_reduce(double v, int op, double* red) {
 // Reduce NV per-thread values with ONE barrier: wave shuffles, lane 0 of each wave
 // parks its partials in red[k*16 + wave], then thread k folds value k across waves
 // and stores it to out[slots[k] * stride].  ops[k]: 0 sum, 1 min, 2 max.
-template <int NV>
+__device__ __forceinline__ void st_agent(double* p, double v);
+// AGENT: the partials are read by OTHER workgroups of the same launch (k_resident): agent-scope write-through stores
+template <int NV, bool AGENT = false>
 __device__ __forceinline__ void block_reduce_store(const double (&v)[NV], const int (&ops)[NV],
                                                    const int (&slots)[NV], double* red,
                                                    double* out, size_t stride) {
@@ -144,7 +146,8 @@ __device__ __forceinline__ void block_reduce_store(const double (&v)[NV], const 
       const double x = red[k * 16 + i];
       r = op == 0 ? r + x : (op == 1 ? fmin(r, x) : fmax(r, x));
     }
-    out[(size_t)slot * stride] = r;
+    if (AGENT) st_agent(out + (size_t)slot * stride, r);
+    else out[(size_t)slot * stride] = r;
   }
 }
 
@@ -3587,6 +3590,7 @@ hipError_t launch_curvature_raw(int nv, int nf, const double* pos, const int32_t
 }
 
 #include "ms_exec.inc"
+#include "ms_resident.inc"
 
 }  // namespace ms
 #if MS_GATE_PROBE

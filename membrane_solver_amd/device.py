@@ -533,6 +533,12 @@ class DeviceMesh:
         return {"active": bool(v[0]), "packs": int(v[1]), "launches_recorded": int(v[2]), "wanted": bool(v[3] & 1),
                 "relax_programs": int(v[3] >> 8)}
 
+    def resident_stats(self):
+        """The resident step kernel (include/membrane_hip.h, ms_resident_stats)."""
+        v = np.zeros(4, dtype=np.int64)
+        self._chk(L.lib().ms_resident_stats(self._h, v.ctypes.data_as(L._I64)), "ms_resident_stats")
+        return {"co_resident": int(v[0]), "launches": int(v[1]), "steps": int(v[2]), "declined": int(v[3])}
+
     EXEC_KINDS = {1: "energy", 2: "gradient", 3: "tilt", 4: "bt", 5: "tsmooth", 6: "tvec", 7: "disk_target", 8: "reduce",
                   9: "direction", 10: "row_dot", 11: "axpy_masked", 12: "memset", 13: "relax"}
 
