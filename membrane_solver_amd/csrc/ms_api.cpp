@@ -3457,6 +3457,8 @@ int resident_run(ms_ctx* c, const ms_minimize_params* mp, int max_steps, double 
   a.m = device_mesh(c);
   a.x = c->buf[MS_BUF_X];
   a.d = c->buf[MS_BUF_D];
+  a.g = c->buf[MS_BUF_G];
+  a.gC = c->buf[MS_BUF_GC];
   a.partials = c->d_res_partials;
   a.bar = c->d_res_bar;
   a.log = c->d_res_log;
@@ -3495,11 +3497,12 @@ int resident_run(ms_ctx* c, const ms_minimize_params* mp, int max_steps, double 
   if (ro->steps > 0) {
     c->h_res_log.resize((size_t)8 * ro->steps);
     HIPCHK(c, hipMemcpy(c->h_res_log.data(), c->d_res_log, sizeof(double) * 8 * (size_t)ro->steps, hipMemcpyDeviceToHost));
-    // x has moved; nothing the step logic carries from earlier evaluations describes it any more
-    c->carry_valid = c->grad_valid = c->factors_valid = c->maxg2_valid = c->bt_valid = false;
-    c->kc_pending = false;
-    c->dir_implicit = false;
   }
+  // x may have moved, and the launch used the G / GC / D buffers for its own (raw) rows even when it declined its first
+  // step: nothing the step logic carries from earlier evaluations is valid any more
+  c->carry_valid = c->grad_valid = c->factors_valid = c->maxg2_valid = c->bt_valid = false;
+  c->kc_pending = false;
+  c->dir_implicit = false;
   if (ro->reason == RES_TIMEOUT) return fail(c, MS_ERR_STATE, "resident step kernel: a grid barrier timed out");
   return MS_OK;
 }

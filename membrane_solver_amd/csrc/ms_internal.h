@@ -402,7 +402,9 @@ inline hipError_t exec_sync(hipStream_t s) {
 struct ResidentArgs {
   DeviceMesh m;
   double* x;               // (nvp,3) positions: read at entry, owned rows written back at exit
-  double* d;               // (nvp,3) direction rows (tile-boundary rows are read by the neighbours)
+  double* d;               // (unused)
+  double* g;               // (nvp,3) raw gradient rows of the last evaluation (tile-boundary rows are read by the
+  double* gC;              //         neighbours); (nvp,3) constraint-row rows, or nullptr
   double* partials;        // [2][2][MS_NPART][n_tiles]: consecutive phases alternate; two trials per search phase
   unsigned int* bar;       // barrier words (zeroed by the host before the launch)
   double* log;             // [n_steps][8] step log rows (ms_minimize's layout), written by workgroup 0
