@@ -3451,7 +3451,7 @@ int resident_run(ms_ctx* c, const ms_minimize_params* mp, int max_steps, double 
     HIPCHK(c, hipMemset(c->d_res_partials, 0, sizeof(double) * 4 * MS_NPART * (size_t)t.n_tiles));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_res_bar), sizeof(unsigned int) * RESIDENT_BAR_WORDS));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_res_log), sizeof(double) * 8 * RES_CHUNK));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_res_result), sizeof(double) * 8));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_res_result), sizeof(double) * 16));
   }
   ResidentArgs a;
   a.m = device_mesh(c);
@@ -3481,7 +3481,7 @@ int resident_run(ms_ctx* c, const ms_minimize_params* mp, int max_steps, double 
   a.max_ent = t.max_ent;
   HIPCHK(c, hipMemsetAsync(c->d_res_bar, 0, sizeof(unsigned int) * RESIDENT_BAR_WORDS, S(c)));
   HIPCHK(c, launch_resident(a, c->resident_lds, c->stream));
-  double res[8];
+  double res[16];
   HIPCHK(c, hipMemcpyAsync(res, c->d_res_result, sizeof(res), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   ro->steps = (int)res[0];
@@ -3494,6 +3494,10 @@ int resident_run(ms_ctx* c, const ms_minimize_params* mp, int max_steps, double 
   if (trace_steps())
     fprintf(stderr, "[mss] resident launch: asked %d steps from step size %.3e -> took %d, reason %d, %d barriers\n", n,
             step_size, ro->steps, ro->reason, (int)res[7]);
+  if (trace_steps() && ro->steps > 0)
+    fprintf(stderr, "[mss]   per step (us, workgroup 0): gradient %.2f | barrier %.2f | lambda+rows+direction %.2f | trial energies "
+                    "%.2f | barrier %.2f | fold %.2f\n", res[8] / ro->steps, res[9] / ro->steps, res[10] / ro->steps,
+            res[11] / ro->steps, res[12] / ro->steps, res[13] / ro->steps);
   if (ro->steps > 0) {
     c->h_res_log.resize((size_t)8 * ro->steps);
     HIPCHK(c, hipMemcpy(c->h_res_log.data(), c->d_res_log, sizeof(double) * 8 * (size_t)ro->steps, hipMemcpyDeviceToHost));

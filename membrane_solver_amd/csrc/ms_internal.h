@@ -408,7 +408,8 @@ struct ResidentArgs {
   double* partials;        // [2][2][MS_NPART][n_tiles]: consecutive phases alternate; two trials per search phase
   unsigned int* bar;       // barrier words (zeroed by the host before the launch)
   double* log;             // [n_steps][8] step log rows (ms_minimize's layout), written by workgroup 0
-  double* result;          // [8]: steps done, reason, step size, energy, volume, min_edge^2, trials, barriers
+  double* result;          // [16]: steps done, reason, step size, energy, volume, min_edge^2, trials, barriers,
+                           //       [8..13] where workgroup 0 spent its time (us, see k_resident)
   int n_steps, volrow, want_vol, atomic, max_iter;
   double step_size, tol, c1, beta, gamma, alpha_max_factor;
   int drift_check;
