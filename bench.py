@@ -473,7 +473,10 @@ def config5_deck(device, steps=40):
                         + f"; tilt_solve_mode {gp.get('tilt_solve_mode')}, {gp.get('tilt_inner_steps')} inner steps",
             "value": steps / dt, "unit": "steps/s", "ms_per_step": 1e3 * dt / steps, "relaxation_ms": 1e3 * t_rel,
             "steps": steps, "energy_end": float(res["energy"]),
-            "note": "launch-latency scale: a step is ~25 tiny launches and two host round trips per inner CG step"}
+            "one_workgroup_interpreter": dm.exec_stats(),
+            "note": ("one tile: the library records its launches and runs them in ONE workgroup (k_exec), each tilt "
+                     "relaxation as one launch with the reference's control flow in the workgroup; what a record costs is "
+                     "its chain of dependent memory round trips (~1.3-3 us), not a launch any more")}
 
 
 def secondary_config(name, freq, mods, cons, stepper_name, *, volume_row, step_size, steps, warmup, device):
