@@ -14,6 +14,18 @@ os.makedirs(out, exist_ok=True)
 ks = glob.glob(os.path.join(root, "gpurun_out", f"{tag}_stats", "*", "*kernel_stats.csv"))
 if ks:
     shutil.copy(ks[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
+# the other BASELINE configurations (tools/r04_profiles.sh): gpurun_out/<tag>_<name>_stats -> profiles/<tag>_<name>_*
+for d in sorted(glob.glob(os.path.join(root, "gpurun_out", f"{tag}_*_stats"))):
+    name = os.path.basename(d)[len(tag) + 1:-len("_stats")]
+    for f in glob.glob(os.path.join(d, "*", "*kernel_stats.csv")):
+        shutil.copy(f, os.path.join(out, f"{tag}_{name}_kernel_stats.csv"))
+    j = os.path.join(root, "gpurun_out", f"{tag}_{name}.json")
+    if os.path.exists(j) and os.path.getsize(j) > 0:
+        shutil.copy(j, os.path.join(out, f"{tag}_{name}.json"))
+for name in ("bench", "bench_s20w5", "bench_forced_sharded"):
+    j = os.path.join(root, "gpurun_out", f"{tag}_{name}.json")
+    if os.path.exists(j) and os.path.getsize(j) > 0:
+        shutil.copy(j, os.path.join(out, f"{tag}_{name}.json"))
 js = os.path.join(root, "gpurun_out", f"{tag}_stats.json")
 if os.path.exists(js):
     shutil.copy(js, os.path.join(out, f"{tag}_bench_under_rocprof.json"))
@@ -38,11 +50,10 @@ def empty_limits(rows):
     return {name: min(EMPTY_NS, EMPTY_FRAC * m) for name, m in longest.items()}
 
 
-kt = glob.glob(os.path.join(root, "gpurun_out", f"{tag}_stats", "*", "*kernel_trace.csv"))
-if kt:
+def write_nonempty(trace_csv, dst):
     durs = collections.defaultdict(list)
     skipped = collections.Counter()
-    trace = [(r["Kernel_Name"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(kt[0]))]
+    trace = [(r["Kernel_Name"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(trace_csv))]
     lim = empty_limits(trace)
     for name, d in trace:
         if d < lim.get(name, 0):
@@ -50,14 +61,23 @@ if kt:
             continue
         durs[name].append(d)
     tot = sum(sum(v) for v in durs.values()) or 1
-    with open(os.path.join(out, f"{tag}_kernel_stats_nonempty.csv"), "w", newline="") as f:
-        f.write(f"# from {os.path.basename(kt[0])}: dispatches of the gated tile kernels shorter than {EMPTY_NS} ns AND than\n")
+    with open(dst, "w", newline="") as f:
+        f.write(f"# from {os.path.basename(trace_csv)}: dispatches of the gated tile kernels shorter than {EMPTY_NS} ns AND than\n")
         f.write(f"# {EMPTY_FRAC} x the instantiation's longest dispatch (gate closed, immediate return) are left out; column EmptyDispatches counts them\n")
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "EmptyDispatches"])
         for name, v in sorted(durs.items(), key=lambda kv: -sum(kv[1])):
             w.writerow([name, len(v), sum(v), "%.3f" % (sum(v) / len(v)), "%.2f" % (100.0 * sum(v) / tot), min(v), max(v),
                         skipped.get(name, 0)])
+
+
+kt = glob.glob(os.path.join(root, "gpurun_out", f"{tag}_stats", "*", "*kernel_trace.csv"))
+if kt:
+    write_nonempty(kt[0], os.path.join(out, f"{tag}_kernel_stats_nonempty.csv"))
+for d in sorted(glob.glob(os.path.join(root, "gpurun_out", f"{tag}_*_stats"))):
+    name = os.path.basename(d)[len(tag) + 1:-len("_stats")]
+    for f in glob.glob(os.path.join(d, "*", "*kernel_trace.csv")):
+        write_nonempty(f, os.path.join(out, f"{tag}_{name}_kernel_stats_nonempty.csv"))
 rows = []
 for sub in ("fetch", "write", "sq"):
     for f in glob.glob(os.path.join(root, "gpurun_out", f"{tag}_{sub}", "*", "*counter_collection.csv")):
