@@ -322,7 +322,7 @@ struct AxpyMaskedArgs {
 // travels as the kernel's argument block.  Results are bit for bit those of the launch-per-kernel path.
 enum : uint16_t {
   CK_ENERGY = 1, CK_GRADIENT, CK_TILT, CK_BT, CK_TS, CK_TVEC, CK_DISK, CK_REDUCE, CK_DIRECTION, CK_ROWDOT,
-  CK_AXPY_MASKED, CK_MEMSET, CK_RELAX
+  CK_AXPY_MASKED, CK_MEMSET, CK_RELAX, CK_RELAX_FUSED
 };
 struct ExecCmdHead {
   uint16_t kind;
@@ -371,6 +371,31 @@ struct ExecRelaxHead {
   int32_t off_dir0, n_dir0, off_dir1, n_dir1;
   int32_t total_bytes, pad;         // record + lists (the interpreter's main loop skips them)
 };
+// CK_RELAX_FUSED: a leaflet relaxation with the frozen geometry held on the CU (ms_relax_fused.inc)
+struct ExecRelaxFusedField {
+  double* tilts;              // in: the projected start field; out: the relaxed field
+  const double* minv;         // Jacobi M^-1 (1 on clamped rows)
+  const double* va;           // barycentric vertex areas (tilt_in / tilt_out in the vertex-area form)
+  const double* bt_vert;      // (nvp,4): [0] = base_k = 2H - c0 of this leaflet
+  const double* kappa;
+  const double* dt_target;    // theta(r) r_hat of the tagged rows (NaN: profile off)
+  const uint8_t* disk;
+  double k_tilt, k_smooth, dt_strength, div_sign;
+  int32_t has_tilt, has_bt, has_ts, has_dt;
+  uint32_t fixed_bit, pad;
+};
+struct ExecRelaxFusedArgs {
+  DeviceMesh m;
+  const double* x;
+  const double* normals;      // unit vertex normals of the frozen surface
+  ExecRelaxFusedField f[2];
+  int32_t nf, solver, max_iters, cap, max_ent, pad;
+  double step_size, tol;
+  unsigned long long* host_box;  // {iterations, evaluations, parity (0), done}
+  unsigned long long ticket;
+};
+size_t relax_fused_lds_bytes(int cap, int max_ent, int max_tile_facets);
+
 struct ExecRecorder {
   hipStream_t stream = nullptr;
   int T = 0;

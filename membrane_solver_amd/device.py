@@ -531,7 +531,7 @@ class DeviceMesh:
         v = np.zeros(4, dtype=np.int64)
         self._chk(L.lib().ms_exec_stats(self._h, v.ctypes.data_as(L._I64)), "ms_exec_stats")
         return {"active": bool(v[0]), "packs": int(v[1]), "launches_recorded": int(v[2]), "wanted": bool(v[3] & 1),
-                "relax_programs": int(v[3] >> 8)}
+                "relax_programs": int((v[3] >> 8) & 0xffffff), "relax_fused": int(v[3] >> 32)}
 
     def resident_stats(self):
         """The resident step kernel (include/membrane_hip.h, ms_resident_stats)."""

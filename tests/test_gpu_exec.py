@@ -129,3 +129,42 @@ def test_multi_tile_meshes_keep_the_launch_per_kernel_path():
     dm.profile_enable(False)
     assert dm.exec_stats()["active"]
     dm.close()
+
+
+@pytest.mark.parametrize("fname", ["traj_config5_deck_gd.npz", "traj_disk6_cg_disktarget_coupled_gd.npz",
+                                   "traj_ico4_cg_btl_coupled_gd.npz", "traj_ico4_gd_leaflet_nested_cg.npz",
+                                   "traj_disk5_gd_btl_backtrack.npz"])
+def test_fused_leaflet_relaxation_agrees_with_the_generic_program(fname, monkeypatch):
+    """Default (LDS-atomic) contexts run leaflet relaxations of one-tile meshes with the frozen geometry on the CU
+    (csrc/ms_relax_fused.inc): the same operations as the recorded kernels, so the same iteration / evaluation counts and
+    fields equal to rounding; whole trajectories agree like any two runs of the default mode do."""
+    def run(fused):
+        monkeypatch.setenv("MS_EXEC_FUSED", "1" if fused else "0")
+        from test_gpu_leaflet import _leaflet_minimizer
+
+        g = load_golden(fname)
+        mesh, mz, _log = _leaflet_minimizer(g, LEAFLET.get(fname, "gd"), observe=False)
+        if fname.startswith("traj_config5") or "disktarget" in fname:
+            mesh.disk_rows_in = mesh.disk_rows_out = g["disk_rows"]
+        _mir, dm = mz._device()
+        rp = mz._tilt_relax_params()
+        counts = None
+        if rp is not None:
+            counts = dm.relax_leaflet_tilts(solver=rp["solver"], max_iters=rp["max_iters"], step_size=rp["step_size"],
+                                            tol=rp["tol"], jacobi=rp["jacobi"])
+        t_in, t_out = dm.get_leaflet_tilts("in"), dm.get_leaflet_tilts("out")
+        res = mz.minimize(int(g["n_steps"]))
+        return counts, t_in, t_out, mesh.positions_view().copy(), float(res["energy"]), dm.exec_stats(), g
+
+    c0, i0, o0, x0, e0, s0, g = run(False)
+    c1, i1, o1, x1, e1, s1, _ = run(True)
+    assert s0["relax_fused"] == 0
+    if c0 is not None:
+        assert s1["relax_fused"] > 0
+        assert c1 == c0, "iteration / evaluation counts of the relaxation differ"
+        scale = max(np.abs(i0).max(), np.abs(o0).max(), 1e-30)
+        assert np.abs(i1 - i0).max() <= 1e-11 * scale and np.abs(o1 - o0).max() <= 1e-11 * scale
+    assert np.abs(x1 - x0).max() <= 1e-8 * np.abs(x0).max()
+    assert abs(e1 - e0) <= 1e-8 * abs(e0)
+    # (no comparison with the fixture's final energy: the extra relaxation call above is not part of its trajectory;
+    # tests/test_gpu_leaflet.py runs the fixtures themselves, through this path in the default mode)
