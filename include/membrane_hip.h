@@ -519,7 +519,9 @@ int ms_tile_stats(ms_ctx *ctx, int64_t *n_tiles, int64_t *facet_instances,
  * (three), 9 gradient, lean instantiation (k_gradient<1,false,256,0,true,true>: analytic
  * bending, uniform surface tension, no separate previous-direction rows)} and resets the
  * counters.  Used by bench.py for the roofline figure. */
-#define MS_PROF_KINDS 11 /* 10: energy launch with four to eight trial evaluations (k_energy<...,8>) */
+#define MS_PROF_KINDS 13 /* 10: energy launch with four to eight trial evaluations (k_energy<...,8>);
+                          * 11: tilt smoothness pass (k_tsmooth); 12: tilt search pass (k_tsearch: several step
+                          * sizes of a relaxation's backtracking ladder, every tilt module, one launch) */
 int ms_profile_enable(ms_ctx *ctx, int on);
 int ms_profile_read(ms_ctx *ctx, double total_ms[MS_PROF_KINDS],
                     int64_t launches[MS_PROF_KINDS]);
@@ -549,6 +551,13 @@ int ms_exec_stats(ms_ctx *ctx, int64_t stats[4]);
  * MS_RESIDENT=0 switches it off.  stats: {co-residency (-1 not asked, 0 no, 1 yes), launches, steps taken, steps
  * declined}.  No reference counterpart. */
 int ms_resident_stats(ms_ctx *ctx, int64_t stats[4]);
+/* Tilt relaxations of multi-tile meshes: the backtracking search (runtime/steppers/tilt_relaxation.py:326-347,
+ * 380-398, 918-973, 1150-1230: up to twelve halvings of the step on E(P(t + step*src)), positions frozen) runs as
+ * search passes -- one launch evaluates several step sizes of the ladder for every tilt-reading module of both
+ * leaflets (k_tsearch) -- with the iteration and evaluation counts of the sequential loop.  Module sets the pass
+ * does not cover (disk targets, a lone tilt module on the single field, consistent mass there) and MS_TSEARCH=0 keep
+ * one launch per module, field and trial.  stats: {search passes launched, step sizes evaluated by them}. */
+int ms_tsearch_stats(ms_ctx *ctx, int64_t stats[2]);
 /* Diagnostic of the same interpreter: on != 0 arms a device buffer to which every record run appends its duration
  * (s_memrealtime); a call also returns what has accumulated since the last one, per (kind, mode) pair: rows of
  * {kind, mode | instance << 16, count, total microseconds} (max_rows rows of 4 doubles; NULL: just arm / disarm). */

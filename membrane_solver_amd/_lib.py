@@ -201,6 +201,7 @@ SIGNATURES = {
     "ms_queue_stats": (ctypes.c_int, [_P, _I64]),
     "ms_exec_stats": (ctypes.c_int, [_P, _I64]),
     "ms_resident_stats": (ctypes.c_int, [_P, _I64]),
+    "ms_tsearch_stats": (ctypes.c_int, [_P, _I64]),
     "ms_exec_trace": (ctypes.c_int, [_P, ctypes.c_int, _D, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "ms_shard_peer_export": (ctypes.c_int, [_P, _P]),
     "ms_shard_peer_open": (ctypes.c_int, [_P, _P]),

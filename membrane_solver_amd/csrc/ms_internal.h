@@ -475,6 +475,36 @@ hipError_t launch_tvec(int mode, int tile0, int tile1, int nv, int T, const uint
                        const double* normals, double* out, double coef, int flag, double* partials,
                        int n_tiles, hipStream_t s, uint8_t fixed_bit = VF_TILT_FIXED,
                        int s_gn2 = MS_S_TGNORM2, int s_rz = MS_S_TRZ);
+// Tilt search pass (ms_tsearch.inc): with the positions frozen, the energies of the tilt-reading modules of up to two
+// fields at up to MS_MAX_TRIALS step sizes of ONE backtracking ladder in ONE facet pass -- the trial rows
+// P(t + coef_j src) (k_tvec mode 2) are formed where they are staged, never written; trial j's per-tile partials go to
+// partials[j] in the slots the single-trial kernels use (k_bt<0>, k_tsmooth<0>, k_tvec mode 4), by the same sums.
+struct TsearchField {
+  const double* tilts;     // (nvp,3) current tangent tilts
+  const double* src;       // (nvp,3) search direction rows (the gradient or the CG direction)
+  const double* bt_vert;   // (nvp,4) record of the energy pass at these positions (bending_tilt on)
+  const double* kappa;     // (nvp) bending rigidity of this field
+  const double* va;        // (nvp) barycentric vertex areas (tilt_form 2)
+  double div_sign;         // -1 inner leaflet, +1 otherwise
+  double k_tilt;           // tilt modulus
+  double k_smooth;         // smoothness rigidity
+  int tilt_form;           // 0: module off; 1: per-facet form (k_bt<0>'s fused term / k_tilt<0>); 2: vertex-area form
+  int s_ebt, s_etilt, s_ets;  // reduction slots; s_ebt / s_ets < 0: module off
+  int fixed_bit;           // vertex flag bit that clamps a row of this field
+};
+struct TsearchArgs {
+  DeviceMesh m;
+  int tile0, tile1;
+  const double* x;
+  const double* normals;   // (nvp,3) frozen unit vertex normals
+  int n_fields, n_trials;
+  TsearchField f[2];
+  double coef[MS_MAX_TRIALS];       // sign * step_j
+  double* partials[MS_MAX_TRIALS];  // partial set of trial j
+};
+size_t tsearch_lds_bytes(int cap, int n_fields, int n_trials);
+hipError_t launch_tsearch(const TsearchArgs& a, int cap, hipStream_t s);
+
 // One fold launch.  set[]: the trials of a multi-trial launch in TRIAL order (the last one = the ordinary outputs); a
 // plain fold has one set.
 struct FoldSet {

@@ -211,6 +211,15 @@ __device__ __forceinline__ double axpy1(double x, double alpha, double d) {
 #endif
 }
 
+// A relaxation's trial row P(t + coef src), P = projection onto the tangent plane of the frozen unit normal n
+// (tilt_relaxation.py:330-334), spelled out ONCE: k_tvec mode 2 writes such rows, the search pass (ms_tsearch.inc) and
+// the fused one-tile relaxation form them where they are used -- the same doubles at every site.
+__device__ __forceinline__ V3 tilt_trial_row(V3 t0, V3 s, V3 n, double coef) {
+  const V3 q = mk(axpy1(t0.x, coef, s.x), axpy1(t0.y, coef, s.y), axpy1(t0.z, coef, s.z));
+  const double dt = dot_pinned(q, n);
+  return mk(axpy1(q.x, -dt, n.x), axpy1(q.y, -dt, n.y), axpy1(q.z, -dt, n.z));
+}
+
 // Cross-kernel scalars (the folded reductions and the decision words k_reduce derives from them) travel with
 // agent-scope accesses on BOTH sides: write-through `sc1` stores, `sc1` vector loads that bypass the CU's L1 and never
 // go through the scalar data cache.  They are the only data in the library that one kernel writes and the next one
@@ -2577,12 +2586,8 @@ __device__ __forceinline__ void tvec_body(const TvecArgs& a, int block_id) {
     } else {
       const V3 t0 = mk(tilts[o], tilts[o + 1], tilts[o + 2]);
       V3 r = t0;
-      if (!(tfix && flag)) {
-        const V3 q = mk(t0.x + coef * src[o], t0.y + coef * src[o + 1], t0.z + coef * src[o + 2]);
-        const V3 n = mk(normals[o], normals[o + 1], normals[o + 2]);
-        const double dt = dot(q, n);
-        r = mk(q.x - dt * n.x, q.y - dt * n.y, q.z - dt * n.z);
-      }
+      if (!(tfix && flag))
+        r = tilt_trial_row(t0, mk(src[o], src[o + 1], src[o + 2]), mk(normals[o], normals[o + 1], normals[o + 2]), coef);
       out[o] = r.x;
       out[o + 1] = r.y;
       out[o + 2] = r.z;
@@ -3592,6 +3597,7 @@ hipError_t launch_curvature_raw(int nv, int nf, const double* pos, const int32_t
 
 #include "ms_exec.inc"
 #include "ms_resident.inc"
+#include "ms_tsearch.inc"
 
 }  // namespace ms
 #if MS_GATE_PROBE

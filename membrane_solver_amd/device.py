@@ -511,11 +511,11 @@ class DeviceMesh:
 
     def profile_read(self):
         """-> {kind: (total_ms, launches)} per kernel kind (include/membrane_hip.h, ms_profile_read)."""
-        ms = np.zeros(11)
-        n = np.zeros(11, dtype=np.int64)
+        ms = np.zeros(13)
+        n = np.zeros(13, dtype=np.int64)
         self._chk(L.lib().ms_profile_read(self._h, _pd(ms), n.ctypes.data_as(L._I64)), "ms_profile_read")
         names = ("energy", "gradient", "direction", "reduce", "tilt", "bending_tilt", "tilt_vec", "energy_pair", "energy_triple",
-                 "gradient_lean", "energy_multi")
+                 "gradient_lean", "energy_multi", "tilt_smoothness", "tilt_search")
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
     def queue_stats(self):
@@ -538,6 +538,12 @@ class DeviceMesh:
         v = np.zeros(4, dtype=np.int64)
         self._chk(L.lib().ms_resident_stats(self._h, v.ctypes.data_as(L._I64)), "ms_resident_stats")
         return {"co_resident": int(v[0]), "launches": int(v[1]), "steps": int(v[2]), "declined": int(v[3])}
+
+    def tsearch_stats(self):
+        """Search passes of the tilt relaxations (include/membrane_hip.h, ms_tsearch_stats)."""
+        v = np.zeros(2, dtype=np.int64)
+        self._chk(L.lib().ms_tsearch_stats(self._h, v.ctypes.data_as(L._I64)), "ms_tsearch_stats")
+        return {"passes": int(v[0]), "step_sizes": int(v[1])}
 
     EXEC_KINDS = {1: "energy", 2: "gradient", 3: "tilt", 4: "bt", 5: "tsmooth", 6: "tvec", 7: "disk_target", 8: "reduce",
                   9: "direction", 10: "row_dot", 11: "axpy_masked", 12: "memset", 13: "relax"}

@@ -1,0 +1,158 @@
+"""The search pass of the tilt relaxations (csrc/ms_tsearch.inc: several step sizes of the backtracking ladder of
+runtime/steppers/tilt_relaxation.py:326-347, 380-398, 918-973, 1150-1230 in one launch, every tilt module of both
+leaflets) against the launch-per-module-and-trial path it replaces on multi-tile meshes (MS_TSEARCH=0): with fixed-order
+sums the relaxed fields, iteration and evaluation counts are EQUAL bit for bit -- the pass forms the same trial rows and
+the same per-tile partial sums.  (Parity with the reference / the oracle port is what test_gpu_leaflet.py and
+test_gpu_bending_tilt.py check through the same entry points, which now run this pass.)"""
+
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mesh(freq=14):
+    from membrane_solver_amd import meshgen
+
+    P, T = meshgen.icosphere(freq)
+    return meshgen.smooth_displace(P, 0.05), T, None
+
+
+def _tangent(P, T, seed, amp):
+    from oracle import minimizer_port as mp
+
+    rng = np.random.default_rng(seed)
+    nrm = mp.unit_vertex_normals(P, T)
+    t = amp * rng.normal(size=P.shape)
+    return t - np.einsum("ij,ij->i", t, nrm)[:, None] * nrm
+
+
+class _Env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            os.environ[k] = v
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _single(P, T, tl, fixed, smooth, tsearch, step, solver, iters, tile):
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd.device import DeviceMesh
+
+    with _Env(MS_TSEARCH="1" if tsearch else "0", MS_DETERMINISTIC="1"):
+        dm = DeviceMesh(P, T, tile_vertices=tile)
+    nv = len(P)
+    dm.set_surface_tension(np.ones(len(T)))
+    dm.set_bending_params(np.full(nv, 1.3), np.full(nv, 0.2))
+    dm.set_tilts(tl, 2.0)
+    dm.set_tilt_fixed(fixed)
+    mods = L.MS_MOD_SURFACE | L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT
+    if smooth:
+        dm.set_tilt_smoothness(0.6)
+        mods |= L.MS_MOD_TILT_SMOOTH
+    dm.set_params(modules=mods)
+    out = []
+    for _ in range(2):  # (the second call starts where the first search pattern left the predictor)
+        it, ev = dm.relax_tilts(solver=solver, max_iters=iters, step_size=step, jacobi=True)
+        out.append((it, ev, dm.get_tilts().copy()))
+    st = dm.tsearch_stats()
+    dm.close()
+    return out, st
+
+
+@pytest.mark.parametrize("tile", [64, 256])
+@pytest.mark.parametrize("solver,step,smooth", [("cg", 0.05, False), ("gd", 0.05, True), ("cg", 40.0, True), ("gd", 1.0e3, False)])
+def test_single_field_search_pass_equals_trial_launches(tile, solver, step, smooth):
+    """step 0.05: the first step size passes; 40 / 1e3: the ladder halves several times (8-trial passes, a second
+    pass behind them)."""
+    P, T, _ = _mesh(14)
+    tl = _tangent(P, T, 5, 0.2)
+    fixed = np.zeros(len(P), bool)
+    fixed[::11] = True
+    a, st_a = _single(P, T, tl, fixed, smooth, True, step, solver, 4, tile)
+    b, st_b = _single(P, T, tl, fixed, smooth, False, step, solver, 4, tile)
+    assert st_a["passes"] > 0 and st_b["passes"] == 0
+    if step > 1.0:
+        assert st_a["step_sizes"] > st_a["passes"]  # multi-trial passes ran
+    for (ia, ea, ta), (ib, eb, tb) in zip(a, b):
+        assert (ia, ea) == (ib, eb)
+        assert np.array_equal(ta, tb)
+    assert np.allclose(a[-1][2][fixed], tl[fixed], rtol=0, atol=1e-12)  # clamped rows: projected once, never moved
+
+
+def _leaflets(P, T, tin, tout, fin, mods_bt, tsearch, step, solver, iters, tile):
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd.device import DeviceMesh
+
+    with _Env(MS_TSEARCH="1" if tsearch else "0", MS_DETERMINISTIC="1"):
+        dm = DeviceMesh(P, T, tile_vertices=tile)
+    dm.set_surface_tension(np.ones(len(T)))
+    dm.set_leaflet_tilts("in", tin, tilt_fixed=fin, tilt_modulus=1.3, smoothness=0.4)
+    dm.set_leaflet_tilts("out", tout, tilt_modulus=0.7, mass_mode="consistent", smoothness=0.25)
+    mods = L.MS_MOD_SURFACE | L.MS_MOD_TILT_IN | L.MS_MOD_TILT_OUT | L.MS_MOD_TILT_SMOOTH_IN | L.MS_MOD_TILT_SMOOTH_OUT
+    if mods_bt:
+        dm.set_leaflet_bending("in", 1.2, 0.05)
+        dm.set_leaflet_bending("out", 0.8, -0.1)
+        mods |= L.MS_MOD_BENDING_TILT_IN | L.MS_MOD_BENDING_TILT_OUT
+    dm.set_params(modules=mods)
+    out = []
+    for _ in range(2):
+        it, ev = dm.relax_leaflet_tilts(solver=solver, max_iters=iters, step_size=step, jacobi=True)
+        out.append((it, ev, dm.get_leaflet_tilts("in").copy(), dm.get_leaflet_tilts("out").copy()))
+    st = dm.tsearch_stats()
+    dm.close()
+    return out, st
+
+
+@pytest.mark.parametrize("tile", [64, 256])
+@pytest.mark.parametrize("solver,step,bt", [("cg", 0.05, True), ("gd", 0.05, False), ("cg", 60.0, True), ("gd", 500.0, True)])
+def test_leaflet_search_pass_equals_trial_launches(tile, solver, step, bt):
+    P, T, _ = _mesh(14)
+    tin, tout = _tangent(P, T, 7, 0.2), _tangent(P, T, 8, 0.15)
+    fin = np.zeros(len(P), bool)
+    fin[::13] = True
+    a, st_a = _leaflets(P, T, tin, tout, fin, bt, True, step, solver, 3, tile)
+    b, st_b = _leaflets(P, T, tin, tout, fin, bt, False, step, solver, 3, tile)
+    assert st_a["passes"] > 0 and st_b["passes"] == 0
+    for (ia, ea, xa, ya), (ib, eb, xb, yb) in zip(a, b):
+        assert (ia, ea) == (ib, eb)
+        assert np.array_equal(xa, xb) and np.array_equal(ya, yb)
+
+
+def test_search_pass_declines_what_it_does_not_cover():
+    """A lone tilt module on the single field (k_tilt keeps its per-facet form) and one-tile meshes (the interpreter's
+    relaxation program) do not go through the pass."""
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd.device import DeviceMesh
+
+    P, T, _ = _mesh(14)
+    tl = _tangent(P, T, 9, 0.2)
+    dm = DeviceMesh(P, T, tile_vertices=64)
+    dm.set_surface_tension(np.ones(len(T)))
+    dm.set_tilts(tl, 2.0)
+    dm.set_tilt_smoothness(0.5)
+    dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_TILT | L.MS_MOD_TILT_SMOOTH)
+    dm.relax_tilts(solver="cg", max_iters=2, step_size=0.05, jacobi=True)
+    assert dm.tsearch_stats()["passes"] == 0
+    dm.close()
+    P1, T1, _ = _mesh(4)
+    dm = DeviceMesh(P1, T1)
+    assert dm.tile_stats()["n_tiles"] == 1
+    dm.set_surface_tension(np.ones(len(T1)))
+    dm.set_bending_params(np.full(len(P1), 1.3), np.full(len(P1), 0.2))
+    dm.set_tilts(_tangent(P1, T1, 2, 0.2), 2.0)
+    dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT)
+    dm.relax_tilts(solver="cg", max_iters=2, step_size=0.05, jacobi=True)
+    assert dm.tsearch_stats()["passes"] == 0
+    dm.close()
