@@ -491,6 +491,7 @@ struct TsearchField {
   int tilt_form;           // 0: module off; 1: per-facet form (k_bt<0>'s fused term / k_tilt<0>); 2: vertex-area form
   int s_ebt, s_etilt, s_ets;  // reduction slots; s_ebt / s_ets < 0: module off
   int fixed_bit;           // vertex flag bit that clamps a row of this field
+  double* trial_out;       // single-trial pass: the trial rows of the owned vertices are written here (or nullptr)
 };
 struct TsearchArgs {
   DeviceMesh m;
@@ -504,6 +505,32 @@ struct TsearchArgs {
 };
 size_t tsearch_lds_bytes(int cap, int n_fields, int n_trials);
 hipError_t launch_tsearch(const TsearchArgs& a, int cap, hipStream_t s);
+
+// Tilt gradient pass (ms_tsearch.inc): energies and tilt gradients of every tilt-reading module of up to two fields at the
+// current tilts, positions frozen, then k_tvec mode 0 on the finished rows -- one launch per evaluation of a relaxation.
+struct TgradField {
+  const double* tilts;
+  const double* bt_vert;
+  const double* kappa;
+  const double* va;        // tilt_form 2
+  const double* minv;      // Jacobi M^-1 (the <r, M^-1 r> partial)
+  double* grad;            // (nvp,3) out: dE/dt, clamped rows zero
+  double div_sign, k_tilt, k_smooth;
+  int tilt_form;           // 0 off; 1 per-facet energy, gradient k t_v A_v with the gathered barycentric area (k_tilt<1>); 2 vertex-area form (k_tvec mode 4)
+  int s_ebt, s_etilt, s_ets, s_gn2, s_rz;
+  int fixed_bit;
+};
+struct TgradArgs {
+  DeviceMesh m;
+  int tile0, tile1;
+  const double* x;
+  int n_fields;
+  TgradField f[2];
+  double* partials;
+};
+size_t tgrad_lds_bytes(int T, int cap, int max_ent, int n_fields);
+// combine: a corner's module terms are added before the gather (default mode); false: module by module, the per-module launches' sums
+hipError_t launch_tgrad(const TgradArgs& a, int cap, int max_ent, bool combine, hipStream_t s);
 
 // One fold launch.  set[]: the trials of a multi-trial launch in TRIAL order (the last one = the ordinary outputs); a
 // plain fold has one set.

@@ -46,11 +46,11 @@ class _Env:
                 os.environ[k] = v
 
 
-def _single(P, T, tl, fixed, smooth, tsearch, step, solver, iters, tile):
+def _single(P, T, tl, fixed, smooth, tsearch, step, solver, iters, tile, det=True):
     from membrane_solver_amd import _lib as L
     from membrane_solver_amd.device import DeviceMesh
 
-    with _Env(MS_TSEARCH="1" if tsearch else "0", MS_DETERMINISTIC="1"):
+    with _Env(MS_TSEARCH="1" if tsearch else "0", MS_DETERMINISTIC="1" if det else "0"):
         dm = DeviceMesh(P, T, tile_vertices=tile)
     nv = len(P)
     dm.set_surface_tension(np.ones(len(T)))
@@ -91,11 +91,11 @@ def test_single_field_search_pass_equals_trial_launches(tile, solver, step, smoo
     assert np.allclose(a[-1][2][fixed], tl[fixed], rtol=0, atol=1e-12)  # clamped rows: projected once, never moved
 
 
-def _leaflets(P, T, tin, tout, fin, mods_bt, tsearch, step, solver, iters, tile):
+def _leaflets(P, T, tin, tout, fin, mods_bt, tsearch, step, solver, iters, tile, det=True):
     from membrane_solver_amd import _lib as L
     from membrane_solver_amd.device import DeviceMesh
 
-    with _Env(MS_TSEARCH="1" if tsearch else "0", MS_DETERMINISTIC="1"):
+    with _Env(MS_TSEARCH="1" if tsearch else "0", MS_DETERMINISTIC="1" if det else "0"):
         dm = DeviceMesh(P, T, tile_vertices=tile)
     dm.set_surface_tension(np.ones(len(T)))
     dm.set_leaflet_tilts("in", tin, tilt_fixed=fin, tilt_modulus=1.3, smoothness=0.4)
@@ -128,6 +128,32 @@ def test_leaflet_search_pass_equals_trial_launches(tile, solver, step, bt):
     for (ia, ea, xa, ya), (ib, eb, xb, yb) in zip(a, b):
         assert (ia, ea) == (ib, eb)
         assert np.array_equal(xa, xb) and np.array_equal(ya, yb)
+
+
+@pytest.mark.parametrize("step", [0.05, 60.0])
+def test_default_mode_agrees_with_trial_launches(step):
+    """Default mode (per-vertex sums of the shape kernels by LDS atomics): the gradient pass adds a corner's module
+    terms before the gather -- same counts, fields equal to rounding."""
+    from conftest import relerr
+
+    P, T, _ = _mesh(14)
+    tin, tout = _tangent(P, T, 7, 0.2), _tangent(P, T, 8, 0.15)
+    fin = np.zeros(len(P), bool)
+    fin[::13] = True
+    a, st_a = _leaflets(P, T, tin, tout, fin, True, True, step, "cg", 3, 256, det=False)
+    b, _ = _leaflets(P, T, tin, tout, fin, True, False, step, "cg", 3, 256, det=False)
+    assert st_a["passes"] > 0
+    for (ia, ea, xa, ya), (ib, eb, xb, yb) in zip(a, b):
+        assert (ia, ea) == (ib, eb)
+        assert relerr(xa, xb) < 1e-11 and relerr(ya, yb) < 1e-11
+    tl = _tangent(P, T, 5, 0.2)
+    fixed = np.zeros(len(P), bool)
+    fixed[::11] = True
+    a, _ = _single(P, T, tl, fixed, True, True, step, "cg", 4, 256, det=False)
+    b, _ = _single(P, T, tl, fixed, True, False, step, "cg", 4, 256, det=False)
+    for (ia, ea, ta), (ib, eb, tb) in zip(a, b):
+        assert (ia, ea) == (ib, eb)
+        assert relerr(ta, tb) < 1e-11
 
 
 def test_search_pass_declines_what_it_does_not_cover():
