@@ -205,6 +205,13 @@ struct TiltArgs {
   double* va_out;         // mode 3: barycentric vertex areas (nvp) or nullptr
   double* fields;         // mode 5: curvature fields, four planes of (fields_rows, 3) -- see k_tilt
   int64_t fields_rows;
+  // mode 3, the set-up of a relaxation in the same launch: proj_out receives P(tilts) of the owned rows (k_tvec mode 2
+  // with step 0, on the normals just formed); finish_minv: `minv` receives the clamped INVERSE of the diagonal (k_tvec
+  // mode 3: 1 where the diagonal is <= 1e-12 and on rows clamped by fixed_bit) -- when no smoothness term is to be
+  // added to the diagonal first
+  double* proj_out = nullptr;
+  int finish_minv = 0;
+  int fixed_bit = 0;
 };
 
 struct DiskTargetArgs {   // tilt_disk_target_in.py:160-286

@@ -2029,8 +2029,21 @@ __device__ __forceinline__ void tilt_body(const TiltArgs& a, int cap, int max_en
       a.tilts_out[o] = nrm.x;
       a.tilts_out[o + 1] = nrm.y;
       a.tilts_out[o + 2] = nrm.z;
-      if (a.minv) a.minv[t.v_lo + tid] = a.k_tilt * aw;  // raw diagonal; k_tvec mode 3 clamps and inverts
+      if (a.minv) {  // raw diagonal (k_tvec mode 3 clamps and inverts), or finished here
+        double dg = a.k_tilt * aw;
+        if (a.finish_minv) {
+          if (!(dg > 1.0e-12) || (a.m.vflags[t.v_lo + tid] & a.fixed_bit)) dg = 1.0;
+          dg = 1.0 / dg;
+        }
+        a.minv[t.v_lo + tid] = dg;
+      }
       if (a.va_out) a.va_out[t.v_lo + tid] = aw;         // barycentric vertex area (mesh.py:671-730)
+      if (a.proj_out) {
+        const V3 r = tilt_trial_row(tv, tv, nrm, 0.0);
+        a.proj_out[o] = r.x;
+        a.proj_out[o + 1] = r.y;
+        a.proj_out[o + 2] = r.z;
+      }
     }
   }
   if (MODE != 2 && MODE != 3 && MODE != 4 && MODE != 5) {

@@ -46,7 +46,7 @@ class _Env:
                 os.environ[k] = v
 
 
-def _single(P, T, tl, fixed, smooth, tsearch, step, solver, iters, tile, det=True):
+def _single(P, T, tl, fixed, smooth, tsearch, step, solver, iters, tile, det=True, calls=2):
     from membrane_solver_amd import _lib as L
     from membrane_solver_amd.device import DeviceMesh
 
@@ -63,7 +63,7 @@ def _single(P, T, tl, fixed, smooth, tsearch, step, solver, iters, tile, det=Tru
         mods |= L.MS_MOD_TILT_SMOOTH
     dm.set_params(modules=mods)
     out = []
-    for _ in range(2):  # (the second call starts where the first search pattern left the predictor)
+    for _ in range(calls):  # (a later call starts where the search pattern before it left the predictor)
         it, ev = dm.relax_tilts(solver=solver, max_iters=iters, step_size=step, jacobi=True)
         out.append((it, ev, dm.get_tilts().copy()))
     st = dm.tsearch_stats()
@@ -89,6 +89,22 @@ def test_single_field_search_pass_equals_trial_launches(tile, solver, step, smoo
         assert (ia, ea) == (ib, eb)
         assert np.array_equal(ta, tb)
     assert np.allclose(a[-1][2][fixed], tl[fixed], rtol=0, atol=1e-12)  # clamped rows: projected once, never moved
+
+
+def test_whole_ladder_rejected():
+    """A step size far too large: every one of the twelve halvings is rejected (13 evaluations, nothing moves).  From
+    the second such search on both passes are queued back to back."""
+    P, T, _ = _mesh(14)
+    tl = _tangent(P, T, 5, 0.2)
+    fixed = np.zeros(len(P), bool)
+    fixed[::11] = True
+    a, st_a = _single(P, T, tl, fixed, True, True, 1.0e30, "gd", 3, 256, calls=3)
+    b, _ = _single(P, T, tl, fixed, True, False, 1.0e30, "gd", 3, 256, calls=3)
+    for (ia, ea, ta), (ib, eb, tb) in zip(a, b):
+        assert (ia, ea) == (ib, eb) == (1, 13)
+        assert np.array_equal(ta, tb)
+    assert np.allclose(a[0][2], a[-1][2], rtol=0, atol=1e-14)  # (every call projects once more)
+    assert st_a == {"passes": 3 + 3 + 2 + 2, "step_sizes": 3 * 12}  # gradient passes; 1 + 8 + 3, then 8 + 4 twice
 
 
 def _leaflets(P, T, tin, tout, fin, mods_bt, tsearch, step, solver, iters, tile, det=True):
