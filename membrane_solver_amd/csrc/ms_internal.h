@@ -212,6 +212,11 @@ struct TiltArgs {
   double* proj_out = nullptr;
   int finish_minv = 0;
   int fixed_bit = 0;
+  // mode 3 also as the projection pass of up to two more fields (mode 2's arithmetic on the same normals):
+  // fld_out[k] <- fld_in[k] - (fld_in[k].n) n on the owned rows -- the leaflet trial projections of an energy evaluation
+  // that needs the normals anyway (bending_tilt_in/out)
+  const double* fld_in[2] = {nullptr, nullptr};
+  double* fld_out[2] = {nullptr, nullptr};
 };
 
 struct DiskTargetArgs {   // tilt_disk_target_in.py:160-286
@@ -506,6 +511,11 @@ struct TsearchArgs {
   const double* x;
   const double* normals;   // (nvp,3) frozen unit vertex normals
   int n_fields, n_trials;
+  // the same pass as the tilt-module energy evaluation of a SHAPE trial (one step size, plain): positions x + alpha d
+  // (d != nullptr), the fields' rows taken as they are (already projected onto that surface), tilt_form 1
+  const double* d;
+  double alpha;
+  int plain;
   TsearchField f[2];
   double coef[MS_MAX_TRIALS];       // sign * step_j
   double* partials[MS_MAX_TRIALS];  // partial set of trial j

@@ -2038,6 +2038,15 @@ __device__ __forceinline__ void tilt_body(const TiltArgs& a, int cap, int max_en
         a.minv[t.v_lo + tid] = dg;
       }
       if (a.va_out) a.va_out[t.v_lo + tid] = aw;         // barycentric vertex area (mesh.py:671-730)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (a.fld_in[k] != nullptr) {  // (MODE 2's projection, expression for expression)
+          const V3 tk = mk(a.fld_in[k][o], a.fld_in[k][o + 1], a.fld_in[k][o + 2]);
+          const double dk = dot(tk, nrm);
+          a.fld_out[k][o] = tk.x - dk * nrm.x;
+          a.fld_out[k][o + 1] = tk.y - dk * nrm.y;
+          a.fld_out[k][o + 2] = tk.z - dk * nrm.z;
+        }
       if (a.proj_out) {
         const V3 r = tilt_trial_row(tv, tv, nrm, 0.0);
         a.proj_out[o] = r.x;

@@ -198,3 +198,50 @@ def test_search_pass_declines_what_it_does_not_cover():
     dm.relax_tilts(solver="cg", max_iters=2, step_size=0.05, jacobi=True)
     assert dm.tsearch_stats()["passes"] == 0
     dm.close()
+
+
+def _leaflet_ctx(P, T, tin, tout, fin, tsearch, tile):
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd.device import DeviceMesh
+
+    with _Env(MS_TSEARCH="1" if tsearch else "0", MS_DETERMINISTIC="1"):
+        dm = DeviceMesh(P, T, tile_vertices=tile)
+    dm.set_surface_tension(np.ones(len(T)))
+    dm.set_leaflet_tilts("in", tin, tilt_fixed=fin, tilt_modulus=1.3, smoothness=0.4)
+    dm.set_leaflet_tilts("out", tout, tilt_modulus=0.7, smoothness=0.25)
+    dm.set_leaflet_bending("in", 1.2, 0.05)
+    dm.set_leaflet_bending("out", 0.8, -0.1)
+    dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_TILT_IN | L.MS_MOD_TILT_OUT | L.MS_MOD_TILT_SMOOTH_IN |
+                  L.MS_MOD_TILT_SMOOTH_OUT | L.MS_MOD_BENDING_TILT_IN | L.MS_MOD_BENDING_TILT_OUT)
+    return dm
+
+
+@pytest.mark.parametrize("tile", [64, 256])
+def test_shape_trial_energies_through_the_pass(tile):
+    """Energy-only evaluations (the energy at x, the trials of the shape line search) take the tilt modules' facet
+    passes as ONE launch; the energies and the steps they decide agree with the launch-per-module path (energies 1e-13,
+    accepted step sizes and trial counts equal)."""
+    from membrane_solver_amd import _lib as L
+
+    P, T, _ = _mesh(14)
+    tin, tout = _tangent(P, T, 7, 0.2), _tangent(P, T, 8, 0.15)
+    fin = np.zeros(len(P), bool)
+    fin[::13] = True
+    logs = []
+    for on in (True, False):
+        dm = _leaflet_ctx(P, T, tin, tout, fin, on, tile)
+        log = [dm.energy().copy()]
+        for _ in range(3):
+            r = dm.step(stepper=L.MS_STEPPER_GD, step_size=1e-3, tol=0.0)
+            log.append((r.success, r.alpha, r.trials, r.energy))
+            dm.relax_leaflet_tilts(solver="cg", max_iters=2, step_size=0.05, jacobi=True)
+        log.append(dm.energy().copy())
+        logs.append((log, dm.tsearch_stats(), dm.get_positions().copy()))
+        dm.close()
+    (la, sa, xa), (lb, sb, xb) = logs
+    assert sa["passes"] > sb["passes"] == 0
+    assert np.allclose(la[0], lb[0], rtol=1e-13, atol=0) and np.allclose(la[-1], lb[-1], rtol=1e-12, atol=0)
+    for ra, rb in zip(la[1:-1], lb[1:-1]):
+        assert ra[:3] == rb[:3]
+        assert abs(ra[3] - rb[3]) <= 1e-12 * abs(rb[3])
+    assert np.allclose(xa, xb, rtol=0, atol=1e-13)
