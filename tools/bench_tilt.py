@@ -46,11 +46,18 @@ mz = Minimizer(mesh, mesh.global_parameters, GradientDescent(), EnergyModuleMana
 E0 = mz.compute_energy()
 mz.minimize(5, sync_mesh=False)
 dm = mesh._hip_mirror.dm
+# timed: the steps as a caller runs them
+ts0 = dm.tsearch_stats()
+t0 = time.perf_counter()
+res = mz.minimize(args.steps, sync_mesh=False)
+dt = time.perf_counter() - t0
+ts1 = dm.tsearch_stats()
+# the same number of steps once more with an event pair around every launch (per-kernel averages; slower)
 dm.profile_enable(True)
 dm.profile_read()
 t0 = time.perf_counter()
 res = mz.minimize(args.steps, sync_mesh=False)
-dt = time.perf_counter() - t0
+dtp = time.perf_counter() - t0
 prof = dm.profile_read()
 dm.profile_enable(False)
 # relaxation alone
@@ -61,6 +68,9 @@ dtr = time.perf_counter() - t1
 out = {"workload": f"icosphere f={args.freq} (nv={nv}, nf={nf}), {' + '.join(mods)}, GD shape stepper, "
                    f"nested Jacobi-CG tilt relaxation ({args.inner} inner steps)",
        "steps_per_s": args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
+       "steps_per_s_with_launch_events": args.steps / dtp,
+       "search_passes_per_step": (ts1["passes"] - ts0["passes"]) / args.steps,
+       "step_sizes_per_step": (ts1["step_sizes"] - ts0["step_sizes"]) / args.steps,
        "relax_ms": 1e3 * dtr, "relax_iters": it, "relax_evals": ev,
        "energy_start": E0, "energy_end": res["energy"],
        "kernels_per_step": {k: {"avg_us": 1e3 * ms / n, "launches_per_step": n / args.steps}
