@@ -814,6 +814,11 @@ def sharded_extra_leg(args, rank, world, local_rank, freq, steps, warmup, exchan
                         if exchange == "peer" else "RCCL all-gather")}
     if exchange == "peer" and lib:
         out["peer_memory"] = be.dm.peer_memory_kind()
+        cs = be.dm.shard_chain_stats()
+        out["device_side_decisions"] = dict(cs, note="trials whose Armijo decision was ALSO taken on the device from the ranks' "
+                                            "headers (the host replays it), with the commit, the gradient + direction pass of "
+                                            "the accepted point and its exchange queued behind the decision word: queued / ran "
+                                            "(main trial accepted) / adopted by the next step / dropped; since ms_create")
     be.dm.close()
     return out
 

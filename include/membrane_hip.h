@@ -485,6 +485,15 @@ int ms_shard_step(ms_ctx *ctx, const ms_stepper_params *params, double step_size
                   double tol, ms_step_result *out);
 /* number of exchanges done so far by ms_shard_step on this context */
 int64_t ms_shard_exchange_count(const ms_ctx *ctx);
+/* Peer-to-peer transport with in-kernel flag words: ms_shard_step also takes a trial's Armijo decision on the device
+ * (from the scalar headers every rank has in its slab, added in rank order: the host's arithmetic), and queues what an
+ * acceptance is followed by -- the commit x <- x + alpha d, the gradient + direction pass of the new point and that
+ * pass's exchange -- behind it, gated on the decision word; the host replays the decision from the same headers
+ * (a difference is an error) and the next ms_shard_step takes the pass's results instead of queueing it
+ * (runtime/minimizer.py:1189-1535, line_search.py:386-392: no reference counterpart, same trajectory).
+ * MS_SHARD_CHAIN=0 switches it off.  stats: {chains queued, chains that ran (main trial accepted), adopted by the next
+ * step, dropped (the next step wanted another pass)}. */
+int ms_shard_chain_stats(const ms_ctx *ctx, int64_t stats[4]);
 /* ranks of the context's RCCL communicator as ncclCommCount reports them (0: no communicator) */
 int ms_shard_comm_ranks(ms_ctx *ctx);
 /* Kind of device memory the peer exchange's receive slabs and flag words live in: 0 uncached (MTYPE_UC, what the

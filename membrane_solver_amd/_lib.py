@@ -186,6 +186,7 @@ SIGNATURES = {
     "ms_shard_step": (ctypes.c_int, [_P, ctypes.POINTER(ms_stepper_params), ctypes.c_double, ctypes.c_double,
                                      ctypes.POINTER(ms_step_result)]),
     "ms_shard_exchange_count": (ctypes.c_int64, [_P]),
+    "ms_shard_chain_stats": (ctypes.c_int, [_P, _I64]),
     "ms_shard_comm_ranks": (ctypes.c_int, [_P]),
     "ms_shard_peer_memory_kind": (ctypes.c_int, [_P]),
     "ms_state_bytes": (ctypes.c_size_t, [_P]),

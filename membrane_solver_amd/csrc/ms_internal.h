@@ -598,7 +598,8 @@ hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_of
                                   const double* recv, size_t stride, double* scal_all, hipStream_t s,
                                   unsigned long long* host_seq = nullptr, unsigned long long ticket = 0,
                                   bool remote_written = false, const unsigned long long* wait_flags = nullptr,
-                                  unsigned long long wait_ticket = 0, unsigned long long* host_err = nullptr);
+                                  unsigned long long wait_ticket = 0, unsigned long long* host_err = nullptr,
+                                  const uint32_t* gate = nullptr, uint32_t gate_want = 0);
 hipError_t launch_post_seq(unsigned long long* host_seq, unsigned long long ticket, hipStream_t s);
 // profiling only: *out = (*gate == want), one lane, queued right behind a gated launch (ms_profile_*)
 hipError_t launch_gate_probe(const uint32_t* gate, uint32_t want, uint32_t* out, hipStream_t s);
@@ -612,13 +613,26 @@ struct PeerFlags {
 hipError_t launch_pack_peers(const int32_t* rows, int n_rows, const double* const* bufs, const int* ncomp, int n_bufs,
                              const double* scal, double* const* dst, int world, hipStream_t s,
                              const PeerFlags* d_flags = nullptr, unsigned int* d_arrived = nullptr, int me = 0,
-                             unsigned long long ticket = 0);
+                             unsigned long long ticket = 0, const uint32_t* gate = nullptr, uint32_t gate_want = 0);
+// the Armijo decision of a sharded trial from the scalar headers in this rank's slab (k_shard_decide)
+struct ShardDecideArgs {
+  const double* recv;      // slab of this exchange: world x stride doubles, rank r's header at recv + r * stride
+  size_t stride;
+  int world;
+  int has_alt, alt_off;    // pair launch: trial 0's slots sit alt_off further in the header
+  int slot_a, slot_b;      // energy slots whose rank-ordered sums add up to the trial energy (-1: module off)
+  double rhs_alt, rhs_main;
+  uint32_t* dec_out;
+  unsigned long long* post;  // pinned {value, value XOR ticket} pair for the host's replay (or nullptr)
+  unsigned long long ticket;
+};
+hipError_t launch_shard_decide(const ShardDecideArgs& a, hipStream_t s);
 hipError_t launch_flag_peers(unsigned long long* const* peer_flags, int me, int world, unsigned long long ticket,
                              hipStream_t s);
 
 hipError_t launch_axpy_rows(int64_t row0, int64_t row1, const int32_t* extra, int n_extra,
                             const uint8_t* vflags, double* x, const double* y, double coef,
-                            hipStream_t s);
+                            hipStream_t s, const uint32_t* gate = nullptr, uint32_t gate_want = 0);
 hipError_t launch_row_dot(int tile0, int tile1, int nv, int T, const double* g, const double* gC, double* partials,
                           int n_tiles, hipStream_t s);
 hipError_t launch_direction(int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* g,

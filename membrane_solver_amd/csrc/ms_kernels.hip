@@ -3239,7 +3239,10 @@ __device__ __forceinline__ void st_sys_f64(double* p, double v) {
 // the pack): every block completes its stores (system-scope fence), then counts itself in at agent scope; the last one
 // has thereby acquired all the others' and publishes the ticket with a system-scope release
 __global__ void k_pack_peers(const int32_t* rows, int n_rows, RowBufs b, const double* scal, PeerDst dst,
-                             const PeerFlags* flags, unsigned int* arrived, int me, unsigned long long ticket) {
+                             const PeerFlags* flags, unsigned int* arrived, int me, unsigned long long ticket,
+                             const uint32_t* gate, uint32_t gate_want) {
+  // (an exchange queued behind a decision every rank takes from the same doubles: skipped by all of them or by none)
+  if (gate != nullptr && ld_agent(gate) != gate_want) return;
   double* send = dst.p[blockIdx.y];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < MS_NSCAL) st_sys_f64(send + j, ld_agent(scal + j));
@@ -3272,7 +3275,8 @@ __global__ void k_unpack_boundary(const int32_t* rows_all, const int32_t* row_of
                                   RowBufs b, const double* recv, size_t stride, double* scal_all,
                                   unsigned long long* host_seq, unsigned long long ticket,
                                   const unsigned long long* wait_flags, unsigned long long wait_ticket,
-                                  unsigned long long* host_err) {
+                                  unsigned long long* host_err, const uint32_t* gate, uint32_t gate_want) {
+  if (gate != nullptr && ld_agent(gate) != gate_want) return;
   const int r = blockIdx.y;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const double* src = recv + (size_t)r * stride;
@@ -3338,7 +3342,7 @@ hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_of
                                   const double* recv, size_t stride, double* scal_all, hipStream_t s,
                                   unsigned long long* host_seq, unsigned long long ticket, bool remote_written,
                                   const unsigned long long* wait_flags, unsigned long long wait_ticket,
-                                  unsigned long long* host_err) {
+                                  unsigned long long* host_err, const uint32_t* gate, uint32_t gate_want) {
   if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
   RowBufs b{};
   b.n = n_bufs;
@@ -3350,16 +3354,17 @@ hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_of
   const int n = max_rows > MS_NSCAL ? max_rows : MS_NSCAL;
   if (remote_written)
     hipLaunchKernelGGL(k_unpack_boundary<true>, dim3((n + 255) / 256, world), dim3(256), 0, s, rows_all, row_off,
-                       me, b, recv, stride, scal_all, host_seq, ticket, wait_flags, wait_ticket, host_err);
+                       me, b, recv, stride, scal_all, host_seq, ticket, wait_flags, wait_ticket, host_err, gate, gate_want);
   else
     hipLaunchKernelGGL(k_unpack_boundary<false>, dim3((n + 255) / 256, world), dim3(256), 0, s, rows_all, row_off,
-                       me, b, recv, stride, scal_all, host_seq, ticket, nullptr, 0ull, nullptr);
+                       me, b, recv, stride, scal_all, host_seq, ticket, nullptr, 0ull, nullptr, gate, gate_want);
   return hipGetLastError();
 }
 
 hipError_t launch_pack_peers(const int32_t* rows, int n_rows, const double* const* bufs, const int* ncomp, int n_bufs,
                              const double* scal, double* const* dst, int world, hipStream_t s,
-                             const PeerFlags* d_flags, unsigned int* d_arrived, int me, unsigned long long ticket) {
+                             const PeerFlags* d_flags, unsigned int* d_arrived, int me, unsigned long long ticket,
+                             const uint32_t* gate, uint32_t gate_want) {
   if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
   if (world > 16) return hipErrorInvalidValue;
   RowBufs b{};
@@ -3373,7 +3378,7 @@ hipError_t launch_pack_peers(const int32_t* rows, int n_rows, const double* cons
   for (int r = 0; r < world; ++r) d.p[r] = dst[r];
   const int n = n_rows > MS_NSCAL ? n_rows : MS_NSCAL;
   hipLaunchKernelGGL(k_pack_peers, dim3((n + 255) / 256, world), dim3(256), 0, s, rows, n_rows, b, scal, d, d_flags,
-                     d_arrived, me, ticket);
+                     d_arrived, me, ticket, gate, gate_want);
   return hipGetLastError();
 }
 
@@ -3395,6 +3400,38 @@ __global__ void k_post_seq(unsigned long long* host_seq, unsigned long long tick
   *reinterpret_cast<volatile unsigned long long*>(host_seq) = ticket;
 }
 
+// The Armijo decision of a SHARDED trial, on the device: queued behind the unpack kernel of the trial's exchange (every
+// rank's scalar header is in this rank's slab by then), one lane adds the ranks' energy slots in rank order -- the
+// host's fold, rounding for rounding (shard_exchange_take / shard_energy_of) -- and tests trial 0 (a pair launch's
+// other trial, header slots SH_ALT + s) and the main trial against their right-hand sides.  Every rank reads the same
+// doubles and writes the same word; the kernels queued behind it (commit, gradient + direction pass, their exchange)
+// are gated on it.  The host replays the decision from the headers it receives and compares (post).
+__global__ void k_shard_decide(ShardDecideArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  auto ld = [&](const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+  uint32_t code = DEC_CONTINUE;
+  for (int t = a.has_alt ? 0 : 1; t < 2 && code == DEC_CONTINUE; ++t) {
+    const int base = t == 0 ? a.alt_off : 0;
+    double e = 0.0;
+    for (int k = 0; k < 2; ++k) {
+      const int slot = k == 0 ? a.slot_a : a.slot_b;
+      if (slot < 0) continue;
+      double acc = 0.0;
+      for (int r = 0; r < a.world; ++r) acc += ld(a.recv + (size_t)r * a.stride + base + slot);
+      e += acc;
+    }
+    e += 0.0;  // (the host adds the penalty term here: 0.0 without that module -- the only case this kernel is queued in)
+    if (e <= (t == 0 ? a.rhs_alt : a.rhs_main)) code = t == 0 ? DEC_ACCEPT_SIDE : DEC_ACCEPT_MAIN;
+  }
+  st_agent(a.dec_out, code);
+  if (a.post != nullptr) post_entry(a.post, 0, (unsigned long long)code, a.ticket);
+}
+hipError_t launch_shard_decide(const ShardDecideArgs& a, hipStream_t s) {
+  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
+  hipLaunchKernelGGL(k_shard_decide, dim3(1), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+
 __global__ void k_gate_probe(const uint32_t* gate, uint32_t want, uint32_t* out) {
   *out = ld_agent(gate) == want ? 1u : 0u;
 }
@@ -3412,7 +3449,9 @@ hipError_t launch_post_seq(unsigned long long* host_seq, unsigned long long tick
 
 // x[i] += coef * y[i] on movable rows of [row0, row1) and of an explicit row list (shard commit)
 __global__ void k_axpy_rows(int64_t row0, int64_t row1, const int32_t* extra, int n_extra,
-                            const uint8_t* vflags, double* x, const double* y, double coef) {
+                            const uint8_t* vflags, double* x, const double* y, double coef, const uint32_t* gate,
+                            uint32_t gate_want) {
+  if (gate != nullptr && ld_agent(gate) != gate_want) return;
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n_own = row1 - row0;
   int64_t v;
@@ -3428,12 +3467,12 @@ __global__ void k_axpy_rows(int64_t row0, int64_t row1, const int32_t* extra, in
 
 hipError_t launch_axpy_rows(int64_t row0, int64_t row1, const int32_t* extra, int n_extra,
                             const uint8_t* vflags, double* x, const double* y, double coef,
-                            hipStream_t s) {
+                            hipStream_t s, const uint32_t* gate, uint32_t gate_want) {
   if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
   const int64_t n = (row1 - row0) + n_extra;
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_axpy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, row0, row1, extra,
-                     n_extra, vflags, x, y, coef);
+                     n_extra, vflags, x, y, coef, gate, gate_want);
   return hipGetLastError();
 }
 

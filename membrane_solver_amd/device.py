@@ -453,6 +453,12 @@ class DeviceMesh:
     def shard_exchange_count(self) -> int:
         return int(L.lib().ms_shard_exchange_count(self._h))
 
+    def shard_chain_stats(self):
+        """Device-side trial decisions of ms_shard_step and the passes chained behind them (ms_shard_chain_stats)."""
+        v = np.zeros(4, dtype=np.int64)
+        self._chk(L.lib().ms_shard_chain_stats(self._h, v.ctypes.data_as(L._I64)), "ms_shard_chain_stats")
+        return {"queued": int(v[0]), "ran": int(v[1]), "adopted": int(v[2]), "dropped": int(v[3])}
+
     def peer_memory_kind(self) -> str:
         """Memory kind of the peer exchange's slabs / flag words (ms_shard_peer_memory_kind)."""
         k = int(L.lib().ms_shard_peer_memory_kind(self._h))

@@ -37,7 +37,7 @@ be.configure(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING, gamma=np.full(nf, 1.1)
 be.enable_peer_exchange()
 drv = LibraryShardedStepper(be, stepper=L.MS_STEPPER_CG, reuse_energy0=2)
 log, step = [], 1e-3
-for _ in range(8):
+for _ in range(12):
     r = drv.step(step, tol=1e-9)
     log.append((float(r.success), r.next_step, r.energy, r.grad_norm, int(r.trials)))
     step = r.next_step
@@ -45,15 +45,19 @@ for _ in range(8):
         drv.reset()
 torch.cuda.synchronize()
 dist.barrier()
-print("RESULT " + json.dumps({"rank": rank, "log": log, "exchanges": drv.exchanges}), flush=True)
+print("RESULT " + json.dumps({"rank": rank, "log": log, "exchanges": drv.exchanges,
+                              "chain": be.dm.shard_chain_stats()}), flush=True)
 dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("wait", ["kernel", "stream"])
+@pytest.mark.parametrize("wait", ["kernel", "kernel-host-decisions", "stream"])
 def test_two_processes_exchange_through_ipc_mapped_slabs(wait):
-    """wait "kernel": flag kernel + bounded in-kernel wait (the default); "stream": MS_PEER_WAIT=stream, the flag words
-    raised and awaited by hipStreamWriteValue64 / hipStreamWaitValue64 on the IPC-mapped words."""
+    """wait "kernel": flag words raised by the pack kernel + bounded in-kernel wait (the default) -- and with them the
+    device-side trial decisions: the commit, the gradient + direction pass and its exchange run behind the decision
+    word on both ranks, the next step adopts them; "kernel-host-decisions": the same transport with MS_SHARD_CHAIN=0;
+    "stream": MS_PEER_WAIT=stream, the flag words raised and awaited by hipStreamWriteValue64 / hipStreamWaitValue64 on
+    the IPC-mapped words (host decisions)."""
     from membrane_solver_amd import _lib as L
     from membrane_solver_amd import meshgen
     from membrane_solver_amd.device import DeviceMesh
@@ -66,8 +70,11 @@ def test_two_processes_exchange_through_ipc_mapped_slabs(wait):
         env = dict(os.environ, MS_ROOT=ROOT, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
         env.pop("MS_PEER_WAIT", None)
+        env.pop("MS_SHARD_CHAIN", None)
         if wait == "stream":
             env["MS_PEER_WAIT"] = "stream"
+        if wait == "kernel-host-decisions":
+            env["MS_SHARD_CHAIN"] = "0"
         procs.append(subprocess.Popen([sys.executable, "-c", RANK_SCRIPT], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = []
@@ -93,7 +100,7 @@ def test_two_processes_exchange_through_ipc_mapped_slabs(wait):
     dm.set_bending_params(np.full(nv, 0.9), np.full(nv, 0.1))
     dm.set_params(modules=L.MS_MOD_SURFACE | L.MS_MOD_BENDING)
     ref, step = [], 1e-3
-    for _ in range(8):
+    for _ in range(12):
         r = dm.step(stepper=L.MS_STEPPER_CG, step_size=step, tol=1e-9, reuse_energy0=2)
         ref.append((float(r.success), r.next_step, r.energy, r.grad_norm, int(r.trials)))
         step = r.next_step
@@ -111,3 +118,9 @@ def test_two_processes_exchange_through_ipc_mapped_slabs(wait):
         assert np.allclose(got[:, 3], ref[:, 3], rtol=1e-9)
         assert o["exchanges"] > 0
     assert outs[0]["exchanges"] == outs[1]["exchanges"]
+    assert outs[0]["chain"] == outs[1]["chain"]
+    if wait == "kernel":
+        ch = outs[0]["chain"]
+        assert ch["ran"] >= 2 and ch["adopted"] >= 1 and ch["queued"] >= ch["ran"], ch
+    else:
+        assert outs[0]["chain"]["queued"] == 0
