@@ -549,6 +549,7 @@ size_t tgrad_lds_bytes(int T, int cap, int max_ent, int n_fields);
 // combine: a corner's module terms are added before the gather (default mode); false: module by module, the per-module launches' sums
 hipError_t launch_tgrad(const TgradArgs& a, int cap, int max_ent, bool combine, hipStream_t s);
 
+hipError_t launch_tvec2(const TvecArgs& a, const TvecArgs& b, int n_blocks, hipStream_t s);
 // One fold launch.  set[]: the trials of a multi-trial launch in TRIAL order (the last one = the ordinary outputs); a
 // plain fold has one set.
 struct FoldSet {

@@ -2631,6 +2631,18 @@ __device__ __forceinline__ void tvec_body(const TvecArgs& a, int block_id) {
 
 __global__ __launch_bounds__(BLOCK) void k_tvec(TvecArgs a) { tvec_body(a, (int)blockIdx.x); }
 
+// the same vector op on the two leaflet fields in one launch (grid y = field)
+__global__ __launch_bounds__(BLOCK) void k_tvec2(TvecArgs a, TvecArgs b) {
+  if (blockIdx.y == 0) tvec_body(a, (int)blockIdx.x);
+  else tvec_body(b, (int)blockIdx.x);
+}
+hipError_t launch_tvec2(const TvecArgs& a, const TvecArgs& b, int n_blocks, hipStream_t s) {
+  if (n_blocks <= 0) return hipSuccess;
+  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
+  hipLaunchKernelGGL(k_tvec2, dim3(n_blocks, 2), dim3(BLOCK), 0, s, a, b);
+  return hipGetLastError();
+}
+
 hipError_t launch_tvec(int mode, int tile0, int tile1, int nv, int T, const uint8_t* vflags, double* tg,
                        const double* minv, double* dir, const double* tilts, const double* src,
                        const double* normals, double* out, double coef, int flag, double* partials,
