@@ -374,6 +374,9 @@ __device__ __forceinline__ TileCtx tile_ctx(const DeviceMesh& m, int tile) {
 #ifndef MS_KA_SLOTS
 #define MS_KA_SLOTS 5  // workgroups per CU the headline k_energy instances are compiled for
 #endif
+#ifndef MS_ROW_TWO_PASS
+#define MS_ROW_TWO_PASS 0
+#endif
 #ifndef MS_LEAN_SLOTS
 #define MS_LEAN_SLOTS 5  // workgroups per CU the lean k_gradient instance is compiled for (<= 96 VGPRs)
 #endif
@@ -1077,7 +1080,11 @@ __device__ __forceinline__ void gradient_body(const GradientArgs& a, int cap_rt,
   double* tl = kp + (LEAF ? cap : 0);         // LEAF: tilts
   double* stg = tl + (LEAF ? 3 * cap : 0);
   // ATOMIC: stg holds the per-vertex accumulators (ds_add_f64) instead of per-corner columns
-  constexpr int NACC = VOLROW ? 6 : 3;  // ATOMIC: gradient (and constraint-row) accumulator columns
+  // MS_ROW_TWO_PASS (A/B build): the constraint row's gC through the SAME three accumulator columns in a second sweep
+  // over the facets (cross products of the staged positions only) instead of three columns of its own -- five
+  // workgroups per CU instead of four
+  constexpr bool ROW2 = MS_ROW_TWO_PASS != 0 && VOLROW && ATOMIC;
+  constexpr int NACC = (VOLROW && !ROW2) ? 6 : 3;  // ATOMIC: gradient (and constraint-row) accumulator columns
   double* red = stg + (ATOMIC ? NACC : (VOLROW ? 18 : 9)) * T;
   uint16_t* vent = reinterpret_cast<uint16_t*>(red + 4 * 16);
   uint8_t* lfl = reinterpret_cast<uint8_t*>(vent + (ATOMIC ? 0 : ((max_ent + 3) & ~3)));
@@ -1326,7 +1333,7 @@ __device__ __forceinline__ void gradient_body(const GradientArgs& a, int cap_rt,
           G1 = G1 + pen_factor * w1;
           G2 = G2 + pen_factor * w2;
         }
-        if (VOLROW && ATOMIC) {
+        if (VOLROW && ATOMIC && !ROW2) {
           const double s6 = 1.0 / 6.0;
           const int no = t.n_owned;
           double* c = stg + 3 * T;
@@ -1549,10 +1556,34 @@ __device__ __forceinline__ void gradient_body(const GradientArgs& a, int cap_rt,
 #endif
       gy = stg[T + tid];
       gz = stg[2 * T + tid];
-      if (VOLROW) {
+      if (VOLROW && !ROW2) {
         cx = stg[3 * T + tid];
         cy = stg[4 * T + tid];
         cz = stg[5 * T + tid];
+      }
+    }
+    if (ROW2) {
+      __syncthreads();  // (every owner has read its gradient row)
+      if (tid < T) stg[tid] = stg[T + tid] = stg[2 * T + tid] = 0.0;
+      __syncthreads();
+      const double s6 = 1.0 / 6.0;
+      const int no = t.n_owned;
+      for (int c0f = t.f0; c0f < t.f1; c0f += T) {
+        const int p = c0f + tid;
+        if (p >= t.f1) continue;
+        const TileFacet tf = facet_unpack<PACKED>(facet_load<PACKED>(a.m, (size_t)p));
+        if (!(tf.flags & TF_BODY)) continue;
+        const V3 v0 = lds_row3(px, tf.l0), v1 = lds_row3(px, tf.l1), v2 = lds_row3(px, tf.l2);
+        const V3 w0 = cross(v1, v2), w1 = cross(v2, v0), w2 = cross(v0, v1);
+        if (tf.l0 < no) { atomicAdd(&stg[tf.l0], s6 * w0.x); atomicAdd(&stg[T + tf.l0], s6 * w0.y); atomicAdd(&stg[2 * T + tf.l0], s6 * w0.z); }
+        if (tf.l1 < no) { atomicAdd(&stg[tf.l1], s6 * w1.x); atomicAdd(&stg[T + tf.l1], s6 * w1.y); atomicAdd(&stg[2 * T + tf.l1], s6 * w1.z); }
+        if (tf.l2 < no) { atomicAdd(&stg[tf.l2], s6 * w2.x); atomicAdd(&stg[T + tf.l2], s6 * w2.y); atomicAdd(&stg[2 * T + tf.l2], s6 * w2.z); }
+      }
+      __syncthreads();
+      if (tid < t.n_owned) {
+        cx = stg[tid];
+        cy = stg[T + tid];
+        cz = stg[2 * T + tid];
       }
     }
   }
@@ -1635,13 +1666,13 @@ __device__ __forceinline__ void gradient_body(const GradientArgs& a, int cap_rt,
 }
 
 template <int BENDMODE, bool VOLROW, int TT, int CAPC, bool ATOMIC, bool LEAN = false>
-__global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? (VOLROW ? 4 : MS_LEAN_SLOTS) : 3) : 1) MS_WPE_GRADIENT void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
+__global__ __launch_bounds__(TT ? TT : 512, LEAN ? (ATOMIC ? ((VOLROW && !MS_ROW_TWO_PASS) ? 4 : MS_LEAN_SLOTS) : 3) : 1) MS_WPE_GRADIENT void k_gradient(GradientArgs a, int cap_rt, int max_ent) {
   extern __shared__ double lds[];
   gradient_body<BENDMODE, VOLROW, TT, CAPC, ATOMIC, LEAN>(a, cap_rt, max_ent, lds, (int)blockIdx.x);
 }
 
 size_t gradient_lds_bytes(int T, int cap, int max_ent, bool bend, bool volrow, bool atomic, bool leaf) {
-  const size_t cols = atomic ? (volrow ? 6 : 3) : (volrow ? 18 : 9);
+  const size_t cols = atomic ? ((volrow && !MS_ROW_TWO_PASS) ? 6 : 3) : (volrow ? 18 : 9);
   size_t d = 3 * (size_t)cap + (bend ? 5 * (size_t)cap : 0) + (leaf ? 4 * (size_t)cap : 0) + cols * (size_t)T + 4 * 16;
   return d * sizeof(double) + (atomic ? 0 : u16_bytes(T, max_ent)) + (((size_t)cap + 15) / 16) * 16;
 }
