@@ -545,8 +545,8 @@ struct TgradArgs {
   TgradField f[2];
   double* partials;
 };
-size_t tgrad_lds_bytes(int T, int cap, int max_ent, int n_fields);
-// combine: a corner's module terms are added before the gather (default mode); false: module by module, the per-module launches' sums
+size_t tgrad_lds_bytes(int T, int cap, int max_ent, int n_fields, bool atomic, bool need_a3);
+// combine: a corner's module terms are added and accumulated per vertex by LDS atomics (default mode); false: staged and gathered module by module, the per-module launches' sums
 hipError_t launch_tgrad(const TgradArgs& a, int cap, int max_ent, bool combine, hipStream_t s);
 
 hipError_t launch_tvec2(const TvecArgs& a, const TvecArgs& b, int n_blocks, hipStream_t s);

@@ -148,8 +148,8 @@ def test_leaflet_search_pass_equals_trial_launches(tile, solver, step, bt):
 
 @pytest.mark.parametrize("step", [0.05, 60.0])
 def test_default_mode_agrees_with_trial_launches(step):
-    """Default mode (per-vertex sums of the shape kernels by LDS atomics): the gradient pass adds a corner's module
-    terms before the gather -- same counts, fields equal to rounding."""
+    """Default mode (per-vertex sums by LDS atomics, as in the shape kernels): the gradient pass adds a corner's module
+    terms and accumulates them per owned vertex with ds_add_f64 -- same counts, fields equal to rounding."""
     from conftest import relerr
 
     P, T, _ = _mesh(14)
