@@ -818,7 +818,9 @@ def sharded_extra_leg(args, rank, world, local_rank, freq, steps, warmup, exchan
         out["device_side_decisions"] = dict(cs, note="trials whose Armijo decision was ALSO taken on the device from the ranks' "
                                             "headers (the host replays it), with the commit, the gradient + direction pass of "
                                             "the accepted point and its exchange queued behind the decision word: queued / ran "
-                                            "(main trial accepted) / adopted by the next step / dropped; since ms_create")
+                                            "(main trial accepted) / adopted by the next step / dropped; ahead_*: first trials of "
+                                            "the search two steps on, queued behind the chain with a device-side test whether that "
+                                            "search happens; since ms_create")
     be.dm.close()
     return out
 

@@ -491,9 +491,15 @@ int64_t ms_shard_exchange_count(const ms_ctx *ctx);
  * pass's exchange -- behind it, gated on the decision word; the host replays the decision from the same headers
  * (a difference is an error) and the next ms_shard_step takes the pass's results instead of queueing it
  * (runtime/minimizer.py:1189-1535, line_search.py:386-392: no reference counterpart, same trajectory).
- * MS_SHARD_CHAIN=0 switches it off.  stats: {chains queued, chains that ran (main trial accepted), adopted by the next
- * step, dropped (the next step wanted another pass)}. */
-int ms_shard_chain_stats(const ms_ctx *ctx, int64_t stats[4]);
+ * Behind the chain, in the CG steady state (the pass it queues yields a history direction that is no descent direction,
+ * that step fails without a trial, the stepper is reset): the FIRST TRIAL of the search after it -- energy launch,
+ * exchange, and a device-side decision that first tests from the direction exchange's headers whether that search
+ * happens at all and forms its right-hand sides -- is queued as well and adopted by the step it belongs to.
+ * MS_SHARD_CHAIN=0 switches all of it off; the trial queued ahead is OFF unless MS_SHARD_AHEAD=1 (at world 1 it gains
+ * in the steady two-trial pattern what it loses on rejected trials).  stats: {chains queued, chains
+ * that ran (main trial accepted), adopted by the next step, dropped (the next step wanted another pass), trials queued
+ * ahead, adopted, dropped, 0}. */
+int ms_shard_chain_stats(const ms_ctx *ctx, int64_t stats[8]);
 /* ranks of the context's RCCL communicator as ncclCommCount reports them (0: no communicator) */
 int ms_shard_comm_ranks(ms_ctx *ctx);
 /* Kind of device memory the peer exchange's receive slabs and flag words live in: 0 uncached (MTYPE_UC, what the

@@ -626,6 +626,18 @@ struct ShardDecideArgs {
   uint32_t* dec_out;
   unsigned long long* post;  // pinned {value, value XOR ticket} pair for the host's replay (or nullptr)
   unsigned long long ticket;
+  const uint32_t* gate;    // the trial itself was gated on this word (nullptr: it always ran); closed: DEC_STOP
+  uint32_t gate_want;
+  // go_kind 1: the trial was queued AHEAD of its step -- the search of a steepest-descent restart behind a direction
+  // with history that is expected to be no descent direction.  Whether it happens (<g,d> >= 0 of that direction, not
+  // converged, unguarded range) and its right-hand sides energy0 + c alpha (-|g|^2) are formed here, from the headers
+  // of the direction exchange (recv_dir) and the accepted trial's energy and min edge (keep_in): DEC_STOP if it does not
+  int go_kind;
+  const double* keep_in;   // {energy, min edge^2} of the accepted trial, left by the launch that decided it (keep_out)
+  double* keep_out;        // this launch's main trial: the same two doubles for a trial queued ahead behind ITS chain
+  const double* recv_dir;
+  double tol, c1, alpha_main, alpha_alt;
+  int has_faces;
 };
 hipError_t launch_shard_decide(const ShardDecideArgs& a, hipStream_t s);
 hipError_t launch_flag_peers(unsigned long long* const* peer_flags, int me, int world, unsigned long long ticket,

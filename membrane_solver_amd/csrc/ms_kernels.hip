@@ -3452,19 +3452,52 @@ __global__ void k_post_seq(unsigned long long* host_seq, unsigned long long tick
 __global__ void k_shard_decide(ShardDecideArgs a) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   auto ld = [&](const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
-  uint32_t code = DEC_CONTINUE;
-  for (int t = a.has_alt ? 0 : 1; t < 2 && code == DEC_CONTINUE; ++t) {
-    const int base = t == 0 ? a.alt_off : 0;
+  // the energy the host calls shard_energy_of: the ranks' slots in rank order, then the slots in module order
+  auto energy_of = [&](const double* slab, int base) {
     double e = 0.0;
     for (int k = 0; k < 2; ++k) {
       const int slot = k == 0 ? a.slot_a : a.slot_b;
       if (slot < 0) continue;
       double acc = 0.0;
-      for (int r = 0; r < a.world; ++r) acc += ld(a.recv + (size_t)r * a.stride + base + slot);
+      for (int r = 0; r < a.world; ++r) acc += ld(slab + (size_t)r * a.stride + base + slot);
       e += acc;
     }
     e += 0.0;  // (the host adds the penalty term here: 0.0 without that module -- the only case this kernel is queued in)
-    if (e <= (t == 0 ? a.rhs_alt : a.rhs_main)) code = t == 0 ? DEC_ACCEPT_SIDE : DEC_ACCEPT_MAIN;
+    return e;
+  };
+  uint32_t code = DEC_CONTINUE;
+  double rhs_alt = a.rhs_alt, rhs_main = a.rhs_main;
+  if (a.gate != nullptr && ld_agent(a.gate) != a.gate_want) {
+    code = DEC_STOP;  // (the trial this launch would decide never ran)
+  } else if (a.go_kind != 0) {
+    // a trial queued AHEAD of its step (ms_shard_step: the search of the restart after a history direction that is no
+    // descent direction): does that search happen at all, and its right-hand sides -- the host's expressions
+    const double e0 = ld_agent(a.keep_in), me2 = ld_agent(a.keep_in + 1);
+    double gn2 = 0.0, gdd = 0.0;
+    for (int r = 0; r < a.world; ++r) gn2 += ld(a.recv_dir + (size_t)r * a.stride + MS_S_GNORM2);
+    for (int r = 0; r < a.world; ++r) gdd += ld(a.recv_dir + (size_t)r * a.stride + MS_S_GDOTD);
+    double mg2 = ld(a.recv_dir + MS_S_MAXG2);
+    for (int r = 1; r < a.world; ++r) mg2 = fmax(mg2, ld(a.recv_dir + (size_t)r * a.stride + MS_S_MAXG2));
+    const double min_edge = a.has_faces ? sqrt(me2) : 0.0;
+    const double safe = min_edge > 0.0 ? __dmul_rn(0.3, min_edge) : INFINITY;
+    const double first = a.has_alt ? a.alpha_alt : a.alpha_main;
+    const bool go = gdd >= 0.0 && !(sqrt(gn2) < a.tol) && __dmul_rn(first, sqrt(mg2)) < safe;
+    if (!go) code = DEC_STOP;
+    const double slope = -gn2;
+    rhs_alt = __dadd_rn(e0, __dmul_rn(__dmul_rn(a.c1, a.alpha_alt), slope));
+    rhs_main = __dadd_rn(e0, __dmul_rn(__dmul_rn(a.c1, a.alpha_main), slope));
+  }
+  for (int t = a.has_alt ? 0 : 1; t < 2 && code == DEC_CONTINUE; ++t) {
+    const double e = energy_of(a.recv, t == 0 ? a.alt_off : 0);
+    if (e <= (t == 0 ? rhs_alt : rhs_main)) code = t == 0 ? DEC_ACCEPT_SIDE : DEC_ACCEPT_MAIN;
+  }
+  if (a.keep_out != nullptr && code != DEC_STOP) {
+    // what a trial queued ahead behind THIS trial's chain needs of it, kept outside the slab (which a fast peer may be
+    // writing the exchange three tickets on into by then): the main trial's energy and min edge^2, the host's folds
+    st_agent(a.keep_out, energy_of(a.recv, 0));
+    double m2 = ld(a.recv + MS_S_MINEDGE2);
+    for (int r = 1; r < a.world; ++r) m2 = fmin(m2, ld(a.recv + (size_t)r * a.stride + MS_S_MINEDGE2));
+    st_agent(a.keep_out + 1, m2);
   }
   st_agent(a.dec_out, code);
   if (a.post != nullptr) post_entry(a.post, 0, (unsigned long long)code, a.ticket);

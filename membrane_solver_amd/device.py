@@ -455,9 +455,10 @@ class DeviceMesh:
 
     def shard_chain_stats(self):
         """Device-side trial decisions of ms_shard_step and the passes chained behind them (ms_shard_chain_stats)."""
-        v = np.zeros(4, dtype=np.int64)
+        v = np.zeros(8, dtype=np.int64)
         self._chk(L.lib().ms_shard_chain_stats(self._h, v.ctypes.data_as(L._I64)), "ms_shard_chain_stats")
-        return {"queued": int(v[0]), "ran": int(v[1]), "adopted": int(v[2]), "dropped": int(v[3])}
+        return {"queued": int(v[0]), "ran": int(v[1]), "adopted": int(v[2]), "dropped": int(v[3]),
+                "ahead_queued": int(v[4]), "ahead_adopted": int(v[5]), "ahead_dropped": int(v[6])}
 
     def peer_memory_kind(self) -> str:
         """Memory kind of the peer exchange's slabs / flag words (ms_shard_peer_memory_kind)."""

@@ -43,19 +43,25 @@ for _ in range(12):
     step = r.next_step
     if not r.success:
         drv.reset()
+# ... and the same loop inside the library (ms_minimize over ms_shard_step): there the first trial of the search two
+# steps on is queued behind the chain as well
+o = drv.run(24, step, tol=1e-9)
+run = (int(o.accepted), int(o.trials), float(o.step_size), float(o.energy_eval), float(o.grad_norm))
 torch.cuda.synchronize()
 dist.barrier()
-print("RESULT " + json.dumps({"rank": rank, "log": log, "exchanges": drv.exchanges,
+print("RESULT " + json.dumps({"rank": rank, "log": log, "run": run, "exchanges": drv.exchanges,
                               "chain": be.dm.shard_chain_stats()}), flush=True)
 dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("wait", ["kernel", "kernel-host-decisions", "stream"])
+@pytest.mark.parametrize("wait", ["kernel", "kernel-ahead", "kernel-host-decisions", "stream"])
 def test_two_processes_exchange_through_ipc_mapped_slabs(wait):
     """wait "kernel": flag words raised by the pack kernel + bounded in-kernel wait (the default) -- and with them the
     device-side trial decisions: the commit, the gradient + direction pass and its exchange run behind the decision
-    word on both ranks, the next step adopts them; "kernel-host-decisions": the same transport with MS_SHARD_CHAIN=0;
+    word on both ranks, the next step adopts them; "kernel-ahead": MS_SHARD_AHEAD=1 on top -- the first trial of the search
+    two steps on is queued behind the chain, with a device-side test whether that search happens, and adopted by its step;
+    "kernel-host-decisions": the same transport with MS_SHARD_CHAIN=0;
     "stream": MS_PEER_WAIT=stream, the flag words raised and awaited by hipStreamWriteValue64 / hipStreamWaitValue64 on
     the IPC-mapped words (host decisions)."""
     from membrane_solver_amd import _lib as L
@@ -71,6 +77,9 @@ def test_two_processes_exchange_through_ipc_mapped_slabs(wait):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
         env.pop("MS_PEER_WAIT", None)
         env.pop("MS_SHARD_CHAIN", None)
+        env.pop("MS_SHARD_AHEAD", None)
+        if wait == "kernel-ahead":
+            env["MS_SHARD_AHEAD"] = "1"
         if wait == "stream":
             env["MS_PEER_WAIT"] = "stream"
         if wait == "kernel-host-decisions":
@@ -106,6 +115,13 @@ def test_two_processes_exchange_through_ipc_mapped_slabs(wait):
         step = r.next_step
         if not r.success:
             dm.reset_stepper()
+    mp = L.ms_minimize_params()
+    mp.stepper = L.ms_stepper_params(int(L.MS_STEPPER_CG), 10, 0.7, 1e-4, 1.5, 10.0, 10, 0.0, 2)
+    mp.step_size, mp.tol = float(step), 1e-9
+    mp.fixed_step_mode, mp.fixed_step = 0, float(step)
+    mp.max_zero_steps, mp.step_size_floor = 10, 1e-8
+    o, _ = dm.minimize(mp, 24)
+    ref_run = (int(o.accepted), int(o.trials), float(o.step_size), float(o.energy_eval), float(o.grad_norm))
     dm.close()
     ref = np.array(ref)
     assert ref[:, 0].sum() >= 2
@@ -117,10 +133,17 @@ def test_two_processes_exchange_through_ipc_mapped_slabs(wait):
         assert np.allclose(got[:, 2], ref[:, 2], rtol=1e-12)
         assert np.allclose(got[:, 3], ref[:, 3], rtol=1e-9)
         assert o["exchanges"] > 0
+        assert tuple(o["run"][:2]) == ref_run[:2], (o["run"], ref_run)
+        assert np.allclose(o["run"][2:4], ref_run[2:4], rtol=1e-12) and np.isclose(o["run"][4], ref_run[4], rtol=1e-9)
     assert outs[0]["exchanges"] == outs[1]["exchanges"]
     assert outs[0]["chain"] == outs[1]["chain"]
-    if wait == "kernel":
+    if wait in ("kernel", "kernel-ahead"):
         ch = outs[0]["chain"]
         assert ch["ran"] >= 2 and ch["adopted"] >= 1 and ch["queued"] >= ch["ran"], ch
+        if wait == "kernel-ahead":
+            assert ch["ahead_queued"] >= 1 and ch["ahead_adopted"] >= 1, ch
+            assert ch["ahead_adopted"] + ch["ahead_dropped"] <= ch["ahead_queued"], ch
+        else:
+            assert ch["ahead_queued"] == 0
     else:
         assert outs[0]["chain"]["queued"] == 0
