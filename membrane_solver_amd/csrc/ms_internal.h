@@ -591,30 +591,6 @@ struct FoldArgs {
 };
 hipError_t launch_reduce(const FoldArgs& a, hipStream_t s);
 
-hipError_t launch_pack_boundary(const int32_t* rows, int n_rows, const double* const* bufs,
-                                const int* ncomp, int n_bufs, const double* scal, double* send,
-                                hipStream_t s);
-hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_off, int me, int world,
-                                  int max_rows, double* const* bufs, const int* ncomp, int n_bufs,
-                                  const double* recv, size_t stride, double* scal_all, hipStream_t s,
-                                  unsigned long long* host_seq = nullptr, unsigned long long ticket = 0,
-                                  bool remote_written = false, const unsigned long long* wait_flags = nullptr,
-                                  unsigned long long wait_ticket = 0, unsigned long long* host_err = nullptr,
-                                  const uint32_t* gate = nullptr, uint32_t gate_want = 0);
-hipError_t launch_post_seq(unsigned long long* host_seq, unsigned long long ticket, hipStream_t s);
-// profiling only: *out = (*gate == want), one lane, queued right behind a gated launch (ms_profile_*)
-hipError_t launch_gate_probe(const uint32_t* gate, uint32_t want, uint32_t* out, hipStream_t s);
-// peer-to-peer exchange: pack straight into every peer's slab (dst[r] = that peer's slot for this rank), raise this
-// rank's flag on every peer; the unpack kernel waits (bounded) for every peer's flag here
-struct PeerFlags {
-  unsigned long long* p[16];  // this exchange parity's flag rows of the peers (device table: ms_ctx::d_peer_flagtab)
-};
-// d_flags != nullptr: the last block to finish for a peer raises this rank's word there (no flag kernel); d_arrived: 16
-// zeroed counters
-hipError_t launch_pack_peers(const int32_t* rows, int n_rows, const double* const* bufs, const int* ncomp, int n_bufs,
-                             const double* scal, double* const* dst, int world, hipStream_t s,
-                             const PeerFlags* d_flags = nullptr, unsigned int* d_arrived = nullptr, int me = 0,
-                             unsigned long long ticket = 0, const uint32_t* gate = nullptr, uint32_t gate_want = 0);
 // the Armijo decision of a sharded trial from the scalar headers in this rank's slab (k_shard_decide)
 struct ShardDecideArgs {
   const double* recv;      // slab of this exchange: world x stride doubles, rank r's header at recv + r * stride
@@ -639,6 +615,33 @@ struct ShardDecideArgs {
   double tol, c1, alpha_main, alpha_alt;
   int has_faces;
 };
+hipError_t launch_pack_boundary(const int32_t* rows, int n_rows, const double* const* bufs,
+                                const int* ncomp, int n_bufs, const double* scal, double* send,
+                                hipStream_t s);
+hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_off, int me, int world,
+                                  int max_rows, double* const* bufs, const int* ncomp, int n_bufs,
+                                  const double* recv, size_t stride, double* scal_all, hipStream_t s,
+                                  unsigned long long* host_seq = nullptr, unsigned long long ticket = 0,
+                                  bool remote_written = false, const unsigned long long* wait_flags = nullptr,
+                                  unsigned long long wait_ticket = 0, unsigned long long* host_err = nullptr,
+                                  const uint32_t* gate = nullptr, uint32_t gate_want = 0,
+                                  // the trial decision this exchange feeds, taken by the header block that arrives last
+                                  // (dec_arrived: a zeroed counter); nullptr: none
+                                  const ShardDecideArgs* decide = nullptr, unsigned int* dec_arrived = nullptr);
+hipError_t launch_post_seq(unsigned long long* host_seq, unsigned long long ticket, hipStream_t s);
+// profiling only: *out = (*gate == want), one lane, queued right behind a gated launch (ms_profile_*)
+hipError_t launch_gate_probe(const uint32_t* gate, uint32_t want, uint32_t* out, hipStream_t s);
+// peer-to-peer exchange: pack straight into every peer's slab (dst[r] = that peer's slot for this rank), raise this
+// rank's flag on every peer; the unpack kernel waits (bounded) for every peer's flag here
+struct PeerFlags {
+  unsigned long long* p[16];  // this exchange parity's flag rows of the peers (device table: ms_ctx::d_peer_flagtab)
+};
+// d_flags != nullptr: the last block to finish for a peer raises this rank's word there (no flag kernel); d_arrived: 16
+// zeroed counters
+hipError_t launch_pack_peers(const int32_t* rows, int n_rows, const double* const* bufs, const int* ncomp, int n_bufs,
+                             const double* scal, double* const* dst, int world, hipStream_t s,
+                             const PeerFlags* d_flags = nullptr, unsigned int* d_arrived = nullptr, int me = 0,
+                             unsigned long long ticket = 0, const uint32_t* gate = nullptr, uint32_t gate_want = 0);
 hipError_t launch_shard_decide(const ShardDecideArgs& a, hipStream_t s);
 hipError_t launch_flag_peers(unsigned long long* const* peer_flags, int me, int world, unsigned long long ticket,
                              hipStream_t s);

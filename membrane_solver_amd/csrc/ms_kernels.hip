@@ -3312,145 +3312,13 @@ __global__ void k_flag_peers(PeerFlags f, int me, int world, unsigned long long 
   const int r = threadIdx.x;
   if (r < world) __hip_atomic_store(f.p[r] + me, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// grid (ceil(max_rows/256), world); recv = world x stride doubles
-template <bool REMOTE>
-__global__ void k_unpack_boundary(const int32_t* rows_all, const int32_t* row_off, int me,
-                                  RowBufs b, const double* recv, size_t stride, double* scal_all,
-                                  unsigned long long* host_seq, unsigned long long ticket,
-                                  const unsigned long long* wait_flags, unsigned long long wait_ticket,
-                                  unsigned long long* host_err, const uint32_t* gate, uint32_t gate_want) {
-  if (gate != nullptr && ld_agent(gate) != gate_want) return;
-  const int r = blockIdx.y;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const double* src = recv + (size_t)r * stride;
-  if (REMOTE && wait_flags != nullptr) {
-    // peer-to-peer exchange: rank r's message is complete once its flag word here has reached the exchange's ticket.
-    // BOUNDED wait (a peer that never arrives ends it after ~2 s with an error word for the host instead of a wave
-    // that never finishes); the workgroup's other waves sit at the barrier meanwhile.
-    __shared__ int arrived;
-    if (threadIdx.x == 0) {
-      bool ok = false;
-      for (long it = 0; it < (1L << 22) && !ok; ++it) {
-        ok = __hip_atomic_load(wait_flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= wait_ticket;
-        if (!ok) __builtin_amdgcn_s_sleep(32);
-      }
-      arrived = ok ? 1 : 0;
-      if (!ok && host_err) st_sys(host_err, (1ull << 62) | ((unsigned long long)r << 32) | (wait_ticket & 0xffffffffull));
-    }
-    __syncthreads();
-    if (!arrived) return;
-  }
-  // REMOTE: the slab was written by other GPUs (peer-to-peer exchange): read it with system-scope loads, past this
-  // GPU's caches
-  auto ld = [&](const double* q) {
-    return REMOTE ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : *q;
-  };
-  if (j < MS_NSCAL) scal_all[r * MS_NSCAL + j] = ld(src + j);
-  if (host_seq != nullptr && blockIdx.x == 0) {
-    // the host only waits for the scalars (the rows are consumed by later kernels of the same stream): rank r's
-    // header is complete once this workgroup has written it -> post its sequence word, no extra kernel
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __threadfence_system();
-      *reinterpret_cast<volatile unsigned long long*>(host_seq + r) = ticket;
-    }
-  }
-  if (r == me) return;
-  const int n_rows = row_off[r + 1] - row_off[r];
-  if (j >= n_rows) return;
-  const size_t v = (size_t)rows_all[row_off[r] + j];
-  const double* i = src + MS_NSCAL + (size_t)j * b.comps;
-  for (int k = 0; k < b.n; ++k)
-    for (int c = 0; c < b.ncomp[k]; ++c) b.p[k][v * b.ncomp[k] + c] = ld(i++);
-}
-
-hipError_t launch_pack_boundary(const int32_t* rows, int n_rows, const double* const* bufs,
-                                const int* ncomp, int n_bufs, const double* scal, double* send,
-                                hipStream_t s) {
-  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
-  RowBufs b{};
-  b.n = n_bufs;
-  for (int k = 0; k < n_bufs; ++k) {
-    b.p[k] = const_cast<double*>(bufs[k]);
-    b.ncomp[k] = ncomp[k];
-    b.comps += ncomp[k];
-  }
-  const int n = n_rows > MS_NSCAL ? n_rows : MS_NSCAL;
-  hipLaunchKernelGGL(k_pack_boundary, dim3((n + 255) / 256), dim3(256), 0, s, rows, n_rows, b, scal, send);
-  return hipGetLastError();
-}
-
-hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_off, int me, int world,
-                                  int max_rows, double* const* bufs, const int* ncomp, int n_bufs,
-                                  const double* recv, size_t stride, double* scal_all, hipStream_t s,
-                                  unsigned long long* host_seq, unsigned long long ticket, bool remote_written,
-                                  const unsigned long long* wait_flags, unsigned long long wait_ticket,
-                                  unsigned long long* host_err, const uint32_t* gate, uint32_t gate_want) {
-  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
-  RowBufs b{};
-  b.n = n_bufs;
-  for (int k = 0; k < n_bufs; ++k) {
-    b.p[k] = bufs[k];
-    b.ncomp[k] = ncomp[k];
-    b.comps += ncomp[k];
-  }
-  const int n = max_rows > MS_NSCAL ? max_rows : MS_NSCAL;
-  if (remote_written)
-    hipLaunchKernelGGL(k_unpack_boundary<true>, dim3((n + 255) / 256, world), dim3(256), 0, s, rows_all, row_off,
-                       me, b, recv, stride, scal_all, host_seq, ticket, wait_flags, wait_ticket, host_err, gate, gate_want);
-  else
-    hipLaunchKernelGGL(k_unpack_boundary<false>, dim3((n + 255) / 256, world), dim3(256), 0, s, rows_all, row_off,
-                       me, b, recv, stride, scal_all, host_seq, ticket, nullptr, 0ull, nullptr, gate, gate_want);
-  return hipGetLastError();
-}
-
-hipError_t launch_pack_peers(const int32_t* rows, int n_rows, const double* const* bufs, const int* ncomp, int n_bufs,
-                             const double* scal, double* const* dst, int world, hipStream_t s,
-                             const PeerFlags* d_flags, unsigned int* d_arrived, int me, unsigned long long ticket,
-                             const uint32_t* gate, uint32_t gate_want) {
-  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
-  if (world > 16) return hipErrorInvalidValue;
-  RowBufs b{};
-  b.n = n_bufs;
-  for (int k = 0; k < n_bufs; ++k) {
-    b.p[k] = const_cast<double*>(bufs[k]);
-    b.ncomp[k] = ncomp[k];
-    b.comps += ncomp[k];
-  }
-  PeerDst d{};
-  for (int r = 0; r < world; ++r) d.p[r] = dst[r];
-  const int n = n_rows > MS_NSCAL ? n_rows : MS_NSCAL;
-  hipLaunchKernelGGL(k_pack_peers, dim3((n + 255) / 256, world), dim3(256), 0, s, rows, n_rows, b, scal, d, d_flags,
-                     d_arrived, me, ticket, gate, gate_want);
-  return hipGetLastError();
-}
-
-hipError_t launch_flag_peers(unsigned long long* const* peer_flags, int me, int world, unsigned long long ticket,
-                             hipStream_t s) {
-  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
-  if (world > 16) return hipErrorInvalidValue;
-  PeerFlags f{};
-  for (int r = 0; r < world; ++r) f.p[r] = peer_flags[r];
-  hipLaunchKernelGGL(k_flag_peers, dim3(1), dim3(64), 0, s, f, me, world, ticket);
-  return hipGetLastError();
-}
-
-
-// One word to the pinned mailbox after everything queued before it on the stream has completed
-// (a kernel boundary orders the earlier kernels' host writes before this one).
-__global__ void k_post_seq(unsigned long long* host_seq, unsigned long long ticket) {
-  __threadfence_system();
-  *reinterpret_cast<volatile unsigned long long*>(host_seq) = ticket;
-}
-
-// The Armijo decision of a SHARDED trial, on the device: queued behind the unpack kernel of the trial's exchange (every
-// rank's scalar header is in this rank's slab by then), one lane adds the ranks' energy slots in rank order -- the
+// The Armijo decision of a SHARDED trial, on the device: taken by the unpack kernel of the trial's exchange once every
+// rank's scalar header is in this rank's slab (the header block that arrives last), one lane adds the ranks' energy slots in rank order -- the
 // host's fold, rounding for rounding (shard_exchange_take / shard_energy_of) -- and tests trial 0 (a pair launch's
 // other trial, header slots SH_ALT + s) and the main trial against their right-hand sides.  Every rank reads the same
 // doubles and writes the same word; the kernels queued behind it (commit, gradient + direction pass, their exchange)
 // are gated on it.  The host replays the decision from the headers it receives and compares (post).
-__global__ void k_shard_decide(ShardDecideArgs a) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void shard_decide(const ShardDecideArgs& a) {
   auto ld = [&](const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
   // the energy the host calls shard_energy_of: the ranks' slots in rank order, then the slots in module order
   auto energy_of = [&](const double* slab, int base) {
@@ -3502,6 +3370,161 @@ __global__ void k_shard_decide(ShardDecideArgs a) {
   st_agent(a.dec_out, code);
   if (a.post != nullptr) post_entry(a.post, 0, (unsigned long long)code, a.ticket);
 }
+__global__ void k_shard_decide(ShardDecideArgs a) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) shard_decide(a);
+}
+// grid (ceil(max_rows/256), world); recv = world x stride doubles
+template <bool REMOTE>
+__global__ void k_unpack_boundary(const int32_t* rows_all, const int32_t* row_off, int me,
+                                  RowBufs b, const double* recv, size_t stride, double* scal_all,
+                                  unsigned long long* host_seq, unsigned long long ticket,
+                                  const unsigned long long* wait_flags, unsigned long long wait_ticket,
+                                  unsigned long long* host_err, const uint32_t* gate, uint32_t gate_want,
+                                  int has_decide, ShardDecideArgs dec, unsigned int* dec_arrived) {
+  if (gate != nullptr && ld_agent(gate) != gate_want) {
+    // (the decision this exchange would have fed: the trial never ran)
+    if (has_decide && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) shard_decide(dec);
+    return;
+  }
+  const int r = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const double* src = recv + (size_t)r * stride;
+  if (REMOTE && wait_flags != nullptr) {
+    // peer-to-peer exchange: rank r's message is complete once its flag word here has reached the exchange's ticket.
+    // BOUNDED wait (a peer that never arrives ends it after ~2 s with an error word for the host instead of a wave
+    // that never finishes); the workgroup's other waves sit at the barrier meanwhile.
+    __shared__ int arrived;
+    if (threadIdx.x == 0) {
+      bool ok = false;
+      for (long it = 0; it < (1L << 22) && !ok; ++it) {
+        ok = __hip_atomic_load(wait_flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= wait_ticket;
+        if (!ok) __builtin_amdgcn_s_sleep(32);
+      }
+      arrived = ok ? 1 : 0;
+      if (!ok && host_err) st_sys(host_err, (1ull << 62) | ((unsigned long long)r << 32) | (wait_ticket & 0xffffffffull));
+    }
+    __syncthreads();
+    if (!arrived) return;
+  }
+  // REMOTE: the slab was written by other GPUs (peer-to-peer exchange): read it with system-scope loads, past this
+  // GPU's caches
+  auto ld = [&](const double* q) {
+    return REMOTE ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : *q;
+  };
+  if (j < MS_NSCAL) scal_all[r * MS_NSCAL + j] = ld(src + j);
+  if (host_seq != nullptr && blockIdx.x == 0) {
+    // the host only waits for the scalars (the rows are consumed by later kernels of the same stream): rank r's
+    // header is complete once this workgroup has written it -> post its sequence word, no extra kernel
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence_system();
+      *reinterpret_cast<volatile unsigned long long*>(host_seq + r) = ticket;
+    }
+  }
+  if (has_decide && blockIdx.x == 0 && threadIdx.x == 0) {
+    // the header block that comes last has every rank's header in the slab behind it (each waited for its rank's flag):
+    // it takes the trial's decision (no kernel of its own behind this one)
+    const unsigned int before = __hip_atomic_fetch_add(dec_arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (before == gridDim.y - 1) {
+      __hip_atomic_store(dec_arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      shard_decide(dec);
+    }
+  }
+  if (r == me) return;
+  const int n_rows = row_off[r + 1] - row_off[r];
+  if (j >= n_rows) return;
+  const size_t v = (size_t)rows_all[row_off[r] + j];
+  const double* i = src + MS_NSCAL + (size_t)j * b.comps;
+  for (int k = 0; k < b.n; ++k)
+    for (int c = 0; c < b.ncomp[k]; ++c) b.p[k][v * b.ncomp[k] + c] = ld(i++);
+}
+
+hipError_t launch_pack_boundary(const int32_t* rows, int n_rows, const double* const* bufs,
+                                const int* ncomp, int n_bufs, const double* scal, double* send,
+                                hipStream_t s) {
+  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
+  RowBufs b{};
+  b.n = n_bufs;
+  for (int k = 0; k < n_bufs; ++k) {
+    b.p[k] = const_cast<double*>(bufs[k]);
+    b.ncomp[k] = ncomp[k];
+    b.comps += ncomp[k];
+  }
+  const int n = n_rows > MS_NSCAL ? n_rows : MS_NSCAL;
+  hipLaunchKernelGGL(k_pack_boundary, dim3((n + 255) / 256), dim3(256), 0, s, rows, n_rows, b, scal, send);
+  return hipGetLastError();
+}
+
+hipError_t launch_unpack_boundary(const int32_t* rows_all, const int32_t* row_off, int me, int world,
+                                  int max_rows, double* const* bufs, const int* ncomp, int n_bufs,
+                                  const double* recv, size_t stride, double* scal_all, hipStream_t s,
+                                  unsigned long long* host_seq, unsigned long long ticket, bool remote_written,
+                                  const unsigned long long* wait_flags, unsigned long long wait_ticket,
+                                  unsigned long long* host_err, const uint32_t* gate, uint32_t gate_want,
+                                  const ShardDecideArgs* decide, unsigned int* dec_arrived) {
+  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
+  ShardDecideArgs dec;
+  memset(&dec, 0, sizeof(dec));
+  if (decide != nullptr) dec = *decide;
+  const int has_decide = (decide != nullptr && dec_arrived != nullptr) ? 1 : 0;
+  RowBufs b{};
+  b.n = n_bufs;
+  for (int k = 0; k < n_bufs; ++k) {
+    b.p[k] = bufs[k];
+    b.ncomp[k] = ncomp[k];
+    b.comps += ncomp[k];
+  }
+  const int n = max_rows > MS_NSCAL ? max_rows : MS_NSCAL;
+  if (remote_written)
+    hipLaunchKernelGGL(k_unpack_boundary<true>, dim3((n + 255) / 256, world), dim3(256), 0, s, rows_all, row_off,
+                       me, b, recv, stride, scal_all, host_seq, ticket, wait_flags, wait_ticket, host_err, gate, gate_want,
+                       has_decide, dec, dec_arrived);
+  else
+    hipLaunchKernelGGL(k_unpack_boundary<false>, dim3((n + 255) / 256, world), dim3(256), 0, s, rows_all, row_off,
+                       me, b, recv, stride, scal_all, host_seq, ticket, nullptr, 0ull, nullptr, gate, gate_want, has_decide, dec,
+                       dec_arrived);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_peers(const int32_t* rows, int n_rows, const double* const* bufs, const int* ncomp, int n_bufs,
+                             const double* scal, double* const* dst, int world, hipStream_t s,
+                             const PeerFlags* d_flags, unsigned int* d_arrived, int me, unsigned long long ticket,
+                             const uint32_t* gate, uint32_t gate_want) {
+  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
+  if (world > 16) return hipErrorInvalidValue;
+  RowBufs b{};
+  b.n = n_bufs;
+  for (int k = 0; k < n_bufs; ++k) {
+    b.p[k] = const_cast<double*>(bufs[k]);
+    b.ncomp[k] = ncomp[k];
+    b.comps += ncomp[k];
+  }
+  PeerDst d{};
+  for (int r = 0; r < world; ++r) d.p[r] = dst[r];
+  const int n = n_rows > MS_NSCAL ? n_rows : MS_NSCAL;
+  hipLaunchKernelGGL(k_pack_peers, dim3((n + 255) / 256, world), dim3(256), 0, s, rows, n_rows, b, scal, d, d_flags,
+                     d_arrived, me, ticket, gate, gate_want);
+  return hipGetLastError();
+}
+
+hipError_t launch_flag_peers(unsigned long long* const* peer_flags, int me, int world, unsigned long long ticket,
+                             hipStream_t s) {
+  if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
+  if (world > 16) return hipErrorInvalidValue;
+  PeerFlags f{};
+  for (int r = 0; r < world; ++r) f.p[r] = peer_flags[r];
+  hipLaunchKernelGGL(k_flag_peers, dim3(1), dim3(64), 0, s, f, me, world, ticket);
+  return hipGetLastError();
+}
+
+
+// One word to the pinned mailbox after everything queued before it on the stream has completed
+// (a kernel boundary orders the earlier kernels' host writes before this one).
+__global__ void k_post_seq(unsigned long long* host_seq, unsigned long long ticket) {
+  __threadfence_system();
+  *reinterpret_cast<volatile unsigned long long*>(host_seq) = ticket;
+}
+
 hipError_t launch_shard_decide(const ShardDecideArgs& a, hipStream_t s) {
   if (hipError_t es_ = exec_sync(s); es_ != hipSuccess) return es_;  // (not recorded: runs behind what was)
   hipLaunchKernelGGL(k_shard_decide, dim3(1), dim3(64), 0, s, a);
