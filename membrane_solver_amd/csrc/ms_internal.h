@@ -142,6 +142,11 @@ struct EnergyArgs {
   const uint32_t* gate;
   uint32_t gate_want;
   const double* bt_normals;  // leaflet bending_tilt: unit vertex normals of the evaluated positions (signed H, K_dir = n)
+  // energy-only evaluation of BOTH leaflets' bending_tilt in one launch: the second leaflet's record from the same
+  // curvature sums with its own (kappa, c0) (no factor outputs: fK / fA serve one leaflet at a time)
+  double* bt_vert2 = nullptr;
+  const double* kappa2 = nullptr;
+  const double* c02 = nullptr;
   int atomic;             // accumulate per-vertex sums with LDS atomics (not bitwise reproducible)
   // multi-trial launch (pair = n >= 2): trials 0 .. n-2 of the ladder are evaluated in the same launch at alpha_side[j]
   // into partials_side[j] (energy only unless xt/fK/fA_side[j] are given: j < 2), trial n-1 at `alpha` with the

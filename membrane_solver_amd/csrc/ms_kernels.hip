@@ -812,6 +812,16 @@ __device__ __forceinline__ void energy_body(EnergyArgs& a, int cap_rt, int max_e
       rec[1] = aAe;
       rec[2] = kappa * ratio * H;
       rec[3] = 0.0;
+      if (a.bt_vert2 != nullptr) {  // the other leaflet's record: same sums, its own (kappa, c0)
+        const double kappa_b = a.kappa2[v], c0_b = a.c02[v];
+        double base_b = (2.0 * H) - c0_b;
+        if (!interior) base_b = 0.0;
+        double* rec_b = a.bt_vert2 + 4 * (size_t)v;
+        rec_b[0] = base_b;
+        rec_b[1] = aAe;
+        rec_b[2] = kappa_b * ratio * H;
+        rec_b[3] = 0.0;
+      }
     } else if (a.bending_model == MS_BEND_HELFRICH) {
       double term = (2.0 * H) - c0;
       if (!interior) term = 0.0;
