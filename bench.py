@@ -825,6 +825,14 @@ def sharded_extra_leg(args, rank, world, local_rank, freq, steps, warmup, exchan
     return out
 
 
+def headline_from_peer_leg(peer, steps, warmup, rccl_value, weak=False, pin=""):
+    """bench.py --gpus N runs the same steps through both library drivers; the line's value is the peer-exchange leg's
+    only if that leg is the same measurement (library driver, same steps and warm-up, strong scaling) and was faster."""
+    return bool(isinstance(peer, dict) and peer.get("driver") == "library" and peer.get("steps") == steps and
+                peer.get("warmup") == warmup and float(peer.get("value", 0.0) or 0.0) > float(rccl_value) and
+                pin != "rccl" and not weak)
+
+
 def main_sharded(args, rank, world, local_rank):
     """--gpus N (N > 1, or MS_BENCH_FORCE_SHARDED=1 at N = 1): tiles sharded over the ranks, one process per GPU,
     halo all-gathers over RCCL; timed with barrier + synchronize on both sides and the MAX over ranks."""
@@ -992,9 +1000,8 @@ def main_sharded(args, rank, world, local_rank):
         # above and (leg "peer_exchange") the peer-to-peer one.  The line's value is the faster one's; the other keeps
         # its figures under its own key.  MS_BENCH_HEADLINE=rccl pins the all-gather driver.
         peer = extra.get("peer_exchange")
-        use_peer = (isinstance(peer, dict) and peer.get("driver") == "library" and peer.get("steps") == args.steps and
-                    peer.get("warmup") == args.warmup and float(peer.get("value", 0.0)) > args.steps / dt and
-                    os.environ.get("MS_BENCH_HEADLINE", "") != "rccl" and not args.weak)
+        use_peer = headline_from_peer_leg(peer, args.steps, args.warmup, args.steps / dt, args.weak,
+                                          os.environ.get("MS_BENCH_HEADLINE", ""))
         par_text = (f"tiles (facet blocks) sharded over {world} GPUs; per exchange one RCCL "
                     f"all-gather of [{L.MS_NSCAL} scalars | <= {be.boundary['max_rows']} boundary rows] "
                     f"per rank" + ("" if be.exchange_mode == "halo" else

@@ -278,3 +278,20 @@ def test_bench_leg_budget_and_shared_mesh(tmp_path, monkeypatch):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     assert out[0][1].shape == (180, 3) and 3 in caches[1]
     assert not list(tmp_path.iterdir())                        # rank 0 removed the files
+
+
+def test_bench_headline_selection_between_the_two_sharded_drivers():
+    """bench.py --gpus N: the line's value is the peer-exchange leg's only when that leg is the same measurement and
+    faster; a skipped / failed leg, another step count, the weak-scaling run or MS_BENCH_HEADLINE=rccl keep the RCCL
+    all-gather driver's."""
+    import bench
+
+    leg = {"driver": "library", "steps": 200, "warmup": 30, "value": 13000.0}
+    assert bench.headline_from_peer_leg(leg, 200, 30, 12400.0)
+    assert not bench.headline_from_peer_leg(leg, 200, 30, 13500.0)
+    assert not bench.headline_from_peer_leg(leg, 20, 5, 12400.0)
+    assert not bench.headline_from_peer_leg(dict(leg, driver="python"), 200, 30, 12400.0)
+    assert not bench.headline_from_peer_leg(leg, 200, 30, 12400.0, weak=True)
+    assert not bench.headline_from_peer_leg(leg, 200, 30, 12400.0, pin="rccl")
+    assert not bench.headline_from_peer_leg(None, 200, 30, 12400.0)
+    assert not bench.headline_from_peer_leg({"note": "peer-to-peer exchange could not be set up on every rank"}, 200, 30, 1.0)
