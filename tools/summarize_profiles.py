@@ -22,7 +22,8 @@ for d in sorted(glob.glob(os.path.join(root, "gpurun_out", f"{tag}_*_stats"))):
     j = os.path.join(root, "gpurun_out", f"{tag}_{name}.json")
     if os.path.exists(j) and os.path.getsize(j) > 0:
         shutil.copy(j, os.path.join(out, f"{tag}_{name}.json"))
-for name in ("bench", "bench_s20w5", "bench_forced_sharded"):
+for name in ("bench", "bench_s20w5", "bench_forced_sharded", "tilt_single_field_2M_events_first",
+             "tilt_two_leaflets_2M_events_first"):
     j = os.path.join(root, "gpurun_out", f"{tag}_{name}.json")
     if os.path.exists(j) and os.path.getsize(j) > 0:
         shutil.copy(j, os.path.join(out, f"{tag}_{name}.json"))
