@@ -245,3 +245,33 @@ def test_shape_trial_energies_through_the_pass(tile):
         assert ra[:3] == rb[:3]
         assert abs(ra[3] - rb[3]) <= 1e-12 * abs(rb[3])
     assert np.allclose(xa, xb, rtol=0, atol=1e-13)
+
+
+def test_full_size_relaxations_equal_trial_launches():
+    """BASELINE's headline size (2 048 000 facets, 4001 tiles): one two-leaflet relaxation and one single-field
+    relaxation with a ladder that halves, through the passes and through the launch-per-module-and-trial path, fixed-order
+    sums: counts and fields equal bit for bit."""
+    from membrane_solver_amd import meshgen
+
+    P, T = meshgen.icosphere(320)
+    P = meshgen.smooth_displace(P, 0.05)
+    rng = np.random.default_rng(11)
+    r = P / np.linalg.norm(P, axis=1)[:, None]  # (close enough to the vertex normals for a tangent start)
+    def tangent(amp):
+        t = amp * rng.normal(size=P.shape)
+        return t - np.einsum("ij,ij->i", t, r)[:, None] * r
+    tin, tout, tl = tangent(0.2), tangent(0.15), tangent(0.2)
+    fin = np.zeros(len(P), bool)
+    fin[::13] = True
+    a, st = _leaflets(P, T, tin, tout, fin, True, True, 0.05, "cg", 2, 256)
+    b, _ = _leaflets(P, T, tin, tout, fin, True, False, 0.05, "cg", 2, 256)
+    assert st["passes"] > 0
+    for (ia, ea, xa, ya), (ib, eb, xb, yb) in zip(a, b):
+        assert (ia, ea) == (ib, eb)
+        assert np.array_equal(xa, xb) and np.array_equal(ya, yb)
+    a, st = _single(P, T, tl, fin, True, True, 40.0, "cg", 2, 256)
+    b, _ = _single(P, T, tl, fin, True, False, 40.0, "cg", 2, 256)
+    assert st["step_sizes"] > st["passes"]
+    for (ia, ea, ta), (ib, eb, tb) in zip(a, b):
+        assert (ia, ea) == (ib, eb)
+        assert np.array_equal(ta, tb)
