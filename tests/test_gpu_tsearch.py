@@ -275,3 +275,78 @@ def test_full_size_relaxations_equal_trial_launches():
     for (ia, ea, ta), (ib, eb, tb) in zip(a, b):
         assert (ia, ea) == (ib, eb)
         assert np.array_equal(ta, tb)
+
+
+def test_full_size_leaflet_relaxation_matches_the_oracle_port():
+    """2 048 000 facets: one two-leaflet relaxation (Jacobi CG, two inner steps) through the gradient and search
+    passes against the CPU oracle port of relax_leaflet_tilts (runtime/steppers/tilt_relaxation.py:426-1478): the same
+    iteration and evaluation counts, fields to 1e-9 of their norm."""
+    from conftest import relerr
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+    from oracle import minimizer_port as mp
+
+    P, T = meshgen.icosphere(320)
+    P = meshgen.smooth_displace(P, 0.05)
+    rng = np.random.default_rng(5)
+    nrm = mp.unit_vertex_normals(P, T)
+    tin = 0.2 * rng.normal(size=P.shape)
+    tin -= np.einsum("ij,ij->i", tin, nrm)[:, None] * nrm
+    tout = 0.15 * rng.normal(size=P.shape)
+    tout -= np.einsum("ij,ij->i", tout, nrm)[:, None] * nrm
+    fin = np.zeros(len(P), bool)
+    fin[::13] = True
+    gp = {"tilt_modulus_in": 1.3, "tilt_modulus_out": 0.7, "bending_modulus": 0.4, "tilt_solve_mode": "nested",
+          "tilt_solver": "cg", "tilt_step_size": 0.05, "tilt_inner_steps": 2}
+    mods = ["tilt_in", "tilt_out", "tilt_smoothness_in", "tilt_smoothness_out"]
+    p = mp.Problem(positions=P, tri=T, tilts_in=tin, tilts_out=tout, tilt_fixed_in=fin, energy_modules=mods, gp=gp)
+    dm = DeviceMesh(P, T)
+    dm.set_leaflet_tilts("in", tin, tilt_fixed=fin, tilt_modulus=1.3, smoothness=0.4)
+    dm.set_leaflet_tilts("out", tout, tilt_modulus=0.7, smoothness=0.4)
+    dm.set_params(modules=L.MS_MOD_TILT_IN | L.MS_MOD_TILT_OUT | L.MS_MOD_TILT_SMOOTH_IN | L.MS_MOD_TILT_SMOOTH_OUT)
+    stats = mp.relax_leaflet_tilts(p, P)
+    it, ev = dm.relax_leaflet_tilts(solver="cg", max_iters=2, step_size=0.05, jacobi=True)
+    assert dm.tsearch_stats()["passes"] > 0
+    assert (it, ev) == (stats["iters"], stats["evals"])
+    assert relerr(dm.get_leaflet_tilts("in"), p.tilts_in) < 1e-9
+    assert relerr(dm.get_leaflet_tilts("out"), p.tilts_out) < 1e-9
+    dm.close()
+
+
+def test_full_size_single_field_relaxation_with_halvings_matches_the_oracle_port():
+    """2 048 000 facets, tilt + bending_tilt + tilt_smoothness, a step size that makes the ladder halve several times
+    (multi-trial passes): counts equal the oracle port's relax_tilts (tilt_relaxation.py:237-424), field to 1e-9."""
+    from conftest import relerr
+    from membrane_solver_amd import _lib as L
+    from membrane_solver_amd import meshgen
+    from membrane_solver_amd.device import DeviceMesh
+    from oracle import minimizer_port as mp
+
+    P, T = meshgen.icosphere(320)
+    P = meshgen.smooth_displace(P, 0.05)
+    nv = len(P)
+    rng = np.random.default_rng(6)
+    nrm = mp.unit_vertex_normals(P, T)
+    tl = 0.2 * rng.normal(size=P.shape)
+    tl -= np.einsum("ij,ij->i", tl, nrm)[:, None] * nrm
+    tfix = np.zeros(nv, bool)
+    tfix[::11] = True
+    gp = {"bending_modulus": 1.3, "spontaneous_curvature": 0.2, "tilt_rigidity": 2.0, "tilt_smoothness_rigidity": 0.7,
+          "tilt_solve_mode": "nested", "tilt_solver": "cg", "tilt_step_size": 40.0, "tilt_inner_steps": 2}
+    p = mp.Problem(positions=P, tri=T, tilts=tl, tilt_fixed=tfix, energy_modules=["tilt", "tilt_smoothness", "bending_tilt"],
+                   gp=gp)
+    st = mp.relax_tilts(p, p.positions)
+    dm = DeviceMesh(P, T)
+    dm.set_surface_tension(np.ones(len(T)))
+    dm.set_bending_params(np.full(nv, 1.3), np.full(nv, 0.2))
+    dm.set_tilts(tl, 2.0)
+    dm.set_tilt_smoothness(0.7)
+    dm.set_tilt_fixed(tfix)
+    dm.set_params(modules=L.MS_MOD_TILT | L.MS_MOD_BENDING_TILT | L.MS_MOD_TILT_SMOOTH)
+    iters, evals = dm.relax_tilts(solver="cg", max_iters=2, step_size=40.0, jacobi=True)
+    ts = dm.tsearch_stats()
+    assert ts["step_sizes"] > ts["passes"] > 0  # (passes with several step sizes ran)
+    assert (iters, evals) == (st["iters"], st["evals"])
+    assert relerr(dm.get_tilts(), p.tilts) < 1e-9
+    dm.close()
