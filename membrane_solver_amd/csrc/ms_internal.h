@@ -339,7 +339,7 @@ struct AxpyMaskedArgs {
 // travels as the kernel's argument block.  Results are bit for bit those of the launch-per-kernel path.
 enum : uint16_t {
   CK_ENERGY = 1, CK_GRADIENT, CK_TILT, CK_BT, CK_TS, CK_TVEC, CK_DISK, CK_REDUCE, CK_DIRECTION, CK_ROWDOT,
-  CK_AXPY_MASKED, CK_MEMSET, CK_RELAX, CK_RELAX_FUSED
+  CK_AXPY_MASKED, CK_MEMSET, CK_RELAX, CK_RELAX_FUSED, CK_TSEARCH  // (CK_TSEARCH: the single-step-size form of k_tsearch, mode = fields)
 };
 struct ExecCmdHead {
   uint16_t kind;

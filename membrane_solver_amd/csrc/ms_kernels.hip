@@ -3765,9 +3765,9 @@ hipError_t launch_curvature_raw(int nv, int nf, const double* pos, const int32_t
   return hipGetLastError();
 }
 
+#include "ms_tsearch.inc"
 #include "ms_exec.inc"
 #include "ms_resident.inc"
-#include "ms_tsearch.inc"
 
 }  // namespace ms
 #if MS_GATE_PROBE

@@ -553,7 +553,7 @@ class DeviceMesh:
         return {"passes": int(v[0]), "step_sizes": int(v[1])}
 
     EXEC_KINDS = {1: "energy", 2: "gradient", 3: "tilt", 4: "bt", 5: "tsmooth", 6: "tvec", 7: "disk_target", 8: "reduce",
-                  9: "direction", 10: "row_dot", 11: "axpy_masked", 12: "memset", 13: "relax"}
+                  9: "direction", 10: "row_dot", 11: "axpy_masked", 12: "memset", 13: "relax", 14: "relax_fused", 15: "tsearch"}
 
     def exec_trace(self, on: bool = True):
         """Per-record durations of the one-workgroup interpreter since the last call (ms_exec_trace):
