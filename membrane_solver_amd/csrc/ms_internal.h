@@ -222,6 +222,15 @@ struct TiltArgs {
   // that needs the normals anyway (bending_tilt_in/out)
   const double* fld_in[2] = {nullptr, nullptr};
   double* fld_out[2] = {nullptr, nullptr};
+  // mode 3 as the set-up of a TWO-field relaxation in one launch (the normals and the vertex areas are the same): the
+  // second field's projection, diagonal and area outputs
+  const double* tilts_b = nullptr;
+  double* proj_out_b = nullptr;
+  double* minv_b = nullptr;
+  double* va_out_b = nullptr;
+  double k_tilt_b = 0.0;
+  int finish_minv_b = 0;
+  int fixed_bit_b = 0;
 };
 
 struct DiskTargetArgs {   // tilt_disk_target_in.py:160-286

@@ -2094,6 +2094,23 @@ __device__ __forceinline__ void tilt_body(const TiltArgs& a, int cap, int max_en
         a.proj_out[o + 1] = r.y;
         a.proj_out[o + 2] = r.z;
       }
+      // the second field of the relaxation: the same three outputs
+      if (a.minv_b) {
+        double dg = a.k_tilt_b * aw;
+        if (a.finish_minv_b) {
+          if (!(dg > 1.0e-12) || (a.m.vflags[t.v_lo + tid] & a.fixed_bit_b)) dg = 1.0;
+          dg = 1.0 / dg;
+        }
+        a.minv_b[t.v_lo + tid] = dg;
+      }
+      if (a.va_out_b) a.va_out_b[t.v_lo + tid] = aw;
+      if (a.proj_out_b) {
+        const V3 tb = mk(a.tilts_b[o], a.tilts_b[o + 1], a.tilts_b[o + 2]);
+        const V3 r = tilt_trial_row(tb, tb, nrm, 0.0);
+        a.proj_out_b[o] = r.x;
+        a.proj_out_b[o + 1] = r.y;
+        a.proj_out_b[o + 2] = r.z;
+      }
     }
   }
   if (MODE != 2 && MODE != 3 && MODE != 4 && MODE != 5) {
